@@ -1,0 +1,27 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+@pytest.fixture(scope='session')
+def golden():
+    def load(name):
+        return dict(np.load(os.path.join(GOLDEN, name + '.npz')))
+    return load
+
+
+def golden_tree(g):
+    """{'MLP_0': {'Dense_i': {'kernel','bias'}}} from a g5_* fixture."""
+    n = len([k for k in g if k.startswith('kernel')])
+    return {'MLP_0': {'Dense_%d' % i: {'kernel': g['kernel%d' % i], 'bias': g['bias%d' % i]} for i in range(n)}}
