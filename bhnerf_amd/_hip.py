@@ -1,0 +1,135 @@
+"""ctypes binding of libbhnerf_hip.so (include/bhnerf_hip.h).
+
+PyTorch is used only as the owner of device memory and streams: every call passes raw
+``data_ptr()`` addresses and the current HIP stream handle through the C ABI.  There is no CPU
+fallback: if the library cannot be loaded, or a call fails, a ``HipError`` is raised.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, 'csrc')
+LIB_PATH = os.path.join(CSRC, 'libbhnerf_hip.so')
+
+BHN_F32, BHN_BF16 = 0, 1
+MODES = {'f32': BHN_F32, 'fp32': BHN_F32, 'float32': BHN_F32, 'bf16': BHN_BF16, 'bfloat16': BHN_BF16}
+
+
+class HipError(RuntimeError):
+    pass
+
+
+class bhn_model(C.Structure):
+    _fields_ = [('net_depth', C.c_int32), ('net_width', C.c_int32), ('posenc_deg', C.c_int32),
+                ('do_skip', C.c_int32), ('scale', C.c_float), ('rmin', C.c_float), ('rmax', C.c_float),
+                ('z_width', C.c_float)]
+
+
+class bhn_geom(C.Structure):
+    _fields_ = [('R', C.c_int64), ('G', C.c_int64), ('S', C.c_int32), ('x', C.c_void_p), ('y', C.c_void_p),
+                ('z', C.c_void_p), ('Omega', C.c_void_p), ('t_geo', C.c_void_p), ('w', C.c_void_p),
+                ('dom', C.c_void_p)]
+
+
+class bhn_frames(C.Structure):
+    _fields_ = [('B', C.c_int32), ('tM0', C.c_void_p)]
+
+
+_P, _I32, _I64, _F, _SZ = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
+_MP, _GP, _FP = C.POINTER(bhn_model), C.POINTER(bhn_geom), C.POINTER(bhn_frames)
+
+# name -> (restype, argtypes); must list every symbol include/bhnerf_hip.h declares
+SIGNATURES = {
+    'bhn_version': (C.c_int, []),
+    'bhn_last_error': (C.c_char_p, []),
+    'bhn_param_count': (_I64, [_MP]),
+    'bhn_param_layout': (C.c_int, [_MP, C.POINTER(_I64), C.POINTER(_I64), C.POINTER(_I32)]),
+    'bhn_geom_prepare': (C.c_int, [_P, _P, _P, _P, _P, _I32, _I64, _F, _F, _F, _P, _P, _P]),
+    'bhn_radiative_transfer_fwd': (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _P]),
+    'bhn_radiative_transfer_bwd': (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _P]),
+    'bhn_packed_bytes': (_SZ, [_MP, _I32]),
+    'bhn_pack_weights': (C.c_int, [_MP, _I32, _P, _P, _P]),
+    'bhn_predict_fwd': (C.c_int, [_MP, _I32, _P, _GP, _FP, _P, _P]),
+    'bhn_render_fwd': (C.c_int, [_MP, _I32, _P, _GP, _FP, _P, _P]),
+    'bhn_render_bwd_workspace_bytes': (_SZ, [_MP, _I32, _I32]),
+    'bhn_render_bwd': (C.c_int, [_MP, _I32, _P, _GP, _FP, _P, _P, _P, _SZ, _P]),
+    'bhn_chi2_image': (C.c_int, [_P, _P, _P, _P, _F, _I32, _I32, _I32, _I64, _P, _P, _P]),
+    'bhn_adam_step': (C.c_int, [_P, _P, _P, _P, _I64, _I64, _F, _F, _F, _F, _F, _P]),
+    'bhn_selftest': (C.c_int, [C.POINTER(_I32)]),
+}
+
+_lib = None
+
+
+def build(verbose=False):
+    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    res = subprocess.run(['make', '-C', CSRC, '-j4'], capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout[-4000:])
+        print(res.stderr[-4000:])
+    if res.returncode != 0:
+        raise HipError('building libbhnerf_hip.so failed (make -C %s)' % CSRC)
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library; raises HipError (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipError('%s not found: run `python -c "import __graft_entry__ as g; g.build()"` '
+                           '(or make -C bhnerf_amd/csrc). There is no CPU fallback.' % LIB_PATH)
+        try:
+            handle = C.CDLL(LIB_PATH)
+        except OSError as exc:
+            raise HipError('cannot load %s: %s' % (LIB_PATH, exc))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise HipError('libbhnerf_hip: %s (code %d)' % (lib().bhn_last_error().decode(), rc))
+
+
+def stream_ptr(device=None):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t):
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def require_device(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise HipError('device tensor required (the HIP path has no CPU fallback)')
+
+
+def as_f32(x, device):
+    """Contiguous float32 device tensor from array-like input (host->device copy if needed)."""
+    if isinstance(x, torch.Tensor):
+        return x.to(device=device, dtype=torch.float32).contiguous()
+    return torch.as_tensor(np.ascontiguousarray(np.asarray(x, dtype=np.float32)), device=device)
+
+
+def make_model(net_depth, net_width, posenc_deg, do_skip, scale, rmin, rmax, z_width):
+    big = 3.0e38
+    clip = lambda v: float(min(max(v, -big), big))
+    return bhn_model(int(net_depth), int(net_width), int(posenc_deg), int(bool(do_skip)), clip(scale), clip(rmin),
+                     clip(rmax), clip(z_width))
+
+
+def selftest():
+    res = (C.c_int32 * 8)()
+    check(lib().bhn_selftest(res))
+    return list(res), lib().bhn_last_error().decode()

@@ -1,0 +1,279 @@
+// Building blocks of the fused predictor kernels (gfx950 / CDNA4).
+//
+// Data flow (DESIGN.md "fused predictor"): one wave owns 32 points.  Activations are kept
+// TRANSPOSED, H^T [features x points]: the point is the MFMA column (lane & 31), features live in
+// registers.  A layer is  H_{l+1}^T = W_l^T . H_l^T  with  A = W_l^T (LDS, pre-packed in fragment
+// order) and  B = H_l^T (registers).  The 32x32 f32 accumulator of v_mfma_f32_32x32x16_bf16 has
+// its column on the lane and rows (r&3)+8*(r>>2)+4*(lane>>5) in its 16 registers, so registers
+// 8s..8s+7 of an accumulator ARE the B fragment of k-step s of the next layer: activations never
+// leave registers between layers.
+//
+// Canonical register order of a 32-feature block: element j (0..7) of k-step s (0..1) of lane-half
+// h is feature 16*s + 8*(j>>2) + 4*h + (j&3).   (phi below)
+#pragma once
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+#define DEVI __device__ __forceinline__
+
+// feature index inside a 16-feature k-step for (lane half h, element j)
+DEVI constexpr int phi16(int h, int j) { return 8 * (j >> 2) + 4 * h + (j & 3); }
+
+// ---------------------------------------------------------------------------------------------
+// Precision policies
+// ---------------------------------------------------------------------------------------------
+struct PolBF16 {
+    static constexpr int MODE = BHN_BF16;
+    static constexpr int NWAVES = 8;            // 2 waves per SIMD, <=256 VGPRs each
+    static constexpr int NTHREADS = NWAVES * 64;
+    static constexpr int ELEM_BYTES = 2;
+    static constexpr int FRAG_BYTES = 1024;     // 64 lanes x 8 bf16
+    using frag = bf16x8;
+    static DEVI frag zero() { frag f; for (int j = 0; j < 8; ++j) f[j] = (__bf16)0.f; return f; }
+    static DEVI frag lds_frag(const char *chunk, int f, int lane) {
+        return *reinterpret_cast<const frag *>(chunk + f * FRAG_BYTES + lane * 16);
+    }
+    static DEVI f32x16 mma(const frag &a, const frag &b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+    static DEVI void set(frag &f, int j, float v) { f[j] = (__bf16)v; }
+    static DEVI float get(const frag &f, int j) { return (float)f[j]; }
+    static DEVI float fsin_rev(float rev) { return __builtin_amdgcn_sinf(rev); }   // sin(2*pi*rev)
+    static DEVI float fcos_rev(float rev) { return __builtin_amdgcn_cosf(rev); }
+    static DEVI float fexp(float x) { return __expf(x); }
+    static constexpr bool FAST_TRIG = true;
+};
+
+struct PolF32 {
+    static constexpr int MODE = BHN_F32;
+    static constexpr int NWAVES = 4;            // 1 wave per SIMD, 512 registers each
+    static constexpr int NTHREADS = NWAVES * 64;
+    static constexpr int ELEM_BYTES = 4;
+    static constexpr int FRAG_BYTES = 2048;     // 2 halves x 64 lanes x 4 f32
+    using frag = f32x8;
+    static DEVI frag zero() { frag f; for (int j = 0; j < 8; ++j) f[j] = 0.f; return f; }
+    static DEVI frag lds_frag(const char *chunk, int f, int lane) {
+        const f32x4 lo = *reinterpret_cast<const f32x4 *>(chunk + f * FRAG_BYTES + lane * 16);
+        const f32x4 hi = *reinterpret_cast<const f32x4 *>(chunk + f * FRAG_BYTES + 1024 + lane * 16);
+        frag r;
+        for (int j = 0; j < 4; ++j) { r[j] = lo[j]; r[4 + j] = hi[j]; }
+        return r;
+    }
+    // v_mfma_f32_32x32x2_f32: k = lane>>5, so element j of both operands pairs features
+    // (8*(j>>2)+(j&3)) [h=0] and (+4) [h=1] -- the same phi16 map as the bf16 fragment.
+    static DEVI f32x16 mma(const frag &a, const frag &b, f32x16 c) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], c, 0, 0, 0);
+        return c;
+    }
+    static DEVI void set(frag &f, int j, float v) { f[j] = v; }
+    static DEVI float get(const frag &f, int j) { return f[j]; }
+    static DEVI float fexp(float x) { return expf(x); }
+    static constexpr bool FAST_TRIG = false;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Kernel arguments (passed by value)
+// ---------------------------------------------------------------------------------------------
+struct FusedArgs {
+    // model
+    int depth;            // hidden layers
+    int skip_mask;        // bit l set: layer l consumes concat[h, enc]
+    float scale;
+    // geometry
+    const float *x, *y, *z, *Omega, *t_geo, *w;
+    const uint8_t *dom;
+    long long P, G, R;
+    int Sx;               // max(S,1)
+    // frames
+    const double *tM0;
+    int B;
+    // packed weights
+    const char *packed;
+    unsigned fwd_off, bwd_off, bias_off, wout_off;   // byte offsets inside `packed`
+    // outputs / inputs of the individual kernels
+    float *emission;      // predict: (B,P)
+    float *images;        // render fwd: (B,Sx,R)
+    const float *dimages; // render bwd
+    float *slabs;         // render bwd: per-workgroup dW slabs
+    long long slab_floats;
+    // tiling
+    int tiles_per_frame;
+    long long total_tiles;
+};
+
+// Packed-weight geometry for hidden width W
+template <int W, class Pol>
+struct Pack {
+    static constexpr int MT = W / 32;                 // 32-row output tiles per hidden layer
+    static constexpr int KS = W / 16;                 // 16-feature k-steps of a hidden input
+    static constexpr int CH = KS + 2;                 // fragments per chunk (hidden + enc block)
+    static constexpr int CHUNK_BYTES = CH * Pol::FRAG_BYTES;
+    static_assert(2 * MT <= CH, "layer-0 chunk must hold all its fragments");
+    // forward image: chunk 0 = layer 0 (frag m*2+ks), chunks 1+(l-1)*MT+m = hidden layer l tile m
+    // (frag ks, enc block at KS,KS+1), last chunk = output layer (frag ks, row 0 real).
+    static DEVI constexpr int fwd_chunks(int depth) { return 1 + (depth - 1) * MT + 1; }
+    // transposed image (delta chain through hidden layer l>=1): chunk (l-1)*MT+m, frag ks:
+    //   element = kernel_l[32m+i][16ks+phi]
+    static DEVI constexpr int bwd_chunks(int depth) { return (depth - 1) * MT; }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Double-buffered weight ring: global (L2) -> registers -> LDS, one barrier per chunk.
+// ---------------------------------------------------------------------------------------------
+template <int CHUNK_BYTES, int NTHREADS>
+struct Stager {
+    static constexpr int PIECES = (CHUNK_BYTES + NTHREADS * 16 - 1) / (NTHREADS * 16);
+    uint4 st[PIECES];
+    // every thread always loads (the tail piece re-reads the last 16 bytes) so that st[] is fully
+    // initialised and stays in registers; only the store is guarded
+    DEVI void load(const char *src) {
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            int off = (i * NTHREADS + (int)threadIdx.x) * 16;
+            off = off < CHUNK_BYTES ? off : CHUNK_BYTES - 16;
+            st[i] = *reinterpret_cast<const uint4 *>(src + off);
+        }
+    }
+    DEVI void store(char *dst) const {
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const int off = (i * NTHREADS + (int)threadIdx.x) * 16;
+            if (off < CHUNK_BYTES) *reinterpret_cast<uint4 *>(dst + off) = st[i];
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Per-point prologue: velocity warp (emission.py:200-210) + positional encoding (network.py:118-122)
+// ---------------------------------------------------------------------------------------------
+struct PointState {
+    bool live;        // contributes: in range, inside the domain, after injection, finite
+    long long p;      // flat point index inside the frame
+};
+
+template <class Pol, int DEG>
+DEVI void point_prologue(const FusedArgs &a, int b, long long p, bool inb, typename Pol::frag (&enc)[2],
+                         bool &live) {
+    const int lane = threadIdx.x & 63;
+    const int h = lane >> 5;
+    float x = 0.f, y = 0.f, z = 0.f, om = 0.f, tg = 0.f;
+    bool dom = false;
+    if (inb) {
+        x = a.x[p]; y = a.y[p]; z = a.z[p]; om = a.Omega[p]; tg = a.t_geo[p];
+        dom = a.dom[p] != 0;
+    }
+    // t_M = (t_frame - t_start_obs)/GM_c3 + t_geo - t_injection in double: the f32 reference loses
+    // ~6e-5 here (|t_geo| ~ 1e3), the oracle is float64 (DESIGN.md "numerics").
+    const double tM = a.tM0[b] + (double)tg;
+    const bool pre = tM < 0.0;                                  // emission.py:204-205 -> NaN
+    const double rev_d = tM * (double)om * 0.15915494309189535; // theta / (2 pi)
+    const double fr = rev_d - floor(rev_d);
+    float s, c;
+    if (Pol::FAST_TRIG) {
+        s = __builtin_amdgcn_sinf((float)fr);
+        c = __builtin_amdgcn_cosf((float)fr);
+    } else {
+        sincosf((float)(fr * 6.283185307179586), &s, &c);
+    }
+    // rot_z(-theta) (utils.py:126-132 with angle=-theta): x' = c x + s y, y' = -s x + c y, z' = z
+    float u[3];
+    u[0] = c * x + s * y;
+    u[1] = c * y - s * x;
+    u[2] = z;
+    const bool finite_theta = !pre && (fr == fr);
+    bool valid[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        valid[k] = finite_theta && isfinite(u[k]);               // network.py:226
+        u[k] = valid[k] ? u[k] / a.scale : 0.f;                  // network.py:227,229
+    }
+    live = inb && dom && valid[0];                               // emission.py:370-373, network.py:232
+    // encoded features, canonical order [u | sin(2^i u_c) i-major | cos(2^i u_c)] (network.py:118-122)
+    float feat[BHN_ENC_PAD];
+#pragma unroll
+    for (int q = 0; q < BHN_ENC_PAD; ++q) feat[q] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) feat[k] = u[k];
+#pragma unroll
+    for (int i = 0; i < DEG; ++i) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float arg = u[k] * (float)(1 << i);
+            float sv, cv;
+            if (Pol::FAST_TRIG) {
+                const float rev = __builtin_amdgcn_fractf(arg * 0.15915494309189535f);
+                sv = __builtin_amdgcn_sinf(rev);
+                cv = __builtin_amdgcn_cosf(rev);
+            } else {
+                sincosf(arg, &sv, &cv);
+            }
+            feat[3 + 3 * i + k] = sv;
+            feat[3 + 3 * DEG + 3 * i + k] = cv;
+        }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v0 = feat[16 * ks + phi16(0, j)];
+            const float v1 = feat[16 * ks + phi16(1, j)];
+            Pol::set(enc[ks], j, h ? v1 : v0);
+        }
+}
+
+// bias rows of output tile m as the initial accumulator: acc[r] = bias[32m + (r&3)+8(r>>2)+4h]
+DEVI f32x16 bias_acc(const float *bias_lds, int m, int h) {
+    f32x16 acc;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(bias_lds + 32 * m + 8 * g4 + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[4 * g4 + e] = v[e];
+    }
+    return acc;
+}
+
+// One 32-row output tile of a hidden layer: acc = bias + sum_ks A[ks] . act[ks] (+ enc block)
+template <int W, class Pol>
+DEVI f32x16 tile_matmul(const char *chunk, const typename Pol::frag (&act)[W / 16],
+                        const typename Pol::frag (&enc)[2], bool with_enc, f32x16 acc) {
+    const int lane = threadIdx.x & 63;
+    constexpr int KS = W / 16;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) acc = Pol::mma(Pol::lds_frag(chunk, ks, lane), act[ks], acc);
+    if (with_enc) {
+        acc = Pol::mma(Pol::lds_frag(chunk, KS, lane), enc[0], acc);
+        acc = Pol::mma(Pol::lds_frag(chunk, KS + 1, lane), enc[1], acc);
+    }
+    return acc;
+}
+
+// relu + repack accumulator tile m into the next layer's B fragments 2m, 2m+1; returns the
+// 16-bit relu mask (bit r set where acc[r] > 0)
+template <int W, class Pol>
+DEVI unsigned relu_pack(const f32x16 &acc, int m, typename Pol::frag (&next)[W / 16]) {
+    unsigned mask = 0;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = acc[8 * s + j];
+            const bool pos = v > 0.f;
+            mask |= pos ? (1u << (8 * s + j)) : 0u;
+            Pol::set(next[2 * m + s], j, pos ? v : 0.f);
+        }
+    return mask;
+}
+
+// wave-level sum over the 32 lanes of each half (lanes 0-31 and 32-63 independently)
+DEVI float half_wave_sum(float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}

@@ -1,0 +1,317 @@
+// Fused NeRF_Predictor forward (network.py:191-237) and fused image-plane prediction
+// (network.py:373-420): warp -> posenc -> skip-MLP -> sigmoid/masks [-> x w -> sum over the ray].
+#include "fused_common.h"
+
+// ---------------------------------------------------------------------------------------------
+// packed weight image
+// ---------------------------------------------------------------------------------------------
+struct PackedLayout {
+    int CH, chunk_bytes, n_fwd, n_bwd;
+    size_t fwd_off, bwd_off, bias_off, wout_off, total;
+};
+
+static void packed_layout(const MlpShape &s, int mode, PackedLayout *L) {
+    const int frag_bytes = (mode == BHN_BF16) ? 1024 : 2048;
+    const int MT = s.width / 32, KS = s.width / 16;
+    L->CH = KS + 2;
+    L->chunk_bytes = L->CH * frag_bytes;
+    L->n_fwd = 1 + (s.depth - 1) * MT + 1;
+    L->n_bwd = (s.depth - 1) * MT;
+    L->fwd_off = 0;
+    L->bwd_off = (size_t)L->n_fwd * L->chunk_bytes;
+    L->bias_off = L->bwd_off + (size_t)L->n_bwd * L->chunk_bytes;
+    L->wout_off = L->bias_off + (size_t)(s.depth + 1) * s.width * 4;
+    L->total = L->wout_off + (size_t)s.width * 4;
+}
+
+extern "C" size_t bhn_packed_bytes(const bhn_model *m, int32_t mode) {
+    MlpShape s;
+    if (bhn_mlp_shape(m, &s) != BHN_OK) return 0;
+    PackedLayout L;
+    packed_layout(s, mode, &L);
+    return L.total;
+}
+
+struct PackArgs {
+    MlpShape s;
+    PackedLayout L;
+    int mode;
+    const float *params;
+    char *packed;
+};
+
+__global__ void pack_weights_kernel(PackArgs a) {
+    const MlpShape &s = a.s;
+    const int W = s.width, MT = W / 32, KS = W / 16, CH = a.L.CH, D = s.depth;
+    const long long n_frag_elems = (long long)(a.L.n_fwd + a.L.n_bwd) * CH * 512;
+    const long long n_bias = (long long)(D + 1) * W;
+    const long long total = n_frag_elems + n_bias + W;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        if (t >= n_frag_elems) {
+            const long long u = t - n_frag_elems;
+            if (u < n_bias) {
+                const int l = (int)(u / W), o = (int)(u % W);
+                float v = 0.f;
+                if (l < D) v = a.params[s.bias_off[l] + o];
+                else if (o == 0) v = a.params[s.bias_off[D]];
+                reinterpret_cast<float *>(a.packed + a.L.bias_off)[u] = v;
+            } else {
+                const int k = (int)(u - n_bias);
+                reinterpret_cast<float *>(a.packed + a.L.wout_off)[k] = a.params[s.kernel_off[D] + k];
+            }
+            continue;
+        }
+        const int j = (int)(t & 7);
+        const int lane = (int)((t >> 3) & 63);
+        const int f = (int)((t >> 9) % CH);
+        const int c = (int)((t >> 9) / CH);       // chunk index over fwd then bwd images
+        const int i = lane & 31, h = lane >> 5;
+        const int ph = 8 * (j >> 2) + 4 * h + (j & 3);
+        float v = 0.f;
+        bool fwd = c < a.L.n_fwd;
+        if (fwd) {
+            if (c == 0) {                                   // layer 0: frag = m*2 + ks
+                if (f < 2 * MT) {
+                    const int m = f >> 1, q = 16 * (f & 1) + ph;
+                    if (q < s.F) v = a.params[s.kernel_off[0] + (long long)q * W + 32 * m + i];
+                }
+            } else if (c == a.L.n_fwd - 1) {                // output layer, only row 0 is real
+                if (f < KS && i == 0) v = a.params[s.kernel_off[D] + 16 * f + ph];
+            } else {
+                const int l = 1 + (c - 1) / MT, m = (c - 1) % MT;
+                if (f < KS) {
+                    v = a.params[s.kernel_off[l] + (long long)(16 * f + ph) * W + 32 * m + i];
+                } else if (s.skip_in[l]) {
+                    const int q = 16 * (f - KS) + ph;
+                    if (q < s.F) v = a.params[s.kernel_off[l] + (long long)(W + q) * W + 32 * m + i];
+                }
+            }
+        } else {
+            const int cb = c - a.L.n_fwd;
+            const int l = 1 + cb / MT, m = cb % MT;
+            if (f < KS) v = a.params[s.kernel_off[l] + (long long)(32 * m + i) * W + 16 * f + ph];
+        }
+        char *img = a.packed + (fwd ? a.L.fwd_off + (size_t)c * a.L.chunk_bytes
+                                    : a.L.bwd_off + (size_t)(c - a.L.n_fwd) * a.L.chunk_bytes);
+        if (a.mode == BHN_BF16) {
+            reinterpret_cast<__bf16 *>(img + f * 1024 + lane * 16)[j] = (__bf16)v;
+        } else {
+            reinterpret_cast<float *>(img + f * 2048 + (j >> 2) * 1024 + lane * 16)[j & 3] = v;
+        }
+    }
+}
+
+extern "C" int bhn_pack_weights(const bhn_model *m, int32_t mode, const float *params, void *packed, void *stream) {
+    BHN_CHECK_ARG(params && packed, "null pointer");
+    BHN_CHECK_ARG(mode == BHN_F32 || mode == BHN_BF16, "bad mode %d", mode);
+    PackArgs a;
+    int rc = bhn_mlp_shape(m, &a.s);
+    if (rc != BHN_OK) return rc;
+    packed_layout(a.s, mode, &a.L);
+    a.mode = mode;
+    a.params = params;
+    a.packed = (char *)packed;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, a);
+    BHN_HIP(hipGetLastError());
+    return BHN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward kernel
+// ---------------------------------------------------------------------------------------------
+template <int W, class Pol, int DEG, bool RENDER>
+__global__ __launch_bounds__(Pol::NTHREADS) void fused_fwd_kernel(FusedArgs a) {
+    using PK = Pack<W, Pol>;
+    using frag = typename Pol::frag;
+    constexpr int CB = PK::CHUNK_BYTES, MT = PK::MT, KS = PK::KS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *ring = smem;                                              // 2 x CB
+    float *bias_lds = reinterpret_cast<float *>(smem + 2 * CB);      // (depth+1) x W
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 31, h = lane >> 5;
+    for (int i = tid; i < (a.depth + 1) * W; i += Pol::NTHREADS)
+        bias_lds[i] = reinterpret_cast<const float *>(a.packed + a.bias_off)[i];
+
+    const char *fwd = a.packed + a.fwd_off;
+    Stager<CB, Pol::NTHREADS> stg;
+    stg.load(fwd);
+    stg.store(ring);
+    __syncthreads();
+    int par = 0;
+
+    for (long long tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
+        const int b = (int)(tile / a.tiles_per_frame);
+        const long long p = (tile % a.tiles_per_frame) * (Pol::NWAVES * 32) + wv * 32 + pl;
+        const bool inb = p < a.P;
+        frag enc[2];
+        bool live;
+        point_prologue<Pol, DEG>(a, b, p, inb, enc, live);
+
+        frag act[KS], next[KS];
+        // ---- layer 0 (chunk 0: fragment m*2+ks) -------------------------------------------
+        {
+            stg.load(fwd + CB);
+            const char *ch = ring + par * CB;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                f32x16 acc = bias_acc(bias_lds, m, h);
+                acc = Pol::mma(Pol::lds_frag(ch, 2 * m, lane), enc[0], acc);
+                acc = Pol::mma(Pol::lds_frag(ch, 2 * m + 1, lane), enc[1], acc);
+                relu_pack<W, Pol>(acc, m, act);
+            }
+            stg.store(ring + (par ^ 1) * CB);
+            __syncthreads();
+            par ^= 1;
+        }
+        // ---- hidden layers 1..depth-1 -----------------------------------------------------
+        int q = 1;
+        for (int l = 1; l < a.depth; ++l) {
+            const bool sk = (a.skip_mask >> l) & 1;
+            const float *bl = bias_lds + l * W;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                stg.load(fwd + (size_t)(q + 1) * CB);
+                f32x16 acc = tile_matmul<W, Pol>(ring + par * CB, act, enc, sk, bias_acc(bl, m, h));
+                relu_pack<W, Pol>(acc, m, next);
+                stg.store(ring + (par ^ 1) * CB);
+                __syncthreads();
+                par ^= 1;
+                ++q;
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) act[ks] = next[ks];
+        }
+        // ---- output layer (row 0 of the tile is the pre-activation) -----------------------
+        float outv;
+        {
+            stg.load(fwd);                                            // chunk 0 for the next tile
+            f32x16 acc = tile_matmul<W, Pol>(ring + par * CB, act, enc, false, bias_acc(bias_lds + a.depth * W, 0, h));
+            outv = acc[0];
+            stg.store(ring + (par ^ 1) * CB);
+            __syncthreads();
+            par ^= 1;
+        }
+        // ---- epilogue: sigmoid(out - 10), masks (network.py:230-232) ----------------------
+        float e = 0.f;
+        if (h == 0 && live) e = 1.f / (1.f + Pol::fexp(10.f - outv));
+        if (!RENDER) {
+            if (h == 0 && inb) a.emission[(long long)b * a.P + p] = e;
+        } else {
+            // x J g^2 dtau Sigma and sum over the ray (network.py:415-419, kgeo.py:621); a 32-point
+            // wave tile may straddle rays when G % 32 != 0 -> segmented sum + one atomic per ray.
+            const long long ray = inb ? p / a.G : -1;
+            unsigned long long rem = __ballot(h == 0 && inb);
+            while (rem) {
+                const int first = __ffsll((long long)rem) - 1;
+                const long long r0 = __shfl(ray, first, 64);
+                const bool mine = (h == 0) && inb && (ray == r0);
+                for (int s = 0; s < a.Sx; ++s) {
+                    float v = (mine && e != 0.f) ? a.w[(long long)s * a.P + p] * e : 0.f;
+                    v = half_wave_sum(v);
+                    if (lane == first) atomicAdd(a.images + ((long long)b * a.Sx + s) * a.R + r0, v);
+                }
+                rem &= ~__ballot(mine);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+int fused_fill_args(const bhn_model *m, int32_t mode, const void *packed, const bhn_geom *geom,
+                    const bhn_frames *fr, bool need_w, FusedArgs *a, MlpShape *s, int nwaves) {
+    BHN_CHECK_ARG(m && packed && geom && fr, "null pointer");
+    BHN_CHECK_ARG(mode == BHN_F32 || mode == BHN_BF16, "bad mode %d", mode);
+    int rc = bhn_mlp_shape(m, s);
+    if (rc != BHN_OK) return rc;
+    if (m->posenc_deg != 3) {
+        bhn_set_error("fused kernels are instantiated for posenc_deg=3 only (got %d)", m->posenc_deg);
+        return BHN_EUNSUPPORTED;
+    }
+    BHN_CHECK_ARG(geom->R > 0 && geom->G > 0 && geom->S >= 0 && geom->S <= 4, "bad geometry sizes");
+    BHN_CHECK_ARG(geom->x && geom->y && geom->z && geom->Omega && geom->t_geo && geom->dom, "null geometry array");
+    BHN_CHECK_ARG(!need_w || geom->w, "render needs geom->w");
+    BHN_CHECK_ARG(fr->B > 0 && fr->tM0, "bad frames");
+    BHN_CHECK_ARG(m->scale > 0.f, "scale must be positive");
+    PackedLayout L;
+    packed_layout(*s, mode, &L);
+    memset(a, 0, sizeof(*a));
+    a->depth = s->depth;
+    for (int l = 0; l <= s->depth; ++l) a->skip_mask |= s->skip_in[l] << l;
+    a->scale = m->scale;
+    a->x = geom->x; a->y = geom->y; a->z = geom->z; a->Omega = geom->Omega; a->t_geo = geom->t_geo;
+    a->w = geom->w; a->dom = geom->dom;
+    a->R = geom->R; a->G = geom->G; a->P = geom->R * geom->G;
+    a->Sx = geom->S > 0 ? geom->S : 1;
+    a->tM0 = fr->tM0; a->B = fr->B;
+    a->packed = (const char *)packed;
+    a->fwd_off = (unsigned)L.fwd_off; a->bwd_off = (unsigned)L.bwd_off;
+    a->bias_off = (unsigned)L.bias_off; a->wout_off = (unsigned)L.wout_off;
+    const long long pts_per_tile = (long long)nwaves * 32;
+    a->tiles_per_frame = (int)((a->P + pts_per_tile - 1) / pts_per_tile);
+    a->total_tiles = (long long)a->tiles_per_frame * a->B;
+    return BHN_OK;
+}
+
+template <int W, class Pol, bool RENDER>
+static int launch_fwd_w(FusedArgs &a, hipStream_t st) {
+    using PK = Pack<W, Pol>;
+    const size_t lds = 2 * PK::CHUNK_BYTES + (size_t)(a.depth + 1) * W * 4;
+    auto kern = fused_fwd_kernel<W, Pol, 3, RENDER>;
+    static bool attr_done = false;
+    static int occ = 1;
+    if (!attr_done) {
+        BHN_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        int o = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, kern, Pol::NTHREADS, lds) == hipSuccess && o > 0) occ = o;
+        attr_done = true;
+    }
+    int dev = 0;
+    BHN_HIP(hipGetDevice(&dev));
+    long long grid = (long long)bhn_num_cus(dev) * occ;
+    if (grid > a.total_tiles) grid = a.total_tiles;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(Pol::NTHREADS), lds, st, a);
+    BHN_HIP(hipGetLastError());
+    return BHN_OK;
+}
+
+template <class Pol, bool RENDER>
+static int launch_fwd(FusedArgs &a, int width, hipStream_t st) {
+    switch (width) {
+        case 32: return launch_fwd_w<32, Pol, RENDER>(a, st);
+        case 64: return launch_fwd_w<64, Pol, RENDER>(a, st);
+        case 128: return launch_fwd_w<128, Pol, RENDER>(a, st);
+        case 256: return launch_fwd_w<256, Pol, RENDER>(a, st);
+        default:
+            bhn_set_error("net_width %d: fused kernels are built for 32, 64, 128, 256", width);
+            return BHN_EUNSUPPORTED;
+    }
+}
+
+extern "C" int bhn_predict_fwd(const bhn_model *m, int32_t mode, const void *packed, const bhn_geom *geom,
+                               const bhn_frames *fr, float *emission, void *stream) {
+    FusedArgs a;
+    MlpShape s;
+    BHN_CHECK_ARG(emission, "null emission");
+    const int nw = (mode == BHN_BF16) ? PolBF16::NWAVES : PolF32::NWAVES;
+    int rc = fused_fill_args(m, mode, packed, geom, fr, false, &a, &s, nw);
+    if (rc != BHN_OK) return rc;
+    a.emission = emission;
+    return mode == BHN_BF16 ? launch_fwd<PolBF16, false>(a, s.width, (hipStream_t)stream)
+                            : launch_fwd<PolF32, false>(a, s.width, (hipStream_t)stream);
+}
+
+extern "C" int bhn_render_fwd(const bhn_model *m, int32_t mode, const void *packed, const bhn_geom *geom,
+                              const bhn_frames *fr, float *images, void *stream) {
+    FusedArgs a;
+    MlpShape s;
+    BHN_CHECK_ARG(images, "null images");
+    const int nw = (mode == BHN_BF16) ? PolBF16::NWAVES : PolF32::NWAVES;
+    int rc = fused_fill_args(m, mode, packed, geom, fr, true, &a, &s, nw);
+    if (rc != BHN_OK) return rc;
+    a.images = images;
+    BHN_HIP(hipMemsetAsync(images, 0, sizeof(float) * (size_t)a.B * a.Sx * a.R, (hipStream_t)stream));
+    return mode == BHN_BF16 ? launch_fwd<PolBF16, true>(a, s.width, (hipStream_t)stream)
+                            : launch_fwd<PolF32, true>(a, s.width, (hipStream_t)stream);
+}

@@ -1,0 +1,118 @@
+// Device self-checks of the lane maps the fused kernels rely on (exact small-integer data):
+//   [0] v_mfma_f32_32x32x16_bf16 A/B/C maps   [1] v_mfma_f32_32x32x2_f32 maps
+//   [2] accumulator -> next B operand chaining (phi16 order), bf16     [3] same, f32
+//   [4] ds_read_b64_tr_b16 as a [k][n] -> B-operand transposed read
+#include "fused_common.h"
+
+DEVI int ia(int i, int k) { return ((i * 3 + k * 5) % 7) - 3; }   // asymmetric integer operands
+DEVI int ib(int k, int n) { return ((k * 2 + n * 7) % 9) - 4; }
+
+__global__ void selftest_kernel(int *res, short *dump) {
+    __shared__ __attribute__((aligned(16))) short img[64 * 32];   // [k][n], 64-byte rows
+    const int lane = threadIdx.x & 63, r31 = lane & 31, h = lane >> 5;
+    int bad;
+    // ---- [0] bf16 32x32x16: A[row r31][k=8h+j], B[k=8h+j][col r31], C col=r31,row=(r&3)+8(r>>2)+4h
+    {
+        bf16x8 a, b;
+        for (int j = 0; j < 8; ++j) { a[j] = (__bf16)(float)ia(r31, 8 * h + j); b[j] = (__bf16)(float)ib(8 * h + j, r31); }
+        f32x16 c = {};
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+        bad = 0;
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            int ref = 0;
+            for (int k = 0; k < 16; ++k) ref += ia(row, k) * ib(k, r31);
+            bad += (c[r] != (float)ref);
+        }
+        atomicAdd(res + 0, bad);
+    }
+    // ---- [1] f32 32x32x2: A[i=r31][k=h], B[k=h][j=r31]
+    {
+        f32x16 c = {};
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32((float)ia(r31, h), (float)ib(h, r31), c, 0, 0, 0);
+        bad = 0;
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int ref = ia(row, 0) * ib(0, r31) + ia(row, 1) * ib(1, r31);
+            bad += (c[r] != (float)ref);
+        }
+        atomicAdd(res + 1, bad);
+    }
+    // ---- [2]/[3] chain: X = A1.B1 (32x32, K=16);  Y = A2.X with A2[i][feature], K=32 in phi16 order
+    {
+        // X[f][n] = sum_k ia(f,k) ib(k,n), |X| small integers (exact in bf16: |X| <= 16*3*4=192 < 256)
+        bf16x8 a, b;
+        for (int j = 0; j < 8; ++j) { a[j] = (__bf16)(float)ia(r31, 8 * h + j); b[j] = (__bf16)(float)ib(8 * h + j, r31); }
+        f32x16 x = {};
+        x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, x, 0, 0, 0);
+        f32x16 y = {}, y32 = {};
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 xb, a2;
+            for (int j = 0; j < 8; ++j) {
+                xb[j] = (__bf16)x[8 * s + j];
+                a2[j] = (__bf16)(float)(((r31 + 2 * (16 * s + phi16(h, j))) % 5) - 2);   // A2[i][f], f = 16s+phi
+            }
+            y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, xb, y, 0, 0, 0);
+            for (int j = 0; j < 8; ++j)
+                y32 = __builtin_amdgcn_mfma_f32_32x32x2f32((float)(((r31 + 2 * (16 * s + phi16(h, j))) % 5) - 2), x[8 * s + j], y32, 0, 0, 0);
+        }
+        bad = 0;
+        int bad32 = 0;
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            int ref = 0;
+            for (int f = 0; f < 32; ++f) {
+                int xf = 0;
+                for (int k = 0; k < 16; ++k) xf += ia(f, k) * ib(k, r31);
+                ref += (((row + 2 * f) % 5) - 2) * xf;
+            }
+            bad += (y[r] != (float)ref);
+            bad32 += (y32[r] != (float)ref);
+        }
+        atomicAdd(res + 2, bad);
+        atomicAdd(res + 3, bad32);
+    }
+    // ---- [4] transposed LDS read: image img[k][n] (k = 0..15 rows of 32 shorts), B operand wants
+    //          lane (n = r31, h): elements j -> img[8h+j][n]
+    {
+        for (int t = threadIdx.x; t < 64 * 32; t += 64) img[t] = (short)(t + 1);
+        __syncthreads();
+        const int gi = lane >> 4, t16 = lane & 15, q = t16 >> 2, pp = t16 & 3;
+        const int n0 = 16 * (gi & 1);
+        bad = 0;
+        for (int rd = 0; rd < 2; ++rd) {
+            const int k0 = 8 * (gi >> 1) + 4 * rd;
+            const short *addr = img + (k0 + q) * 32 + n0 + 4 * pp;
+            s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)addr);
+            for (int e = 0; e < 4; ++e) {
+                const short want = img[(8 * h + 4 * rd + e) * 32 + r31];
+                bad += (v[e] != want);
+                dump[(lane * 2 + rd) * 4 + e] = v[e];
+            }
+        }
+        atomicAdd(res + 4, bad);
+    }
+}
+
+extern "C" int bhn_selftest(int32_t *results_host) {
+    BHN_CHECK_ARG(results_host, "null results");
+    int *d_res = nullptr;
+    short *d_dump = nullptr;
+    BHN_HIP(hipMalloc(&d_res, 8 * sizeof(int)));
+    BHN_HIP(hipMalloc(&d_dump, 512 * sizeof(short)));
+    BHN_HIP(hipMemset(d_res, 0, 8 * sizeof(int)));
+    hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, 0, d_res, d_dump);
+    BHN_HIP(hipGetLastError());
+    BHN_HIP(hipMemcpy(results_host, d_res, 8 * sizeof(int), hipMemcpyDeviceToHost));
+    short dump[512];
+    BHN_HIP(hipMemcpy(dump, d_dump, sizeof(dump), hipMemcpyDeviceToHost));
+    if (results_host[4] != 0) {   // help diagnose the transposed-read map from one run
+        char buf[400];
+        int n = 0;
+        for (int l = 0; l < 20 && n < 360; ++l) n += snprintf(buf + n, sizeof(buf) - n, "%d:%d,%d,%d,%d ", l, dump[l * 8], dump[l * 8 + 1], dump[l * 8 + 2], dump[l * 8 + 3]);
+        bhn_set_error("tr16 read map mismatch; lane:first-read values = %s", buf);
+    }
+    (void)hipFree(d_res);
+    (void)hipFree(d_dump);
+    return BHN_OK;
+}

@@ -1,0 +1,342 @@
+// Stand-alone pieces of the hot path: geometry fold, radiative-transfer ray sum (kgeo.py:595-622),
+// chi^2 (network.py:476-484), Adam (network.py:173-174), plus the ABI bookkeeping.
+#include <math.h>
+#include <stdarg.h>
+
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------
+// error string / version / device cache
+// ------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void bhn_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" int bhn_version(void) { return BHN_ABI_VERSION; }
+extern "C" const char *bhn_last_error(void) { return g_err; }
+
+int bhn_num_cus(int device) {
+    static int cache[64];
+    if (device < 0 || device >= 64) return 256;
+    if (cache[device] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || n <= 0)
+            n = 256;
+        cache[device] = n;
+    }
+    return cache[device];
+}
+
+// ------------------------------------------------------------------------------------------
+// MLP shape / flat parameter layout (flax tree order, network.py:56-62)
+// ------------------------------------------------------------------------------------------
+int bhn_mlp_shape(const bhn_model *m, MlpShape *s) {
+    BHN_CHECK_ARG(m && s, "null model");
+    BHN_CHECK_ARG(m->net_depth >= 2 && m->net_depth <= 8, "net_depth %d outside 2..8", m->net_depth);
+    BHN_CHECK_ARG(m->net_width >= 32 && m->net_width <= 256 && m->net_width % 32 == 0,
+                  "net_width %d must be a multiple of 32 in 32..256", m->net_width);
+    BHN_CHECK_ARG(m->posenc_deg >= 0 && m->posenc_deg <= 4, "posenc_deg %d outside 0..4", m->posenc_deg);
+    memset(s, 0, sizeof(*s));
+    s->depth = m->net_depth;
+    s->width = m->net_width;
+    s->F = 3 + 6 * m->posenc_deg;
+    const int skip_layer = m->net_depth / 2;
+    int cur = s->F;
+    int64_t off = 0;
+    for (int i = 0; i <= s->depth; ++i) {
+        s->in_dim[i] = cur;
+        s->skip_in[i] = (cur == s->width + s->F) ? 1 : 0;
+        const int out = (i == s->depth) ? 1 : s->width;
+        s->kernel_off[i] = off;
+        off += (int64_t)cur * out;
+        s->bias_off[i] = off;
+        off += out;
+        cur = s->width;
+        if (m->do_skip && i < s->depth && i % skip_layer == 0 && i > 0) cur = s->width + s->F;
+    }
+    s->nparams = off;
+    if (s->skip_in[s->depth]) {
+        bhn_set_error("net_depth %d with do_skip feeds the skip-concat into the output layer; "
+                      "the fused kernels support depths 4, 6, 8 (or do_skip=0)", m->net_depth);
+        return BHN_EUNSUPPORTED;
+    }
+    return BHN_OK;
+}
+
+extern "C" int64_t bhn_param_count(const bhn_model *m) {
+    MlpShape s;
+    if (bhn_mlp_shape(m, &s) != BHN_OK) return -1;
+    return s.nparams;
+}
+
+extern "C" int bhn_param_layout(const bhn_model *m, int64_t *kernel_off, int64_t *bias_off, int32_t *in_dim) {
+    MlpShape s;
+    int rc = bhn_mlp_shape(m, &s);
+    if (rc != BHN_OK) return rc;
+    for (int i = 0; i <= s.depth; ++i) {
+        if (kernel_off) kernel_off[i] = s.kernel_off[i];
+        if (bias_off) bias_off[i] = s.bias_off[i];
+        if (in_dim) in_dim[i] = s.in_dim[i];
+    }
+    return BHN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// geometry fold: w[s][p] = g^2 dtau Sigma J_s, dom[p] = inside the supervised region
+// ------------------------------------------------------------------------------------------
+__global__ void geom_prepare_kernel(const float *__restrict__ coords, const float *__restrict__ g,
+                                    const float *__restrict__ dtau, const float *__restrict__ Sigma,
+                                    const float *__restrict__ J, int S, int64_t P, float rmin2, float rmax2,
+                                    float z_width, float *__restrict__ w, uint8_t *__restrict__ dom) {
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < P; p += (int64_t)gridDim.x * blockDim.x) {
+        const float x = coords[p], y = coords[P + p], z = coords[2 * P + p];
+        // emission.py:370-373: r^2 < rmin^2, r^2 > rmax^2, |z| > z_width are zeroed
+        const float r2 = __fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z));
+        dom[p] = (r2 < rmin2 || r2 > rmax2 || fabsf(z) > z_width) ? 0 : 1;
+        const float gg = g[p];
+        const float base = gg * gg * dtau[p] * Sigma[p];   // kgeo.py:621 factor order g^2 * e * dtau * Sigma
+        if (S == 0) {
+            w[p] = base;
+        } else {
+            for (int s = 0; s < S; ++s) w[(int64_t)s * P + p] = base * J[(int64_t)s * P + p];
+        }
+    }
+}
+
+extern "C" int bhn_geom_prepare(const float *coords, const float *g, const float *dtau, const float *Sigma,
+                                const float *J, int32_t S, int64_t P, float rmin, float rmax, float z_width,
+                                float *w_out, uint8_t *dom_out, void *stream) {
+    BHN_CHECK_ARG(coords && g && dtau && Sigma && w_out && dom_out, "null pointer");
+    BHN_CHECK_ARG(P > 0 && S >= 0 && S <= 4, "bad P=%lld or S=%d", (long long)P, S);
+    BHN_CHECK_ARG(S == 0 || J, "S>0 needs J");
+    const int threads = 256;
+    const int blocks = (int)((P + threads - 1) / threads < 4096 ? (P + threads - 1) / threads : 4096);
+    hipLaunchKernelGGL(geom_prepare_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, coords, g, dtau,
+                       Sigma, J, S, P, rmin * rmin, rmax * rmax, z_width, w_out, dom_out);
+    BHN_HIP(hipGetLastError());
+    return BHN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// radiative transfer stand-alone (HBM-bound): a group of LPR lanes owns one ray, keeps the
+// ray's weights g^2 dtau Sigma in registers and streams the N emission planes past them.
+// Algorithmic bytes per launch: 4*N*R*G (e) + 12*R*G (g,dtau,Sigma) + 4*N*R (img).
+// ------------------------------------------------------------------------------------------
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+template <int LPR, int KCH, bool VEC, bool BWD>
+__global__ __launch_bounds__(256) void rt_kernel(const float *__restrict__ ein, const float *__restrict__ g,
+                                                 const float *__restrict__ dtau, const float *__restrict__ Sigma,
+                                                 float *__restrict__ out, int64_t N, int64_t R, int64_t G) {
+    constexpr int RPB = 256 / LPR;   // rays per block
+    const int sub = threadIdx.x % LPR;
+    const int64_t ray = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR;
+    const bool ray_ok = ray < R;
+    const int64_t rbase = ray * G;
+    float w[KCH][4];
+#pragma unroll
+    for (int c = 0; c < KCH; ++c) {
+        const int64_t k = (int64_t)(c * LPR + sub) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[c][i] = 0.f;
+        if (!ray_ok) continue;
+        if (VEC) {
+            if (k < G) {
+                const float4 a = *reinterpret_cast<const float4 *>(g + rbase + k);
+                const float4 b = *reinterpret_cast<const float4 *>(dtau + rbase + k);
+                const float4 s = *reinterpret_cast<const float4 *>(Sigma + rbase + k);
+                w[c][0] = a.x * a.x * b.x * s.x; w[c][1] = a.y * a.y * b.y * s.y;
+                w[c][2] = a.z * a.z * b.z * s.z; w[c][3] = a.w * a.w * b.w * s.w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (k + i < G) {
+                    const float a = g[rbase + k + i];
+                    w[c][i] = a * a * dtau[rbase + k + i] * Sigma[rbase + k + i];
+                }
+        }
+    }
+    const int64_t plane = R * G;
+    for (int64_t n = 0; n < N; ++n) {
+        if (!BWD) {
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < KCH; ++c) {
+                const int64_t k = (int64_t)(c * LPR + sub) * 4;
+                if (!ray_ok) continue;
+                if (VEC) {
+                    if (k < G) {
+                        const f4v e = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(ein + n * plane + rbase + k));
+                        acc += w[c][0] * e.x + w[c][1] * e.y + w[c][2] * e.z + w[c][3] * e.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (k + i < G) acc += w[c][i] * ein[n * plane + rbase + k + i];
+                }
+            }
+#pragma unroll
+            for (int o = LPR / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+            if (sub == 0 && ray_ok) out[n * R + ray] = acc;
+        } else {
+            if (!ray_ok) continue;
+            const float d = ein[n * R + ray];
+#pragma unroll
+            for (int c = 0; c < KCH; ++c) {
+                const int64_t k = (int64_t)(c * LPR + sub) * 4;
+                if (VEC) {
+                    if (k < G) {
+                        f4v v = {d * w[c][0], d * w[c][1], d * w[c][2], d * w[c][3]};
+                        __builtin_nontemporal_store(v, reinterpret_cast<f4v *>(out + n * plane + rbase + k));
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (k + i < G) out[n * plane + rbase + k + i] = d * w[c][i];
+                }
+            }
+        }
+    }
+}
+
+template <bool BWD>
+static int rt_launch(const float *in, const float *g, const float *dtau, const float *Sigma, float *out, int64_t N,
+                     int64_t R, int64_t G, hipStream_t st) {
+    BHN_CHECK_ARG(in && g && dtau && Sigma && out, "null pointer");
+    BHN_CHECK_ARG(N > 0 && R > 0 && G > 0, "bad sizes N=%lld R=%lld G=%lld", (long long)N, (long long)R, (long long)G);
+    BHN_CHECK_ARG(G <= 1024, "G=%lld > 1024 samples per ray is not supported", (long long)G);
+    const bool vec = (G % 4 == 0) && (((uintptr_t)in | (uintptr_t)g | (uintptr_t)dtau | (uintptr_t)Sigma | (uintptr_t)out) % 16 == 0);
+    const int64_t quads = (G + 3) / 4;
+    int lpr = 1;
+    while (lpr < 64 && lpr < quads) lpr <<= 1;
+    const int kch = (int)((quads + lpr - 1) / lpr);   // <= 4 because G <= 1024
+#define RT_GO(L, K)                                                                                               \
+    do {                                                                                                          \
+        const int64_t blocks = (R + (256 / L) - 1) / (256 / L);                                                   \
+        if (vec)                                                                                                  \
+            hipLaunchKernelGGL((rt_kernel<L, K, true, BWD>), dim3((unsigned)blocks), dim3(256), 0, st, in, g, dtau, Sigma, out, N, R, G); \
+        else                                                                                                      \
+            hipLaunchKernelGGL((rt_kernel<L, K, false, BWD>), dim3((unsigned)blocks), dim3(256), 0, st, in, g, dtau, Sigma, out, N, R, G); \
+    } while (0)
+    if (lpr < 64) {
+        switch (lpr) {
+            case 1: RT_GO(1, 1); break;
+            case 2: RT_GO(2, 1); break;
+            case 4: RT_GO(4, 1); break;
+            case 8: RT_GO(8, 1); break;
+            case 16: RT_GO(16, 1); break;
+            default: RT_GO(32, 1); break;
+        }
+    } else {
+        switch (kch) {
+            case 1: RT_GO(64, 1); break;
+            case 2: RT_GO(64, 2); break;
+            case 3: RT_GO(64, 3); break;
+            default: RT_GO(64, 4); break;
+        }
+    }
+#undef RT_GO
+    BHN_HIP(hipGetLastError());
+    return BHN_OK;
+}
+
+extern "C" int bhn_radiative_transfer_fwd(const float *e, const float *g, const float *dtau, const float *Sigma,
+                                          float *img, int64_t N, int64_t R, int64_t G, void *stream) {
+    return rt_launch<false>(e, g, dtau, Sigma, img, N, R, G, (hipStream_t)stream);
+}
+
+extern "C" int bhn_radiative_transfer_bwd(const float *dimg, const float *g, const float *dtau, const float *Sigma,
+                                          float *de, int64_t N, int64_t R, int64_t G, void *stream) {
+    return rt_launch<true>(dimg, g, dtau, Sigma, de, N, R, G, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// chi^2 on images (network.py:476-484).  One block per (frame, stokes) plane.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum_256(float v, float *red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    const int wv = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[wv] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void chi2_image_kernel(const float *__restrict__ images, const float *__restrict__ target,
+                                                         const float *__restrict__ sigma, const float *__restrict__ offset,
+                                                         float scale, int dtype, int64_t R, float *__restrict__ loss,
+                                                         float *__restrict__ dimages) {
+    __shared__ float red[4];
+    const int64_t plane = blockIdx.x;
+    const float *img = images + plane * R;
+    if (dtype == 0) {   // 'full': sum |(img - target - offset)/sigma|^2 (network.py:477)
+        float acc = 0.f;
+        for (int64_t r = threadIdx.x; r < R; r += 256) {
+            const float s = sigma[plane * R + r];
+            const float d = (img[r] - target[plane * R + r] - offset[plane * R + r]) / s;
+            acc += d * d;
+            if (dimages) dimages[plane * R + r] = 2.f * scale * d / s;
+        }
+        const float tot = block_sum_256(acc, red);
+        if (threadIdx.x == 0) atomicAdd(loss, scale * tot);
+    } else {            // 'lc': light curve = image summed over pixels (network.py:479-480)
+        float acc = 0.f;
+        for (int64_t r = threadIdx.x; r < R; r += 256) acc += img[r];
+        const float lc = block_sum_256(acc, red);
+        const float s = sigma[plane];
+        const float d = (lc - target[plane] - offset[plane]) / s;
+        if (threadIdx.x == 0) atomicAdd(loss, scale * d * d);
+        if (dimages) {
+            const float gr = 2.f * scale * d / s;
+            for (int64_t r = threadIdx.x; r < R; r += 256) dimages[plane * R + r] = gr;
+        }
+    }
+}
+
+extern "C" int bhn_chi2_image(const float *images, const float *target, const float *sigma, const float *offset,
+                              float scale, int32_t dtype, int32_t B, int32_t Sx, int64_t R, float *loss,
+                              float *dimages, void *stream) {
+    BHN_CHECK_ARG(images && target && sigma && offset && loss, "null pointer");
+    BHN_CHECK_ARG(dtype == 0 || dtype == 1, "image dtype (%d) not supported", dtype);
+    BHN_CHECK_ARG(B > 0 && Sx > 0 && R > 0, "bad sizes");
+    BHN_HIP(hipMemsetAsync(loss, 0, sizeof(float), (hipStream_t)stream));
+    hipLaunchKernelGGL(chi2_image_kernel, dim3(B * Sx), dim3(256), 0, (hipStream_t)stream, images, target, sigma,
+                       offset, scale, dtype, R, loss, dimages);
+    BHN_HIP(hipGetLastError());
+    return BHN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Adam with the reference's update form (optax.scale_by_adam + scale(-lr))
+// ------------------------------------------------------------------------------------------
+__global__ void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                            float *__restrict__ v, int64_t n, float lr, float b1, float b2, float eps, float c1,
+                            float c2, float gs) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * gs;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= lr * (mi / c1) / (sqrtf(vi / c2) + eps);
+    }
+}
+
+extern "C" int bhn_adam_step(float *params, const float *grads, float *m, float *v, int64_t n, int64_t t, float lr,
+                             float b1, float b2, float eps, float grad_scale, void *stream) {
+    BHN_CHECK_ARG(params && grads && m && v && n > 0 && t >= 1, "bad adam arguments");
+    const float c1 = (float)(1.0 - pow((double)b1, (double)t));
+    const float c2 = (float)(1.0 - pow((double)b2, (double)t));
+    const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, n, lr, b1,
+                       b2, eps, c1, c2, grad_scale);
+    BHN_HIP(hipGetLastError());
+    return BHN_OK;
+}

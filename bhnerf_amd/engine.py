@@ -1,0 +1,205 @@
+"""Device engine: prepared ray geometry + fused predictor/render calls through the C ABI.
+
+This is the layer the reference-shaped API (network.py / optimization.py of this package) is
+built on.  Everything here runs on the HIP library; nothing falls back to the CPU.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _hip
+from .constants import GM_c3_hr
+
+
+def _flat(t, n):
+    return t.reshape(n).contiguous()
+
+
+class RayGeometry:
+    """Static per-(ray, sample) inputs resident in HBM, laid out as flat [ray][sample] planes.
+
+    Replaces the per-iteration broadcasts of the reference (kgeo.py:618-621 g^2*dtau*Sigma,
+    network.py:416-417 J, emission.py:370-373 domain mask) with a one-off fold
+    (``bhn_geom_prepare``).  coords (3,*sp,G); Omega/t_geos/g/dtau/Sigma (*sp,G) or scalars;
+    J None/scalar 1.0 or (S,*sp,G).
+    """
+
+    def __init__(self, coords, Omega, g, dtau, Sigma, t_geos, J=None, rmin=0.0, rmax=np.inf, z_width=np.inf,
+                 device='cuda'):
+        dev = torch.device(device)
+        coords = _hip.as_f32(coords, dev)
+        self.spatial = tuple(coords.shape[1:-1])
+        self.G = int(coords.shape[-1])
+        self.R = int(np.prod(self.spatial)) if self.spatial else 1
+        self.P = self.R * self.G
+        P = self.P
+        full = tuple(coords.shape[1:])
+
+        def plane(v):
+            v = _hip.as_f32(v, dev)
+            return _flat(v.expand(full) if v.shape != full else v, P)
+
+        self.coords = coords.reshape(3, P).contiguous()
+        self.Omega, self.t_geo = plane(Omega), plane(t_geos)
+        g, dtau, Sigma = plane(g), plane(dtau), plane(Sigma)
+        if J is None or np.isscalar(J) or (hasattr(J, 'ndim') and J.ndim == 0):
+            if J is not None and float(J) != 1.0:
+                g = g * float(np.sqrt(abs(float(J))))        # scalar J folds into w = g^2 ...
+                if float(J) < 0:
+                    raise ValueError('negative scalar J is not supported')
+            self.S, Jt = 0, None
+        else:
+            Jt = _hip.as_f32(J, dev)
+            self.S = int(Jt.shape[0])
+            Jt = Jt.reshape(self.S, P).contiguous()
+        self.Sx = max(self.S, 1)
+        self.w = torch.empty((self.Sx, P), dtype=torch.float32, device=dev)
+        self.dom = torch.empty((P,), dtype=torch.uint8, device=dev)
+        self.rmin, self.rmax, self.z_width = float(rmin), float(rmax), float(z_width)
+        _hip.check(_hip.lib().bhn_geom_prepare(
+            _hip.ptr(self.coords), _hip.ptr(g), _hip.ptr(dtau), _hip.ptr(Sigma), _hip.ptr(Jt), self.S, P,
+            self.rmin, self.rmax, self.z_width, _hip.ptr(self.w), _hip.ptr(self.dom), _hip.stream_ptr(dev)))
+        self.device = dev
+
+    def c_struct(self):
+        c = self.coords
+        return _hip.bhn_geom(self.R, self.G, self.S, c[0].data_ptr(), c[1].data_ptr(), c[2].data_ptr(),
+                             self.Omega.data_ptr(), self.t_geo.data_ptr(), self.w.data_ptr(), self.dom.data_ptr())
+
+    @property
+    def active_fraction(self):
+        return float(self.dom.float().mean().item())
+
+
+def frame_offsets(t_frames, t_start_obs, t_injection, GM_c3, device):
+    """tM0[b] = (t_frames[b]-t_start_obs)/GM_c3 - t_injection in float64 (emission.py:200-201)."""
+    t = np.atleast_1d(np.asarray(t_frames, dtype=np.float64))
+    tM0 = (t - float(t_start_obs)) / float(GM_c3) - float(t_injection)
+    return torch.as_tensor(tM0, dtype=torch.float64, device=device)
+
+
+class FusedPredictor:
+    """NeRF_Predictor hyper-parameters + packed weights bound to the fused HIP kernels."""
+
+    def __init__(self, net_depth=4, net_width=128, posenc_deg=3, do_skip=True, scale=1.0, rmin=0.0,
+                 rmax=np.inf, z_width=np.inf, mode='bf16', device='cuda'):
+        self.mode = _hip.MODES[mode] if isinstance(mode, str) else int(mode)
+        self.model = _hip.make_model(net_depth, net_width, posenc_deg, do_skip, scale, rmin, rmax, z_width)
+        self.device = torch.device(device)
+        lib = _hip.lib()
+        self.nparams = int(lib.bhn_param_count(C.byref(self.model)))
+        if self.nparams < 0:
+            raise _hip.HipError(lib.bhn_last_error().decode())
+        n = net_depth + 1
+        ko, bo, ind = (C.c_int64 * n)(), (C.c_int64 * n)(), (C.c_int32 * n)()
+        _hip.check(lib.bhn_param_layout(C.byref(self.model), ko, bo, ind))
+        self.kernel_off, self.bias_off, self.in_dim = list(ko), list(bo), list(ind)
+        self.out_dim = [net_width] * net_depth + [1]
+        self.packed = torch.empty((int(lib.bhn_packed_bytes(C.byref(self.model), self.mode)),), dtype=torch.uint8,
+                                  device=self.device)
+        self._ws = None
+
+    # -- parameters --------------------------------------------------------------------------
+    def flatten(self, tree):
+        """{'MLP_0': {'Dense_i': {'kernel','bias'}}} -> flat float32 device tensor (flax tree order)."""
+        flat = torch.empty((self.nparams,), dtype=torch.float32, device=self.device)
+        mlp = tree['MLP_0'] if 'MLP_0' in tree else tree
+        for i, (ko, bo, fi, fo) in enumerate(zip(self.kernel_off, self.bias_off, self.in_dim, self.out_dim)):
+            k = _hip.as_f32(mlp['Dense_%d' % i]['kernel'], self.device)
+            if tuple(k.shape) != (fi, fo):
+                raise ValueError('Dense_%d kernel shape %s, expected %s' % (i, tuple(k.shape), (fi, fo)))
+            flat[ko:ko + fi * fo] = k.reshape(-1)
+            flat[bo:bo + fo] = _hip.as_f32(mlp['Dense_%d' % i]['bias'], self.device).reshape(-1)
+        return flat
+
+    def unflatten(self, flat):
+        tree = {}
+        for i, (ko, bo, fi, fo) in enumerate(zip(self.kernel_off, self.bias_off, self.in_dim, self.out_dim)):
+            tree['Dense_%d' % i] = {'kernel': flat[ko:ko + fi * fo].view(fi, fo), 'bias': flat[bo:bo + fo]}
+        return {'MLP_0': tree}
+
+    def pack(self, flat):
+        _hip.require_device(flat)
+        assert flat.dtype == torch.float32 and flat.numel() == self.nparams and flat.is_contiguous()
+        _hip.check(_hip.lib().bhn_pack_weights(C.byref(self.model), self.mode, _hip.ptr(flat), _hip.ptr(self.packed),
+                                               _hip.stream_ptr(self.device)))
+
+    # -- fused calls ---------------------------------------------------------------------------
+    def _frames(self, tM0):
+        assert tM0.dtype == torch.float64 and tM0.is_cuda and tM0.is_contiguous()
+        return _hip.bhn_frames(int(tM0.numel()), tM0.data_ptr())
+
+    def predict(self, geom, tM0):
+        """NeRF_Predictor.__call__ (network.py:191-237) -> emission (B, P) float32."""
+        B = int(tM0.numel())
+        out = torch.empty((B, geom.P), dtype=torch.float32, device=self.device)
+        gs, fs = geom.c_struct(), self._frames(tM0)
+        _hip.check(_hip.lib().bhn_predict_fwd(C.byref(self.model), self.mode, _hip.ptr(self.packed), C.byref(gs),
+                                              C.byref(fs), _hip.ptr(out), _hip.stream_ptr(self.device)))
+        return out
+
+    def render(self, geom, tM0, out=None):
+        """image_plane_prediction (network.py:373-420) -> images (B, Sx, R) float32."""
+        B = int(tM0.numel())
+        if out is None:
+            out = torch.empty((B, geom.Sx, geom.R), dtype=torch.float32, device=self.device)
+        gs, fs = geom.c_struct(), self._frames(tM0)
+        _hip.check(_hip.lib().bhn_render_fwd(C.byref(self.model), self.mode, _hip.ptr(self.packed), C.byref(gs),
+                                             C.byref(fs), _hip.ptr(out), _hip.stream_ptr(self.device)))
+        return out
+
+    def workspace(self):
+        if self._ws is None:
+            n = int(_hip.lib().bhn_render_bwd_workspace_bytes(C.byref(self.model), self.mode,
+                                                              self.device.index or 0))
+            if n == 0:
+                raise _hip.HipError(_hip.lib().bhn_last_error().decode() or 'render_bwd workspace query failed')
+            self._ws = torch.empty((n,), dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def render_bwd(self, geom, tM0, dimages, out=None):
+        """d loss / d params given d loss / d images (B,Sx,R): the reverse of ``render``."""
+        assert dimages.dtype == torch.float32 and dimages.is_contiguous() and dimages.is_cuda
+        if out is None:
+            out = torch.empty((self.nparams,), dtype=torch.float32, device=self.device)
+        ws = self.workspace()
+        gs, fs = geom.c_struct(), self._frames(tM0)
+        _hip.check(_hip.lib().bhn_render_bwd(C.byref(self.model), self.mode, _hip.ptr(self.packed), C.byref(gs),
+                                             C.byref(fs), _hip.ptr(dimages), _hip.ptr(out), _hip.ptr(ws), ws.numel(),
+                                             _hip.stream_ptr(self.device)))
+        return out
+
+
+class RenderFunction(torch.autograd.Function):
+    """images = render(params) with the fused HIP forward/backward (torch.autograd glue only)."""
+
+    @staticmethod
+    def forward(ctx, flat, predictor, geom, tM0):
+        predictor.pack(flat)
+        ctx.predictor, ctx.geom, ctx.tM0 = predictor, geom, tM0
+        return predictor.render(geom, tM0)
+
+    @staticmethod
+    def backward(ctx, dimages):
+        return ctx.predictor.render_bwd(ctx.geom, ctx.tM0, dimages.contiguous()), None, None, None
+
+
+def chi2_image(images, target, sigma, offset, scale, dtype, want_grad=True):
+    """loss_fn_image (network.py:476-484) on device -> (loss[1], dimages or None)."""
+    code = {'full': 0, 'lc': 1}.get(dtype)
+    if code is None:
+        raise AttributeError('image dtype ({}) not supported'.format(dtype))
+    B, Sx, R = images.shape
+    loss = torch.empty((1,), dtype=torch.float32, device=images.device)
+    dimg = torch.empty_like(images) if want_grad else None
+    _hip.check(_hip.lib().bhn_chi2_image(_hip.ptr(images), _hip.ptr(target), _hip.ptr(sigma), _hip.ptr(offset),
+                                         float(scale), code, B, Sx, R, _hip.ptr(loss), _hip.ptr(dimg),
+                                         _hip.stream_ptr(images.device)))
+    return loss, dimg
+
+
+def adam_step(params, grads, m, v, t, lr, b1=0.9, b2=0.999, eps=1e-8, grad_scale=1.0):
+    _hip.check(_hip.lib().bhn_adam_step(_hip.ptr(params), _hip.ptr(grads), _hip.ptr(m), _hip.ptr(v), params.numel(),
+                                        int(t), float(lr), b1, b2, eps, float(grad_scale),
+                                        _hip.stream_ptr(params.device)))

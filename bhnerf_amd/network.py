@@ -1,0 +1,420 @@
+"""bhnerf.network hot-path API on the MI355X engine (reference: bhnerf/network.py).
+
+Same names, argument order and error behaviour as the reference for the functions on the hot
+path: ``posenc``, ``MLP``, ``NeRF_Predictor``, ``image_plane_prediction``, ``loss_fn_image``,
+``gradient_step_image``, ``test_image``, ``sample_3d_grid``, ``raytracing_args``.  Where the
+reference builds a JAX expression that XLA compiles, this module calls the fused HIP kernels through
+``engine`` (C ABI, include/bhnerf_hip.h).  Parameters/outputs are torch device tensors.
+
+Data-parallel semantics (network.py:620): each process (one per GPU) computes the SUM of
+chi^2 over its own frames, gradients are AVERAGED over processes with one RCCL all-reduce of the
+flat gradient buffer, then every rank applies the identical Adam update.
+"""
+import glob
+import os
+from collections import OrderedDict
+from pathlib import Path
+
+import numpy as np
+import torch
+import yaml
+
+from . import _hip, constants, engine, units, utils
+
+safe_sin = lambda x: (torch.sin(torch.remainder(x, 100 * np.pi)) if isinstance(x, torch.Tensor)
+                      else np.sin(x % (100 * np.pi)))                       # network.py:16
+
+
+def posenc(x, deg):
+    """[x, sin(2^i x), sin(2^i x + pi/2)] (network.py:98-122); NumPy or torch, same feature order
+    as the fused kernel's prologue."""
+    if deg == 0:
+        return x
+    xp = utils._xp(x)
+    if xp is torch:
+        scales = torch.tensor([2.0 ** i for i in range(deg)], dtype=x.dtype, device=x.device)
+        xb = (x[..., None, :] * scales[:, None]).reshape(*x.shape[:-1], -1)
+        return torch.cat([x, safe_sin(torch.cat([xb, xb + 0.5 * np.pi], dim=-1))], dim=-1)
+    scales = np.array([2 ** i for i in range(deg)])
+    xb = np.reshape(x[..., None, :] * scales[:, None], list(x.shape[:-1]) + [-1])
+    return np.concatenate([x, safe_sin(np.concatenate([xb, xb + 0.5 * np.pi], axis=-1))], axis=-1)
+
+
+class ParamTree(dict):
+    """{'MLP_0': {'Dense_i': {'kernel','bias'}}} whose leaves are views of one flat f32 buffer."""
+    flat = None
+
+
+class MLP:
+    """Shape descriptor of the reference MLP (network.py:18-64).  The evaluation itself only exists
+    fused inside ``NeRF_Predictor.apply`` (csrc/fused_fwd.hip)."""
+
+    def __init__(self, net_depth=4, net_width=128, activation='relu', out_channel=1, do_skip=True):
+        if out_channel != 1:
+            raise AttributeError('out_channel={} not supported (every reference driver uses 1)'.format(out_channel))
+        self.net_depth, self.net_width, self.activation = net_depth, net_width, activation
+        self.out_channel, self.do_skip = out_channel, do_skip
+
+    def layer_dims(self, in_features):
+        dims, cur = [], in_features
+        skip_layer = self.net_depth // 2 if self.do_skip else None
+        for i in range(self.net_depth):
+            dims.append((cur, self.net_width))
+            cur = self.net_width
+            if self.do_skip and i % skip_layer == 0 and i > 0:        # network.py:59-61
+                cur = self.net_width + in_features
+        dims.append((cur, self.out_channel))
+        return dims
+
+    def init(self, seed, in_features, device='cpu'):
+        """he_uniform kernels, zero biases (network.py:50 / flax Dense defaults).  torch RNG: NOT
+        bit-identical to jax.random.PRNGKey(seed) (parity unpinned for initialisation)."""
+        gen = torch.Generator().manual_seed(int(seed))
+        tree = {}
+        for i, (fi, fo) in enumerate(self.layer_dims(in_features)):
+            lim = float(np.sqrt(6.0 / fi))
+            k = (torch.rand((fi, fo), generator=gen, dtype=torch.float32) * 2.0 - 1.0) * lim
+            tree['Dense_%d' % i] = {'kernel': k.to(device), 'bias': torch.zeros((fo,), dtype=torch.float32, device=device)}
+        return {'MLP_0': tree}
+
+
+def _default_device():
+    if not torch.cuda.is_available():
+        raise _hip.HipError('no HIP device visible: bhnerf_amd has no CPU fallback')
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+class TrainState:
+    """flax TrainState stand-in: step, params, Adam moments, apply_fn (network.py:171-189)."""
+
+    def __init__(self, apply_fn, flat, predictor, num_iters, lr_init, lr_final):
+        self.apply_fn, self.predictor = apply_fn, predictor
+        self.flat = flat
+        self.m = torch.zeros_like(flat)
+        self.v = torch.zeros_like(flat)
+        self.step = 0
+        self.num_iters, self.lr_init, self.lr_final = int(num_iters), float(lr_init), float(lr_final)
+        self.grad = torch.zeros(flat.numel() + _world()[1], dtype=torch.float32, device=flat.device)
+
+    @property
+    def params(self):
+        tree = ParamTree(self.predictor.engine().unflatten(self.flat))
+        tree.flat = self.flat
+        return tree
+
+    def learning_rate(self, count=None):
+        """optax.polynomial_schedule(lr_init, lr_final, power=1, transition_steps=num_iters)."""
+        count = self.step if count is None else count
+        frac = 1.0 - min(count, self.num_iters) / float(self.num_iters)
+        return (self.lr_init - self.lr_final) * frac + self.lr_final
+
+    def apply_gradients(self, grads, grad_scale=1.0):
+        engine.adam_step(self.flat, grads, self.m, self.v, self.step + 1, self.learning_rate(), grad_scale=grad_scale)
+        self.step += 1
+        return self
+
+    def state_dict(self):
+        return {'step': self.step, 'params': self.flat.cpu(), 'm': self.m.cpu(), 'v': self.v.cpu()}
+
+    def load_state_dict(self, sd):
+        self.step = int(sd['step'])
+        self.flat.copy_(sd['params'])
+        self.m.copy_(sd['m'])
+        self.v.copy_(sd['v'])
+
+
+def _world():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+class NeRF_Predictor:
+    """Predict emission at (time-frame, point) samples (network.py:124-252).  Field order matches
+    the reference dataclass so that ``NeRF_Predictor(rmax, rmin, rmax, z_width)`` works unchanged.
+    Extra keyword-only fields: ``mode`` ('bf16' throughput / 'f32' parity) and ``device``."""
+
+    def __init__(self, scale=1.0, rmin=0.0, rmax=np.inf, z_width=np.inf, posenc_deg=3, posenc_var=2e-5,
+                 net_depth=4, net_width=128, activation='relu', out_channel=1, do_skip=True, *, mode='bf16',
+                 device=None):
+        if activation not in ('relu', torch.relu, torch.nn.functional.relu):
+            raise AttributeError('only the relu activation is supported')
+        if out_channel != 1:
+            raise AttributeError('out_channel must be 1')
+        self.scale, self.rmin, self.rmax, self.z_width = scale, rmin, rmax, z_width
+        self.posenc_deg, self.posenc_var = posenc_deg, posenc_var
+        self.net_depth, self.net_width, self.activation = net_depth, net_width, 'relu'
+        self.out_channel, self.do_skip = out_channel, do_skip
+        self.mode, self.device = mode, device
+        self._engine, self._engine_key, self._geoms = None, None, OrderedDict()
+
+    # -- engine / geometry caches ----------------------------------------------------------------
+    def engine(self):
+        key = (self.scale, self.rmin, self.rmax, self.z_width, self.posenc_deg, self.net_depth, self.net_width,
+               self.do_skip, self.mode)
+        if self._engine is None or self._engine_key != key:
+            dev = torch.device(self.device) if self.device is not None else _default_device()
+            self._engine = engine.FusedPredictor(self.net_depth, self.net_width, self.posenc_deg, self.do_skip,
+                                                 self.scale, self.rmin, self.rmax, self.z_width, self.mode, dev)
+            self._engine_key = key
+            self._geoms.clear()
+        return self._engine
+
+    def geometry(self, coords, Omega, t_geos, J=None, g=None, dtau=None, Sigma=None):
+        """Prepared RayGeometry for these arrays, cached on the identity of the inputs."""
+        key = tuple(id(v) for v in (coords, Omega, t_geos, J, g, dtau, Sigma)) + (self.rmin, self.rmax, self.z_width)
+        hit = self._geoms.get(key)
+        if hit is not None:
+            return hit[0]
+        dev = self.engine().device
+        one = 1.0
+        geom = engine.RayGeometry(coords, Omega, one if g is None else g, one if dtau is None else dtau,
+                                  one if Sigma is None else Sigma, t_geos, J, self.rmin, self.rmax, self.z_width, dev)
+        self._geoms[key] = (geom, (coords, Omega, t_geos, J, g, dtau, Sigma))   # keep ids alive
+        while len(self._geoms) > 8:
+            self._geoms.popitem(last=False)
+        return geom
+
+    # -- reference API -----------------------------------------------------------------------------
+    def init_params(self, raytracing_args=None, seed=1):
+        mlp = MLP(self.net_depth, self.net_width, self.activation, self.out_channel, self.do_skip)
+        eng = self.engine()
+        flat = eng.flatten(mlp.init(seed, 3 + 6 * self.posenc_deg, 'cpu'))
+        tree = ParamTree(eng.unflatten(flat))
+        tree.flat = flat
+        return tree
+
+    def flat_params(self, params):
+        flat = getattr(params, 'flat', None)
+        if flat is None:
+            flat = self.engine().flatten(params['params'] if 'params' in params else params)
+        return flat
+
+    def init_state(self, params, num_iters=5000, lr_init=1e-4, lr_final=1e-6, lr_inject=None, checkpoint_dir=''):
+        # lr_inject is inert in the reference too: the t_injection parameter is commented out
+        # (network.py:176-180, 235).
+        flat = self.flat_params(params).clone()
+        state = TrainState(self.apply, flat, self, num_iters, lr_init, lr_final)
+        ckpt = latest_checkpoint(checkpoint_dir)
+        if ckpt is not None:                                                   # network.py:185
+            state.load_state_dict(torch.load(ckpt, map_location='cpu'))
+        return state
+
+    def apply(self, variables, t_frames, t_units, coords, Omega, t_start_obs, t_geos, t_injection):
+        """emission = sigmoid(MLP(posenc(warp(coords)/scale)) - 10), masked (network.py:191-237).
+        Returns a float32 device tensor shaped (*t_frames.shape, *coords.shape[1:])."""
+        eng = self.engine()
+        params = variables['params'] if isinstance(variables, dict) and 'params' in variables else variables
+        eng.pack(self.flat_params(params))
+        geom = self.geometry(coords, Omega, t_geos)
+        tM0, scalar_t = _frame_offsets(t_frames, t_units, t_start_obs, t_injection, eng.device)
+        e = eng.predict(geom, tM0)
+        sp = tuple(np.shape(coords)[1:])
+        return e.reshape(sp) if scalar_t else e.reshape((tM0.numel(),) + sp)
+
+    __call__ = apply
+
+    def save_params(self, directory, filename='NeRF_Predictor_params.yml'):
+        directory = Path(directory)
+        directory.mkdir(parents=True, exist_ok=True)
+        keys = ['scale', 'rmin', 'rmax', 'z_width', 'posenc_deg', 'posenc_var', 'net_depth', 'net_width',
+                'out_channel', 'do_skip']                                       # network.py:242
+        with open(directory.joinpath(filename), 'w') as f:
+            yaml.dump({k: (float(getattr(self, k)) if isinstance(getattr(self, k), (float, np.floating))
+                           else getattr(self, k)) for k in keys}, f)
+
+    @classmethod
+    def from_yml(cls, directory, filename='NeRF_Predictor_params.yml', **kw):
+        params = yaml.safe_load(Path(directory).joinpath(filename).read_text())
+        return cls(**params, **kw)
+
+
+def latest_checkpoint(checkpoint_dir):
+    if not checkpoint_dir:
+        return None
+    found = glob.glob(os.path.join(checkpoint_dir, 'checkpoint_*'))
+    found = [f for f in found if f.rsplit('_', 1)[-1].isdigit()]
+    return max(found, key=lambda f: int(f.rsplit('_', 1)[-1])) if found else None
+
+
+def _frame_offsets(t_frames, t_units, t_start_obs, t_injection, device):
+    """float64 tM0 per frame (emission.py:176-201 unit handling)."""
+    if isinstance(t_frames, torch.Tensor) and t_frames.dtype == torch.float64 and t_frames.is_cuda \
+            and getattr(t_frames, '_bhn_is_tM0', False):
+        return t_frames, False
+    if units.is_quantity(t_start_obs):
+        t_units = t_start_obs.unit
+        t_start_obs = float(t_start_obs.value)
+    GM_c3 = constants.GM_c3(t_units) if t_units is not None else 1.0
+    if units.is_quantity(t_frames):
+        t_frames = t_frames.to(t_units).value
+    if isinstance(t_frames, torch.Tensor):
+        t_frames = t_frames.detach().cpu().numpy()
+    tf = np.asarray(t_frames, dtype=np.float64)
+    if isinstance(t_injection, torch.Tensor):
+        t_injection = float(t_injection)
+    return engine.frame_offsets(tf, t_start_obs, t_injection, GM_c3, device), tf.ndim == 0
+
+
+def _stokes_or_none(J):
+    """None for the unpolarised J=1.0 of raytracing_args (network.py:850), else J itself."""
+    if J is None or (np.ndim(J) == 0 and float(J) == 1.0):
+        return None
+    return J
+
+
+def _bound_predictor(fn):
+    owner = getattr(fn, '__self__', None)
+    return owner if isinstance(owner, NeRF_Predictor) else None
+
+
+def _image_shape(images, B, S, sp, scalar_t):
+    """(B,Sx,R) -> the reference's output shape, incl. the jnp.squeeze quirk (network.py:418)."""
+    if S == 0:
+        out = images.reshape((B,) + sp)
+        return out.reshape(sp) if scalar_t else out
+    out = images.reshape((B, S) + sp)
+    return torch.squeeze(out) if not scalar_t else torch.squeeze(out.reshape((S,) + sp))
+
+
+def image_plane_prediction(params, predictor_fn, t_frames, coords, Omega, J, g, dtau, Sigma, t_start_obs, t_geos,
+                           t_injection, t_units):
+    """Predict image pixels from emission (network.py:373-420).  With a ``NeRF_Predictor.apply``
+    as ``predictor_fn`` the whole chain runs in one fused kernel and is differentiable w.r.t.
+    ``params`` (the fused backward); any other callable is evaluated then integrated with the
+    stand-alone radiative-transfer kernel."""
+    pred = _bound_predictor(predictor_fn)
+    if pred is None:
+        from . import kgeo
+        emission = predictor_fn({'params': params}, t_frames, t_units, coords, Omega, t_start_obs, t_geos, t_injection)
+        if not np.isscalar(J):
+            Jt = _hip.as_f32(J, emission.device)
+            emission = utils.expand_dims(Jt, emission.ndim + 1, 0) * utils.expand_dims(emission, emission.ndim + 1, 1)
+            emission = torch.squeeze(emission)
+        return kgeo.radiative_trasfer(emission, g, dtau, Sigma)
+    eng = pred.engine()
+    geom = pred.geometry(coords, Omega, t_geos, _stokes_or_none(J), g, dtau, Sigma)
+    tM0, scalar_t = _frame_offsets(t_frames, t_units, t_start_obs, t_injection, eng.device)
+    flat = pred.flat_params(params)
+    images = engine.RenderFunction.apply(flat, eng, geom, tM0)
+    return _image_shape(images, int(tM0.numel()), geom.S, geom.spatial, scalar_t)
+
+
+def loss_fn_image(params, predictor_fn, target, sigma, offset, t_frames, coords, Omega, J, g, dtau, Sigma,
+                  t_start_obs, t_geos, t_injection, scale, t_units, dtype):
+    """L2 loss on image pixels ('full') or light curves ('lc') (network.py:422-484)."""
+    images = image_plane_prediction(params, predictor_fn, t_frames, coords, Omega, J, g, dtau, Sigma, t_start_obs,
+                                    t_geos, t_injection, t_units)
+    dev = images.device
+    target, sigma, offset = (_hip.as_f32(v, dev) for v in (target, sigma, offset))
+    if dtype == 'full':
+        loss = torch.sum(torch.abs((images - target - offset) / sigma) ** 2)
+    elif dtype == 'lc':
+        lightcurve = images.sum(dim=(-1, -2))
+        loss = torch.sum(torch.abs((lightcurve - target - offset) / sigma) ** 2)
+    else:
+        raise AttributeError('image dtype ({}) not supported'.format(dtype))
+    return scale * loss, [images]
+
+
+def _step_image(state, t_units, dtype, target, sigma, offset, t_frames, coords, Omega, J, g, dtau, Sigma,
+                t_start_obs, t_geos, t_injection, scale, train):
+    """Per-process body of gradient_step_image / test_image with no torch.autograd in the loop:
+    pack -> fused render -> chi^2 kernel -> fused backward -> all-reduce -> Adam."""
+    if dtype not in ('full', 'lc'):
+        raise AttributeError('image dtype ({}) not supported'.format(dtype))
+    pred = state.predictor
+    eng = pred.engine()
+    dev = eng.device
+    geom = pred.geometry(coords, Omega, t_geos, _stokes_or_none(J), g, dtau, Sigma)
+    tM0, _ = _frame_offsets(t_frames, t_units, t_start_obs, t_injection, dev)
+    B = int(tM0.numel())
+    eng.pack(state.flat)
+    images = eng.render(geom, tM0)
+    tshape = (B, geom.Sx, geom.R) if dtype == 'full' else (B, geom.Sx)
+    tgt, sig, off = (_hip.as_f32(v, dev).reshape(tshape) for v in (target, sigma, offset))
+    loss, dimg = engine.chi2_image(images, tgt, sig, off, scale, dtype, want_grad=train)
+    rank, world = _world()
+    if train:
+        n = eng.nparams
+        buf = state.grad
+        eng.render_bwd(geom, tM0, dimg, out=buf[:n])
+        if world > 1:                                    # jax.lax.pmean(grads) (network.py:620)
+            import torch.distributed as dist
+            buf[n:].zero_()
+            buf[n + rank] = loss[0]
+            dist.all_reduce(buf)                         # one RCCL all-reduce: grads + per-rank losses
+            loss_vec = buf[n:].clone()
+        else:
+            loss_vec = loss
+        state.apply_gradients(buf[:n], grad_scale=1.0 / world)
+    else:
+        if world > 1:
+            import torch.distributed as dist
+            parts = [torch.empty_like(loss) for _ in range(world)]
+            dist.all_gather(parts, loss)
+            loss_vec = torch.cat(parts)
+        else:
+            loss_vec = loss
+    # leading axis = this process's "device" slot of the reference's pmap output
+    out = images.reshape((1, B) + ((geom.S,) if geom.S else ()) + geom.spatial)
+    return loss_vec, state, out
+
+
+def gradient_step_image(state, t_units, dtype, target, sigma, offset, t_frames, coords, Omega, J, g, dtau, Sigma,
+                        t_start_obs, t_geos, t_injection, scale):
+    """value_and_grad + pmean + apply_gradients (network.py:566-622).  Returns (loss[ndev], state,
+    images[1, b_local, [S], H, W]); loss holds every rank's per-device chi^2 sum."""
+    return _step_image(state, t_units, dtype, target, sigma, offset, t_frames, coords, Omega, J, g, dtau, Sigma,
+                       t_start_obs, t_geos, t_injection, scale, True)
+
+
+def test_image(state, t_units, dtype, target, sigma, offset, t_frames, coords, Omega, J, g, dtau, Sigma,
+               t_start_obs, t_geos, t_injection, scale):
+    """Forward-only twin of gradient_step_image (network.py:684-739)."""
+    return _step_image(state, t_units, dtype, target, sigma, offset, t_frames, coords, Omega, J, g, dtau, Sigma,
+                       t_start_obs, t_geos, t_injection, scale, False)
+
+
+test_image.__test__ = False   # not a pytest test
+
+
+def sample_3d_grid(apply_fn, params, t_frame=0, t_start_obs=0, Omega=0, fov=None, coords=None, resolution=64, chunk=-1):
+    """Sample the network on a 3-D grid (network.py:797-840)."""
+    if (coords is None) and (fov is not None):
+        grid_1d = np.linspace(-fov / 2, fov / 2, resolution)
+        coords = np.array(np.meshgrid(grid_1d, grid_1d, grid_1d, indexing='ij'))
+    elif coords is None:
+        raise AttributeError('Either coords or fov+resolution must be provided')
+    t_units = t_frame.unit if units.is_quantity(t_frame) else None
+    resolution = coords.shape[-1]
+    chunk = resolution if chunk < 0 else chunk
+    emission = []
+    for c in range(resolution // chunk):
+        coords_chunk = np.ascontiguousarray(coords[:, c * chunk:(c + 1) * chunk, :, :])
+        Omega_chunk = Omega if np.isscalar(Omega) else Omega[c * chunk:(c + 1) * chunk, :, :]
+        emission.append(apply_fn({'params': params}, t_frame, t_units, coords_chunk, Omega_chunk, t_start_obs, 0.0, 0.0))
+    return torch.cat(emission, dim=0).cpu().numpy()
+
+
+def raytracing_args(geos, Omega, t_injection, t_start_obs, J=1.0):
+    """Ordered dict of the non-optimised ray-tracing arguments (network.py:850-894).  ``geos`` is
+    any mapping/object with x, y, z, dtau, Sigma, t and the Doppler factor ``g``; computing g from
+    the 4-velocity (kgeo.py:199-248) is outside the hot path."""
+    get = (lambda k: geos[k]) if isinstance(geos, dict) else (lambda k: getattr(geos, k))
+    try:
+        gfac = get('g')
+    except (KeyError, AttributeError):
+        raise AttributeError('geos must carry the Doppler factor "g" (kgeo.doppler_factor is not part of this build)')
+    f32 = lambda v: np.ascontiguousarray(np.asarray(v, dtype=np.float32))
+    return OrderedDict({
+        'coords': f32(np.array([get('x'), get('y'), get('z')])),
+        'Omega': f32(Omega),
+        'J': J if np.isscalar(J) else f32(J),
+        'g': f32(gfac),
+        'dtau': f32(get('dtau')),
+        'Sigma': f32(get('Sigma')),
+        't_start_obs': t_start_obs,
+        't_geos': f32(get('t')),
+        't_injection': t_injection})

@@ -1,0 +1,238 @@
+"""bhnerf.optimization on one-process-per-GPU (reference: bhnerf/optimization.py).
+
+The reference drives ``jax.pmap`` from a single process: a batch of frame indices is reshaped to
+(ndev, b/ndev, ...) (optimization.py:289-291, 360-362) and gradients are ``pmean``-ed
+(network.py:620).  Here every GPU has its own process (``torch.distributed``, backend "nccl" = RCCL
+over xGMI): rank r takes the r-th contiguous slice of the same batch, the flat gradient buffer is
+all-reduced once per step and divided by the world size, and every rank applies the identical Adam
+step -- the same mean-of-per-device-sums arithmetic.  All ranks must draw the same batch indices:
+``TemporalBatchedArgs.sample`` uses a generator seeded identically on every rank.
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import network, units
+
+try:  # progress bar is optional
+    from tqdm.auto import tqdm
+except Exception:  # pragma: no cover
+    tqdm = lambda x, **kw: x
+
+
+def device_count():
+    """Number of data-parallel workers (the reference's jax.device_count())."""
+    return network._world()[1]
+
+
+def shard(xs):
+    """This rank's contiguous slice of the leading (batch) axis (optimization.py:360-362)."""
+    rank, world = network._world()
+    def one(x):
+        if x.shape[0] % world:
+            raise ValueError('batch size {} is not divisible by the number of devices {}'.format(x.shape[0], world))
+        n = x.shape[0] // world
+        return x[rank * n:(rank + 1) * n]
+    if isinstance(xs, (list, tuple)):
+        return [one(x) for x in xs]
+    return one(xs)
+
+
+def total_movie_loss(batchsize, state, train_step, raytracing_args, return_frames=False):
+    """Chunk the movie into frame batches and sum the loss over all frames (optimization.py:14-66)."""
+    nt = train_step.args[0].num_frames
+    ndev = device_count()
+    if nt % ndev:
+        raise AttributeError('batch size should be an integer multiplication of the device number')
+    nt_tilde = nt - nt % batchsize
+    indices = np.array_split(np.arange(0, nt_tilde), nt_tilde / batchsize) if nt_tilde else []
+    nt_tilde1 = int(ndev * np.ceil(nt / ndev))
+    indices.append(np.arange(nt_tilde, nt_tilde1) % nt)
+
+    frames, total_loss = [], 0.0
+    for inds in indices:
+        if inds.size == 0:
+            break
+        loss, state, images = train_step(state, raytracing_args, inds, update_state=False)
+        total_loss += float(loss.sum())
+        if return_frames:
+            if ndev > 1:
+                import torch.distributed as dist
+                parts = [torch.empty_like(images) for _ in range(ndev)]
+                dist.all_gather(parts, images.contiguous())
+                images = torch.cat(parts, dim=0)
+            nlast = 2 if np.isscalar(np.atleast_1d(raytracing_args)[0]['J']) else 3
+            frames.append(images.reshape((-1,) + tuple(images.shape[-nlast:])).cpu().numpy())
+    output = total_loss / nt
+    if return_frames:
+        output = (output, np.concatenate(frames)[:nt])
+    return output
+
+
+class Optimizer(object):
+    """Gradient-descent loop over the network parameters (optimization.py:68-143).
+
+    hparams: 'num_iters', 'lr_init' (1e-4), 'lr_final' (1e-6), 'lr_inject' (None), 'seed' (1)."""
+
+    def __init__(self, hparams, predictor, raytracing_args, save_period=-1, checkpoint_dir='', keep=5):
+        self.step = 0
+        self.init_step = 0
+        self.num_iters = hparams['num_iters']
+        self.checkpoint_dir = checkpoint_dir
+        self.save_period = self.num_iters if save_period < 0 else save_period
+        self.loss = np.inf
+        self.keep = keep
+        self.seed = hparams.get('seed', 1)
+        params = predictor.init_params(raytracing_args, seed=self.seed)
+        self.state = predictor.init_state(params=params, num_iters=self.num_iters,
+                                          lr_init=hparams.get('lr_init', 1e-4), lr_final=hparams.get('lr_final', 1e-6),
+                                          lr_inject=hparams.get('lr_inject', None), checkpoint_dir=self.checkpoint_dir)
+        if checkpoint_dir != '' and network._world()[0] == 0:
+            predictor.save_params(checkpoint_dir)
+        self.log_fns = []
+
+    def log(self):
+        for log_fn in self.log_fns:
+            log_fn(self)
+
+    def save_checkpoint(self):
+        if (self.checkpoint_dir != '') and ((self.step % self.save_period == 0) or (self.step == self.final_step)):
+            if network._world()[0] == 0:
+                os.makedirs(self.checkpoint_dir, exist_ok=True)
+                torch.save(self.state.state_dict(), os.path.join(self.checkpoint_dir, 'checkpoint_%d' % int(self.step)))
+                old = sorted((f for f in os.listdir(self.checkpoint_dir) if f.startswith('checkpoint_')
+                              and f.rsplit('_', 1)[-1].isdigit()), key=lambda f: int(f.rsplit('_', 1)[-1]))
+                for f in old[:-self.keep]:
+                    os.remove(os.path.join(self.checkpoint_dir, f))
+
+    def run(self, batchsize, train_step, raytracing_args, log_fns=[]):
+        self.init_step = int(self.state.step) + 1
+        self.final_step = self.init_step + self.num_iters
+        self.log_fns = list(np.atleast_1d(log_fns))
+        self.train_step = train_step
+        self.raytracing_args = raytracing_args
+        try:
+            for self.step in tqdm(range(self.init_step, self.final_step), desc='iteration',
+                                  disable=network._world()[0] != 0):
+                batch_indices = train_step.args[0].sample(batchsize)
+                self.loss, self.state, images = train_step(self.state, raytracing_args, indices=batch_indices)
+                self.log()
+                self.save_checkpoint()
+        except KeyboardInterrupt:
+            return
+
+    @property
+    def params(self):
+        return self.state.params
+
+
+class TrainStep(object):
+    """Container of per-loss step functions (optimization.py:145-272)."""
+
+    def __init__(self, dtype, args, grad_pmap, test_pmap, scale):
+        self.dtype = np.atleast_1d(dtype)
+        self.args = np.atleast_1d(args)
+        self.grad_pmap = np.atleast_1d(grad_pmap)
+        self.test_pmap = np.atleast_1d(test_pmap)
+        self.scale = np.atleast_1d(scale)
+        if np.any([units.unit_name(arg.t_units) not in ('hr', 'h') for arg in self.args]):
+            raise AttributeError('only hr units supported')
+        assert self.dtype.size == self.args.size == self.test_pmap.size == \
+            self.grad_pmap.size == self.scale.size, 'input list sizes are not equal'
+        self.num_losses = self.dtype.size
+
+    def __call__(self, state, raytracing_args, indices, update_state=True):
+        total_loss = 0.0
+        total_images = 0.0
+        raytracing_args = np.atleast_1d(raytracing_args)
+        if update_state:
+            call_fn = self.grad_pmap
+            raytracing_args = [raytracing_args[np.random.choice(len(raytracing_args))]]
+        else:
+            call_fn = self.test_pmap
+        for rt_arg in raytracing_args:                       # sub-pixel ray sets (optimization.py:174)
+            for i in range(self.num_losses):
+                loss, state, images = call_fn[i](state, self.t_units, self.dtype[i], *self.args[i][indices],
+                                                 *rt_arg.values(), float(self.scale[i]))
+                total_loss = total_loss + loss / len(raytracing_args)
+                total_images = total_images + images / len(raytracing_args)
+        return total_loss, state, total_images
+
+    def __add__(self, other):
+        return TrainStep(np.append(self.dtype, other.dtype), np.append(self.args, other.args),
+                         np.append(self.grad_pmap, other.grad_pmap), np.append(self.test_pmap, other.test_pmap),
+                         np.append(self.scale, other.scale))
+
+    @classmethod
+    def image(cls, t_frames, target, sigma=1.0, offset=0.0, scale=1.0, dtype='full'):
+        """Training step for image-plane measurements: 'full' pixels or 'lc' light curves."""
+        target = np.asarray(target)
+        sigma = sigma * np.ones_like(target)
+        offset = offset * np.ones_like(target)
+        args = TemporalBatchedArgs(t_frames, [target, sigma, offset])
+        return cls(dtype, args, network.gradient_step_image, network.test_image, scale)
+
+    @classmethod
+    def eht(cls, *a, **kw):
+        raise NotImplementedError('visibility-domain training (loss_fn_eht) is the next hot-path row (SURVEY 8f1)')
+
+    @property
+    def t_units(self):
+        return self.args[0].t_units
+
+
+class TemporalBatchedArgs(object):
+    """Per-frame arrays + frame times, batched by frame index (optimization.py:274-302).  The
+    arrays stay resident on the device; a batch is a device gather of this rank's index slice."""
+
+    def __init__(self, t_frames, args=[]):
+        self.t_frames = t_frames
+        if not isinstance(args, list):
+            args = [args]
+        self.num_frames = len(t_frames)
+        assert all([self.num_frames == arg.shape[0] for arg in args])
+        self.host_args = [np.asarray(a, dtype=np.float32) for a in args]
+        self.t_values = np.asarray(units.strip(t_frames), dtype=np.float64)
+        self.args = self.host_args + [self.t_values]
+        self.default_t_units = units.hr
+        self._dev = None
+        self._rng = np.random.default_rng(int(os.environ.get('BHNERF_BATCH_SEED', '0')))
+
+    def sample(self, batchsize, replace=False):
+        """Random frame batch; identical on every rank (same seed, same call sequence)."""
+        return self._rng.choice(self.num_frames, batchsize, replace=replace)
+
+    def __getitem__(self, key):
+        key = shard(np.atleast_1d(np.asarray(key)))
+        if torch.cuda.is_available():
+            if self._dev is None:
+                dev = torch.device('cuda', torch.cuda.current_device())
+                self._dev = [torch.as_tensor(a, device=dev) for a in self.host_args]
+            idx = torch.as_tensor(key, device=self._dev[0].device if self._dev else 'cuda')
+            out = [a.index_select(0, idx) for a in self._dev]
+        else:
+            out = [a[key, ...] for a in self.host_args]
+        out.append(self.t_values[key])
+        return out
+
+    @property
+    def t_units(self):
+        return self.t_frames.unit if units.is_quantity(self.t_frames) else self.default_t_units
+
+    @property
+    def t_start_obs(self):
+        return self.t_frames[0]
+
+
+class LogFn(object):
+    """Call ``log_fn(optimizer)`` every ``log_period`` iterations (optimization.py:349-357)."""
+
+    def __init__(self, log_fn, log_period=1):
+        self.log_period = log_period
+        self.log_fn = log_fn
+
+    def __call__(self, optimizer):
+        if self.log_period > 0:
+            if (optimizer.step == 1) or ((optimizer.step % self.log_period) == 0):
+                self.log_fn(optimizer)

@@ -1,0 +1,136 @@
+/*
+ * bhnerf_hip.h -- C ABI of libbhnerf_hip.so: the MI355X (gfx950) implementation of the one
+ * hot path of aviadlevis/bhnerf (velocity warp -> positional encoding -> skip-MLP ->
+ * sigmoid/masks -> radiative-transfer ray sum -> chi^2 -> Adam).
+ *
+ * The reference has no FFI layer: its seams are Python callables.  Each entry
+ * point below names the reference function(s) (file:line under the reference tree) whose
+ * arithmetic it replaces; the bhnerf_amd Python modules bind them with ctypes behind the reference's own
+ * Python signatures (INTEGRATION.md shows the stub a bhnerf maintainer would add).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a BHN_E* code otherwise; bhn_last_error() gives a
+ *     thread-local message.  Nothing aborts, nothing prints.
+ *   - the CALLER owns and allocates every buffer (device memory unless marked host); workspace
+ *     sizes are queried with bhn_*_bytes().  No hidden allocation, no hidden synchronisation,
+ *     no global mutable state except the error string and a per-device property cache.
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it and the call returns
+ *     immediately (graph-capturable: no malloc/free/sync inside).
+ *   - arrays are C-contiguous float32 unless stated.  P = R*G points per frame, flat index
+ *     p = ray*G + sample (the reference's (H,W,G) layout flattened).  S = number of Stokes
+ *     planes, 0 meaning "J is the scalar 1" (unpolarised); Sx = max(S,1).
+ *   - `mode` selects the arithmetic of the MLP GEMMs: BHN_F32 = f32 MFMA (exact fmaf chains,
+ *     parity mode), BHN_BF16 = bf16 operands, f32 accumulate (throughput mode).
+ */
+#ifndef BHNERF_HIP_H
+#define BHNERF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BHN_ABI_VERSION 1
+
+enum { BHN_OK = 0, BHN_EINVAL = 1, BHN_EUNSUPPORTED = 2, BHN_EHIP = 3, BHN_EWORKSPACE = 4 };
+enum { BHN_F32 = 0, BHN_BF16 = 1 };
+
+/* NeRF_Predictor hyper-parameters: network.py:147-157 (scale,rmin,rmax,z_width,posenc_deg,
+ * net_depth,net_width,do_skip; activation=relu and out_channel=1 are fixed as in every driver). */
+typedef struct {
+    int32_t net_depth;    /* hidden Dense+ReLU layers, 2..8 (network.py:153) */
+    int32_t net_width;    /* 32..256, multiple of 32 (network.py:154)        */
+    int32_t posenc_deg;   /* 0..4, 3+6*deg <= 32 features (network.py:151)   */
+    int32_t do_skip;      /* skip-concat after layer depth/2 (network.py:59-61) */
+    float scale, rmin, rmax, z_width;
+} bhn_model;
+
+/* Geodesic-side inputs, prepared once per ray set by bhn_geom_prepare (arrays of P floats). */
+typedef struct {
+    int64_t R, G;         /* rays (H*W) and samples per ray (ngeo)            */
+    int32_t S;            /* Stokes planes (0 = unpolarised)                  */
+    const float *x, *y, *z;   /* coords (3,H,W,G) planes, network.py:874      */
+    const float *Omega;   /* angular velocity per point (emission.py:204)     */
+    const float *t_geo;   /* slow-light time per point (emission.py:200)      */
+    const float *w;       /* (Sx,P) folded g^2*dtau*Sigma*J_s (kgeo.py:621, network.py:417) */
+    const uint8_t *dom;   /* (P) 1 inside rmin<=r<=rmax,|z|<=z_width (emission.py:370-373)   */
+} bhn_geom;
+
+/* Frames of one step.  tM0[b] = (t_frames[b]-t_start_obs)/GM_c3 - t_injection, float64, device
+ * (emission.py:200-201 evaluated per frame on the host in double). */
+typedef struct {
+    int32_t B;
+    const double *tM0;
+} bhn_frames;
+
+int bhn_version(void);
+const char *bhn_last_error(void);
+
+/* Number of float32 parameters / offset table of the flat parameter buffer.  Layout = flax
+ * param tree order: Dense_0.kernel (in,out) row-major, Dense_0.bias, Dense_1.kernel, ...
+ * (network.py:56-62). */
+int64_t bhn_param_count(const bhn_model *m);
+/* kernel_off/bias_off: host arrays of net_depth+1 entries; in_dim likewise (may be NULL). */
+int bhn_param_layout(const bhn_model *m, int64_t *kernel_off, int64_t *bias_off, int32_t *in_dim);
+
+/* One-off fold of the static per-point factors.  Replaces the per-iteration broadcasts of
+ * kgeo.py:618-621 (g^2*dtau*Sigma), network.py:416-417 (J) and emission.py:370-373 (domain
+ * mask, evaluated on the UN-warped coords).  J may be NULL (S=0).  coords is (3,P). */
+int bhn_geom_prepare(const float *coords, const float *g, const float *dtau, const float *Sigma,
+                     const float *J, int32_t S, int64_t P, float rmin, float rmax, float z_width,
+                     float *w_out, uint8_t *dom_out, void *stream);
+
+/* kgeo.radiative_trasfer (kgeo.py:595-622) stand-alone: img[n,r] = sum_k g^2 e[n,r,k] dtau Sigma.
+ * e is (N,R,G) with N = product of leading axes; g,dtau,Sigma are (R,G).  bwd: de = dimg * w. */
+int bhn_radiative_transfer_fwd(const float *e, const float *g, const float *dtau, const float *Sigma,
+                               float *img, int64_t N, int64_t R, int64_t G, void *stream);
+int bhn_radiative_transfer_bwd(const float *dimg, const float *g, const float *dtau, const float *Sigma,
+                               float *de, int64_t N, int64_t R, int64_t G, void *stream);
+
+/* Re-layout of the flat f32 parameters into MFMA-fragment order (forward and transposed images,
+ * biases).  Must be re-run after every parameter update; `packed` is bhn_packed_bytes() big. */
+size_t bhn_packed_bytes(const bhn_model *m, int32_t mode);
+int bhn_pack_weights(const bhn_model *m, int32_t mode, const float *params, void *packed, void *stream);
+
+/* NeRF_Predictor.__call__ (network.py:191-237) fused: warp (emission.py:143-211) -> posenc
+ * (network.py:98-122) -> MLP (network.py:18-64) -> sigmoid(out-10) -> domain fill -> injection
+ * mask.  emission is (B,P).  geom->w may be NULL here. */
+int bhn_predict_fwd(const bhn_model *m, int32_t mode, const void *packed, const bhn_geom *geom,
+                    const bhn_frames *fr, float *emission, void *stream);
+
+/* image_plane_prediction (network.py:373-420) fused with the predictor: images (B,Sx,R), no
+ * emission is materialised.  The kernel zero-fills `images` itself. */
+int bhn_render_fwd(const bhn_model *m, int32_t mode, const void *packed, const bhn_geom *geom,
+                   const bhn_frames *fr, float *images, void *stream);
+
+/* Reverse of bhn_render_fwd w.r.t. the parameters (jax.value_and_grad in network.py:617):
+ * dimages (B,Sx,R) -> dparams (flat f32, overwritten).  Recomputes the forward per tile; weight
+ * gradients are accumulated in per-workgroup slabs inside `workspace` and reduced at the end
+ * (deterministic, no float atomics). */
+size_t bhn_render_bwd_workspace_bytes(const bhn_model *m, int32_t mode, int32_t device);
+int bhn_render_bwd(const bhn_model *m, int32_t mode, const void *packed, const bhn_geom *geom,
+                   const bhn_frames *fr, const float *dimages, float *dparams, void *workspace,
+                   size_t workspace_bytes, void *stream);
+
+/* loss_fn_image (network.py:476-484): dtype 0 = 'full', 1 = 'lc'.  target/sigma/offset are
+ * (B,Sx,R) for 'full', (B,Sx) for 'lc'.  Writes loss[0] = scale*chi^2 and dimages = dloss/dimages
+ * (pass NULL to skip the gradient). */
+int bhn_chi2_image(const float *images, const float *target, const float *sigma, const float *offset,
+                   float scale, int32_t dtype, int32_t B, int32_t Sx, int64_t R, float *loss,
+                   float *dimages, void *stream);
+
+/* optax.adam + polynomial_schedule(power=1) as used by init_state (network.py:173-174, 621):
+ * g' = g*grad_scale (the 1/ndev of pmean, network.py:620); t = 1-based update count. */
+int bhn_adam_step(float *params, const float *grads, float *m, float *v, int64_t n, int64_t t, float lr,
+                  float b1, float b2, float eps, float grad_scale, void *stream);
+
+/* Device self-checks of the MFMA / LDS-transpose lane maps the kernels rely on (exact integer
+ * data).  results: 8 int32 mismatch counts on the host, all 0 when the maps hold. */
+int bhn_selftest(int32_t *results_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BHNERF_HIP_H */
