@@ -130,7 +130,7 @@ def test_chi2_and_adam(dev):
     assert abs(loss.item() - ref) < 1e-5 * ref
     assert relerr(dimg.cpu().numpy(), 2 * 0.7 * (img - tgt - off) / sig ** 2) < 1e-5
     loss, dimg = engine.chi2_image(t(img), t(tgt[..., 0]), t(sig[..., 0]), t(off[..., 0]), 0.7, 'lc')
-    ref = onp.loss_image(img.astype(np.float64), tgt[..., 0], sig[..., 0], off[..., 0], 0.7, 'lc')
+    ref = onp.loss_image(img.astype(np.float64)[..., None], tgt[..., 0], sig[..., 0], off[..., 0], 0.7, 'lc')
     assert abs(loss.item() - ref) < 1e-4 * ref
     d = (img.astype(np.float64).sum(-1) - tgt[..., 0] - off[..., 0]) / sig[..., 0] ** 2
     assert relerr(dimg.cpu().numpy(), np.broadcast_to((2 * 0.7 * d)[..., None], img.shape)) < 1e-4
