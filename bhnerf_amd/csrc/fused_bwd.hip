@@ -1,8 +1,649 @@
+// Reverse of the fused render w.r.t. the MLP parameters (jax.value_and_grad of loss_fn_image,
+// network.py:617).  Three kernels (DESIGN.md "backward"):
+//
+//   chain_kernel  per 32-point wave tile: recompute the forward, dE = sum_s dimg*w, dout = dE*e*(1-e),
+//                 delta chain gA_{l-1} = (W_l gA_l) * relu'(a_{l-1}) with the same register-chained MFMA
+//                 structure as the forward.  Every 32x32 tile of h_l (layer inputs) and gA_l (gradients
+//                 w.r.t. pre-activations) is transposed through a wave-private LDS scratch
+//                 (ds_read_b64_tr_b16) and streamed to an HBM "tape" already in MFMA fragment order
+//                 [lane = feature][8 points].
+//   dw_kernel     weight-gradient GEMMs dW_l^T[out x in] = sum_points gA_l^T . in_l with K = points:
+//                 a workgroup owns ONE layer's whole dW^T in registers (<= 288 KB) and streams its
+//                 share of the tape through LDS; bias gradients come from a constant ones B-fragment.
+//                 One slab flush per workgroup at the end: no float atomics, deterministic.
+//   reduce_kernel sums the slabs of each layer's workgroups into the flat dparams (flax tree order).
 #include "fused_common.h"
-extern "C" size_t bhn_render_bwd_workspace_bytes(const bhn_model *m, int32_t mode, int32_t device) { return 0; }
+
+struct TapeLayout {
+    long long NQ;                              // 32-point groups on the tape
+    long long h_off[BHN_MAX_LAYERS + 1];       // h_l, l = 1..depth  (inputs of layer l)
+    long long ga_off[BHN_MAX_LAYERS];          // gA_l, l = 0..depth-1
+    long long enc_off, dout_off, total;
+};
+
+struct BwdArgs {
+    FusedArgs f;
+    char *tape;
+    TapeLayout t;
+    // dW jobs: job j = layer j (0..depth), workgroups [wg_begin[j], wg_begin[j+1])
+    int wg_begin[BHN_MAX_LAYERS + 2];
+    int accumulate;                            // 1: add to what the slabs already hold
+    float *dparams;
+    long long kernel_off[BHN_MAX_LAYERS + 1], bias_off[BHN_MAX_LAYERS + 1];
+    int in_dim[BHN_MAX_LAYERS + 1];
+    int F;
+    long long nparams;
+};
+
+template <int W, class Pol>
+struct BwdGeom {
+    static constexpr int MT = W / 32;
+    static constexpr int TILE_BYTES = 2 * Pol::FRAG_BYTES;          // 32 features x 32 points
+    static constexpr int NTMAX = MT + 2;                            // h tiles + enc tile + ones tile
+    static constexpr int SLAB_FLOATS = MT * NTMAX * 1024;
+    // wave grid of the dW kernel
+    static constexpr int WR = (MT >= 4) ? 4 : MT;
+    static constexpr int WC = Pol::NWAVES / WR >= 1 ? Pol::NWAVES / WR : 1;
+    static constexpr int WRR = (Pol::NWAVES < WR) ? Pol::NWAVES : WR;   // f32 policy has 4 waves
+    static constexpr int WCC = Pol::NWAVES / WRR;
+    static constexpr int MPW = (MT + WRR - 1) / WRR;
+    static constexpr int NPW_ALL = (NTMAX + WCC - 1) / WCC;          // B tiles owned per wave
+    static constexpr int NPASS = (NPW_ALL + 4) / 5;                    // <= 5 B tiles accumulated per sweep
+    static constexpr int NPW = (NPW_ALL + NPASS - 1) / NPASS;
+    // wave-private transpose scratch of the chain kernel: [32 points][32 features] + row padding
+    static constexpr int ROW_BYTES = 32 * Pol::ELEM_BYTES + 16;
+    static constexpr int SCR_BYTES = 32 * ROW_BYTES;
+    static constexpr int GROUP_BYTES = (2 * MT + 1) * TILE_BYTES;   // A tiles + h tiles + enc tile
+};
+
+// ---------------------------------------------------------------------------------------------
+// tile emission: 32x32 (feature x point) register tile -> fragment-ordered tape tile
+// ---------------------------------------------------------------------------------------------
+template <class Pol, int ROW_BYTES>
+DEVI void emit_frags(char *scr, char *dst, const typename Pol::frag &f0, const typename Pol::frag &f1) {
+    // f0/f1 = k-steps 0/1 of a 32-feature block in B-operand order: element j of f_s is feature
+    // 16s + 8(j>>2) + 4h + (j&3) of point (lane&31): elements 4c..4c+3 are 4 consecutive features.
+    const int lane = threadIdx.x & 63, pt = lane & 31, h = lane >> 5;
+    if constexpr (Pol::ELEM_BYTES == 2) {
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        const s16x8 a0 = __builtin_bit_cast(s16x8, f0), a1 = __builtin_bit_cast(s16x8, f1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                s16x4 pk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pk[e] = s ? a1[4 * c + e] : a0[4 * c + e];
+                *reinterpret_cast<s16x4 *>(scr + pt * ROW_BYTES + (16 * s + 8 * c + 4 * h) * 2) = pk;
+            }
+        const int gi = lane >> 4, t16 = lane & 15, q4 = t16 >> 2, pp = t16 & 3;
+        const int n0 = 16 * (gi & 1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const char *ad = scr + (16 * s + 8 * (gi >> 1) + q4) * ROW_BYTES + (n0 + 4 * pp) * 2;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)ad);
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(ad + 4 * ROW_BYTES));
+            s16x8 fr;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { fr[e] = lo[e]; fr[4 + e] = hi[e]; }
+            *reinterpret_cast<s16x8 *>(dst + s * 1024 + lane * 16) = fr;
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                f32x4 pk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pk[e] = s ? Pol::get(f1, 4 * c + e) : Pol::get(f0, 4 * c + e);
+                *reinterpret_cast<f32x4 *>(scr + pt * ROW_BYTES + (16 * s + 8 * c + 4 * h) * 4) = pk;
+            }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                f32x4 fr;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    fr[e] = *reinterpret_cast<const float *>(scr + (16 * s + 8 * h + 4 * hf + e) * ROW_BYTES + pt * 4);
+                *reinterpret_cast<f32x4 *>(dst + s * 2048 + hf * 1024 + lane * 16) = fr;
+            }
+    }
+}
+
+template <int W, class Pol>
+DEVI void pack_tile(const f32x16 &v, int m, typename Pol::frag (&next)[W / 16]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Pol::set(next[2 * m + s], j, v[8 * s + j]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// chain kernel
+// ---------------------------------------------------------------------------------------------
+// weight-chunk stream of one tile: forward chunks 0..NCF-1, then the transposed chunks of hidden
+// layers depth-1 .. 1 (delta chain); wraps to the next tile's chunk 0
+template <int MT, int CB>
+DEVI const char *chunk_source(int seq, int NSEQ, int NCF, int depth, const char *fwd, const char *bwd) {
+    if (seq >= NSEQ) seq -= NSEQ;
+    if (seq < NCF) return fwd + (size_t)seq * CB;
+    const int i = seq - NCF;
+    const int l = depth - 1 - i / MT, m = i % MT;
+    return bwd + (size_t)((l - 1) * MT + m) * CB;
+}
+
+template <int W, class Pol, int DEG>
+__global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
+    using PK = Pack<W, Pol>;
+    using BG = BwdGeom<W, Pol>;
+    using frag = typename Pol::frag;
+    constexpr int CB = PK::CHUNK_BYTES, MT = PK::MT, KS = PK::KS;
+    constexpr int MW = (MT + 1) / 2;                                   // mask words per layer per lane
+    const FusedArgs &a = A.f;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *ring = smem;
+    float *bias_lds = reinterpret_cast<float *>(smem + 2 * CB);
+    float *wout_lds = bias_lds + (a.depth + 1) * W;
+    char *scr_all = reinterpret_cast<char *>(wout_lds + W);
+    unsigned *mask_all = reinterpret_cast<unsigned *>(scr_all + Pol::NWAVES * BG::SCR_BYTES);
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 31, h = lane >> 5;
+    char *scr = scr_all + wv * BG::SCR_BYTES;
+    unsigned *mask_w = mask_all + (size_t)wv * a.depth * MW * 64;       // [layer][word][lane]
+    for (int i = tid; i < (a.depth + 1) * W; i += Pol::NTHREADS)
+        bias_lds[i] = reinterpret_cast<const float *>(a.packed + a.bias_off)[i];
+    for (int i = tid; i < W; i += Pol::NTHREADS) wout_lds[i] = reinterpret_cast<const float *>(a.packed + a.wout_off)[i];
+
+    const int NCF = PK::fwd_chunks(a.depth);
+    const int NSEQ = NCF + (a.depth - 1) * MT;
+    const char *fwd = a.packed + a.fwd_off, *bwd = a.packed + a.bwd_off;
+    const int depth_ = a.depth;
+#define chunk_src(seq_) chunk_source<MT, CB>((seq_), NSEQ, NCF, depth_, fwd, bwd)
+    Stager<CB, Pol::NTHREADS> stg;
+    stg.load(fwd);
+    stg.store(ring);
+    __syncthreads();
+    int par = 0;
+#define RING_STEP_BEGIN(seq) stg.load(chunk_src((seq) + 1)); const char *ch = ring + par * CB;
+#define RING_STEP_END() stg.store(ring + (par ^ 1) * CB); __syncthreads(); par ^= 1;
+
+    for (long long tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
+        const int b = (int)(tile / a.tiles_per_frame);
+        const long long p = (tile % a.tiles_per_frame) * (Pol::NWAVES * 32) + wv * 32 + pl;
+        const bool inb = p < a.P;
+        const long long q = tile * Pol::NWAVES + wv;                     // 32-point group on the tape
+        frag enc[2];
+        bool live;
+        point_prologue<Pol, DEG>(a, b, p, inb, enc, live);
+        // the encoded inputs are the B operand of dW_0 and of the skip layer
+        emit_frags<Pol, BG::ROW_BYTES>(scr, A.tape + A.t.enc_off + q * BG::TILE_BYTES, enc[0], enc[1]);
+        frag act[KS], next[KS];
+        int seq = 0;
+        // ---- forward recompute, layer 0 -------------------------------------------------------
+        {
+            RING_STEP_BEGIN(seq)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                f32x16 acc = bias_acc(bias_lds, m, h);
+                acc = Pol::mma(Pol::lds_frag(ch, 2 * m, lane), enc[0], acc);
+                acc = Pol::mma(Pol::lds_frag(ch, 2 * m + 1, lane), enc[1], acc);
+                const unsigned mk = relu_pack<W, Pol>(acc, m, act);
+                emit_frags<Pol, BG::ROW_BYTES>(scr, A.tape + A.t.h_off[1] + (q * MT + m) * BG::TILE_BYTES, act[2 * m], act[2 * m + 1]);
+                unsigned *mwp = mask_w + (0 * MW + (m >> 1)) * 64 + lane;
+                if (m & 1) *mwp |= mk << 16; else *mwp = mk;
+            }
+            RING_STEP_END()
+            ++seq;
+        }
+        // ---- hidden layers 1..depth-1 ---------------------------------------------------------
+        for (int l = 1; l < a.depth; ++l) {
+            const bool sk = (a.skip_mask >> l) & 1;
+            const float *bl = bias_lds + l * W;
+            char *hdst = A.tape + A.t.h_off[l + 1] + q * MT * BG::TILE_BYTES;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                RING_STEP_BEGIN(seq)
+                f32x16 acc = tile_matmul<W, Pol>(ch, act, enc, sk, bias_acc(bl, m, h));
+                const unsigned mk = relu_pack<W, Pol>(acc, m, next);
+                emit_frags<Pol, BG::ROW_BYTES>(scr, hdst + m * BG::TILE_BYTES, next[2 * m], next[2 * m + 1]);
+                unsigned *mwp = mask_w + (l * MW + (m >> 1)) * 64 + lane;
+                if (m & 1) *mwp |= mk << 16; else *mwp = mk;
+                RING_STEP_END()
+                ++seq;
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) act[ks] = next[ks];
+        }
+        // ---- output layer, dE, dout -----------------------------------------------------------
+        float dout;
+        {
+            RING_STEP_BEGIN(seq)
+            f32x16 acc = tile_matmul<W, Pol>(ch, act, enc, false, bias_acc(bias_lds + a.depth * W, 0, h));
+            RING_STEP_END()
+            ++seq;
+            float d = 0.f;
+            if (h == 0 && live) {
+                const float e = 1.f / (1.f + Pol::fexp(10.f - acc[0]));
+                const long long ray = p / a.G;
+                float dE = 0.f;
+                for (int s = 0; s < a.Sx; ++s)
+                    dE += a.dimages[((long long)b * a.Sx + s) * a.R + ray] * a.w[(long long)s * a.P + p];
+                d = dE * e * (1.f - e);                                // sigmoid'(out-10) = e(1-e)
+            }
+            dout = __shfl(d, pl, 64);                                   // both lane halves need it
+            if (h == 0) reinterpret_cast<float *>(A.tape + A.t.dout_off)[q * 32 + pl] = d;
+        }
+        // ---- gA_{depth-1} = wout * dout * relu'(a_{depth-1}) -----------------------------------
+        frag dl[KS];
+        {
+            char *gdst = A.tape + A.t.ga_off[a.depth - 1] + q * MT * BG::TILE_BYTES;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const unsigned mw = mask_w[((a.depth - 1) * MW + (m >> 1)) * 64 + lane] >> ((m & 1) * 16);
+                f32x16 g;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x4 wv4 = *reinterpret_cast<const f32x4 *>(wout_lds + 32 * m + 8 * g4 + 4 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) g[4 * g4 + e] = ((mw >> (4 * g4 + e)) & 1) ? wv4[e] * dout : 0.f;
+                }
+                pack_tile<W, Pol>(g, m, dl);
+                emit_frags<Pol, BG::ROW_BYTES>(scr, gdst + m * BG::TILE_BYTES, dl[2 * m], dl[2 * m + 1]);
+            }
+        }
+        // ---- delta chain through hidden layers depth-1 .. 1 -----------------------------------
+        for (int l = a.depth - 1; l >= 1; --l) {
+            char *gdst = A.tape + A.t.ga_off[l - 1] + q * MT * BG::TILE_BYTES;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                RING_STEP_BEGIN(seq)
+                f32x16 acc = {};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) acc = Pol::mma(Pol::lds_frag(ch, ks, lane), dl[ks], acc);
+                const unsigned mw = mask_w[((l - 1) * MW + (m >> 1)) * 64 + lane] >> ((m & 1) * 16);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = ((mw >> r) & 1) ? acc[r] : 0.f;
+                pack_tile<W, Pol>(acc, m, next);
+                emit_frags<Pol, BG::ROW_BYTES>(scr, gdst + m * BG::TILE_BYTES, next[2 * m], next[2 * m + 1]);
+                RING_STEP_END()
+                ++seq;
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) dl[ks] = next[ks];
+        }
+    }
+#undef RING_STEP_BEGIN
+#undef RING_STEP_END
+#undef chunk_src
+}
+
+// ---------------------------------------------------------------------------------------------
+// dW kernel
+// ---------------------------------------------------------------------------------------------
+// global -> registers -> LDS copy of one 32-point group image [A tiles][h tiles][enc tile]
+template <int UNITS, int NTHREADS, int OFF_H, int OFF_E, int AH_BYTES, int TB>
+struct GroupStager {
+    static constexpr int PIECES = (UNITS + NTHREADS - 1) / NTHREADS;
+    u32x4 st[PIECES];
+    bool out_job, has_h;
+    const char *srcA, *srcH, *srcE;
+    const float *srcD;
+    DEVI void load(long long q) {
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            int u = i * NTHREADS + (int)threadIdx.x;
+            u = u < UNITS ? u : UNITS - 1;
+            const int off = u * 16;
+            const char *src;
+            if (off < OFF_H) {
+                if (out_job) src = reinterpret_cast<const char *>(srcD + q * 32) + (off < 128 ? off : 0);
+                else src = srcA + q * (long long)AH_BYTES + off;
+            } else if (off < OFF_E) src = has_h ? srcH + q * (long long)AH_BYTES + (off - OFF_H) : srcE + q * TB;
+            else src = srcE + q * TB + (off - OFF_E);
+            st[i] = *reinterpret_cast<const u32x4 *>(src);
+        }
+    }
+    DEVI void store(char *dst) const {
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const int u = i * NTHREADS + (int)threadIdx.x;
+            if (u < UNITS) *reinterpret_cast<u32x4 *>(dst + u * 16) = st[i];
+        }
+    }
+};
+
+template <int W, class Pol>
+__global__ __launch_bounds__(Pol::NTHREADS) void dw_kernel(BwdArgs A) {
+    using BG = BwdGeom<W, Pol>;
+    using frag = typename Pol::frag;
+    constexpr int MT = BG::MT, TB = BG::TILE_BYTES;
+    constexpr int GB = BG::GROUP_BYTES;
+    constexpr int UNITS = GB / 16;
+    // LDS group image: [A tiles: MT][h tiles: MT][enc tile]
+    constexpr int OFF_H = MT * TB, OFF_E = 2 * MT * TB;
+    const int depth = A.f.depth;
+    extern __shared__ __attribute__((aligned(16))) char smem[];       // 2 x GB
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, i31 = lane & 31, h = lane >> 5;
+
+    int job = 0;
+    while (job < depth && (int)blockIdx.x >= A.wg_begin[job + 1]) ++job;
+    const int nwg = A.wg_begin[job + 1] - A.wg_begin[job];
+    const int kb = blockIdx.x - A.wg_begin[job];
+    const long long q0 = A.t.NQ * kb / nwg, q1 = A.t.NQ * (kb + 1) / nwg;
+
+    // operands of this job: A = gA_job (or dout for the output layer), B = inputs of layer `job`
+    const bool out_job = job == depth;
+    const bool has_h = job >= 1;
+    const bool has_enc = job == 0 || ((A.f.skip_mask >> job) & 1);
+    const int mtA = out_job ? 1 : MT;
+    const int nH = has_h ? MT : 0;
+    const int nB = nH + (has_enc ? 1 : 0);                             // real B tiles; tile nB = ones
+    const char *srcA = out_job ? nullptr : A.tape + A.t.ga_off[job];
+    const char *srcH = has_h ? A.tape + A.t.h_off[job] : nullptr;
+    const char *srcE = A.tape + A.t.enc_off;
+    const float *srcD = reinterpret_cast<const float *>(A.tape + A.t.dout_off);
+
+    GroupStager<UNITS, Pol::NTHREADS, OFF_H, OFF_E, MT * TB, TB> gs;
+    gs.out_job = out_job; gs.has_h = has_h; gs.srcA = srcA; gs.srcH = srcH; gs.srcE = srcE; gs.srcD = srcD;
+#define load_group(q) gs.load(q)
+#define store_group(dst) gs.store(dst)
+    const int wr = wv % BG::WRR, wc = wv / BG::WRR;
+    frag ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) Pol::set(ones, j, 1.f);
+    float *slab = A.f.slabs + (long long)blockIdx.x * BG::SLAB_FLOATS;
+    // bf16: the next group is prefetched into registers while this one is consumed; f32 (parity
+    // mode, 17 pieces per thread) copies without overlap to stay inside the register file
+    constexpr bool PREFETCH = Pol::ELEM_BYTES == 2;
+
+    // a wave owns MPW A-tiles x NPW_ALL B-tiles of dW^T; they are accumulated NPW at a time
+    // (NPASS sweeps over the K range; NPASS = 1 in bf16 mode)
+    for (int pass = 0; pass < BG::NPASS; ++pass) {
+        const int nbase = wc * BG::NPW_ALL + pass * BG::NPW;
+        const int nend = (wc + 1) * BG::NPW_ALL;
+        f32x16 acc[BG::MPW][BG::NPW];
+#pragma unroll
+        for (int mi = 0; mi < BG::MPW; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < BG::NPW; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+        __syncthreads();
+        if (q0 < q1) {
+            load_group(q0);
+            store_group(smem);
+        }
+        __syncthreads();
+        int par = 0;
+        for (long long q = q0; q < q1; ++q) {
+            if (PREFETCH && q + 1 < q1) load_group(q + 1);
+            const char *gp = smem + par * GB;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                frag af[BG::MPW];
+#pragma unroll
+                for (int mi = 0; mi < BG::MPW; ++mi) {
+                    const int m = wr * BG::MPW + mi;
+                    if (out_job) {   // A[row 0][k = point] = dout, other rows zero
+                        const float *dv = reinterpret_cast<const float *>(gp);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) Pol::set(af[mi], j, i31 == 0 ? dv[16 * s + 8 * h + j] : 0.f);
+                    } else af[mi] = Pol::lds_frag(gp + (m < MT ? m : 0) * TB, s, lane);
+                }
+#pragma unroll
+                for (int ni = 0; ni < BG::NPW; ++ni) {
+                    const int n = nbase + ni;
+                    if (n > nB || n >= nend) continue;
+                    frag bf;
+                    if (n < nH) bf = Pol::lds_frag(gp + OFF_H + n * TB, s, lane);
+                    else if (n < nB) bf = Pol::lds_frag(gp + OFF_E, s, lane);
+                    else bf = ones;
+#pragma unroll
+                    for (int mi = 0; mi < BG::MPW; ++mi)
+                        if (wr * BG::MPW + mi < mtA) acc[mi][ni] = Pol::mma(af[mi], bf, acc[mi][ni]);
+                }
+            }
+            if (q + 1 < q1) {
+                if (!PREFETCH) load_group(q + 1);
+                store_group(smem + (par ^ 1) * GB);
+            }
+            __syncthreads();
+            par ^= 1;
+        }
+        // ---- flush this pass's partial dW^T tiles: slab[(m*NTMAX+n)][r/4][lane][r%4] ------------
+#pragma unroll
+        for (int mi = 0; mi < BG::MPW; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < BG::NPW; ++ni) {
+                const int m = wr * BG::MPW + mi, n = nbase + ni;
+                if (m >= mtA || n > nB || n >= nend) continue;
+                float *tp = slab + (long long)(m * BG::NTMAX + n) * 1024;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][4 * g4 + e];
+                    f32x4 *dst = reinterpret_cast<f32x4 *>(tp + g4 * 256 + lane * 4);
+                    if (A.accumulate) {
+                        const f32x4 old = *dst;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += old[e];
+                    }
+                    *dst = v;
+                }
+            }
+    }
+#undef load_group
+#undef store_group
+}
+
+// ---------------------------------------------------------------------------------------------
+// slab reduction -> flat dparams (flax tree order)
+// ---------------------------------------------------------------------------------------------
+template <int W, class Pol>
+__global__ void reduce_kernel(BwdArgs A) {
+    using BG = BwdGeom<W, Pol>;
+    constexpr int MT = BG::MT;
+    const int depth = A.f.depth;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < A.nparams; t += (long long)gridDim.x * blockDim.x) {
+        int l = 0;
+        while (l < depth && t >= A.kernel_off[l + 1]) ++l;
+        const bool is_bias = t >= A.bias_off[l];
+        int o, kin = 0;
+        if (is_bias) o = (int)(t - A.bias_off[l]);
+        else {
+            const int outw = (l == depth) ? 1 : W;
+            o = (int)((t - A.kernel_off[l]) % outw);
+            kin = (int)((t - A.kernel_off[l]) / outw);
+        }
+        // A-side position of output feature o
+        const int m = o >> 5, row = o & 31;
+        const int hh = (row >> 2) & 1, r = (row & 3) + 4 * (row >> 3);
+        // B-side tile / column of input feature kin
+        const bool has_h = l >= 1, has_enc = (l == 0) || ((A.f.skip_mask >> l) & 1);
+        const int nH = has_h ? MT : 0, nB = nH + (has_enc ? 1 : 0);
+        int n, col;
+        if (is_bias) { n = nB; col = 0; }
+        else if (l == 0) { n = 0; col = kin; }
+        else if (kin < W) { n = kin >> 5; col = kin & 31; }
+        else { n = nH; col = kin - W; }
+        const long long idx = (long long)(m * BG::NTMAX + n) * 1024 + (r >> 2) * 256 + (col + 32 * hh) * 4 + (r & 3);
+        float sum = 0.f;
+        for (int wg = A.wg_begin[l]; wg < A.wg_begin[l + 1]; ++wg) sum += A.f.slabs[(long long)wg * BG::SLAB_FLOATS + idx];
+        A.dparams[t] = sum;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host
+// ---------------------------------------------------------------------------------------------
+int fused_fill_args(const bhn_model *m, int32_t mode, const void *packed, const bhn_geom *geom,
+                    const bhn_frames *fr, bool need_w, FusedArgs *a, MlpShape *s, int nwaves);
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+template <int W, class Pol>
+static void tape_layout(int depth, long long NQ, TapeLayout *t) {
+    using BG = BwdGeom<W, Pol>;
+    memset(t, 0, sizeof(*t));
+    t->NQ = NQ;
+    long long off = 0;
+    const long long per_tensor = NQ * BG::MT * (long long)BG::TILE_BYTES;
+    for (int l = 1; l <= depth; ++l) { t->h_off[l] = off; off += per_tensor; }
+    for (int l = 0; l < depth; ++l) { t->ga_off[l] = off; off += per_tensor; }
+    t->enc_off = off; off += NQ * (long long)BG::TILE_BYTES;
+    t->dout_off = off; off += NQ * 128;
+    t->total = (long long)align_up((size_t)off + 256, 256);      // +256: tail pieces may re-read past the end
+}
+
+template <int W, class Pol>
+static long long bytes_per_group(int depth) {
+    using BG = BwdGeom<W, Pol>;
+    return (long long)(2 * depth * BG::MT + 1) * BG::TILE_BYTES + 128;
+}
+
+template <int W, class Pol>
+static int bwd_run(const bhn_model *m, int32_t mode, const void *packed, const bhn_geom *geom, const bhn_frames *fr,
+                   const float *dimages, float *dparams, void *workspace, size_t workspace_bytes, hipStream_t st,
+                   size_t *query_bytes, int query_B, long long query_P, int device) {
+    using BG = BwdGeom<W, Pol>;
+    using PK = Pack<W, Pol>;
+    const int ncu = bhn_num_cus(device);
+    const int grid_dw = ncu;                                           // one dW workgroup per CU
+    const size_t slab_bytes = align_up((size_t)grid_dw * BG::SLAB_FLOATS * 4, 256);
+    if (query_bytes) {
+        const long long tiles = (query_P + Pol::NWAVES * 32 - 1) / (Pol::NWAVES * 32) * query_B;
+        TapeLayout t;
+        tape_layout<W, Pol>(m->net_depth, tiles * Pol::NWAVES, &t);
+        *query_bytes = slab_bytes + (size_t)t.total;
+        return BHN_OK;
+    }
+    BwdArgs A;
+    memset(&A, 0, sizeof(A));
+    MlpShape s;
+    int rc = fused_fill_args(m, mode, packed, geom, fr, true, &A.f, &s, Pol::NWAVES);
+    if (rc != BHN_OK) return rc;
+    BHN_CHECK_ARG(dimages && dparams && workspace, "null pointer");
+    const int depth = s.depth;
+    // frames per pass so that the tape fits the workspace (same layout function as the size query)
+    const long long groups_per_frame = (long long)A.f.tiles_per_frame * Pol::NWAVES;
+    TapeLayout t1;
+    tape_layout<W, Pol>(depth, groups_per_frame, &t1);
+    if (workspace_bytes < slab_bytes + (size_t)t1.total) {
+        bhn_set_error("render_bwd workspace too small: %zu bytes, need >= %zu (slabs %zu + one frame of tape %lld)",
+                      workspace_bytes, slab_bytes + (size_t)t1.total, slab_bytes, t1.total);
+        return BHN_EWORKSPACE;
+    }
+    long long fpp = 1;
+    while (fpp < A.f.B) {
+        TapeLayout tn;
+        tape_layout<W, Pol>(depth, groups_per_frame * (fpp + 1), &tn);
+        if (slab_bytes + (size_t)tn.total > workspace_bytes) break;
+        ++fpp;
+    }
+    A.f.slabs = reinterpret_cast<float *>(workspace);
+    A.tape = reinterpret_cast<char *>(workspace) + slab_bytes;
+    A.f.slab_floats = BG::SLAB_FLOATS;
+    A.f.dimages = dimages;
+    A.dparams = dparams;
+    A.nparams = s.nparams;
+    A.F = s.F;
+    for (int l = 0; l <= depth; ++l) { A.kernel_off[l] = s.kernel_off[l]; A.bias_off[l] = s.bias_off[l]; A.in_dim[l] = s.in_dim[l]; }
+    A.kernel_off[depth + 1] = s.nparams;
+    // dW jobs: workgroups proportional to MFMA work (A tiles x B tiles incl. the ones tile)
+    {
+        double work[BHN_MAX_LAYERS + 1], tot = 0;
+        for (int l = 0; l <= depth; ++l) {
+            const int mtA = (l == depth) ? 1 : BG::MT;
+            const int nB = (l >= 1 ? BG::MT : 0) + ((l == 0 || s.skip_in[l]) ? 1 : 0);
+            work[l] = (double)mtA * (nB + 1) + 2.0 * (mtA + nB);    // + streaming cost of the operands
+            tot += work[l];
+        }
+        int used = 0;
+        A.wg_begin[0] = 0;
+        for (int l = 0; l <= depth; ++l) {
+            int n = (int)(grid_dw * work[l] / tot);
+            if (n < 1) n = 1;
+            if (l == depth) n = grid_dw - used;
+            if (n < 1) n = 1;
+            used += n;
+            A.wg_begin[l + 1] = used;
+        }
+        if (used > grid_dw) {
+            bhn_set_error("internal: dW job split overflow (%d > %d)", used, grid_dw);
+            return BHN_EINVAL;
+        }
+    }
+    const size_t lds_chain = 2 * PK::CHUNK_BYTES + (size_t)(depth + 1) * W * 4 + W * 4 + Pol::NWAVES * BG::SCR_BYTES +
+                             (size_t)Pol::NWAVES * depth * ((BG::MT + 1) / 2) * 64 * 4;
+    const size_t lds_dw = 2 * BG::GROUP_BYTES;
+    auto kchain = chain_kernel<W, Pol, 3>;
+    auto kdw = dw_kernel<W, Pol>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        BHN_HIP(hipFuncSetAttribute((const void *)kchain, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        BHN_HIP(hipFuncSetAttribute((const void *)kdw, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    BHN_CHECK_ARG(lds_chain <= 160 * 1024 && lds_dw <= 160 * 1024, "LDS budget exceeded (chain %zu, dw %zu)", lds_chain, lds_dw);
+    const int B_total = A.f.B;
+    const double *tM0 = A.f.tM0;
+    for (int b0 = 0, pass = 0; b0 < B_total; b0 += (int)fpp, ++pass) {
+        const int nb = (b0 + fpp <= B_total) ? (int)fpp : B_total - b0;
+        A.f.B = nb;
+        A.f.tM0 = tM0 + b0;
+        A.f.dimages = dimages + (long long)b0 * A.f.Sx * A.f.R;
+        A.f.total_tiles = (long long)A.f.tiles_per_frame * nb;
+        tape_layout<W, Pol>(depth, A.f.total_tiles * Pol::NWAVES, &A.t);
+        A.accumulate = pass > 0;
+        long long grid = ncu;
+        if (grid > A.f.total_tiles) grid = A.f.total_tiles;
+        hipLaunchKernelGGL(kchain, dim3((unsigned)grid), dim3(Pol::NTHREADS), lds_chain, st, A);
+        BHN_HIP(hipGetLastError());
+        hipLaunchKernelGGL(kdw, dim3((unsigned)A.wg_begin[depth + 1]), dim3(Pol::NTHREADS), lds_dw, st, A);
+        BHN_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL((reduce_kernel<W, Pol>), dim3(256), dim3(256), 0, st, A);
+    BHN_HIP(hipGetLastError());
+    return BHN_OK;
+}
+
+template <class Pol>
+static int bwd_dispatch(int width, const bhn_model *m, int32_t mode, const void *packed, const bhn_geom *geom,
+                        const bhn_frames *fr, const float *dimages, float *dparams, void *ws, size_t wsb,
+                        hipStream_t st, size_t *qb, int qB, long long qP, int device) {
+    switch (width) {
+        case 32: return bwd_run<32, Pol>(m, mode, packed, geom, fr, dimages, dparams, ws, wsb, st, qb, qB, qP, device);
+        case 64: return bwd_run<64, Pol>(m, mode, packed, geom, fr, dimages, dparams, ws, wsb, st, qb, qB, qP, device);
+        case 128: return bwd_run<128, Pol>(m, mode, packed, geom, fr, dimages, dparams, ws, wsb, st, qb, qB, qP, device);
+        case 256: return bwd_run<256, Pol>(m, mode, packed, geom, fr, dimages, dparams, ws, wsb, st, qb, qB, qP, device);
+        default:
+            bhn_set_error("net_width %d: fused kernels are built for 32, 64, 128, 256", width);
+            return BHN_EUNSUPPORTED;
+    }
+}
+
+extern "C" size_t bhn_render_bwd_workspace_bytes(const bhn_model *m, int32_t mode, int32_t B, int64_t P, int32_t device) {
+    MlpShape s;
+    if (bhn_mlp_shape(m, &s) != BHN_OK || B <= 0 || P <= 0) return 0;
+    size_t q = 0;
+    int rc = (mode == BHN_BF16)
+                 ? bwd_dispatch<PolBF16>(s.width, m, mode, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, &q, B, P, device)
+                 : bwd_dispatch<PolF32>(s.width, m, mode, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, &q, B, P, device);
+    return rc == BHN_OK ? q : 0;
+}
+
 extern "C" int bhn_render_bwd(const bhn_model *m, int32_t mode, const void *packed, const bhn_geom *geom,
                               const bhn_frames *fr, const float *dimages, float *dparams, void *workspace,
                               size_t workspace_bytes, void *stream) {
-    bhn_set_error("render_bwd not built yet");
-    return BHN_EUNSUPPORTED;
+    BHN_CHECK_ARG(m, "null model");
+    BHN_CHECK_ARG(mode == BHN_F32 || mode == BHN_BF16, "bad mode %d", mode);
+    int dev = 0;
+    BHN_HIP(hipGetDevice(&dev));
+    return (mode == BHN_BF16)
+               ? bwd_dispatch<PolBF16>(m->net_width, m, mode, packed, geom, fr, dimages, dparams, workspace, workspace_bytes,
+                                       (hipStream_t)stream, nullptr, 0, 0, dev)
+               : bwd_dispatch<PolF32>(m->net_width, m, mode, packed, geom, fr, dimages, dparams, workspace, workspace_bytes,
+                                      (hipStream_t)stream, nullptr, 0, 0, dev);
 }

@@ -18,6 +18,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #define DEVI __device__ __forceinline__
 
@@ -129,7 +130,7 @@ struct Pack {
 template <int CHUNK_BYTES, int NTHREADS>
 struct Stager {
     static constexpr int PIECES = (CHUNK_BYTES + NTHREADS * 16 - 1) / (NTHREADS * 16);
-    uint4 st[PIECES];
+    u32x4 st[PIECES];
     // every thread always loads (the tail piece re-reads the last 16 bytes) so that st[] is fully
     // initialised and stays in registers; only the store is guarded
     DEVI void load(const char *src) {
@@ -137,14 +138,14 @@ struct Stager {
         for (int i = 0; i < PIECES; ++i) {
             int off = (i * NTHREADS + (int)threadIdx.x) * 16;
             off = off < CHUNK_BYTES ? off : CHUNK_BYTES - 16;
-            st[i] = *reinterpret_cast<const uint4 *>(src + off);
+            st[i] = *reinterpret_cast<const u32x4 *>(src + off);
         }
     }
     DEVI void store(char *dst) const {
 #pragma unroll
         for (int i = 0; i < PIECES; ++i) {
             const int off = (i * NTHREADS + (int)threadIdx.x) * 16;
-            if (off < CHUNK_BYTES) *reinterpret_cast<uint4 *>(dst + off) = st[i];
+            if (off < CHUNK_BYTES) *reinterpret_cast<u32x4 *>(dst + off) = st[i];
         }
     }
 };

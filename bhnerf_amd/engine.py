@@ -149,13 +149,23 @@ class FusedPredictor:
                                              C.byref(fs), _hip.ptr(out), _hip.stream_ptr(self.device)))
         return out
 
-    def workspace(self):
-        if self._ws is None:
-            n = int(_hip.lib().bhn_render_bwd_workspace_bytes(C.byref(self.model), self.mode,
-                                                              self.device.index or 0))
-            if n == 0:
-                raise _hip.HipError(_hip.lib().bhn_last_error().decode() or 'render_bwd workspace query failed')
-            self._ws = torch.empty((n,), dtype=torch.uint8, device=self.device)
+    def workspace(self, B, P):
+        """Backward workspace (slabs + tape).  Sized for all B frames when that fits under
+        ``max_workspace_bytes`` (default 1/4 of the device memory), else for as many frames as fit;
+        ``bhn_render_bwd`` then iterates over frame groups."""
+        lib = _hip.lib()
+        dev = self.device.index or 0
+        full = int(lib.bhn_render_bwd_workspace_bytes(C.byref(self.model), self.mode, B, P, dev))
+        one = int(lib.bhn_render_bwd_workspace_bytes(C.byref(self.model), self.mode, 1, P, dev))
+        if full == 0 or one == 0:
+            raise _hip.HipError(lib.bhn_last_error().decode() or 'render_bwd workspace query failed')
+        cap = getattr(self, 'max_workspace_bytes', None)
+        if cap is None:
+            cap = torch.cuda.get_device_properties(self.device).total_memory // 4
+        want = min(full, max(one, cap))
+        if self._ws is None or self._ws.numel() < want:
+            self._ws = None
+            self._ws = torch.empty((want,), dtype=torch.uint8, device=self.device)
         return self._ws
 
     def render_bwd(self, geom, tM0, dimages, out=None):
@@ -163,7 +173,7 @@ class FusedPredictor:
         assert dimages.dtype == torch.float32 and dimages.is_contiguous() and dimages.is_cuda
         if out is None:
             out = torch.empty((self.nparams,), dtype=torch.float32, device=self.device)
-        ws = self.workspace()
+        ws = self.workspace(int(tM0.numel()), geom.P)
         gs, fs = geom.c_struct(), self._frames(tM0)
         _hip.check(_hip.lib().bhn_render_bwd(C.byref(self.model), self.mode, _hip.ptr(self.packed), C.byref(gs),
                                              C.byref(fs), _hip.ptr(dimages), _hip.ptr(out), _hip.ptr(ws), ws.numel(),

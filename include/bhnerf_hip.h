@@ -106,10 +106,14 @@ int bhn_render_fwd(const bhn_model *m, int32_t mode, const void *packed, const b
                    const bhn_frames *fr, float *images, void *stream);
 
 /* Reverse of bhn_render_fwd w.r.t. the parameters (jax.value_and_grad in network.py:617):
- * dimages (B,Sx,R) -> dparams (flat f32, overwritten).  Recomputes the forward per tile; weight
- * gradients are accumulated in per-workgroup slabs inside `workspace` and reduced at the end
- * (deterministic, no float atomics). */
-size_t bhn_render_bwd_workspace_bytes(const bhn_model *m, int32_t mode, int32_t device);
+ * dimages (B,Sx,R) -> dparams (flat f32, overwritten).  Per 32-point tile the forward is recomputed
+ * and the delta chain is run in registers; layer inputs and pre-activation gradients are streamed
+ * to a fragment-ordered tape inside `workspace`, from which the weight-gradient GEMMs (K = points)
+ * accumulate one layer per workgroup in registers; per-workgroup slabs are reduced at the end
+ * (deterministic, no float atomics).  bhn_render_bwd_workspace_bytes(B,P) is the size that holds
+ * all B frames at once; any workspace that holds the slabs plus ONE frame of tape is accepted and
+ * makes the call iterate over groups of frames. */
+size_t bhn_render_bwd_workspace_bytes(const bhn_model *m, int32_t mode, int32_t B, int64_t P, int32_t device);
 int bhn_render_bwd(const bhn_model *m, int32_t mode, const void *packed, const bhn_geom *geom,
                    const bhn_frames *fr, const float *dimages, float *dparams, void *workspace,
                    size_t workspace_bytes, void *stream);

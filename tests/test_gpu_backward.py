@@ -1,0 +1,207 @@
+"""GPU parity tests of the backward half of the hot path (through the C ABI): parameter gradients of
+loss_fn_image against (i) torch.autograd on the float64 oracle and (ii) the finite differences of
+the REFERENCE's own loss_fn_image stored in the golden fixtures; Adam training steps against the
+oracle trainer; workspace frame-chunking.
+
+Tolerances (error / largest gradient entry, and relative L2): f32 mode L2 1e-4, max 1e-3; bf16 mode
+L2 3e-2, max 1.5e-1 (bf16 activations / deltas on the tape, f32 accumulate; the tiny fixtures have
+only ~100 points to average over).  The max-norm bound is looser than the typical 1e-7..1e-6 f32
+error because a ReLU-net gradient is discontinuous: when one pre-activation lies within f32 rounding
+of zero, f32 and f64 disagree on relu' for that (point, unit) and every layer below it changes by that
+one point's contribution (~1e-4 of the maximum) while the image is unaffected (observed: W=128, S=3)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_tree
+from oracle import oracle_np as onp
+from oracle import oracle_torch as ot
+
+pytestmark = pytest.mark.gpu
+PRED = ['a', 'b', 'c', 'd', 'e', 'f']
+GTOL = {'f32': 1e-3, 'bf16': 1.5e-1}       # max-norm
+L2TOL = {'f32': 1e-4, 'bf16': 3e-2}        # relative L2
+
+
+def l2err(a, b):
+    return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device('cuda:0')
+
+
+def oracle_trainer(g, dtype=torch.float64, **kw):
+    hp = g['hparams']
+    ks, bs = ot.tree_to_lists(golden_tree(g), dtype)
+    t = lambda x: torch.tensor(x, dtype=dtype)
+    geom = dict(coords=t(g['coords']), Omega=t(g['Omega']), t_geos=t(g['t_geos']), g=t(g['g']), dtau=t(g['dtau']),
+                Sigma=t(g['Sigma']), J=(t(g['J']) if g['J'].ndim else None), t_start_obs=float(g['t_start_obs']),
+                t_injection=float(g['t_injection']))
+    hpd = dict(GM_c3=onp.GM_C3_SGRA_HR, scale=hp[0], rmin=hp[1], rmax=hp[2], z_width=hp[3], posenc_deg=int(hp[4]),
+               net_depth=int(hp[5]))
+    return ot.CpuTrainer(ks, bs, geom, hpd, **kw), t
+
+
+def flat_from_lists(ks, bs):
+    """flax tree order: kernel_0, bias_0, kernel_1, ..."""
+    return np.concatenate([np.concatenate([k.detach().numpy().ravel(), b.detach().numpy().ravel()]) for k, b in zip(ks, bs)])
+
+
+def targets(g, dt):
+    S = g['J'].shape[0] if g['J'].ndim else None
+    b = len(g['t_frames'])
+    sp = g['coords'].shape[1:3]
+    if dt == 'full':
+        shape = (b, S) + sp if S else (b,) + sp
+    else:
+        shape = (b, S) if S else (b,)
+    return {k: g[k + '_' + dt].reshape(shape) for k in ('target', 'sigma', 'offset')}
+
+
+def device_setup(g, mode, dev):
+    from bhnerf_amd import network
+    hp = g['hparams']
+    pred = network.NeRF_Predictor(hp[0], hp[1], hp[2], hp[3], posenc_deg=int(hp[4]), net_depth=int(hp[5]),
+                                  net_width=int(hp[6]), mode=mode, device=dev)
+    f = lambda k: np.ascontiguousarray(g[k].astype(np.float32))
+    rt = dict(coords=f('coords'), Omega=f('Omega'), J=(f('J') if g['J'].ndim else 1.0), g=f('g'), dtau=f('dtau'),
+              Sigma=f('Sigma'), t_start_obs=float(g['t_start_obs']), t_geos=f('t_geos'), t_injection=float(g['t_injection']))
+    return pred, rt
+
+
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+@pytest.mark.parametrize('dt', ['full', 'lc'])
+@pytest.mark.parametrize('tag', PRED)
+def test_gradient_vs_oracle_and_reference_fd(dev, golden, tag, dt, mode):
+    from bhnerf_amd import network, units
+    g = golden('g5_predict_' + tag)
+    tr, t = oracle_trainer(g)
+    tg = targets(g, dt)
+    scale = float(g['hparams'][7])
+    loss_ref, _, grads_ref = tr.loss_and_grad(t(g['t_frames']), t(tg['target']), t(tg['sigma']), t(tg['offset']), scale, dt)
+    n = len(tr.k)
+    gref = np.concatenate([np.concatenate([grads_ref[i].numpy().ravel(), grads_ref[n + i].numpy().ravel()]) for i in range(n)])
+
+    pred, rt = device_setup(g, mode, dev)
+    params = pred.engine().flatten(golden_tree(g)).requires_grad_(True)
+    tree = network.ParamTree()
+    tree.flat = params
+    loss, [images] = network.loss_fn_image(tree, pred.apply, tg['target'], tg['sigma'], tg['offset'], g['t_frames'],
+                                           rt['coords'], rt['Omega'], rt['J'], rt['g'], rt['dtau'], rt['Sigma'],
+                                           rt['t_start_obs'], rt['t_geos'], rt['t_injection'], scale, units.hr, dt)
+    loss.backward()
+    gdev = params.grad.cpu().numpy().astype(np.float64)
+    assert abs(loss.item() - loss_ref.item()) <= 10 * GTOL[mode] * abs(loss_ref.item())
+    gmax = np.abs(gref).max()
+    assert gmax > 0
+    err = np.abs(gdev - gref).max() / gmax
+    assert err < GTOL[mode], err
+    assert l2err(gdev, gref) < L2TOL[mode], l2err(gdev, gref)
+    if dt == 'full':      # finite differences of the reference's own loss_fn_image (float64)
+        eng = pred.engine()
+        for (li, i, j), fd in zip(g['fd_idx'], g['fd_val']):
+            idx = eng.kernel_off[li] + i * eng.out_dim[li] + j if i >= 0 else eng.bias_off[li] + j
+            assert abs(gdev[idx] - fd) <= GTOL[mode] * np.abs(g['fd_val']).max() + 2e-5 * abs(fd)
+
+
+@pytest.mark.parametrize('tag', ['a', 'b', 'f'])
+def test_training_steps_match_oracle(dev, golden, tag):
+    """gradient_step_image (pack -> render -> chi2 -> backward -> Adam) x3 == oracle CpuTrainer (f32 mode)."""
+    from bhnerf_amd import network, units
+    g = golden('g5_predict_' + tag)
+    tg = targets(g, 'full')
+    tr, t = oracle_trainer(g, num_iters=3, lr_init=1e-3, lr_final=1e-5)
+    pred, rt = device_setup(g, 'f32', dev)
+    state = pred.init_state(network.ParamTree(golden_tree(g)), num_iters=3, lr_init=1e-3, lr_final=1e-5)
+    for step in range(3):
+        lref, _ = tr.step(t(g['t_frames']), t(tg['target']), t(tg['sigma']), t(tg['offset']), 1.0, 'full')
+        loss, state, images = network.gradient_step_image(
+            state, units.hr, 'full', tg['target'], tg['sigma'], tg['offset'], g['t_frames'], rt['coords'], rt['Omega'],
+            rt['J'], rt['g'], rt['dtau'], rt['Sigma'], rt['t_start_obs'], rt['t_geos'], rt['t_injection'], 1.0)
+        assert loss.shape == (1,) and abs(loss.item() - lref.item()) < 1e-4 * abs(lref.item())
+        assert images.shape[:2] == (1, len(g['t_frames']))
+    assert state.step == 3
+    pref = flat_from_lists(tr.k, tr.b)
+    pdev = state.flat.cpu().numpy()
+    p0 = pred.engine().flatten(golden_tree(g)).cpu().numpy()
+    moved = np.abs(pref - p0).max()
+    assert moved > 1e-4
+    # Adam normalises the step, so parameters move ~lr per step; compare against the total movement
+    assert np.abs(pdev - pref).max() < 2e-2 * moved
+
+
+def test_workspace_frame_chunking_is_equivalent(dev, golden):
+    """A workspace that only holds one frame of tape must give the same gradient (slab accumulation)."""
+    from bhnerf_amd import engine
+    g = golden('g5_predict_e')
+    pred, rt = device_setup(g, 'f32', dev)
+    eng = pred.engine()
+    eng.pack(eng.flatten(golden_tree(g)))
+    geom = pred.geometry(rt['coords'], rt['Omega'], rt['t_geos'], None, rt['g'], rt['dtau'], rt['Sigma'])
+    tM0 = engine.frame_offsets(g['t_frames'], 0.0, rt['t_injection'], onp.GM_C3_SGRA_HR, dev)
+    dimg = torch.rand((len(g['t_frames']), 1, geom.R), device=dev)
+    full = eng.render_bwd(geom, tM0, dimg).clone()
+    eng._ws, eng.max_workspace_bytes = None, 1          # forces the one-frame minimum
+    chunked = eng.render_bwd(geom, tM0, dimg).clone()
+    assert eng._ws.numel() < 0.6 * 1e12
+    assert torch.allclose(full, chunked, rtol=1e-5, atol=1e-6 * float(full.abs().max()))
+    assert float(full.abs().max()) > 0
+
+
+@pytest.mark.parametrize('width,depth,S', [(256, 4, 0), (128, 4, 3), (64, 8, 2), (32, 6, 0)])
+def test_random_problem_f32_and_bf16(dev, width, depth, S):
+    """Larger ragged problem (G=50 rays straddle wave tiles, several workgroup tiles, pre-injection
+    and out-of-domain samples) against the float64 oracle."""
+    from bhnerf_amd import network, units
+    rng = np.random.default_rng(width + depth)
+    H, Wd, G, B = 9, 7, 50, 3
+    alpha, beta = np.meshgrid(np.linspace(-8, 8, H), np.linspace(-8, 8, Wd), indexing='ij')
+    s = np.linspace(-9.6, 9.6, G)
+    inc = np.deg2rad(60.0)
+    coords = np.stack([alpha[..., None] * np.ones(G), beta[..., None] * np.cos(inc) + s * np.sin(inc),
+                       -beta[..., None] * np.sin(inc) + s * np.cos(inc)])
+    r = np.sqrt((coords ** 2).sum(0)) + 0.3
+    geo = dict(coords=coords, Omega=1.0 / (r ** 1.5 + 0.1), t_geos=-(1000.0 - (s + 9.6)) * np.ones_like(r),
+               g=rng.uniform(0.6, 1.4, r.shape), Sigma=r ** 2, dtau=(s[1] - s[0]) / r ** 2)
+    J = None
+    if S:
+        I = rng.uniform(0.5, 1.5, r.shape); chi = rng.uniform(0, np.pi, r.shape)
+        J = np.stack([I, 0.85 * I * np.cos(2 * chi), 0.85 * I * np.sin(2 * chi)])[:S]
+    t_frames = np.sort(rng.uniform(0, 1, B)); t_inj = -(1000.0 - 4.0)
+    # identical inputs on both sides: everything is rounded to float32 first, the oracle then
+    # evaluates those values in float64
+    f32r = lambda v: np.asarray(v, dtype=np.float32).astype(np.float64)
+    geo = {k: f32r(v) for k, v in geo.items()}
+    J = f32r(J) if S else None
+    tree = onp.he_uniform_params(rng, depth, width, 21, dtype=np.float32)
+    for i in range(depth + 1):
+        d = tree['MLP_0']['Dense_%d' % i]
+        d['kernel'] = d['kernel'].astype(np.float64)
+        d['bias'] = f32r(rng.uniform(-0.1, 0.1, d['bias'].shape))
+    g = dict(geo, J=(J if S else np.array(1.0)), t_frames=t_frames, t_start_obs=0.0, t_injection=t_inj,
+             hparams=np.array([8.0, 2.5, 8.0, 4.0, 3, depth, width, 1.0]))
+    for i in range(depth + 1):
+        g['kernel%d' % i] = tree['MLP_0']['Dense_%d' % i]['kernel']; g['bias%d' % i] = tree['MLP_0']['Dense_%d' % i]['bias']
+    tr, t = oracle_trainer(g)
+    shape = (B, S, H, Wd) if S else (B, H, Wd)
+    target = rng.uniform(0, 1e-3, shape); sigma = rng.uniform(0.5, 2.0, shape); offset = np.zeros(shape)
+    loss_ref, img_ref, grads_ref = tr.loss_and_grad(t(t_frames), t(target), t(sigma), t(offset), 1.0, 'full')
+    n = len(tr.k)
+    gref = np.concatenate([np.concatenate([grads_ref[i].numpy().ravel(), grads_ref[n + i].numpy().ravel()]) for i in range(n)])
+    for mode in ('f32', 'bf16'):
+        pred, rt = device_setup(g, mode, dev)
+        params = pred.engine().flatten(golden_tree(g)).requires_grad_(True)
+        ptree = network.ParamTree(); ptree.flat = params
+        loss, [images] = network.loss_fn_image(ptree, pred.apply, target, sigma, offset, t_frames, rt['coords'], rt['Omega'],
+                                               rt['J'], rt['g'], rt['dtau'], rt['Sigma'], 0.0, rt['t_geos'], t_inj, 1.0,
+                                               units.hr, 'full')
+        loss.backward()
+        tol_img = {'f32': 1e-5, 'bf16': 3e-2}[mode]
+        ierr = np.abs(images.detach().cpu().numpy().reshape(img_ref.shape) - img_ref.numpy()).max() / img_ref.abs().max().item()
+        assert ierr < tol_img, (mode, ierr)
+        gerr = np.abs(params.grad.cpu().numpy() - gref).max() / np.abs(gref).max()
+        assert gerr < GTOL[mode], (mode, gerr)
+        assert l2err(params.grad.cpu().numpy(), gref) < L2TOL[mode]
