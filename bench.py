@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: train ray-samples/sec of the image-plane recovery step.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+Workload (BASELINE.json configs[1], "Tutorial3 image-plane recovery"): 128x128 rays x 64 samples per
+ray, 64 frames, 4x256 MLP, bf16 MFMA, 8 frames per GPU per step (weak scaling: the frame batch is
+8*N, the reference's own time-frame data parallelism), loss 'full', Adam with linear decay.
+One step = TemporalBatchedArgs.sample -> pack weights -> fused render -> chi^2 -> fused backward
+(chain + dW GEMM + slab reduce) -> RCCL all-reduce of the flat gradient (N>1) -> Adam.
+Inputs are synthetic geodesic arrays resident in HBM before the timed region; the
+"all-active" variant (rmin=0, rmax=inf, z_width=inf, nothing pre-injection) is used so that every
+ray-sample goes through the full MLP (evaluated points == total points).
+
+Prints ONE JSON line on rank 0 (see the contract in the task description); `roofline` refers to the
+kernel with the largest share of the step, timed live with HIP events on the launch stream, and
+`cpu_baseline` is the oracle's PyTorch-CPU restatement timed on the host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}      # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+
+
+def mlp_flops(depth, width, F=21):
+    """Algorithmic MLP flops per evaluated point: forward, delta chain, weight gradient."""
+    fwd = 2 * (F * width + (depth - 2) * width * width + (width + F) * width + width)
+    chain = 2 * (depth - 1) * width * width
+    train = 3 * fwd - 2 * F * width
+    return fwd, chain, train - fwd - chain, train
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--mode', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--image', type=int, default=128)
+    ap.add_argument('--ngeo', type=int, default=64)
+    ap.add_argument('--frames', type=int, default=64)
+    ap.add_argument('--frames-per-gpu', type=int, default=8)
+    ap.add_argument('--width', type=int, default=256)
+    ap.add_argument('--depth', type=int, default=4)
+    ap.add_argument('--masked', action='store_true', help='use the tutorial domain masks instead of all-active')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-rays', type=int, default=4096, help='rays of one frame in the CPU-baseline sample')
+    return ap.parse_args()
+
+
+def cpu_baseline(args, geo, GM_c3):
+    """The oracle's torch-CPU restatement (5 un-fused GEMMs + autograd + Adam, float32, all host
+    threads: the analogue of the reference's XLA-CPU execution) on a bounded sample of the workload."""
+    from oracle import oracle_np as onp
+    from oracle import oracle_torch as ot
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    R = args.image * args.image
+    nr = min(args.cpu_rays, R)
+    t = lambda v: torch.tensor(np.ascontiguousarray(v), dtype=torch.float32)
+    sub = lambda v: t(v.reshape((-1,) + v.shape[-1:])[:nr].reshape(nr, 1, -1))
+    geom = dict(coords=torch.stack([sub(geo['coords'][i]) for i in range(3)]), Omega=sub(geo['Omega']),
+                t_geos=sub(geo['t_geos']), g=sub(geo['g']), dtau=sub(geo['dtau']), Sigma=sub(geo['Sigma']), J=None,
+                t_start_obs=0.0, t_injection=float(geo['t_injection']))
+    hp = dict(GM_c3=GM_c3, scale=args.fov / 2, rmin=0.0, rmax=float('inf'), z_width=float('inf'), posenc_deg=3,
+              net_depth=args.depth)
+    rng = np.random.default_rng(1)
+    tree = onp.he_uniform_params(rng, args.depth, args.width, 21)
+    ks, bs = ot.tree_to_lists(tree, torch.float32)
+    tr = ot.CpuTrainer(ks, bs, geom, hp, num_iters=1000)
+    tf = torch.tensor([0.3], dtype=torch.float32)
+    target = torch.zeros((1, nr, 1)); sigma = torch.ones((1, nr, 1))
+    tr.step(tf, target, sigma, target, 1.0, 'full')                      # warm-up
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        tr.step(tf, target, sigma, target, 1.0, 'full')
+        times.append(time.perf_counter() - t0)
+    dt = float(np.median(times))
+    return {'value': nr * args.ngeo / dt, 'unit': 'ray-samples/s', 'cores': ncores, 'kind': 'port',
+            'sample': '1 frame x %d rays x %d samples, 4x%d MLP, float32 torch-CPU fwd+bwd+Adam, median of 3 steps (%.2f s/step)'
+                      % (nr, args.ngeo, args.width, dt)}
+
+
+def main():
+    args = parse()
+    args.fov = 16.0
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a HIP device (no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    from bhnerf_amd import _hip, constants, engine, network, optimization, synthetic, units
+    H = W = args.image
+    G, nt = args.ngeo, args.frames
+    geo = synthetic.synthetic_geodesics(H, W, G, fov_M=args.fov, inc_deg=60.0, seed=0)
+    GM_c3 = constants.GM_c3('hr')
+    t_frames = np.linspace(0.0, 1.0, nt)
+    rmax = args.fov / 2
+    if args.masked:
+        pred = network.NeRF_Predictor(rmax, 6.0 * 0 + 2.0, rmax, 4.0, net_depth=args.depth, net_width=args.width,
+                                      mode=args.mode, device=dev)
+    else:
+        pred = network.NeRF_Predictor(rmax, 0.0, np.inf, np.inf, net_depth=args.depth, net_width=args.width,
+                                      mode=args.mode, device=dev)
+    rt_args = network.raytracing_args(
+        dict(x=geo['coords'][0], y=geo['coords'][1], z=geo['coords'][2], dtau=geo['dtau'], Sigma=geo['Sigma'],
+             t=geo['t_geos'], g=geo['g']), geo['Omega'], geo['t_injection'], 0.0 * units.hr, J=1.0)
+    target = synthetic.hotspot_movie(geo, t_frames[::max(1, nt // 8)], GM_c3)     # a few distinct frames,
+    target = np.ascontiguousarray(np.resize(target, (nt, H, W)))                   # tiled over the movie
+    train_step = optimization.TrainStep.image(t_frames * units.hr, target, sigma=1.0, dtype='full')
+    opt = optimization.Optimizer({'num_iters': 5000, 'lr_init': 1e-4, 'lr_final': 1e-6, 'seed': 1}, pred, rt_args)
+    batch = args.frames_per_gpu * world
+    assert batch <= nt, 'frames per step exceed the movie length'
+
+    def one_step():
+        idx = train_step.args[0].sample(batch)
+        opt.loss, opt.state, _ = train_step(opt.state, rt_args, indices=idx)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_step = 1e3 * elapsed / args.steps
+    samples_step = batch * H * W * G
+    value = samples_step / (elapsed / args.steps)
+    loss_now = float(torch.as_tensor(opt.loss).float().mean())
+
+    # ---- per-kernel timing of one rank's share (HIP events on the launch stream) ----------------
+    eng = pred.engine()
+    geom = pred.geometry(rt_args['coords'], rt_args['Omega'], rt_args['t_geos'], None, rt_args['g'], rt_args['dtau'],
+                         rt_args['Sigma'])
+    tM0 = engine.frame_offsets(t_frames[:args.frames_per_gpu], 0.0, geo['t_injection'], GM_c3, dev)
+    dimg = torch.rand((args.frames_per_gpu, 1, geom.R), device=dev) * 1e-3
+    eng.pack(opt.state.flat)
+
+    def timed(fn, reps=5):
+        fn(); torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for a, b in ev:
+            a.record(); fn(); b.record()
+        torch.cuda.synchronize()
+        return float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    lib = _hip.lib()
+    kern_ms = {'fused_fwd_kernel': timed(lambda: eng.render(geom, tM0))}
+    for name, mask in (('chain_kernel', 1), ('dw_kernel', 2), ('reduce_kernel', 4)):
+        lib.bhn_debug_set_bwd_stages(mask)
+        kern_ms[name] = timed(lambda: eng.render_bwd(geom, tM0, dimg))
+    lib.bhn_debug_set_bwd_stages(7)
+    pts = args.frames_per_gpu * geom.P * geom.active_fraction
+    f_fwd, f_chain, f_dw, f_train = mlp_flops(args.depth, args.width)
+    alg = {'fused_fwd_kernel': f_fwd, 'chain_kernel': f_chain, 'dw_kernel': f_dw}
+    dom = max(alg, key=lambda k: kern_ms[k])
+    achieved = alg[dom] * pts / (kern_ms[dom] * 1e-3) / 1e12
+    peak = PEAK_TFLOPS[args.mode]
+    roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
+                'frac': round(achieved / peak, 4), 'traffic': None,
+                'kernel_ms': {k: round(v, 4) for k, v in kern_ms.items()},
+                'step_algorithmic_tflops': round(f_train * value * geom.active_fraction / 1e12 / world, 2)}
+
+    out = {
+        'metric': 'train ray-samples/sec, 128x128x64-sample image-plane recovery', 'value': value,
+        'unit': 'ray-samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': ms_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': args.mode, 'data': 'synthetic',
+        'config': {'workload': 'Tutorial3 image-plane recovery: %dx%d rays x %d samples, %d frames, %dx%d MLP, loss full'
+                               % (H, W, G, nt, args.depth, args.width),
+                   'frames_per_step': batch, 'frames_per_gpu': args.frames_per_gpu, 'parallelism': 'dp%d (time-frames)' % world,
+                   'active_fraction': round(geom.active_fraction, 4), 'loss': loss_now},
+        'roofline': roofline,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(args, geo, GM_c3)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

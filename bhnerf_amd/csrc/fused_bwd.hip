@@ -483,6 +483,13 @@ int fused_fill_args(const bhn_model *m, int32_t mode, const void *packed, const 
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// measurement aid: bit 0 chain kernel, bit 1 dW kernel, bit 2 reduce kernel (default all)
+static thread_local int g_bwd_stages = 7;
+extern "C" int bhn_debug_set_bwd_stages(int32_t mask) {
+    g_bwd_stages = mask & 7;
+    return BHN_OK;
+}
+
 template <int W, class Pol>
 static void tape_layout(int depth, long long NQ, TapeLayout *t) {
     using BG = BwdGeom<W, Pol>;
@@ -599,12 +606,12 @@ static int bwd_run(const bhn_model *m, int32_t mode, const void *packed, const b
         A.accumulate = pass > 0;
         long long grid = ncu;
         if (grid > A.f.total_tiles) grid = A.f.total_tiles;
-        hipLaunchKernelGGL(kchain, dim3((unsigned)grid), dim3(Pol::NTHREADS), lds_chain, st, A);
+        if (g_bwd_stages & 1) hipLaunchKernelGGL(kchain, dim3((unsigned)grid), dim3(Pol::NTHREADS), lds_chain, st, A);
         BHN_HIP(hipGetLastError());
-        hipLaunchKernelGGL(kdw, dim3((unsigned)A.wg_begin[depth + 1]), dim3(Pol::NTHREADS), lds_dw, st, A);
+        if (g_bwd_stages & 2) hipLaunchKernelGGL(kdw, dim3((unsigned)A.wg_begin[depth + 1]), dim3(Pol::NTHREADS), lds_dw, st, A);
         BHN_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL((reduce_kernel<W, Pol>), dim3(256), dim3(256), 0, st, A);
+    if (g_bwd_stages & 4) hipLaunchKernelGGL((reduce_kernel<W, Pol>), dim3(256), dim3(256), 0, st, A);
     BHN_HIP(hipGetLastError());
     return BHN_OK;
 }

@@ -10,6 +10,8 @@ except Exception:  # astropy absent (this image): minimal stand-in
     HAVE_ASTROPY = False
 
     class Unit:
+        __array_ufunc__ = None          # let ndarray * unit defer to Unit.__rmul__
+
         def __init__(self, name, in_hr):
             self.name, self.in_hr = name, float(in_hr)
 
@@ -25,12 +27,16 @@ except Exception:  # astropy absent (this image): minimal stand-in
         def __rmul__(self, value):
             return Quantity(value, self)
 
+        __mul__ = __rmul__
+
         def __repr__(self):
             return 'Unit("%s")' % self.name
 
         __str__ = lambda self: self.name
 
     class Quantity:
+        __array_ufunc__ = None
+
         def __init__(self, value, unit):
             self.value = np.asarray(value, dtype=np.float64) if not np.isscalar(value) else float(value)
             self.unit = unit

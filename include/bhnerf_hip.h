@@ -130,6 +130,10 @@ int bhn_chi2_image(const float *images, const float *target, const float *sigma,
 int bhn_adam_step(float *params, const float *grads, float *m, float *v, int64_t n, int64_t t, float lr,
                   float b1, float b2, float eps, float grad_scale, void *stream);
 
+/* Measurement aid (bench.py): run only some kernels of bhn_render_bwd on this thread.
+ * bit 0 = chain kernel, bit 1 = dW GEMM kernel, bit 2 = slab reduction; default 7. */
+int bhn_debug_set_bwd_stages(int32_t mask);
+
 /* Device self-checks of the MFMA / LDS-transpose lane maps the kernels rely on (exact integer
  * data).  results: 8 int32 mismatch counts on the host, all 0 when the maps hold. */
 int bhn_selftest(int32_t *results_host);
