@@ -62,7 +62,10 @@ def cpu_baseline(args, geo, GM_c3):
     threads: the analogue of the reference's XLA-CPU execution) on a bounded sample of the workload."""
     from oracle import oracle_np as onp
     from oracle import oracle_torch as ot
-    ncores = os.cpu_count() or 1
+    try:
+        ncores = len(os.sched_getaffinity(0))      # cores this process may actually use
+    except AttributeError:
+        ncores = os.cpu_count() or 1
     torch.set_num_threads(ncores)
     R = args.image * args.image
     nr = min(args.cpu_rays, R)

@@ -28,6 +28,7 @@ struct BwdArgs {
     // dW jobs: job j = layer j (0..depth), workgroups [wg_begin[j], wg_begin[j+1])
     int wg_begin[BHN_MAX_LAYERS + 2];
     int accumulate;                            // 1: add to what the slabs already hold
+    int debug;                                 // measurement aid: 1 skip MFMA work, 2 skip tape loads
     float *dparams;
     long long kernel_off[BHN_MAX_LAYERS + 1], bias_off[BHN_MAX_LAYERS + 1];
     int in_dim[BHN_MAX_LAYERS + 1];
@@ -54,6 +55,10 @@ struct BwdGeom {
     static constexpr int ROW_BYTES = 32 * Pol::ELEM_BYTES + 16;
     static constexpr int SCR_BYTES = 32 * ROW_BYTES;
     static constexpr int GROUP_BYTES = (2 * MT + 1) * TILE_BYTES;   // A tiles + h tiles + enc tile
+    // dW kernel, bf16: LDS-DMA ring of NBUF groups (counted vmcnt, raw s_barrier); f32: 2 buffers
+    static constexpr int NBUF = (Pol::ELEM_BYTES == 2) ? ((160 * 1024) / GROUP_BYTES >= 4 ? 4 : 3) : 2;
+    static constexpr int NPIECE = GROUP_BYTES / 1024;               // 1 KiB = one wave-wide 16-B DMA
+    static constexpr int PPW = (NPIECE + Pol::NWAVES - 1) / Pol::NWAVES;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -313,111 +318,165 @@ struct GroupStager {
     }
 };
 
-template <int W, class Pol>
-__global__ __launch_bounds__(Pol::NTHREADS) void dw_kernel(BwdArgs A) {
+// Job types of the dW kernel (compile-time so that the streaming loop is straight-line code)
+enum { JT_FIRST = 0, JT_HIDDEN = 1, JT_SKIP = 2, JT_OUT = 3 };
+
+template <int W, class Pol, int JT>
+DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
     using BG = BwdGeom<W, Pol>;
     using frag = typename Pol::frag;
-    constexpr int MT = BG::MT, TB = BG::TILE_BYTES;
-    constexpr int GB = BG::GROUP_BYTES;
-    constexpr int UNITS = GB / 16;
-    // LDS group image: [A tiles: MT][h tiles: MT][enc tile]
-    constexpr int OFF_H = MT * TB, OFF_E = 2 * MT * TB;
-    const int depth = A.f.depth;
-    extern __shared__ __attribute__((aligned(16))) char smem[];       // 2 x GB
+    constexpr int MT = BG::MT, TB = BG::TILE_BYTES, GB = BG::GROUP_BYTES;
+    constexpr int OFF_H = MT * TB, OFF_E = 2 * MT * TB;               // LDS group image [A][h][enc]
+    constexpr bool out_job = JT == JT_OUT, has_h = JT != JT_FIRST, has_enc = (JT == JT_FIRST || JT == JT_SKIP);
+    constexpr int mtA = out_job ? 1 : MT;                              // A tiles (gA rows; dout is 1 row)
+    constexpr int nH = has_h ? MT : 0, nB = nH + (has_enc ? 1 : 0);    // B tiles; tile nB is the ones tile
+    constexpr int NT = nB + 1;
+    constexpr int WRR = BG::WRR, WCC = BG::WCC, MPW = BG::MPW;
+    constexpr int NPWJ = (NT + WCC - 1) / WCC;                         // B tiles owned by one wave
+    constexpr int NPASS = (NPWJ + 4) / 5, NPW = (NPWJ + NPASS - 1) / NPASS;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, i31 = lane & 31, h = lane >> 5;
-
-    int job = 0;
-    while (job < depth && (int)blockIdx.x >= A.wg_begin[job + 1]) ++job;
     const int nwg = A.wg_begin[job + 1] - A.wg_begin[job];
     const int kb = blockIdx.x - A.wg_begin[job];
     const long long q0 = A.t.NQ * kb / nwg, q1 = A.t.NQ * (kb + 1) / nwg;
-
-    // operands of this job: A = gA_job (or dout for the output layer), B = inputs of layer `job`
-    const bool out_job = job == depth;
-    const bool has_h = job >= 1;
-    const bool has_enc = job == 0 || ((A.f.skip_mask >> job) & 1);
-    const int mtA = out_job ? 1 : MT;
-    const int nH = has_h ? MT : 0;
-    const int nB = nH + (has_enc ? 1 : 0);                             // real B tiles; tile nB = ones
-    const char *srcA = out_job ? nullptr : A.tape + A.t.ga_off[job];
+    const char *srcA = out_job ? nullptr : A.tape + A.t.ga_off[out_job ? 0 : job];
     const char *srcH = has_h ? A.tape + A.t.h_off[job] : nullptr;
     const char *srcE = A.tape + A.t.enc_off;
     const float *srcD = reinterpret_cast<const float *>(A.tape + A.t.dout_off);
-
-    GroupStager<UNITS, Pol::NTHREADS, OFF_H, OFF_E, MT * TB, TB> gs;
-    gs.out_job = out_job; gs.has_h = has_h; gs.srcA = srcA; gs.srcH = srcH; gs.srcE = srcE; gs.srcD = srcD;
-#define load_group(q) gs.load(q)
-#define store_group(dst) gs.store(dst)
-    const int wr = wv % BG::WRR, wc = wv / BG::WRR;
+    const int wr = wv % WRR, wc = wv / WRR;
     frag ones;
 #pragma unroll
     for (int j = 0; j < 8; ++j) Pol::set(ones, j, 1.f);
     float *slab = A.f.slabs + (long long)blockIdx.x * BG::SLAB_FLOATS;
-    // bf16: the next group is prefetched into registers while this one is consumed; f32 (parity
-    // mode, 17 pieces per thread) copies without overlap to stay inside the register file
-    constexpr bool PREFETCH = Pol::ELEM_BYTES == 2;
 
-    // a wave owns MPW A-tiles x NPW_ALL B-tiles of dW^T; they are accumulated NPW at a time
-    // (NPASS sweeps over the K range; NPASS = 1 in bf16 mode)
-    for (int pass = 0; pass < BG::NPASS; ++pass) {
-        const int nbase = wc * BG::NPW_ALL + pass * BG::NPW;
-        const int nend = (wc + 1) * BG::NPW_ALL;
-        f32x16 acc[BG::MPW][BG::NPW];
+    for (int pass = 0; pass < NPASS; ++pass) {
+        const int nbase = wc * NPWJ + pass * NPW;
+        // per-tile LDS offsets and "ones" flags, fixed for the whole stream (no branches in the loop)
+        int boff[NPW];
+        bool bones[NPW];
+        unsigned bkeep[NPW], bone[NPW];
 #pragma unroll
-        for (int mi = 0; mi < BG::MPW; ++mi)
+        for (int ni = 0; ni < NPW; ++ni) {
+            const int n = nbase + ni;
+            boff[ni] = (n < nH) ? OFF_H + n * TB : (has_enc ? OFF_E : OFF_H);
+            bones[ni] = n >= nB;
+            bkeep[ni] = bones[ni] ? 0u : 0xFFFFFFFFu;
+            bone[ni] = bones[ni] ? 0x3F803F80u : 0u;           // two bf16 1.0
+        }
+        f32x16 acc[MPW][NPW];
 #pragma unroll
-            for (int ni = 0; ni < BG::NPW; ++ni)
+        for (int mi = 0; mi < MPW; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NPW; ++ni)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
         __syncthreads();
-        if (q0 < q1) {
-            load_group(q0);
-            store_group(smem);
-        }
-        __syncthreads();
-        int par = 0;
-        for (long long q = q0; q < q1; ++q) {
-            if (PREFETCH && q + 1 < q1) load_group(q + 1);
-            const char *gp = smem + par * GB;
+        auto compute_group = [&](const char *gp) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                frag af[BG::MPW];
+                frag af[MPW];
 #pragma unroll
-                for (int mi = 0; mi < BG::MPW; ++mi) {
-                    const int m = wr * BG::MPW + mi;
-                    if (out_job) {   // A[row 0][k = point] = dout, other rows zero
+                for (int mi = 0; mi < MPW; ++mi) {
+                    if constexpr (out_job) {   // A[row 0][k = point] = dout, other rows zero
                         const float *dv = reinterpret_cast<const float *>(gp);
 #pragma unroll
                         for (int j = 0; j < 8; ++j) Pol::set(af[mi], j, i31 == 0 ? dv[16 * s + 8 * h + j] : 0.f);
-                    } else af[mi] = Pol::lds_frag(gp + (m < MT ? m : 0) * TB, s, lane);
+                    } else af[mi] = Pol::lds_frag(gp + (wr * MPW + mi) * TB, s, lane);
                 }
 #pragma unroll
-                for (int ni = 0; ni < BG::NPW; ++ni) {
-                    const int n = nbase + ni;
-                    if (n > nB || n >= nend) continue;
-                    frag bf;
-                    if (n < nH) bf = Pol::lds_frag(gp + OFF_H + n * TB, s, lane);
-                    else if (n < nB) bf = Pol::lds_frag(gp + OFF_E, s, lane);
-                    else bf = ones;
+                for (int ni = 0; ni < NPW; ++ni) {
+                    frag bf = Pol::lds_frag(gp + boff[ni], s, lane);
+                    if constexpr (Pol::ELEM_BYTES == 2) {   // ones tile: (bits & 0) | bf16x2(1,1), one op per dword
+                        u32x4 bits = __builtin_bit_cast(u32x4, bf);
 #pragma unroll
-                    for (int mi = 0; mi < BG::MPW; ++mi)
-                        if (wr * BG::MPW + mi < mtA) acc[mi][ni] = Pol::mma(af[mi], bf, acc[mi][ni]);
+                        for (int d = 0; d < 4; ++d) bits[d] = (bits[d] & bkeep[ni]) | bone[ni];
+                        bf = __builtin_bit_cast(frag, bits);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) Pol::set(bf, j, bones[ni] ? 1.f : Pol::get(bf, j));
+                    }
+#pragma unroll
+                    for (int mi = 0; mi < MPW; ++mi) acc[mi][ni] = Pol::mma(af[mi], bf, acc[mi][ni]);
                 }
             }
-            if (q + 1 < q1) {
-                if (!PREFETCH) load_group(q + 1);
-                store_group(smem + (par ^ 1) * GB);
+        };
+        if constexpr (Pol::ELEM_BYTES == 2) {
+            // LDS-DMA ring: group q+NBUF-1 is issued right after the barrier that proves buffer
+            // (q-1)%NBUF has been consumed; the counted wait leaves NBUF-2 younger groups in flight.
+            constexpr int NBUF = BG::NBUF, PPW = BG::PPW;
+            const int wvu = __builtin_amdgcn_readfirstlane(wv);
+            const char *sbase[PPW];
+            long long sstride[PPW];
+            int doff[PPW];
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) {
+                int piece = wvu + Pol::NWAVES * i;
+                piece = piece < BG::NPIECE ? piece : BG::NPIECE - 1;
+                const int off = piece * 1024;
+                doff[i] = off;
+                if (off < OFF_H) {
+                    sbase[i] = out_job ? reinterpret_cast<const char *>(srcD) : srcA + off;
+                    sstride[i] = out_job ? 128 : (long long)MT * TB;
+                } else if (off < OFF_E) {
+                    sbase[i] = has_h ? srcH + (off - OFF_H) : srcE + ((off - OFF_H) % TB);
+                    sstride[i] = has_h ? (long long)MT * TB : TB;
+                } else {
+                    sbase[i] = srcE + (off - OFF_E);
+                    sstride[i] = TB;
+                }
+                sbase[i] += lane * 16;
+            }
+            auto issue = [&](long long q, char *buf) {
+                q = q < q1 ? q : q1 - 1;
+#pragma unroll
+                for (int i = 0; i < PPW; ++i)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(sbase[i] + q * sstride[i]),
+                                                     (__attribute__((address_space(3))) void *)(buf + doff[i]), 16, 0, 0);
+            };
+            if (q0 < q1) {
+#pragma unroll
+                for (int j = 0; j < NBUF - 1; ++j) issue(q0 + j, smem + j * GB);
+                int it = 0;
+                for (long long q = q0; q < q1; ++q) {
+                    if (!(A.debug & 2)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * PPW) : "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");      // the raw barrier is not a compiler fence: keep the
+                                                         // DMA issue and the ds_reads below it
+                    const int nx = (it == 0) ? NBUF - 1 : it - 1;
+                    if (!(A.debug & 2)) issue(q + NBUF - 1, smem + nx * GB);
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (!(A.debug & 1)) compute_group(smem + it * GB);
+                    it = (it == NBUF - 1) ? 0 : it + 1;
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        } else {
+            // f32 (parity mode): plain double buffer through registers, no overlap
+            constexpr int UNITS = GB / 16;
+            GroupStager<UNITS, Pol::NTHREADS, OFF_H, OFF_E, MT * TB, TB> gs;
+            gs.out_job = out_job; gs.has_h = has_h; gs.srcA = srcA; gs.srcH = srcH; gs.srcE = srcE; gs.srcD = srcD;
+            if (q0 < q1) {
+                gs.load(q0);
+                gs.store(smem);
             }
             __syncthreads();
-            par ^= 1;
+            int par = 0;
+            for (long long q = q0; q < q1; ++q) {
+                compute_group(smem + par * GB);
+                if (q + 1 < q1) {
+                    gs.load(q + 1);
+                    gs.store(smem + (par ^ 1) * GB);
+                }
+                __syncthreads();
+                par ^= 1;
+            }
         }
         // ---- flush this pass's partial dW^T tiles: slab[(m*NTMAX+n)][r/4][lane][r%4] ------------
 #pragma unroll
-        for (int mi = 0; mi < BG::MPW; ++mi)
+        for (int mi = 0; mi < MPW; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < BG::NPW; ++ni) {
-                const int m = wr * BG::MPW + mi, n = nbase + ni;
-                if (m >= mtA || n > nB || n >= nend) continue;
+            for (int ni = 0; ni < NPW; ++ni) {
+                const int m = wr * MPW + mi, n = nbase + ni;
+                if (m >= mtA || n > nB || n >= (wc + 1) * NPWJ) continue;
                 float *tp = slab + (long long)(m * BG::NTMAX + n) * 1024;
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
@@ -434,8 +493,18 @@ __global__ __launch_bounds__(Pol::NTHREADS) void dw_kernel(BwdArgs A) {
                 }
             }
     }
-#undef load_group
-#undef store_group
+}
+
+template <int W, class Pol>
+__global__ __launch_bounds__(Pol::NTHREADS) void dw_kernel(BwdArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];       // NBUF x GROUP_BYTES
+    const int depth = A.f.depth;
+    int job = 0;
+    while (job < depth && (int)blockIdx.x >= A.wg_begin[job + 1]) ++job;
+    if (job == depth) dw_body<W, Pol, JT_OUT>(A, job, smem);
+    else if (job == 0) dw_body<W, Pol, JT_FIRST>(A, job, smem);
+    else if ((A.f.skip_mask >> job) & 1) dw_body<W, Pol, JT_SKIP>(A, job, smem);
+    else dw_body<W, Pol, JT_HIDDEN>(A, job, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -485,8 +554,10 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // measurement aid: bit 0 chain kernel, bit 1 dW kernel, bit 2 reduce kernel (default all)
 static thread_local int g_bwd_stages = 7;
+static thread_local int g_bwd_debug = 0;
 extern "C" int bhn_debug_set_bwd_stages(int32_t mask) {
     g_bwd_stages = mask & 7;
+    g_bwd_debug = (mask >> 3) & 3;       // bit 3: dW kernel without MFMA work, bit 4: without tape loads
     return BHN_OK;
 }
 
@@ -501,7 +572,7 @@ static void tape_layout(int depth, long long NQ, TapeLayout *t) {
     for (int l = 0; l < depth; ++l) { t->ga_off[l] = off; off += per_tensor; }
     t->enc_off = off; off += NQ * (long long)BG::TILE_BYTES;
     t->dout_off = off; off += NQ * 128;
-    t->total = (long long)align_up((size_t)off + 256, 256);      // +256: tail pieces may re-read past the end
+    t->total = (long long)align_up((size_t)off + 1024, 256);     // +1 KiB: the last dout piece is DMA'd as a full KiB
 }
 
 template <int W, class Pol>
@@ -558,13 +629,14 @@ static int bwd_run(const bhn_model *m, int32_t mode, const void *packed, const b
     A.F = s.F;
     for (int l = 0; l <= depth; ++l) { A.kernel_off[l] = s.kernel_off[l]; A.bias_off[l] = s.bias_off[l]; A.in_dim[l] = s.in_dim[l]; }
     A.kernel_off[depth + 1] = s.nparams;
-    // dW jobs: workgroups proportional to MFMA work (A tiles x B tiles incl. the ones tile)
+    // dW jobs: the kernel is a stream over the tape (HBM-bound), so every layer gets workgroups in
+    // proportion to the bytes it reads per 32-point group (A tiles + B tiles), not to its MFMA count
     {
         double work[BHN_MAX_LAYERS + 1], tot = 0;
         for (int l = 0; l <= depth; ++l) {
-            const int mtA = (l == depth) ? 1 : BG::MT;
+            const int mtA = (l == depth) ? 0 : BG::MT;
             const int nB = (l >= 1 ? BG::MT : 0) + ((l == 0 || s.skip_in[l]) ? 1 : 0);
-            work[l] = (double)mtA * (nB + 1) + 2.0 * (mtA + nB);    // + streaming cost of the operands
+            work[l] = (double)(mtA + nB) + 0.5;
             tot += work[l];
         }
         int used = 0;
@@ -584,7 +656,7 @@ static int bwd_run(const bhn_model *m, int32_t mode, const void *packed, const b
     }
     const size_t lds_chain = 2 * PK::CHUNK_BYTES + (size_t)(depth + 1) * W * 4 + W * 4 + Pol::NWAVES * BG::SCR_BYTES +
                              (size_t)Pol::NWAVES * depth * ((BG::MT + 1) / 2) * 64 * 4;
-    const size_t lds_dw = 2 * BG::GROUP_BYTES;
+    const size_t lds_dw = (size_t)BG::NBUF * BG::GROUP_BYTES;
     auto kchain = chain_kernel<W, Pol, 3>;
     auto kdw = dw_kernel<W, Pol>;
     static bool attr_done = false;
@@ -604,6 +676,7 @@ static int bwd_run(const bhn_model *m, int32_t mode, const void *packed, const b
         A.f.total_tiles = (long long)A.f.tiles_per_frame * nb;
         tape_layout<W, Pol>(depth, A.f.total_tiles * Pol::NWAVES, &A.t);
         A.accumulate = pass > 0;
+        A.debug = g_bwd_debug;
         long long grid = ncu;
         if (grid > A.f.total_tiles) grid = A.f.total_tiles;
         if (g_bwd_stages & 1) hipLaunchKernelGGL(kchain, dim3((unsigned)grid), dim3(Pol::NTHREADS), lds_chain, st, A);

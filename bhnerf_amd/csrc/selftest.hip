@@ -2,6 +2,7 @@
 //   [0] v_mfma_f32_32x32x16_bf16 A/B/C maps   [1] v_mfma_f32_32x32x2_f32 maps
 //   [2] accumulator -> next B operand chaining (phi16 order), bf16     [3] same, f32
 //   [4] ds_read_b64_tr_b16 as a [k][n] -> B-operand transposed read
+//   [5]/[6] global_load_lds_dwordx4 (LDS-DMA) lane placement, destinations below / above 64 KiB
 #include "fused_common.h"
 
 DEVI int ia(int i, int k) { return ((i * 3 + k * 5) % 7) - 3; }   // asymmetric integer operands
@@ -94,6 +95,30 @@ __global__ void selftest_kernel(int *res, short *dump) {
     }
 }
 
+// ---- [5],[6] LDS-DMA (global_load_lds_dwordx4): lane i's 16 bytes land at base + 16*i; destinations
+//      below and above 64 KiB; counted vmcnt + barrier publish them to the other waves
+__global__ void selftest_dma_kernel(const unsigned *src, int *res) {
+    extern __shared__ __attribute__((aligned(16))) char dsm[];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nw = blockDim.x >> 6;
+    // wave w copies KiB w of src to LDS offset 1024*w (low) and 96 KiB + 1024*w (high)
+    for (int rep = 0; rep < 2; ++rep) {
+        char *dst = dsm + (rep ? 96 * 1024 : 0) + wv * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(src) + wv * 1024 + lane * 16),
+                                         (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    int bad_lo = 0, bad_hi = 0;
+    for (int i = threadIdx.x; i < nw * 256; i += blockDim.x) {
+        bad_lo += reinterpret_cast<const unsigned *>(dsm)[i] != src[i];
+        bad_hi += reinterpret_cast<const unsigned *>(dsm + 96 * 1024)[i] != src[i];
+    }
+    atomicAdd(res + 5, bad_lo);
+    atomicAdd(res + 6, bad_hi);
+}
+
 extern "C" int bhn_selftest(int32_t *results_host) {
     BHN_CHECK_ARG(results_host, "null results");
     int *d_res = nullptr;
@@ -103,6 +128,18 @@ extern "C" int bhn_selftest(int32_t *results_host) {
     BHN_HIP(hipMemset(d_res, 0, 8 * sizeof(int)));
     hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, 0, d_res, d_dump);
     BHN_HIP(hipGetLastError());
+    {
+        unsigned *d_src = nullptr;
+        BHN_HIP(hipMalloc(&d_src, 8 * 1024));
+        unsigned hsrc[2048];
+        for (int i = 0; i < 2048; ++i) hsrc[i] = 0x9E3779B9u * (unsigned)(i + 1);
+        BHN_HIP(hipMemcpy(d_src, hsrc, sizeof(hsrc), hipMemcpyHostToDevice));
+        BHN_HIP(hipFuncSetAttribute((const void *)selftest_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL(selftest_dma_kernel, dim3(1), dim3(512), 104 * 1024, 0, d_src, d_res);
+        BHN_HIP(hipGetLastError());
+        BHN_HIP(hipDeviceSynchronize());
+        (void)hipFree(d_src);
+    }
     BHN_HIP(hipMemcpy(results_host, d_res, 8 * sizeof(int), hipMemcpyDeviceToHost));
     short dump[512];
     BHN_HIP(hipMemcpy(dump, d_dump, sizeof(dump), hipMemcpyDeviceToHost));

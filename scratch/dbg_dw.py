@@ -1,0 +1,24 @@
+import sys, numpy as np, torch
+sys.path.insert(0, '/root/repo')
+from bhnerf_amd import _hip, engine, network, synthetic, constants
+dev = torch.device('cuda:0')
+H = W = 128; G = 64; B = 8
+geo = synthetic.synthetic_geodesics(H, W, G)
+pred = network.NeRF_Predictor(8.0, 0.0, np.inf, np.inf, net_depth=4, net_width=256, mode='bf16', device=dev)
+eng = pred.engine()
+geom = pred.geometry(geo['coords'], geo['Omega'], geo['t_geos'], None, geo['g'], geo['dtau'], geo['Sigma'])
+flat = eng.flatten(network.MLP(4, 256).init(1, 21)); eng.pack(flat)
+tM0 = engine.frame_offsets(np.linspace(0, 1, B), 0.0, geo['t_injection'], constants.GM_c3('hr'), dev)
+dimg = torch.rand((B, 1, geom.R), device=dev) * 1e-3
+def timed(fn, reps=4):
+    fn(); torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in ev:
+        a.record(); fn(); b.record()
+    torch.cuda.synchronize()
+    return float(np.mean([a.elapsed_time(b) for a, b in ev]))
+lib = _hip.lib()
+lib.bhn_debug_set_bwd_stages(7); eng.render_bwd(geom, tM0, dimg)
+for name, mask in (('chain', 1), ('dw full', 2), ('dw no-mfma', 2 | 8), ('dw no-loads', 2 | 16), ('dw neither', 2 | 24)):
+    lib.bhn_debug_set_bwd_stages(mask)
+    print(name, '%.3f ms' % timed(lambda: eng.render_bwd(geom, tM0, dimg)))

@@ -30,7 +30,7 @@ def run(width, depth, S, H=9, Wd=7, G=50, B=3):
     target = rng.uniform(0, 1e-3, shape); sigma = rng.uniform(0.5, 2.0, shape); offset = np.zeros(shape)
     loss_ref, img_ref, grads_ref = tr.loss_and_grad(t(t_frames), t(target), t(sigma), t(offset), 1.0, 'full')
     n = len(tr.k)
-    pred, rt = T.device_setup(g, 'f32', dev)
+    pred, rt = T.device_setup(g, 'bf16', dev)
     eng = pred.engine()
     params = eng.flatten(golden_tree(g)).requires_grad_(True)
     ptree = network.ParamTree(); ptree.flat = params
@@ -46,4 +46,6 @@ def run(width, depth, S, H=9, Wd=7, G=50, B=3):
         print('W%d D%d S%d layer %d: kernel err %.2e (at %s, ref %.3e dev %.3e) bias err %.2e | rows-err max by in-block: %s' % (
             width, depth, S, i, ek.max() / gmax, w, grads_ref[i].numpy()[w], k[w], eb.max() / gmax,
             ['%.1e' % (ek[j:j + 32].max() / gmax) for j in range(0, ek.shape[0], 32)]))
-run(128, 4, 3); run(128, 4, 0); run(128, 4, 3, G=64)
+import sys as _s
+MODE = 'bf16'
+run(32, 4, 0); run(256, 4, 0)

@@ -3,8 +3,8 @@ loss_fn_image against (i) torch.autograd on the float64 oracle and (ii) the fini
 the REFERENCE's own loss_fn_image stored in the golden fixtures; Adam training steps against the
 oracle trainer; workspace frame-chunking.
 
-Tolerances (error / largest gradient entry, and relative L2): f32 mode L2 1e-4, max 1e-3; bf16 mode
-L2 3e-2, max 1.5e-1 (bf16 activations / deltas on the tape, f32 accumulate; the tiny fixtures have
+Tolerances (error / largest gradient entry, and relative L2): f32 mode L2 5e-4, max 1e-3; bf16 mode
+L2 5e-2, max 1.5e-1 (bf16 activations / deltas on the tape, f32 accumulate; the tiny fixtures have
 only ~100 points to average over).  The max-norm bound is looser than the typical 1e-7..1e-6 f32
 error because a ReLU-net gradient is discontinuous: when one pre-activation lies within f32 rounding
 of zero, f32 and f64 disagree on relu' for that (point, unit) and every layer below it changes by that
@@ -20,7 +20,7 @@ from oracle import oracle_torch as ot
 pytestmark = pytest.mark.gpu
 PRED = ['a', 'b', 'c', 'd', 'e', 'f']
 GTOL = {'f32': 1e-3, 'bf16': 1.5e-1}       # max-norm
-L2TOL = {'f32': 1e-4, 'bf16': 3e-2}        # relative L2
+L2TOL = {'f32': 5e-4, 'bf16': 5e-2}        # relative L2
 
 
 def l2err(a, b):
