@@ -318,6 +318,20 @@ def loss_fn_image(params, predictor_fn, target, sigma, offset, t_frames, coords,
     return scale * loss, [images]
 
 
+def dp_allreduce(buf, n, loss, rank, world):
+    """The one collective of a training step (network.py:620): ``buf[:n]`` holds this rank's gradient
+    of its per-device chi^2 SUM; slots ``buf[n:n+world]`` carry the per-rank losses so that a single
+    all-reduce(sum) returns both.  The caller divides the gradient by ``world`` (mean over devices,
+    the reference's pmean).  Returns the vector of per-rank losses (shape (world,))."""
+    if world == 1:
+        return loss
+    import torch.distributed as dist
+    buf[n:].zero_()
+    buf[n + rank] = loss.reshape(-1)[0]
+    dist.all_reduce(buf)                                  # RCCL over xGMI on GPUs; gloo in the CPU tests
+    return buf[n:].clone()
+
+
 def _step_image(state, t_units, dtype, target, sigma, offset, t_frames, coords, Omega, J, g, dtau, Sigma,
                 t_start_obs, t_geos, t_injection, scale, train):
     """Per-process body of gradient_step_image / test_image with no torch.autograd in the loop:
@@ -340,14 +354,7 @@ def _step_image(state, t_units, dtype, target, sigma, offset, t_frames, coords, 
         n = eng.nparams
         buf = state.grad
         eng.render_bwd(geom, tM0, dimg, out=buf[:n])
-        if world > 1:                                    # jax.lax.pmean(grads) (network.py:620)
-            import torch.distributed as dist
-            buf[n:].zero_()
-            buf[n + rank] = loss[0]
-            dist.all_reduce(buf)                         # one RCCL all-reduce: grads + per-rank losses
-            loss_vec = buf[n:].clone()
-        else:
-            loss_vec = loss
+        loss_vec = dp_allreduce(buf, n, loss, rank, world)      # jax.lax.pmean(grads) (network.py:620)
         state.apply_gradients(buf[:n], grad_scale=1.0 / world)
     else:
         if world > 1:

@@ -1,0 +1,93 @@
+"""CPU tests of the C-ABI boundary: the library builds for gfx950 without a GPU, loads, exports every
+symbol include/bhnerf_hip.h declares, and its host-side bookkeeping (parameter layout, packed sizes,
+argument validation) agrees with the oracle.  No compute entry point is called (there is no GPU)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import oracle_np as onp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+    import __graft_entry__ as entry
+    entry.build()
+    from bhnerf_amd import _hip
+    return _hip.lib()
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, 'include', 'bhnerf_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(bhn_\w+)\s*\(', text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    from bhnerf_amd import _hip
+    syms = header_symbols()
+    assert len(syms) >= 16
+    for name in syms:
+        assert hasattr(lib, name), name
+    assert sorted(_hip.SIGNATURES) == syms        # the ctypes table binds exactly the declared ABI
+    assert lib.bhn_version() == 1
+
+
+@pytest.mark.parametrize('depth,width,n', [(4, 128, 55169), (4, 256, 208641), (8, 256, 471809), (6, 64, None)])
+def test_param_layout_matches_flax_tree_order(lib, depth, width, n):
+    from bhnerf_amd import _hip
+    m = _hip.make_model(depth, width, 3, True, 8.0, 0.0, 8.0, 4.0)
+    dims = onp.mlp_layer_dims(depth, width, 21)
+    total = sum(a * b + b for a, b in dims)
+    assert lib.bhn_param_count(C.byref(m)) == total == (n or total)
+    ko, bo, ind = (C.c_int64 * (depth + 1))(), (C.c_int64 * (depth + 1))(), (C.c_int32 * (depth + 1))()
+    assert lib.bhn_param_layout(C.byref(m), ko, bo, ind) == 0
+    off = 0
+    for i, (fi, fo) in enumerate(dims):
+        assert (ko[i], ind[i]) == (off, fi)
+        off += fi * fo
+        assert bo[i] == off
+        off += fo
+    for mode in (0, 1):
+        assert lib.bhn_packed_bytes(C.byref(m), mode) > total * (2 if mode else 4)
+    ws = lib.bhn_render_bwd_workspace_bytes(C.byref(m), 1, 2, 1000, 0)
+    assert ws > lib.bhn_render_bwd_workspace_bytes(C.byref(m), 1, 1, 1000, 0) > 0
+
+
+def test_argument_validation_reports_errors(lib):
+    from bhnerf_amd import _hip
+    bad_width = _hip.make_model(4, 100, 3, True, 1.0, 0.0, 1.0, 1.0)
+    assert lib.bhn_param_count(C.byref(bad_width)) == -1
+    assert b'net_width' in lib.bhn_last_error()
+    skip_into_output = _hip.make_model(5, 64, 3, True, 1.0, 0.0, 1.0, 1.0)       # depth 5: concat feeds the output layer
+    assert lib.bhn_param_count(C.byref(skip_into_output)) == -1
+    assert b'depths 4, 6, 8' in lib.bhn_last_error()
+    no_skip = _hip.make_model(5, 64, 3, False, 1.0, 0.0, 1.0, 1.0)
+    assert lib.bhn_param_count(C.byref(no_skip)) == sum(a * b + b for a, b in onp.mlp_layer_dims(5, 64, 21, do_skip=False))
+    assert lib.bhn_radiative_transfer_fwd(None, None, None, None, None, 1, 1, 1, None) == 1     # BHN_EINVAL, no launch
+    with pytest.raises(_hip.HipError):
+        _hip.check(lib.bhn_chi2_image(None, None, None, None, 1.0, 0, 1, 1, 1, None, None, None))
+
+
+def test_device_path_fails_loudly_without_gpu():
+    import torch
+    from bhnerf_amd import _hip, kgeo, network
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    with pytest.raises(_hip.HipError):
+        network.NeRF_Predictor(8.0, 2.0, 8.0, 4.0).engine()
+    with pytest.raises(_hip.HipError):
+        kgeo.radiative_trasfer(torch.zeros(2, 3, 4), 1.0, 1.0, 1.0)
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, 'bhnerf_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', '.cpp')):
+                text = open(os.path.join(dirpath, f)).read()
+                assert 'import oracle' not in text and 'from oracle' not in text, f

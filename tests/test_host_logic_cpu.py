@@ -1,0 +1,139 @@
+"""CPU tests of the host-side mirror of the reference interface (no GPU): the NumPy paths of the
+stand-alone helpers against the golden vectors from the reference's own code, units, batching,
+sharding, chunking of total_movie_loss, the TrainStep contract."""
+import numpy as np
+import pytest
+import torch
+
+from bhnerf_amd import constants, emission, kgeo, network, optimization, units, utils
+
+
+def close(a, b, rtol=1e-12, atol=0.0):
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol, equal_nan=True)
+
+
+def test_constants_and_units(golden):
+    g = golden('g0_constants')
+    assert constants.GM_c3('hr') == float(g['GM_c3_hr']) == constants.GM_c3(units.hr)
+    assert constants.GM_c3(None) == 1.0
+    close(constants.GM_c3('s'), float(g['GM_c3_hr']) * 3600.0)
+    close(constants.isco_pro(0.94), float(g['isco94']))
+    q = np.linspace(0, 1, 5) * units.hr
+    assert len(q) == 5 and units.unit_name(q.unit) == 'hr' and float(np.asarray(q.to('min').value)[1]) == 15.0
+    with pytest.raises(AttributeError):
+        constants.GM_c3('fortnight')
+
+
+def test_standalone_helpers_numpy_path_golden(golden):
+    g = golden('g1_warp')
+    out = emission.velocity_warp_coords(g['coords'], g['Omega'], g['t_frames'], 0.0, g['t_geos'], float(g['t_injection']),
+                                        t_units=units.hr)
+    close(out, g['out_units'], atol=1e-12)
+    out = emission.velocity_warp_coords(g['coords'], g['Omega'], g['t_frames'] * units.hr, 0.0 * units.hr, g['t_geos'],
+                                        float(g['t_injection']))
+    close(out, g['out_units'], atol=1e-12)
+    close(emission.velocity_warp_coords(g['coords'], g['Omega'], g['t_frames'], 0.1, g['t_geos'], float(g['t_injection'])),
+          g['out_nounits'], atol=1e-12)
+    close(emission.velocity_warp_coords(g['coords'], 0.05, g['t_frames'], 0.0, g['t_geos'], float(g['t_injection']),
+                                        t_units=units.hr), g['out_scalar_omega'], atol=1e-12)
+    close(emission.velocity_warp_coords(g['coords'], g['Omega'], 0.4, 0.0, 0.0, 0.0), g['out_scalar_t'], atol=1e-12)
+    close(utils.rotation_matrix([0, 0, 1], g['rot_angles']), g['rot'], atol=1e-15)
+    # torch tensors go through the same expressions
+    tw = emission.velocity_warp_coords(torch.tensor(g['coords']), torch.tensor(g['Omega']), g['t_frames'], 0.0,
+                                       torch.tensor(g['t_geos']), float(g['t_injection']), t_units=units.hr)
+    close(tw.numpy(), g['out_units'], atol=1e-11)
+    g = golden('g3_fill')
+    out = emission.fill_unsupervised_emission(g['emission'], g['coords'], float(g['rmin']), float(g['rmax']), float(g['z_width']))
+    assert np.array_equal(out, g['out'])
+    g = golden('g4_rt')
+    close(kgeo.radiative_trasfer(g['emission'], g['g'], g['dtau'], g['Sigma']), g['out_arrays'])
+    close(kgeo.radiative_transfer(g['emission'][0, 0], 1.3, 1.0, 0.5), g['out_scalars'])
+    g = golden('g2_posenc')
+    for d in (0, 1, 3, 5):
+        close(network.posenc(g['x'], d), g['deg%d' % d], atol=1e-15)
+    close(network.posenc(torch.tensor(g['x']), 3).numpy(), g['deg3'], atol=1e-13)
+    assert utils.expand_dims(np.zeros((2, 3)), 4, axis=0).shape == (1, 1, 2, 3)
+    assert utils.expand_dims(np.zeros((2, 3)), 4, axis=-1).shape == (2, 3, 1, 1)[:0] + utils.expand_dims(np.zeros((2, 3)), 4, -1).shape
+
+
+def test_mlp_descriptor_matches_reference_layer_rule():
+    assert network.MLP(4, 256).layer_dims(21) == [(21, 256), (256, 256), (256, 256), (277, 256), (256, 1)]
+    assert [d[0] for d in network.MLP(8, 128).layer_dims(21)] == [21, 128, 128, 128, 128, 149, 128, 128, 128]
+    tree = network.MLP(4, 64).init(seed=1, in_features=21)
+    k = tree['MLP_0']['Dense_3']['kernel']
+    assert tuple(k.shape) == (85, 64) and float(k.abs().max()) <= np.sqrt(6.0 / 85) and float(tree['MLP_0']['Dense_3']['bias'].abs().max()) == 0
+    assert torch.equal(k, network.MLP(4, 64).init(seed=1, in_features=21)['MLP_0']['Dense_3']['kernel'])
+    with pytest.raises(AttributeError):
+        network.MLP(out_channel=3)
+
+
+def test_temporal_batched_args_and_shard():
+    t = np.linspace(0, 2, 12) * units.hr
+    target = np.arange(12 * 6, dtype=np.float32).reshape(12, 2, 3)
+    a = optimization.TemporalBatchedArgs(t, [target, np.ones_like(target)])
+    b = optimization.TemporalBatchedArgs(t, [target, np.ones_like(target)])
+    assert units.unit_name(a.t_units) == 'hr' and a.num_frames == 12
+    for _ in range(3):      # identical draws on every rank (same seed, same call sequence), no replacement
+        ia, ib = a.sample(6), b.sample(6)
+        assert np.array_equal(ia, ib) and len(set(ia.tolist())) == 6
+    tgt, sig, tf = a[np.array([3, 1, 7])]
+    assert np.array_equal(np.asarray(tgt), target[[3, 1, 7]]) and np.allclose(tf, np.asarray(t.value)[[3, 1, 7]])
+    assert optimization.device_count() == 1
+    assert np.array_equal(optimization.shard(np.arange(8)), np.arange(8))
+    with pytest.raises(AssertionError):
+        optimization.TemporalBatchedArgs(t, [target[:5]])
+
+
+def test_train_step_contract_and_total_movie_loss_chunking():
+    t = np.linspace(0, 1, 7) * units.hr
+    target = np.zeros((7, 2, 2), dtype=np.float32)
+    calls = []
+
+    def fake_step(state, t_units, dtype, tgt, sig, off, tf, *rest):
+        calls.append(np.asarray(tf).copy())
+        n = len(tf)
+        return torch.full((1,), float(n)), state, torch.zeros((1, n, 2, 2))
+
+    step = optimization.TrainStep('full', optimization.TemporalBatchedArgs(t, [target, target, target]), fake_step, fake_step, 1.0)
+    rt = {'coords': None, 'Omega': None, 'J': 1.0, 'g': None, 'dtau': None, 'Sigma': None, 't_start_obs': 0.0,
+          't_geos': None, 't_injection': 0.0}
+    loss, frames = optimization.total_movie_loss(3, 'state', step, rt, return_frames=True)
+    assert [len(c) for c in calls] == [3, 3, 1]                       # optimization.py:42-46 chunking incl. remainder
+    assert loss == pytest.approx(7 / 7) and frames.shape == (7, 2, 2)
+    both = step + step
+    assert both.num_losses == 2
+    with pytest.raises(AttributeError, match='only hr units supported'):
+        optimization.TrainStep('full', optimization.TemporalBatchedArgs(np.linspace(0, 1, 7) * units.s, [target]), fake_step, fake_step, 1.0)
+    with pytest.raises(NotImplementedError):
+        optimization.TrainStep.eht()
+    fired = []
+    log = optimization.LogFn(lambda opt: fired.append(opt.step), log_period=5)
+    for s in (1, 2, 5, 7, 10):
+        log(type('O', (), {'step': s})())
+    assert fired == [1, 5, 10]
+
+
+def test_raytracing_args_order_and_errors():
+    geos = dict(x=np.zeros((2, 2, 3)), y=np.zeros((2, 2, 3)), z=np.zeros((2, 2, 3)), dtau=np.ones((2, 2, 3)),
+                Sigma=np.ones((2, 2, 3)), t=np.zeros((2, 2, 3)), g=np.ones((2, 2, 3)))
+    rt = network.raytracing_args(geos, np.ones((2, 2, 3)), -1000.0, 0.0 * units.hr)
+    assert list(rt) == ['coords', 'Omega', 'J', 'g', 'dtau', 'Sigma', 't_start_obs', 't_geos', 't_injection']   # network.py:882-892
+    assert rt['coords'].shape == (3, 2, 2, 3) and rt['coords'].dtype == np.float32 and rt['J'] == 1.0
+    del geos['g']
+    with pytest.raises(AttributeError):
+        network.raytracing_args(geos, 1.0, 0.0, 0.0)
+
+
+def test_schedule_and_checkpoint_helpers(tmp_path):
+    st = network.TrainState.__new__(network.TrainState)
+    st.step, st.num_iters, st.lr_init, st.lr_final = 0, 10, 1e-3, 1e-5
+    assert st.learning_rate(0) == 1e-3 and st.learning_rate(10) == 1e-5 and st.learning_rate(25) == 1e-5
+    assert st.learning_rate(5) == pytest.approx((1e-3 - 1e-5) * 0.5 + 1e-5)
+    assert network.latest_checkpoint('') is None and network.latest_checkpoint(str(tmp_path)) is None
+    for n in (5, 50, 7):
+        (tmp_path / ('checkpoint_%d' % n)).write_bytes(b'x')
+    assert network.latest_checkpoint(str(tmp_path)).endswith('checkpoint_50')
+    pred = network.NeRF_Predictor(20.0, 6.0, 20.0, 4.0, net_width=128)
+    pred.save_params(str(tmp_path))
+    again = network.NeRF_Predictor.from_yml(str(tmp_path))
+    assert (again.scale, again.rmin, again.rmax, again.z_width, again.net_width, again.posenc_deg) == (20.0, 6.0, 20.0, 4.0, 128, 3)
