@@ -237,7 +237,11 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
                 d = dE * e * (1.f - e);                                // sigmoid'(out-10) = e(1-e)
             }
             dout = __shfl(d, pl, 64);                                   // both lane halves need it
-            if (h == 0) reinterpret_cast<float *>(A.tape + A.t.dout_off)[q * 32 + pl] = d;
+            {   // dout as a 32x32 (feature x point) tile whose feature 0 is dout: the A operand of dW_out
+                frag d0 = Pol::zero(), d1 = Pol::zero();
+                Pol::set(d0, 0, h == 0 ? d : 0.f);
+                emit_frags<Pol, BG::ROW_BYTES>(scr, A.tape + A.t.dout_off + q * BG::TILE_BYTES, d0, d1);
+            }
         }
         // ---- gA_{depth-1} = wout * dout * relu'(a_{depth-1}) -----------------------------------
         frag dl[KS];
@@ -293,7 +297,6 @@ struct GroupStager {
     u32x4 st[PIECES];
     bool out_job, has_h;
     const char *srcA, *srcH, *srcE;
-    const float *srcD;
     DEVI void load(long long q) {
 #pragma unroll
         for (int i = 0; i < PIECES; ++i) {
@@ -302,7 +305,7 @@ struct GroupStager {
             const int off = u * 16;
             const char *src;
             if (off < OFF_H) {
-                if (out_job) src = reinterpret_cast<const char *>(srcD + q * 32) + (off < 128 ? off : 0);
+                if (out_job) src = srcA + q * (long long)TB + (off % TB);      // dout: one tile per group
                 else src = srcA + q * (long long)AH_BYTES + off;
             } else if (off < OFF_E) src = has_h ? srcH + q * (long long)AH_BYTES + (off - OFF_H) : srcE + q * TB;
             else src = srcE + q * TB + (off - OFF_E);
@@ -331,18 +334,20 @@ DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
     constexpr int mtA = out_job ? 1 : MT;                              // A tiles (gA rows; dout is 1 row)
     constexpr int nH = has_h ? MT : 0, nB = nH + (has_enc ? 1 : 0);    // B tiles; tile nB is the ones tile
     constexpr int NT = nB + 1;
-    constexpr int WRR = BG::WRR, WCC = BG::WCC, MPW = BG::MPW;
+    constexpr int WRR = BG::WRR, WCC = BG::WCC;
+    constexpr int MPW = (mtA + WRR - 1) / WRR;                         // A tiles per wave (1 for the output job)
     constexpr int NPWJ = (NT + WCC - 1) / WCC;                         // B tiles owned by one wave
     constexpr int NPASS = (NPWJ + 4) / 5, NPW = (NPWJ + NPASS - 1) / NPASS;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, i31 = lane & 31, h = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nwg = A.wg_begin[job + 1] - A.wg_begin[job];
     const int kb = blockIdx.x - A.wg_begin[job];
     const long long q0 = A.t.NQ * kb / nwg, q1 = A.t.NQ * (kb + 1) / nwg;
-    const char *srcA = out_job ? nullptr : A.tape + A.t.ga_off[out_job ? 0 : job];
+    const char *srcA = out_job ? A.tape + A.t.dout_off : A.tape + A.t.ga_off[out_job ? 0 : job];
+    constexpr long long strideA = out_job ? TB : (long long)MT * TB;       // dout is one tile per group
     const char *srcH = has_h ? A.tape + A.t.h_off[job] : nullptr;
     const char *srcE = A.tape + A.t.enc_off;
-    const float *srcD = reinterpret_cast<const float *>(A.tape + A.t.dout_off);
     const int wr = wv % WRR, wc = wv / WRR;
+    const bool wave_works = wr * MPW < mtA;                            // output job: only the wr == 0 waves
     frag ones;
 #pragma unroll
     for (int j = 0; j < 8; ++j) Pol::set(ones, j, 1.f);
@@ -370,39 +375,52 @@ DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
         __syncthreads();
-        auto compute_group = [&](const char *gp) {
+        // B fragments are fetched two MFMA-pairs ahead of their use (counted lgkmcnt instead of a full
+        // drain after every read): with the two waves of a SIMD in barrier lockstep nothing else hides
+        // the LDS latency.  A fragments of both k-steps are loaded up front.
+        auto load_b = [&](const char *gp, int t) -> frag { return Pol::lds_frag(gp + boff[t % NPW], t / NPW, lane); };
+        auto fix_b = [&](frag bf, int ni) -> frag {   // ones tile: applied when the fragment is consumed
+            if constexpr (Pol::ELEM_BYTES == 2) {      // (bits & 0) | bf16x2(1,1): one op per dword
+                u32x4 bits = __builtin_bit_cast(u32x4, bf);
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                frag af[MPW];
+                for (int d = 0; d < 4; ++d) bits[d] = (bits[d] & bkeep[ni]) | bone[ni];
+                return __builtin_bit_cast(frag, bits);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) Pol::set(bf, j, bones[ni] ? 1.f : Pol::get(bf, j));
+                return bf;
+            }
+        };
+        auto compute_group = [&](const char *gp) {
+            constexpr int NTOT = 2 * NPW, AHEAD = (Pol::ELEM_BYTES == 2) ? 2 : 1;
+            frag af[2][MPW];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
 #pragma unroll
                 for (int mi = 0; mi < MPW; ++mi) {
-                    if constexpr (out_job) {   // A[row 0][k = point] = dout, other rows zero
-                        const float *dv = reinterpret_cast<const float *>(gp);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) Pol::set(af[mi], j, i31 == 0 ? dv[16 * s + 8 * h + j] : 0.f);
-                    } else af[mi] = Pol::lds_frag(gp + (wr * MPW + mi) * TB, s, lane);
+                    af[s][mi] = Pol::lds_frag(gp + (wr * MPW + mi) * TB, s, lane);
                 }
+            frag bq[AHEAD + 1];
 #pragma unroll
-                for (int ni = 0; ni < NPW; ++ni) {
-                    frag bf = Pol::lds_frag(gp + boff[ni], s, lane);
-                    if constexpr (Pol::ELEM_BYTES == 2) {   // ones tile: (bits & 0) | bf16x2(1,1), one op per dword
-                        u32x4 bits = __builtin_bit_cast(u32x4, bf);
+            for (int t = 0; t < AHEAD && t < NTOT; ++t) bq[t] = load_b(gp, t);
 #pragma unroll
-                        for (int d = 0; d < 4; ++d) bits[d] = (bits[d] & bkeep[ni]) | bone[ni];
-                        bf = __builtin_bit_cast(frag, bits);
-                    } else {
+            for (int t = 0; t < NTOT; ++t) {
+                if (t + AHEAD < NTOT) bq[(t + AHEAD) % (AHEAD + 1)] = load_b(gp, t + AHEAD);
+                __builtin_amdgcn_sched_barrier(0);          // keep the prefetch ahead of this step's MFMAs
+                const int s = t / NPW, ni = t % NPW;
+                const frag bnow = fix_b(bq[t % (AHEAD + 1)], ni);
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) Pol::set(bf, j, bones[ni] ? 1.f : Pol::get(bf, j));
-                    }
-#pragma unroll
-                    for (int mi = 0; mi < MPW; ++mi) acc[mi][ni] = Pol::mma(af[mi], bf, acc[mi][ni]);
-                }
+                for (int mi = 0; mi < MPW; ++mi) acc[mi][ni] = Pol::mma(af[s][mi], bnow, acc[mi][ni]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         };
         if constexpr (Pol::ELEM_BYTES == 2) {
             // LDS-DMA ring: group q+NBUF-1 is issued right after the barrier that proves buffer
             // (q-1)%NBUF has been consumed; the counted wait leaves NBUF-2 younger groups in flight.
-            constexpr int NBUF = BG::NBUF, PPW = BG::PPW;
+            // pieces (1 KiB = one wave-wide DMA) this job really needs: [A tiles | dout][h tiles][enc tile]
+            constexpr int NBUF = BG::NBUF;
+            constexpr int PA = out_job ? TB / 1024 : MT * TB / 1024, PH = has_h ? MT * TB / 1024 : 0, PE = has_enc ? TB / 1024 : 0;
+            constexpr int NPJ = PA + PH + PE, PPW = (NPJ + Pol::NWAVES - 1) / Pol::NWAVES;
             const int wvu = __builtin_amdgcn_readfirstlane(wv);
             const char *sbase[PPW];
             long long sstride[PPW];
@@ -410,17 +428,18 @@ DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
 #pragma unroll
             for (int i = 0; i < PPW; ++i) {
                 int piece = wvu + Pol::NWAVES * i;
-                piece = piece < BG::NPIECE ? piece : BG::NPIECE - 1;
-                const int off = piece * 1024;
-                doff[i] = off;
-                if (off < OFF_H) {
-                    sbase[i] = out_job ? reinterpret_cast<const char *>(srcD) : srcA + off;
-                    sstride[i] = out_job ? 128 : (long long)MT * TB;
-                } else if (off < OFF_E) {
-                    sbase[i] = has_h ? srcH + (off - OFF_H) : srcE + ((off - OFF_H) % TB);
-                    sstride[i] = has_h ? (long long)MT * TB : TB;
+                piece = piece < NPJ ? piece : NPJ - 1;                  // tail waves re-issue the last piece
+                if (piece < PA) {
+                    doff[i] = piece * 1024;
+                    sbase[i] = srcA + piece * 1024;
+                    sstride[i] = strideA;
+                } else if (piece < PA + PH) {
+                    doff[i] = OFF_H + (piece - PA) * 1024;
+                    sbase[i] = srcH + (piece - PA) * 1024;
+                    sstride[i] = (long long)MT * TB;
                 } else {
-                    sbase[i] = srcE + (off - OFF_E);
+                    doff[i] = OFF_E + (piece - PA - PH) * 1024;
+                    sbase[i] = srcE + (piece - PA - PH) * 1024;
                     sstride[i] = TB;
                 }
                 sbase[i] += lane * 16;
@@ -444,7 +463,7 @@ DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
                     const int nx = (it == 0) ? NBUF - 1 : it - 1;
                     if (!(A.debug & 2)) issue(q + NBUF - 1, smem + nx * GB);
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (!(A.debug & 1)) compute_group(smem + it * GB);
+                    if (!(A.debug & 1) && wave_works) compute_group(smem + it * GB);
                     it = (it == NBUF - 1) ? 0 : it + 1;
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -453,7 +472,7 @@ DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
             // f32 (parity mode): plain double buffer through registers, no overlap
             constexpr int UNITS = GB / 16;
             GroupStager<UNITS, Pol::NTHREADS, OFF_H, OFF_E, MT * TB, TB> gs;
-            gs.out_job = out_job; gs.has_h = has_h; gs.srcA = srcA; gs.srcH = srcH; gs.srcE = srcE; gs.srcD = srcD;
+            gs.out_job = out_job; gs.has_h = has_h; gs.srcA = srcA; gs.srcH = srcH; gs.srcE = srcE;
             if (q0 < q1) {
                 gs.load(q0);
                 gs.store(smem);
@@ -461,7 +480,7 @@ DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
             __syncthreads();
             int par = 0;
             for (long long q = q0; q < q1; ++q) {
-                compute_group(smem + par * GB);
+                if (wave_works) compute_group(smem + par * GB);
                 if (q + 1 < q1) {
                     gs.load(q + 1);
                     gs.store(smem + (par ^ 1) * GB);
@@ -501,6 +520,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void dw_kernel(BwdArgs A) {
     const int depth = A.f.depth;
     int job = 0;
     while (job < depth && (int)blockIdx.x >= A.wg_begin[job + 1]) ++job;
+    if ((A.debug >> 2) && (A.debug >> 2) - 1 != job) return;
     if (job == depth) dw_body<W, Pol, JT_OUT>(A, job, smem);
     else if (job == 0) dw_body<W, Pol, JT_FIRST>(A, job, smem);
     else if ((A.f.skip_mask >> job) & 1) dw_body<W, Pol, JT_SKIP>(A, job, smem);
@@ -557,7 +577,8 @@ static thread_local int g_bwd_stages = 7;
 static thread_local int g_bwd_debug = 0;
 extern "C" int bhn_debug_set_bwd_stages(int32_t mask) {
     g_bwd_stages = mask & 7;
-    g_bwd_debug = (mask >> 3) & 3;       // bit 3: dW kernel without MFMA work, bit 4: without tape loads
+    g_bwd_debug = (mask >> 3) & 0x7F;    // bit 3: dW kernel without MFMA work, bit 4: without tape loads,
+                                         // bits 5-8: run only dW job (value-1)
     return BHN_OK;
 }
 
@@ -571,7 +592,7 @@ static void tape_layout(int depth, long long NQ, TapeLayout *t) {
     for (int l = 1; l <= depth; ++l) { t->h_off[l] = off; off += per_tensor; }
     for (int l = 0; l < depth; ++l) { t->ga_off[l] = off; off += per_tensor; }
     t->enc_off = off; off += NQ * (long long)BG::TILE_BYTES;
-    t->dout_off = off; off += NQ * 128;
+    t->dout_off = off; off += NQ * (long long)BG::TILE_BYTES;   // dout as an A tile: row 0 = dout, rows 1..31 zero
     t->total = (long long)align_up((size_t)off + 1024, 256);     // +1 KiB: the last dout piece is DMA'd as a full KiB
 }
 

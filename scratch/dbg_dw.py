@@ -19,6 +19,9 @@ def timed(fn, reps=4):
     return float(np.mean([a.elapsed_time(b) for a, b in ev]))
 lib = _hip.lib()
 lib.bhn_debug_set_bwd_stages(7); eng.render_bwd(geom, tM0, dimg)
-for name, mask in (('chain', 1), ('dw full', 2), ('dw no-mfma', 2 | 8), ('dw no-loads', 2 | 16), ('dw neither', 2 | 24)):
+cases = [('chain', 1), ('dw full', 2), ('dw no-mfma', 2 | 8), ('dw no-loads', 2 | 16)]
+for j in range(5):
+    cases += [('job%d full' % j, 2 | ((j + 1) << 5)), ('job%d no-loads' % j, 2 | 16 | ((j + 1) << 5)), ('job%d no-mfma' % j, 2 | 8 | ((j + 1) << 5))]
+for name, mask in cases:
     lib.bhn_debug_set_bwd_stages(mask)
     print(name, '%.3f ms' % timed(lambda: eng.render_bwd(geom, tM0, dimg)))
