@@ -176,14 +176,25 @@ def main():
         return float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
     lib = _hip.lib()
-    kern_ms = {'fused_fwd_kernel': timed(lambda: eng.render(geom, tM0))}
-    for name, mask in (('chain_kernel', 1), ('dw_kernel', 2), ('reduce_kernel', 4)):
+    taped = eng.fits_tape(args.frames_per_gpu, geom.P)
+    if taped:      # the kernels a training step runs: training forward (records the tape), delta chain, dW GEMM
+        kern_ms = {'chain_kernel<MODE_FWD_TRAIN>': timed(lambda: eng.render_train(geom, tM0))}
+        bwd = lambda: eng.render_bwd_tape(geom, tM0, dimg)
+        names = (('chain_kernel<MODE_CHAIN>', 1), ('dw_kernel', 2), ('reduce_kernel', 4))
+        fwd_name, chain_name = 'chain_kernel<MODE_FWD_TRAIN>', 'chain_kernel<MODE_CHAIN>'
+    else:
+        kern_ms = {'fused_fwd_kernel': timed(lambda: eng.render(geom, tM0))}
+        bwd = lambda: eng.render_bwd(geom, tM0, dimg)
+        names = (('chain_kernel<MODE_RECOMPUTE>', 1), ('dw_kernel', 2), ('reduce_kernel', 4))
+        fwd_name, chain_name = 'fused_fwd_kernel', 'chain_kernel<MODE_RECOMPUTE>'
+    for name, mask in names:
         lib.bhn_debug_set_bwd_stages(mask)
-        kern_ms[name] = timed(lambda: eng.render_bwd(geom, tM0, dimg))
+        kern_ms[name] = timed(bwd)
     lib.bhn_debug_set_bwd_stages(7)
+    kern_ms['fused_fwd_kernel (inference)'] = timed(lambda: eng.render(geom, tM0))
     pts = args.frames_per_gpu * geom.P * geom.active_fraction
     f_fwd, f_chain, f_dw, f_train = mlp_flops(args.depth, args.width)
-    alg = {'fused_fwd_kernel': f_fwd, 'chain_kernel': f_chain, 'dw_kernel': f_dw}
+    alg = {fwd_name: f_fwd, chain_name: f_chain, 'dw_kernel': f_dw}
     dom = max(alg, key=lambda k: kern_ms[k])
     achieved = alg[dom] * pts / (kern_ms[dom] * 1e-3) / 1e12
     peak = PEAK_TFLOPS[args.mode]
@@ -191,6 +202,19 @@ def main():
                 'frac': round(achieved / peak, 4), 'traffic': None,
                 'kernel_ms': {k: round(v, 4) for k, v in kern_ms.items()},
                 'step_algorithmic_tflops': round(f_train * value * geom.active_fraction / 1e12 / world, 2)}
+
+    # ---- stand-alone radiative-transfer scan (kgeo.radiative_trasfer, HBM-bound): achieved GB/s ---------
+    # measured at the size SURVEY 8d quotes (config 3: 256x256 rays x 128 samples, B*S = 8*3 planes, ~1 GB)
+    from bhnerf_amd.kgeo import _RadiativeTransfer
+    Nrt, Rrt, Grt = 24, 256 * 256, 128
+    e_rt = torch.rand((Nrt, Rrt, Grt), device=dev)
+    planes = [torch.rand((Rrt, Grt), device=dev) for _ in range(3)]
+    rt_ms = timed(lambda: _RadiativeTransfer.apply(e_rt, *planes), reps=10)
+    rt_bytes = 4 * Nrt * Rrt * Grt + 12 * Rrt * Grt + 4 * Nrt * Rrt                 # SURVEY 8d algorithmic bytes
+    rt_scan = {'kernel': 'rt_kernel', 'bound': 'hbm', 'achieved': round(rt_bytes / (rt_ms * 1e-3) / 1e9, 1), 'peak': 8000.0,
+               'unit': 'GB/s', 'frac': round(rt_bytes / (rt_ms * 1e-3) / 8e12, 4), 'ms': round(rt_ms, 4),
+               'shape': '%d planes x %d rays x %d samples (%.2f GB)' % (Nrt, Rrt, Grt, rt_bytes / 1e9)}
+    del e_rt, planes
 
     out = {
         'metric': 'train ray-samples/sec, 128x128x64-sample image-plane recovery', 'value': value,
@@ -202,6 +226,8 @@ def main():
                    'frames_per_step': batch, 'frames_per_gpu': args.frames_per_gpu, 'parallelism': 'dp%d (time-frames)' % world,
                    'active_fraction': round(geom.active_fraction, 4), 'loss': loss_now},
         'roofline': roofline,
+        'rt_scan': rt_scan,
+        'fwd_images_per_s': round(args.frames_per_gpu / (kern_ms['fused_fwd_kernel (inference)'] * 1e-3), 1),
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(args, geo, GM_c3)

@@ -18,7 +18,7 @@ struct TapeLayout {
     long long NQ;                              // 32-point groups on the tape
     long long h_off[BHN_MAX_LAYERS + 1];       // h_l, l = 1..depth  (inputs of layer l)
     long long ga_off[BHN_MAX_LAYERS];          // gA_l, l = 0..depth-1
-    long long enc_off, dout_off, total;
+    long long enc_off, dout_off, mask_off, e_off, total;   // mask: relu bits [group][layer][word][lane]; e: [group][32] f32
 };
 
 struct BwdArgs {
@@ -65,7 +65,8 @@ struct BwdGeom {
 // tile emission: 32x32 (feature x point) register tile -> fragment-ordered tape tile
 // ---------------------------------------------------------------------------------------------
 template <class Pol, int ROW_BYTES>
-DEVI void emit_frags(char *scr, char *dst, const typename Pol::frag &f0, const typename Pol::frag &f1) {
+DEVI void emit_frags(char *scr, char *dst, const typename Pol::frag &f0, const typename Pol::frag &f1, int dbg = 0) {
+    if (dbg & 2) return;                       // measurement aid: no emission at all
     // f0/f1 = k-steps 0/1 of a 32-feature block in B-operand order: element j of f_s is feature
     // 16s + 8(j>>2) + 4h + (j&3) of point (lane&31): elements 4c..4c+3 are 4 consecutive features.
     const int lane = threadIdx.x & 63, pt = lane & 31, h = lane >> 5;
@@ -91,7 +92,8 @@ DEVI void emit_frags(char *scr, char *dst, const typename Pol::frag &f0, const t
             s16x8 fr;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { fr[e] = lo[e]; fr[4 + e] = hi[e]; }
-            *reinterpret_cast<s16x8 *>(dst + s * 1024 + lane * 16) = fr;
+            if (!(dbg & 1)) __builtin_nontemporal_store(fr, reinterpret_cast<s16x8 *>(dst + s * 1024 + lane * 16));   // streamed: read once, much later
+            else asm volatile("" ::"v"(fr));
         }
     } else {
 #pragma unroll
@@ -111,7 +113,7 @@ DEVI void emit_frags(char *scr, char *dst, const typename Pol::frag &f0, const t
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     fr[e] = *reinterpret_cast<const float *>(scr + (16 * s + 8 * h + 4 * hf + e) * ROW_BYTES + pt * 4);
-                *reinterpret_cast<f32x4 *>(dst + s * 2048 + hf * 1024 + lane * 16) = fr;
+                __builtin_nontemporal_store(fr, reinterpret_cast<f32x4 *>(dst + s * 2048 + hf * 1024 + lane * 16));
             }
     }
 }
@@ -129,16 +131,21 @@ DEVI void pack_tile(const f32x16 &v, int m, typename Pol::frag (&next)[W / 16]) 
 // ---------------------------------------------------------------------------------------------
 // weight-chunk stream of one tile: forward chunks 0..NCF-1, then the transposed chunks of hidden
 // layers depth-1 .. 1 (delta chain); wraps to the next tile's chunk 0
-template <int MT, int CB>
+enum { MODE_RECOMPUTE = 0, MODE_FWD_TRAIN = 1, MODE_CHAIN = 2 };
+
+template <int MT, int CB, int MODE>
 DEVI const char *chunk_source(int seq, int NSEQ, int NCF, int depth, const char *fwd, const char *bwd) {
-    if (seq >= NSEQ) seq -= NSEQ;
-    if (seq < NCF) return fwd + (size_t)seq * CB;
-    const int i = seq - NCF;
+    while (seq >= NSEQ) seq -= NSEQ;
+    if (MODE != MODE_CHAIN && seq < NCF) return fwd + (size_t)seq * CB;
+    const int i = (MODE == MODE_CHAIN) ? seq : seq - NCF;
     const int l = depth - 1 - i / MT, m = i % MT;
     return bwd + (size_t)((l - 1) * MT + m) * CB;
 }
 
-template <int W, class Pol, int DEG>
+// MODE_RECOMPUTE: forward recompute + delta chain in one kernel (any dimages, any workspace size).
+// MODE_FWD_TRAIN:  the training forward: render (images) AND record h tiles, relu bits and e on the tape.
+// MODE_CHAIN:      delta chain only, from the relu bits / e recorded by MODE_FWD_TRAIN.
+template <int W, class Pol, int DEG, int MODE>
 __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
     using PK = Pack<W, Pol>;
     using BG = BwdGeom<W, Pol>;
@@ -146,9 +153,10 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
     constexpr int CB = PK::CHUNK_BYTES, MT = PK::MT, KS = PK::KS;
     constexpr int MW = (MT + 1) / 2;                                   // mask words per layer per lane
     const FusedArgs &a = A.f;
+    const int edbg = (A.debug >> 6) & 3;           // measurement aid for emit_frags
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *ring = smem;
-    float *bias_lds = reinterpret_cast<float *>(smem + 2 * CB);
+    float *bias_lds = reinterpret_cast<float *>(smem + 3 * CB);
     float *wout_lds = bias_lds + (a.depth + 1) * W;
     char *scr_all = reinterpret_cast<char *>(wout_lds + W);
     unsigned *mask_all = reinterpret_cast<unsigned *>(scr_all + Pol::NWAVES * BG::SCR_BYTES);
@@ -161,31 +169,42 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
     for (int i = tid; i < W; i += Pol::NTHREADS) wout_lds[i] = reinterpret_cast<const float *>(a.packed + a.wout_off)[i];
 
     const int NCF = PK::fwd_chunks(a.depth);
-    const int NSEQ = NCF + (a.depth - 1) * MT;
+    const int NSEQ = (MODE == MODE_FWD_TRAIN) ? NCF : (MODE == MODE_CHAIN) ? (a.depth - 1) * MT : NCF + (a.depth - 1) * MT;
     const char *fwd = a.packed + a.fwd_off, *bwd = a.packed + a.bwd_off;
     const int depth_ = a.depth;
-#define chunk_src(seq_) chunk_source<MT, CB>((seq_), NSEQ, NCF, depth_, fwd, bwd)
-    Stager<CB, Pol::NTHREADS> stg;
-    stg.load(fwd);
-    stg.store(ring);
-    __syncthreads();
-    int par = 0;
-#define RING_STEP_BEGIN(seq) stg.load(chunk_src((seq) + 1)); const char *ch = ring + par * CB;
-#define RING_STEP_END() stg.store(ring + (par ^ 1) * CB); __syncthreads(); par ^= 1;
+#define chunk_src(seq_) chunk_source<MT, CB, MODE>((seq_), NSEQ, NCF, depth_, fwd, bwd)
+    // weight ring (3 LDS buffers, LDS-DMA, prefetch distance 2): step c issues chunk c+2, consumes chunk c,
+    // then waits for its own pieces of chunk c+1 with a counted vmcnt that leaves chunk c+2 and this
+    // step's tape stores in flight (vmcnt is in-order and counts stores: a plain wait on the prefetch
+    // would drain the tape stores of the previous step every time).
+    using RG = DmaRing<CB, Pol::NWAVES>;
+    constexpr int ES = (Pol::ELEM_BYTES == 2) ? 2 : 4;                 // global stores of one emit_frags
+    RG::issue(chunk_src(0), ring);
+    RG::issue(chunk_src(1), ring + CB);
+    RG::template wait_prev<0>();
+    lds_barrier();
+    int cur = 0;                                                       // ring slot of the chunk being consumed
+#define RING_STEP_BEGIN(seq) { const int nx = cur >= 1 ? cur - 1 : 2; RG::issue(chunk_src((seq) + 2), ring + nx * CB); } \
+    const char *ch = ring + cur * CB;
+// STORES = tape stores issued by this step after its DMA issue; every step is preceded (in-step or between
+// steps) by at least ES more stores that are younger than the chunk being waited for, so they may stay in flight
+#define RING_STEP_END(STORES) RG::template wait_prev<(STORES) + ES>(); lds_barrier(); cur = cur == 2 ? 0 : cur + 1;
 
     for (long long tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
         const int b = (int)(tile / a.tiles_per_frame);
         const long long p = (tile % a.tiles_per_frame) * (Pol::NWAVES * 32) + wv * 32 + pl;
         const bool inb = p < a.P;
         const long long q = tile * Pol::NWAVES + wv;                     // 32-point group on the tape
-        frag enc[2];
-        bool live;
+        unsigned *mask_g = reinterpret_cast<unsigned *>(A.tape + A.t.mask_off) + q * (long long)(a.depth * MW * 64);
+        float *e_g = reinterpret_cast<float *>(A.tape + A.t.e_off) + q * 32;
+        int seq = 0;
+        frag enc[2], act[KS], next[KS];
+        bool live = false;
+        if constexpr (MODE != MODE_CHAIN) {
         point_prologue<Pol, DEG>(a, b, p, inb, enc, live);
         // the encoded inputs are the B operand of dW_0 and of the skip layer
-        emit_frags<Pol, BG::ROW_BYTES>(scr, A.tape + A.t.enc_off + q * BG::TILE_BYTES, enc[0], enc[1]);
-        frag act[KS], next[KS];
-        int seq = 0;
-        // ---- forward recompute, layer 0 -------------------------------------------------------
+        emit_frags<Pol, BG::ROW_BYTES>(scr, A.tape + A.t.enc_off + q * BG::TILE_BYTES, enc[0], enc[1], edbg);
+        // ---- forward, layer 0 ----------------------------------------------------------------
         {
             RING_STEP_BEGIN(seq)
 #pragma unroll
@@ -194,11 +213,11 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
                 acc = Pol::mma(Pol::lds_frag(ch, 2 * m, lane), enc[0], acc);
                 acc = Pol::mma(Pol::lds_frag(ch, 2 * m + 1, lane), enc[1], acc);
                 const unsigned mk = relu_pack<W, Pol>(acc, m, act);
-                emit_frags<Pol, BG::ROW_BYTES>(scr, A.tape + A.t.h_off[1] + (q * MT + m) * BG::TILE_BYTES, act[2 * m], act[2 * m + 1]);
+                emit_frags<Pol, BG::ROW_BYTES>(scr, A.tape + A.t.h_off[1] + (q * MT + m) * BG::TILE_BYTES, act[2 * m], act[2 * m + 1], edbg);
                 unsigned *mwp = mask_w + (0 * MW + (m >> 1)) * 64 + lane;
                 if (m & 1) *mwp |= mk << 16; else *mwp = mk;
             }
-            RING_STEP_END()
+            RING_STEP_END(ES)
             ++seq;
         }
         // ---- hidden layers 1..depth-1 ---------------------------------------------------------
@@ -211,38 +230,66 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
                 RING_STEP_BEGIN(seq)
                 f32x16 acc = tile_matmul<W, Pol>(ch, act, enc, sk, bias_acc(bl, m, h));
                 const unsigned mk = relu_pack<W, Pol>(acc, m, next);
-                emit_frags<Pol, BG::ROW_BYTES>(scr, hdst + m * BG::TILE_BYTES, next[2 * m], next[2 * m + 1]);
+                emit_frags<Pol, BG::ROW_BYTES>(scr, hdst + m * BG::TILE_BYTES, next[2 * m], next[2 * m + 1], edbg);
                 unsigned *mwp = mask_w + (l * MW + (m >> 1)) * 64 + lane;
                 if (m & 1) *mwp |= mk << 16; else *mwp = mk;
-                RING_STEP_END()
+                RING_STEP_END(ES)
                 ++seq;
             }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) act[ks] = next[ks];
         }
-        // ---- output layer, dE, dout -----------------------------------------------------------
-        float dout;
+        } else {
+            // relu bits recorded by the training forward -> this wave's LDS stash
+            for (int i = 0; i < a.depth * MW; ++i) mask_w[i * 64 + lane] = mask_g[i * 64 + lane];
+        }
+        // ---- output layer -> e ; dE, dout -----------------------------------------------------
+        float dout = 0.f;
         {
-            RING_STEP_BEGIN(seq)
-            f32x16 acc = tile_matmul<W, Pol>(ch, act, enc, false, bias_acc(bias_lds + a.depth * W, 0, h));
-            RING_STEP_END()
-            ++seq;
-            float d = 0.f;
-            if (h == 0 && live) {
-                const float e = 1.f / (1.f + Pol::fexp(10.f - acc[0]));
-                const long long ray = p / a.G;
-                float dE = 0.f;
-                for (int s = 0; s < a.Sx; ++s)
-                    dE += a.dimages[((long long)b * a.Sx + s) * a.R + ray] * a.w[(long long)s * a.P + p];
-                d = dE * e * (1.f - e);                                // sigmoid'(out-10) = e(1-e)
+            float e = 0.f;
+            if constexpr (MODE != MODE_CHAIN) {
+                RING_STEP_BEGIN(seq)
+                f32x16 acc = tile_matmul<W, Pol>(ch, act, enc, false, bias_acc(bias_lds + a.depth * W, 0, h));
+                RING_STEP_END(0)
+                ++seq;
+                if (h == 0 && live) e = 1.f / (1.f + Pol::fexp(10.f - acc[0]));
+            } else {
+                if (h == 0) e = e_g[pl];
             }
-            dout = __shfl(d, pl, 64);                                   // both lane halves need it
-            {   // dout as a 32x32 (feature x point) tile whose feature 0 is dout: the A operand of dW_out
+            if constexpr (MODE == MODE_FWD_TRAIN) {
+                // record what the delta chain needs, then the render epilogue of fused_fwd_kernel
+                for (int i = 0; i < a.depth * MW; ++i) mask_g[i * 64 + lane] = mask_w[i * 64 + lane];
+                if (h == 0) e_g[pl] = e;
+                const long long ray = inb ? p / a.G : -1;
+                unsigned long long rem = __ballot(h == 0 && inb);
+                while (rem) {
+                    const int first = __ffsll((long long)rem) - 1;
+                    const long long r0 = __shfl(ray, first, 64);
+                    const bool mine = (h == 0) && inb && (ray == r0);
+                    for (int s = 0; s < a.Sx; ++s) {
+                        float v = (mine && e != 0.f) ? a.w[(long long)s * a.P + p] * e : 0.f;
+                        v = half_wave_sum(v);
+                        if (lane == first) atomicAdd(a.images + ((long long)b * a.Sx + s) * a.R + r0, v);
+                    }
+                    rem &= ~__ballot(mine);
+                }
+            } else {
+                float d = 0.f;
+                if (h == 0 && inb && e != 0.f) {
+                    const long long ray = p / a.G;
+                    float dE = 0.f;
+                    for (int s = 0; s < a.Sx; ++s)
+                        dE += a.dimages[((long long)b * a.Sx + s) * a.R + ray] * a.w[(long long)s * a.P + p];
+                    d = dE * e * (1.f - e);                            // sigmoid'(out-10) = e(1-e)
+                }
+                dout = __shfl(d, pl, 64);                               // both lane halves need it
+                // dout as a 32x32 (feature x point) tile whose feature 0 is dout: the A operand of dW_out
                 frag d0 = Pol::zero(), d1 = Pol::zero();
                 Pol::set(d0, 0, h == 0 ? d : 0.f);
-                emit_frags<Pol, BG::ROW_BYTES>(scr, A.tape + A.t.dout_off + q * BG::TILE_BYTES, d0, d1);
+                emit_frags<Pol, BG::ROW_BYTES>(scr, A.tape + A.t.dout_off + q * BG::TILE_BYTES, d0, d1, edbg);
             }
         }
+        if constexpr (MODE != MODE_FWD_TRAIN) {
         // ---- gA_{depth-1} = wout * dout * relu'(a_{depth-1}) -----------------------------------
         frag dl[KS];
         {
@@ -258,7 +305,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
                     for (int e = 0; e < 4; ++e) g[4 * g4 + e] = ((mw >> (4 * g4 + e)) & 1) ? wv4[e] * dout : 0.f;
                 }
                 pack_tile<W, Pol>(g, m, dl);
-                emit_frags<Pol, BG::ROW_BYTES>(scr, gdst + m * BG::TILE_BYTES, dl[2 * m], dl[2 * m + 1]);
+                emit_frags<Pol, BG::ROW_BYTES>(scr, gdst + m * BG::TILE_BYTES, dl[2 * m], dl[2 * m + 1], edbg);
             }
         }
         // ---- delta chain through hidden layers depth-1 .. 1 -----------------------------------
@@ -274,13 +321,14 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = ((mw >> r) & 1) ? acc[r] : 0.f;
                 pack_tile<W, Pol>(acc, m, next);
-                emit_frags<Pol, BG::ROW_BYTES>(scr, gdst + m * BG::TILE_BYTES, next[2 * m], next[2 * m + 1]);
-                RING_STEP_END()
+                emit_frags<Pol, BG::ROW_BYTES>(scr, gdst + m * BG::TILE_BYTES, next[2 * m], next[2 * m + 1], edbg);
+                RING_STEP_END(ES)
                 ++seq;
             }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) dl[ks] = next[ks];
         }
+        }   // MODE != MODE_FWD_TRAIN
     }
 #undef RING_STEP_BEGIN
 #undef RING_STEP_END
@@ -577,8 +625,8 @@ static thread_local int g_bwd_stages = 7;
 static thread_local int g_bwd_debug = 0;
 extern "C" int bhn_debug_set_bwd_stages(int32_t mask) {
     g_bwd_stages = mask & 7;
-    g_bwd_debug = (mask >> 3) & 0x7F;    // bit 3: dW kernel without MFMA work, bit 4: without tape loads,
-                                         // bits 5-8: run only dW job (value-1)
+    g_bwd_debug = (mask >> 3) & 0x1FF;    // bit 3: dW kernel without MFMA work, bit 4: without tape loads,
+                                         // bits 5-8: run only dW job (value-1); bit 9: emit without global stores; bit 10: no emit
     return BHN_OK;
 }
 
@@ -593,6 +641,8 @@ static void tape_layout(int depth, long long NQ, TapeLayout *t) {
     for (int l = 0; l < depth; ++l) { t->ga_off[l] = off; off += per_tensor; }
     t->enc_off = off; off += NQ * (long long)BG::TILE_BYTES;
     t->dout_off = off; off += NQ * (long long)BG::TILE_BYTES;   // dout as an A tile: row 0 = dout, rows 1..31 zero
+    t->mask_off = off; off += NQ * (long long)depth * ((BG::MT + 1) / 2) * 256;
+    t->e_off = off; off += NQ * 128;
     t->total = (long long)align_up((size_t)off + 1024, 256);     // +1 KiB: the last dout piece is DMA'd as a full KiB
 }
 
@@ -602,16 +652,19 @@ static long long bytes_per_group(int depth) {
     return (long long)(2 * depth * BG::MT + 1) * BG::TILE_BYTES + 128;
 }
 
+enum { RUN_QUERY = 0, RUN_RECOMPUTE = 1, RUN_FWD_TRAIN = 2, RUN_BWD_TAPE = 3 };
+
 template <int W, class Pol>
-static int bwd_run(const bhn_model *m, int32_t mode, const void *packed, const bhn_geom *geom, const bhn_frames *fr,
-                   const float *dimages, float *dparams, void *workspace, size_t workspace_bytes, hipStream_t st,
-                   size_t *query_bytes, int query_B, long long query_P, int device) {
+static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packed, const bhn_geom *geom,
+                   const bhn_frames *fr, const float *dimages, float *images, float *dparams, void *workspace,
+                   size_t workspace_bytes, hipStream_t st, size_t *query_bytes, int query_B, long long query_P,
+                   int device) {
     using BG = BwdGeom<W, Pol>;
     using PK = Pack<W, Pol>;
     const int ncu = bhn_num_cus(device);
     const int grid_dw = ncu;                                           // one dW workgroup per CU
     const size_t slab_bytes = align_up((size_t)grid_dw * BG::SLAB_FLOATS * 4, 256);
-    if (query_bytes) {
+    if (what == RUN_QUERY) {
         const long long tiles = (query_P + Pol::NWAVES * 32 - 1) / (Pol::NWAVES * 32) * query_B;
         TapeLayout t;
         tape_layout<W, Pol>(m->net_depth, tiles * Pol::NWAVES, &t);
@@ -623,7 +676,8 @@ static int bwd_run(const bhn_model *m, int32_t mode, const void *packed, const b
     MlpShape s;
     int rc = fused_fill_args(m, mode, packed, geom, fr, true, &A.f, &s, Pol::NWAVES);
     if (rc != BHN_OK) return rc;
-    BHN_CHECK_ARG(dimages && dparams && workspace, "null pointer");
+    BHN_CHECK_ARG(workspace, "null workspace");
+    BHN_CHECK_ARG(what == RUN_FWD_TRAIN ? images != nullptr : (dimages && dparams), "null pointer");
     const int depth = s.depth;
     // frames per pass so that the tape fits the workspace (same layout function as the size query)
     const long long groups_per_frame = (long long)A.f.tiles_per_frame * Pol::NWAVES;
@@ -641,10 +695,16 @@ static int bwd_run(const bhn_model *m, int32_t mode, const void *packed, const b
         if (slab_bytes + (size_t)tn.total > workspace_bytes) break;
         ++fpp;
     }
+    if (what != RUN_RECOMPUTE && fpp < A.f.B) {
+        bhn_set_error("the recorded-tape path needs a workspace for all %d frames at once (%zu bytes given); "
+                      "use bhn_render_fwd + bhn_render_bwd, which iterate over frame groups", A.f.B, workspace_bytes);
+        return BHN_EWORKSPACE;
+    }
     A.f.slabs = reinterpret_cast<float *>(workspace);
     A.tape = reinterpret_cast<char *>(workspace) + slab_bytes;
     A.f.slab_floats = BG::SLAB_FLOATS;
     A.f.dimages = dimages;
+    A.f.images = images;
     A.dparams = dparams;
     A.nparams = s.nparams;
     A.F = s.F;
@@ -675,54 +735,82 @@ static int bwd_run(const bhn_model *m, int32_t mode, const void *packed, const b
             return BHN_EINVAL;
         }
     }
-    const size_t lds_chain = 2 * PK::CHUNK_BYTES + (size_t)(depth + 1) * W * 4 + W * 4 + Pol::NWAVES * BG::SCR_BYTES +
+    const size_t lds_chain = 3 * PK::CHUNK_BYTES + (size_t)(depth + 1) * W * 4 + W * 4 + Pol::NWAVES * BG::SCR_BYTES +
                              (size_t)Pol::NWAVES * depth * ((BG::MT + 1) / 2) * 64 * 4;
     const size_t lds_dw = (size_t)BG::NBUF * BG::GROUP_BYTES;
-    auto kchain = chain_kernel<W, Pol, 3>;
+    auto k_rec = chain_kernel<W, Pol, 3, MODE_RECOMPUTE>;
+    auto k_fwd = chain_kernel<W, Pol, 3, MODE_FWD_TRAIN>;
+    auto k_chn = chain_kernel<W, Pol, 3, MODE_CHAIN>;
     auto kdw = dw_kernel<W, Pol>;
     static bool attr_done = false;
     if (!attr_done) {
-        BHN_HIP(hipFuncSetAttribute((const void *)kchain, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        BHN_HIP(hipFuncSetAttribute((const void *)k_rec, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        BHN_HIP(hipFuncSetAttribute((const void *)k_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        BHN_HIP(hipFuncSetAttribute((const void *)k_chn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         BHN_HIP(hipFuncSetAttribute((const void *)kdw, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
     BHN_CHECK_ARG(lds_chain <= 160 * 1024 && lds_dw <= 160 * 1024, "LDS budget exceeded (chain %zu, dw %zu)", lds_chain, lds_dw);
     const int B_total = A.f.B;
     const double *tM0 = A.f.tM0;
+    if (what == RUN_FWD_TRAIN)
+        BHN_HIP(hipMemsetAsync(images, 0, sizeof(float) * (size_t)B_total * A.f.Sx * A.f.R, st));
     for (int b0 = 0, pass = 0; b0 < B_total; b0 += (int)fpp, ++pass) {
         const int nb = (b0 + fpp <= B_total) ? (int)fpp : B_total - b0;
         A.f.B = nb;
         A.f.tM0 = tM0 + b0;
-        A.f.dimages = dimages + (long long)b0 * A.f.Sx * A.f.R;
+        A.f.dimages = dimages ? dimages + (long long)b0 * A.f.Sx * A.f.R : nullptr;
         A.f.total_tiles = (long long)A.f.tiles_per_frame * nb;
         tape_layout<W, Pol>(depth, A.f.total_tiles * Pol::NWAVES, &A.t);
         A.accumulate = pass > 0;
         A.debug = g_bwd_debug;
         long long grid = ncu;
         if (grid > A.f.total_tiles) grid = A.f.total_tiles;
-        if (g_bwd_stages & 1) hipLaunchKernelGGL(kchain, dim3((unsigned)grid), dim3(Pol::NTHREADS), lds_chain, st, A);
+        if (what == RUN_FWD_TRAIN) {
+            hipLaunchKernelGGL(k_fwd, dim3((unsigned)grid), dim3(Pol::NTHREADS), lds_chain, st, A);
+            BHN_HIP(hipGetLastError());
+            continue;
+        }
+        if (g_bwd_stages & 1) {
+            if (what == RUN_BWD_TAPE) hipLaunchKernelGGL(k_chn, dim3((unsigned)grid), dim3(Pol::NTHREADS), lds_chain, st, A);
+            else hipLaunchKernelGGL(k_rec, dim3((unsigned)grid), dim3(Pol::NTHREADS), lds_chain, st, A);
+        }
         BHN_HIP(hipGetLastError());
         if (g_bwd_stages & 2) hipLaunchKernelGGL(kdw, dim3((unsigned)A.wg_begin[depth + 1]), dim3(Pol::NTHREADS), lds_dw, st, A);
         BHN_HIP(hipGetLastError());
     }
-    if (g_bwd_stages & 4) hipLaunchKernelGGL((reduce_kernel<W, Pol>), dim3(256), dim3(256), 0, st, A);
+    if (what != RUN_FWD_TRAIN && (g_bwd_stages & 4)) hipLaunchKernelGGL((reduce_kernel<W, Pol>), dim3(256), dim3(256), 0, st, A);
     BHN_HIP(hipGetLastError());
     return BHN_OK;
 }
 
 template <class Pol>
-static int bwd_dispatch(int width, const bhn_model *m, int32_t mode, const void *packed, const bhn_geom *geom,
-                        const bhn_frames *fr, const float *dimages, float *dparams, void *ws, size_t wsb,
+static int bwd_dispatch(int what, int width, const bhn_model *m, int32_t mode, const void *packed, const bhn_geom *geom,
+                        const bhn_frames *fr, const float *dimages, float *images, float *dparams, void *ws, size_t wsb,
                         hipStream_t st, size_t *qb, int qB, long long qP, int device) {
     switch (width) {
-        case 32: return bwd_run<32, Pol>(m, mode, packed, geom, fr, dimages, dparams, ws, wsb, st, qb, qB, qP, device);
-        case 64: return bwd_run<64, Pol>(m, mode, packed, geom, fr, dimages, dparams, ws, wsb, st, qb, qB, qP, device);
-        case 128: return bwd_run<128, Pol>(m, mode, packed, geom, fr, dimages, dparams, ws, wsb, st, qb, qB, qP, device);
-        case 256: return bwd_run<256, Pol>(m, mode, packed, geom, fr, dimages, dparams, ws, wsb, st, qb, qB, qP, device);
+        case 32: return bwd_run<32, Pol>(what, m, mode, packed, geom, fr, dimages, images, dparams, ws, wsb, st, qb, qB, qP, device);
+        case 64: return bwd_run<64, Pol>(what, m, mode, packed, geom, fr, dimages, images, dparams, ws, wsb, st, qb, qB, qP, device);
+        case 128: return bwd_run<128, Pol>(what, m, mode, packed, geom, fr, dimages, images, dparams, ws, wsb, st, qb, qB, qP, device);
+        case 256: return bwd_run<256, Pol>(what, m, mode, packed, geom, fr, dimages, images, dparams, ws, wsb, st, qb, qB, qP, device);
         default:
             bhn_set_error("net_width %d: fused kernels are built for 32, 64, 128, 256", width);
             return BHN_EUNSUPPORTED;
     }
+}
+
+static int bwd_entry(int what, const bhn_model *m, int32_t mode, const void *packed, const bhn_geom *geom,
+                     const bhn_frames *fr, const float *dimages, float *images, float *dparams, void *workspace,
+                     size_t workspace_bytes, void *stream) {
+    BHN_CHECK_ARG(m, "null model");
+    BHN_CHECK_ARG(mode == BHN_F32 || mode == BHN_BF16, "bad mode %d", mode);
+    int dev = 0;
+    BHN_HIP(hipGetDevice(&dev));
+    return (mode == BHN_BF16)
+               ? bwd_dispatch<PolBF16>(what, m->net_width, m, mode, packed, geom, fr, dimages, images, dparams, workspace,
+                                       workspace_bytes, (hipStream_t)stream, nullptr, 0, 0, dev)
+               : bwd_dispatch<PolF32>(what, m->net_width, m, mode, packed, geom, fr, dimages, images, dparams, workspace,
+                                      workspace_bytes, (hipStream_t)stream, nullptr, 0, 0, dev);
 }
 
 extern "C" size_t bhn_render_bwd_workspace_bytes(const bhn_model *m, int32_t mode, int32_t B, int64_t P, int32_t device) {
@@ -730,21 +818,25 @@ extern "C" size_t bhn_render_bwd_workspace_bytes(const bhn_model *m, int32_t mod
     if (bhn_mlp_shape(m, &s) != BHN_OK || B <= 0 || P <= 0) return 0;
     size_t q = 0;
     int rc = (mode == BHN_BF16)
-                 ? bwd_dispatch<PolBF16>(s.width, m, mode, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, &q, B, P, device)
-                 : bwd_dispatch<PolF32>(s.width, m, mode, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, &q, B, P, device);
+                 ? bwd_dispatch<PolBF16>(RUN_QUERY, s.width, m, mode, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, &q, B, P, device)
+                 : bwd_dispatch<PolF32>(RUN_QUERY, s.width, m, mode, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, &q, B, P, device);
     return rc == BHN_OK ? q : 0;
 }
 
 extern "C" int bhn_render_bwd(const bhn_model *m, int32_t mode, const void *packed, const bhn_geom *geom,
                               const bhn_frames *fr, const float *dimages, float *dparams, void *workspace,
                               size_t workspace_bytes, void *stream) {
-    BHN_CHECK_ARG(m, "null model");
-    BHN_CHECK_ARG(mode == BHN_F32 || mode == BHN_BF16, "bad mode %d", mode);
-    int dev = 0;
-    BHN_HIP(hipGetDevice(&dev));
-    return (mode == BHN_BF16)
-               ? bwd_dispatch<PolBF16>(m->net_width, m, mode, packed, geom, fr, dimages, dparams, workspace, workspace_bytes,
-                                       (hipStream_t)stream, nullptr, 0, 0, dev)
-               : bwd_dispatch<PolF32>(m->net_width, m, mode, packed, geom, fr, dimages, dparams, workspace, workspace_bytes,
-                                      (hipStream_t)stream, nullptr, 0, 0, dev);
+    return bwd_entry(RUN_RECOMPUTE, m, mode, packed, geom, fr, dimages, nullptr, dparams, workspace, workspace_bytes, stream);
+}
+
+extern "C" int bhn_render_fwd_train(const bhn_model *m, int32_t mode, const void *packed, const bhn_geom *geom,
+                                    const bhn_frames *fr, float *images, void *workspace, size_t workspace_bytes,
+                                    void *stream) {
+    return bwd_entry(RUN_FWD_TRAIN, m, mode, packed, geom, fr, nullptr, images, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int bhn_render_bwd_tape(const bhn_model *m, int32_t mode, const void *packed, const bhn_geom *geom,
+                                   const bhn_frames *fr, const float *dimages, float *dparams, void *workspace,
+                                   size_t workspace_bytes, void *stream) {
+    return bwd_entry(RUN_BWD_TAPE, m, mode, packed, geom, fr, dimages, nullptr, dparams, workspace, workspace_bytes, stream);
 }

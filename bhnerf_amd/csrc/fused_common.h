@@ -272,6 +272,44 @@ DEVI unsigned relu_pack(const f32x16 &acc, int m, typename Pol::frag (&next)[W /
     return mask;
 }
 
+// ---------------------------------------------------------------------------------------------
+// LDS-DMA weight ring: chunk c+2 is copied global -> LDS (global_load_lds_dwordx4, no registers)
+// while chunk c is consumed; three buffers.  Every wave issues exactly PPW 1-KiB pieces per chunk
+// (tail waves re-issue the last piece) so that the counted vmcnt below is the same for all waves.
+// ---------------------------------------------------------------------------------------------
+template <int CHUNK_BYTES, int NWAVES>
+struct DmaRing {
+    static constexpr int NPIECE = CHUNK_BYTES / 1024;
+    static constexpr int PPW = (NPIECE + NWAVES - 1) / NWAVES;
+    static_assert(CHUNK_BYTES % 1024 == 0, "chunks are whole KiB");
+    static DEVI void issue(const char *src, char *dst) {
+        const int lane = threadIdx.x & 63;
+        const int wvu = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            int piece = wvu + NWAVES * i;
+            piece = piece < NPIECE ? piece : NPIECE - 1;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + piece * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) void *)(dst + piece * 1024), 16, 0, 0);
+        }
+    }
+    // wait until this wave's pieces of the chunk issued one step ago have landed; YOUNGER = vector-memory
+    // operations this wave has issued since (the next chunk's PPW pieces + this step's tape stores).
+    // A smaller count than the true one is always safe (it only waits longer).
+    template <int STORES>
+    static DEVI void wait_prev() {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + STORES) : "memory");
+    }
+};
+
+// Workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not drain vmcnt, so
+// global stores (tape tiles) and loads (weight prefetch) stay in flight across it.
+DEVI void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 // wave-level sum over the 32 lanes of each half (lanes 0-31 and 32-63 independently)
 DEVI float half_wave_sum(float v) {
 #pragma unroll

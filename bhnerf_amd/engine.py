@@ -181,6 +181,37 @@ class FusedPredictor:
         return out
 
 
+    def fits_tape(self, B, P):
+        """True when the workspace can hold the tape of all B frames (the recorded-tape fast path)."""
+        lib = _hip.lib()
+        full = int(lib.bhn_render_bwd_workspace_bytes(C.byref(self.model), self.mode, B, P, self.device.index or 0))
+        return 0 < full <= self.workspace(B, P).numel()
+
+    def render_train(self, geom, tM0, out=None):
+        """Training forward: images (B,Sx,R) + tape recorded in the workspace (see render_bwd_tape)."""
+        B = int(tM0.numel())
+        if out is None:
+            out = torch.empty((B, geom.Sx, geom.R), dtype=torch.float32, device=self.device)
+        ws = self.workspace(B, geom.P)
+        gs, fs = geom.c_struct(), self._frames(tM0)
+        _hip.check(_hip.lib().bhn_render_fwd_train(C.byref(self.model), self.mode, _hip.ptr(self.packed), C.byref(gs),
+                                                   C.byref(fs), _hip.ptr(out), _hip.ptr(ws), ws.numel(),
+                                                   _hip.stream_ptr(self.device)))
+        return out
+
+    def render_bwd_tape(self, geom, tM0, dimages, out=None):
+        """Gradient from the tape recorded by ``render_train`` (same geom / frames / packed weights)."""
+        assert dimages.dtype == torch.float32 and dimages.is_contiguous() and dimages.is_cuda
+        if out is None:
+            out = torch.empty((self.nparams,), dtype=torch.float32, device=self.device)
+        ws = self.workspace(int(tM0.numel()), geom.P)
+        gs, fs = geom.c_struct(), self._frames(tM0)
+        _hip.check(_hip.lib().bhn_render_bwd_tape(C.byref(self.model), self.mode, _hip.ptr(self.packed), C.byref(gs),
+                                                  C.byref(fs), _hip.ptr(dimages), _hip.ptr(out), _hip.ptr(ws), ws.numel(),
+                                                  _hip.stream_ptr(self.device)))
+        return out
+
+
 class RenderFunction(torch.autograd.Function):
     """images = render(params) with the fused HIP forward/backward (torch.autograd glue only)."""
 

@@ -345,7 +345,8 @@ def _step_image(state, t_units, dtype, target, sigma, offset, t_frames, coords, 
     tM0, _ = _frame_offsets(t_frames, t_units, t_start_obs, t_injection, dev)
     B = int(tM0.numel())
     eng.pack(state.flat)
-    images = eng.render(geom, tM0)
+    taped = train and eng.fits_tape(B, geom.P)      # record the tape while rendering: no recompute later
+    images = eng.render_train(geom, tM0) if taped else eng.render(geom, tM0)
     tshape = (B, geom.Sx, geom.R) if dtype == 'full' else (B, geom.Sx)
     tgt, sig, off = (_hip.as_f32(v, dev).reshape(tshape) for v in (target, sigma, offset))
     loss, dimg = engine.chi2_image(images, tgt, sig, off, scale, dtype, want_grad=train)
@@ -353,7 +354,7 @@ def _step_image(state, t_units, dtype, target, sigma, offset, t_frames, coords, 
     if train:
         n = eng.nparams
         buf = state.grad
-        eng.render_bwd(geom, tM0, dimg, out=buf[:n])
+        (eng.render_bwd_tape if taped else eng.render_bwd)(geom, tM0, dimg, out=buf[:n])
         loss_vec = dp_allreduce(buf, n, loss, rank, world)      # jax.lax.pmean(grads) (network.py:620)
         state.apply_gradients(buf[:n], grad_scale=1.0 / world)
     else:

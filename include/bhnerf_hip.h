@@ -118,6 +118,18 @@ int bhn_render_bwd(const bhn_model *m, int32_t mode, const void *packed, const b
                    const bhn_frames *fr, const float *dimages, float *dparams, void *workspace,
                    size_t workspace_bytes, void *stream);
 
+/* Training fast path (same result as bhn_render_fwd + bhn_render_bwd, one forward less):
+ * bhn_render_fwd_train renders `images` AND records layer inputs, ReLU bits and emission on the tape in
+ * `workspace`; bhn_render_bwd_tape then runs only the delta chain + weight-gradient GEMMs from that
+ * tape.  Both calls must see the same model/geometry/frames and a workspace of at least
+ * bhn_render_bwd_workspace_bytes(B,P) bytes (BHN_EWORKSPACE otherwise: use the pair above). */
+int bhn_render_fwd_train(const bhn_model *m, int32_t mode, const void *packed, const bhn_geom *geom,
+                         const bhn_frames *fr, float *images, void *workspace, size_t workspace_bytes,
+                         void *stream);
+int bhn_render_bwd_tape(const bhn_model *m, int32_t mode, const void *packed, const bhn_geom *geom,
+                        const bhn_frames *fr, const float *dimages, float *dparams, void *workspace,
+                        size_t workspace_bytes, void *stream);
+
 /* loss_fn_image (network.py:476-484): dtype 0 = 'full', 1 = 'lc'.  target/sigma/offset are
  * (B,Sx,R) for 'full', (B,Sx) for 'lc'.  Writes loss[0] = scale*chi^2 and dimages = dloss/dimages
  * (pass NULL to skip the gradient). */

@@ -205,3 +205,25 @@ def test_random_problem_f32_and_bf16(dev, width, depth, S):
         gerr = np.abs(params.grad.cpu().numpy() - gref).max() / np.abs(gref).max()
         assert gerr < GTOL[mode], (mode, gerr)
         assert l2err(params.grad.cpu().numpy(), gref) < L2TOL[mode]
+
+
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+@pytest.mark.parametrize('tag', ['b', 'c', 'f'])
+def test_taped_training_path_equals_recompute_path(dev, golden, tag, mode):
+    """bhn_render_fwd_train + bhn_render_bwd_tape (forward recorded on the tape, delta chain only) must give
+    the images of bhn_render_fwd and the gradient of bhn_render_bwd (recompute) -- same arithmetic."""
+    from bhnerf_amd import engine
+    g = golden('g5_predict_' + tag)
+    pred, rt = device_setup(g, mode, dev)
+    eng = pred.engine()
+    eng.pack(eng.flatten(golden_tree(g)))
+    geom = pred.geometry(rt['coords'], rt['Omega'], rt['t_geos'], rt['J'] if g['J'].ndim else None, rt['g'], rt['dtau'], rt['Sigma'])
+    tM0 = engine.frame_offsets(g['t_frames'], 0.0, rt['t_injection'], onp.GM_C3_SGRA_HR, dev)
+    dimg = torch.randn((len(g['t_frames']), geom.Sx, geom.R), device=dev)
+    img_ref = eng.render(geom, tM0).clone()
+    grad_ref = eng.render_bwd(geom, tM0, dimg).clone()
+    assert eng.fits_tape(int(tM0.numel()), geom.P)
+    img = eng.render_train(geom, tM0)
+    grad = eng.render_bwd_tape(geom, tM0, dimg)
+    assert torch.allclose(img, img_ref, rtol=1e-6, atol=1e-7 * float(img_ref.abs().max()))
+    assert torch.equal(grad, grad_ref)
