@@ -340,3 +340,113 @@ extern "C" int bhn_adam_step(float *params, const float *grads, float *m, float 
     BHN_HIP(hipGetLastError());
     return BHN_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// loss_fn_eht (network.py:541-564): visibilities = A . image, chi^2 on 'vis' | 'amp' | 'cphase'.
+// A is complex64 (interleaved re,im), shape (N, C, nvis, R): C = 1 for vis/amp, 3 for closure
+// phases (the product over the C axis is the bispectrum, network.py:558).  HBM-bound: A is read once
+// in the forward GEMV and once in the backward; algorithmic bytes 2 * 8*N*C*nvis*R.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void eht_vis_kernel(const float *__restrict__ images, const float2 *__restrict__ A,
+                                                      int C, int nvis, int64_t R, float2 *__restrict__ vis) {
+    __shared__ float red[4];
+    const int64_t row = blockIdx.x;                         // (n, c, k)
+    const int64_t n = row / ((int64_t)C * nvis);
+    const float2 *a = A + row * R;
+    const float *img = images + n * R;
+    float re = 0.f, im = 0.f;
+    for (int64_t r = threadIdx.x; r < R; r += 256) {
+        const float2 v = a[r];
+        const float x = img[r];
+        re += v.x * x;
+        im += v.y * x;
+    }
+    const float sre = block_sum_256(re, red);
+    const float sim = block_sum_256(im, red);
+    if (threadIdx.x == 0) vis[row] = make_float2(sre, sim);
+}
+
+// per (n,k): chi^2 term and gv = dL/dRe(vis) + i dL/dIm(vis), written over vis
+__global__ void eht_loss_kernel(float2 *__restrict__ vis, const float *__restrict__ target, const float *__restrict__ sigma,
+                                float scale, int dtype, int64_t N, int C, int nvis, float *__restrict__ loss, int want_grad) {
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    float term = 0.f;
+    if (t < N * nvis) {
+        const int64_t n = t / nvis, k = t % nvis;
+        const float s = sigma[t];
+        if (dtype == 0) {            // 'vis': sum (|vis - target| / sigma)^2, target complex (network.py:548)
+            const float2 v = vis[(n * C) * nvis + k];
+            const float dr = v.x - target[2 * t], di = v.y - target[2 * t + 1];
+            term = (dr * dr + di * di) / (s * s);
+            if (want_grad) vis[(n * C) * nvis + k] = make_float2(2.f * scale * dr / (s * s), 2.f * scale * di / (s * s));
+        } else if (dtype == 1) {     // 'amp': sum |(|vis| - target) / sigma|^2 (network.py:553)
+            const float2 v = vis[(n * C) * nvis + k];
+            const float amp = sqrtf(v.x * v.x + v.y * v.y);
+            const float d = (amp - target[t]) / s;
+            term = d * d;
+            if (want_grad) {
+                const float g = amp > 0.f ? 2.f * scale * d / (s * amp) : 0.f;
+                vis[(n * C) * nvis + k] = make_float2(g * v.x, g * v.y);
+            }
+        } else {                     // 'cphase': sum (1 - cos(target - angle(prod_c vis_c))) / sigma^2 (network.py:558-559)
+            float phi = 0.f;
+            for (int c = 0; c < C; ++c) {
+                const float2 v = vis[(n * C + c) * nvis + k];
+                phi += atan2f(v.y, v.x);
+            }
+            const float d = target[t] - phi;
+            term = (1.f - cosf(d)) / (s * s);
+            if (want_grad) {
+                const float dphi = -scale * sinf(d) / (s * s);          // dL/dphi
+                for (int c = 0; c < C; ++c) {
+                    const float2 v = vis[(n * C + c) * nvis + k];
+                    const float m2 = v.x * v.x + v.y * v.y;
+                    vis[(n * C + c) * nvis + k] = m2 > 0.f ? make_float2(-dphi * v.y / m2, dphi * v.x / m2) : make_float2(0.f, 0.f);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) term += __shfl_xor(term, o, 64);
+    if ((threadIdx.x & 63) == 0 && term != 0.f) atomicAdd(loss, scale * term);
+}
+
+// dimg[n,r] = sum_{c,k} Re(gv) A_re + Im(gv) A_im
+__global__ __launch_bounds__(256) void eht_bwd_kernel(const float2 *__restrict__ gv, const float2 *__restrict__ A, int C, int nvis,
+                                                      int64_t R, float *__restrict__ dimages) {
+    const int64_t n = blockIdx.y;
+    const int64_t r = blockIdx.x * (int64_t)256 + threadIdx.x;
+    if (r >= R) return;
+    float acc = 0.f;
+    const int rows = C * nvis;
+    for (int j = 0; j < rows; ++j) {
+        const float2 g = gv[n * rows + j];                  // wave-uniform: scalar loads
+        const float2 a = A[(n * rows + j) * R + r];
+        acc += g.x * a.x + g.y * a.y;
+    }
+    dimages[n * R + r] = acc;
+}
+
+extern "C" int bhn_chi2_eht(const float *images, const float *A, const float *target, const float *sigma, float scale,
+                            int32_t dtype, int32_t N, int32_t C, int32_t nvis, int64_t R, float *vis_ws, float *loss,
+                            float *dimages, void *stream) {
+    BHN_CHECK_ARG(images && A && target && sigma && vis_ws && loss, "null pointer");
+    BHN_CHECK_ARG(dtype >= 0 && dtype <= 2, "eht dtype (%d) not supported", dtype);
+    BHN_CHECK_ARG(N > 0 && nvis > 0 && R > 0, "bad sizes");
+    BHN_CHECK_ARG((dtype == 2) ? (C >= 1 && C <= 8) : (C == 1), "A must have %s visibilities per closure", dtype == 2 ? "1..8" : "1");
+    hipStream_t st = (hipStream_t)stream;
+    BHN_HIP(hipMemsetAsync(loss, 0, sizeof(float), st));
+    hipLaunchKernelGGL(eht_vis_kernel, dim3((unsigned)(N * C * nvis)), dim3(256), 0, st, images,
+                       reinterpret_cast<const float2 *>(A), C, nvis, R, reinterpret_cast<float2 *>(vis_ws));
+    BHN_HIP(hipGetLastError());
+    const int64_t tot = (int64_t)N * nvis;
+    hipLaunchKernelGGL(eht_loss_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, reinterpret_cast<float2 *>(vis_ws),
+                       target, sigma, scale, dtype, (int64_t)N, C, nvis, loss, dimages ? 1 : 0);
+    BHN_HIP(hipGetLastError());
+    if (dimages) {
+        hipLaunchKernelGGL(eht_bwd_kernel, dim3((unsigned)((R + 255) / 256), (unsigned)N), dim3(256), 0, st,
+                           reinterpret_cast<const float2 *>(vis_ws), reinterpret_cast<const float2 *>(A), C, nvis, R, dimages);
+        BHN_HIP(hipGetLastError());
+    }
+    return BHN_OK;
+}

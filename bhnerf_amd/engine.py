@@ -240,6 +240,61 @@ def chi2_image(images, target, sigma, offset, scale, dtype, want_grad=True):
     return loss, dimg
 
 
+EHT_DTYPES = {'vis': 0, 'amp': 1, 'cphase': 2}
+
+
+def _eht_operands(images, A, target, sigma, dtype):
+    """Flatten (images, A, target, sigma) to the kernel layout; raises the reference's AttributeErrors
+    (network.py:545-562)."""
+    code = EHT_DTYPES.get(dtype)
+    if code is None:
+        raise AttributeError('eht dtype ({}) not supported'.format(dtype))
+    vis_ndim = A.ndim - 1
+    want = target.ndim + (1 if dtype == 'cphase' else 0)
+    if vis_ndim != want:
+        raise AttributeError('visibilities (ndim={}) should have {} dimensions as target (ndim={}) for dtype={}'.format(
+            vis_ndim, '+1' if dtype == 'cphase' else 'same', target.ndim, dtype))
+    R, nvis = int(A.shape[-1]), int(A.shape[-2])
+    C_ = int(A.shape[-3]) if dtype == 'cphase' else 1
+    N = int(np.prod(target.shape[:-1])) if target.ndim > 1 else 1
+    dev = images.device
+    img = images.reshape(N, R).to(torch.float32).contiguous()
+    A = torch.as_tensor(A, device=dev)
+    Ar = torch.view_as_real(A.to(torch.complex64).reshape(N, C_, nvis, R).contiguous())
+    tgt = torch.as_tensor(target, device=dev)
+    tgt = torch.view_as_real(tgt.to(torch.complex64).reshape(N, nvis).contiguous()) if dtype == 'vis' \
+        else tgt.to(torch.float32).reshape(N, nvis).contiguous()
+    sig = torch.as_tensor(sigma, device=dev).to(torch.float32).expand(tuple(target.shape)).reshape(N, nvis).contiguous()
+    return code, img, Ar, tgt, sig, N, C_, nvis, R
+
+
+def chi2_eht(images, A, target, sigma, scale, dtype, want_grad=True):
+    """loss_fn_eht tail (network.py:541-564) on device -> (loss[1], dimages shaped like images or None)."""
+    code, img, Ar, tgt, sig, N, C_, nvis, R = _eht_operands(images, A, target, sigma, dtype)
+    dev = img.device
+    ws = torch.empty((N * C_ * nvis * 2,), dtype=torch.float32, device=dev)
+    loss = torch.empty((1,), dtype=torch.float32, device=dev)
+    dimg = torch.empty_like(img) if want_grad else None
+    _hip.check(_hip.lib().bhn_chi2_eht(_hip.ptr(img), _hip.ptr(Ar), _hip.ptr(tgt), _hip.ptr(sig), float(scale), code, N, C_,
+                                       nvis, R, _hip.ptr(ws), _hip.ptr(loss), _hip.ptr(dimg), _hip.stream_ptr(dev)))
+    return loss, (dimg.reshape(images.shape) if want_grad else None)
+
+
+class EhtChi2Function(torch.autograd.Function):
+    """scale*chi^2 of the visibilities of `images` (differentiable w.r.t. images)."""
+
+    @staticmethod
+    def forward(ctx, images, A, target, sigma, scale, dtype):
+        loss, dimg = chi2_eht(images, A, target, sigma, scale, dtype, want_grad=True)
+        ctx.save_for_backward(dimg)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dimg,) = ctx.saved_tensors
+        return dimg * g, None, None, None, None, None
+
+
 def adam_step(params, grads, m, v, t, lr, b1=0.9, b2=0.999, eps=1e-8, grad_scale=1.0):
     _hip.check(_hip.lib().bhn_adam_step(_hip.ptr(params), _hip.ptr(grads), _hip.ptr(m), _hip.ptr(v), params.numel(),
                                         int(t), float(lr), b1, b2, eps, float(grad_scale),

@@ -318,6 +318,18 @@ def loss_fn_image(params, predictor_fn, target, sigma, offset, t_frames, coords,
     return scale * loss, [images]
 
 
+def loss_fn_eht(params, predictor_fn, target, sigma, A, t_frames, coords, Omega, J, g, dtau, Sigma, t_start_obs,
+                t_geos, t_injection, scale, t_units, dtype):
+    """chi-square loss for EHT observations: 'vis', 'amp' or 'cphase' (network.py:486-564).  ``A`` holds
+    the DFT matrices per frame: (b, nvis, H*W) ('vis'/'amp') or (b, 3, nvis, H*W) ('cphase')."""
+    images = image_plane_prediction(params, predictor_fn, t_frames, coords, Omega, J, g, dtau, Sigma, t_start_obs,
+                                    t_geos, t_injection, t_units)
+    if dtype not in engine.EHT_DTYPES:
+        raise AttributeError('eht dtype ({}) not supported'.format(dtype))
+    loss = engine.EhtChi2Function.apply(images.reshape(tuple(images.shape[:-2]) + (-1,)), A, target, sigma, scale, dtype)
+    return loss, [images]
+
+
 def dp_allreduce(buf, n, loss, rank, world):
     """The one collective of a training step (network.py:620): ``buf[:n]`` holds this rank's gradient
     of its per-device chi^2 SUM; slots ``buf[n:n+world]`` carry the per-rank losses so that a single
@@ -333,10 +345,14 @@ def dp_allreduce(buf, n, loss, rank, world):
 
 
 def _step_image(state, t_units, dtype, target, sigma, offset, t_frames, coords, Omega, J, g, dtau, Sigma,
-                t_start_obs, t_geos, t_injection, scale, train):
-    """Per-process body of gradient_step_image / test_image with no torch.autograd in the loop:
-    pack -> fused render -> chi^2 kernel -> fused backward -> all-reduce -> Adam."""
-    if dtype not in ('full', 'lc'):
+                t_start_obs, t_geos, t_injection, scale, train, eht=False):
+    """Per-process body of gradient_step_image/_eht and test_image/_eht with no torch.autograd in the
+    loop: pack -> fused render -> chi^2 kernel -> fused backward -> all-reduce -> Adam.  For the EHT
+    losses ``offset`` carries the DFT matrices A."""
+    if eht:
+        if dtype not in engine.EHT_DTYPES:
+            raise AttributeError('eht dtype ({}) not supported'.format(dtype))
+    elif dtype not in ('full', 'lc'):
         raise AttributeError('image dtype ({}) not supported'.format(dtype))
     pred = state.predictor
     eng = pred.engine()
@@ -347,9 +363,13 @@ def _step_image(state, t_units, dtype, target, sigma, offset, t_frames, coords, 
     eng.pack(state.flat)
     taped = train and eng.fits_tape(B, geom.P)      # record the tape while rendering: no recompute later
     images = eng.render_train(geom, tM0) if taped else eng.render(geom, tM0)
-    tshape = (B, geom.Sx, geom.R) if dtype == 'full' else (B, geom.Sx)
-    tgt, sig, off = (_hip.as_f32(v, dev).reshape(tshape) for v in (target, sigma, offset))
-    loss, dimg = engine.chi2_image(images, tgt, sig, off, scale, dtype, want_grad=train)
+    if eht:
+        loss, dimg = engine.chi2_eht(images if geom.S else images[:, 0], offset, target, sigma, scale, dtype, want_grad=train)
+        dimg = dimg.reshape(images.shape) if train else None
+    else:
+        tshape = (B, geom.Sx, geom.R) if dtype == 'full' else (B, geom.Sx)
+        tgt, sig, off = (_hip.as_f32(v, dev).reshape(tshape) for v in (target, sigma, offset))
+        loss, dimg = engine.chi2_image(images, tgt, sig, off, scale, dtype, want_grad=train)
     rank, world = _world()
     if train:
         n = eng.nparams
@@ -386,6 +406,23 @@ def test_image(state, t_units, dtype, target, sigma, offset, t_frames, coords, O
 
 
 test_image.__test__ = False   # not a pytest test
+
+
+def gradient_step_eht(state, t_units, dtype, target, sigma, A, t_frames, coords, Omega, J, g, dtau, Sigma,
+                      t_start_obs, t_geos, t_injection, scale):
+    """Gradient step on EHT observables (network.py:624-682); same contract as gradient_step_image."""
+    return _step_image(state, t_units, dtype, target, sigma, A, t_frames, coords, Omega, J, g, dtau, Sigma,
+                       t_start_obs, t_geos, t_injection, scale, True, eht=True)
+
+
+def test_eht(state, t_units, dtype, target, sigma, A, t_frames, coords, Omega, J, g, dtau, Sigma,
+             t_start_obs, t_geos, t_injection, scale):
+    """Forward-only twin of gradient_step_eht (network.py:741-795)."""
+    return _step_image(state, t_units, dtype, target, sigma, A, t_frames, coords, Omega, J, g, dtau, Sigma,
+                       t_start_obs, t_geos, t_injection, scale, False, eht=True)
+
+
+test_eht.__test__ = False
 
 
 def sample_3d_grid(apply_fn, params, t_frame=0, t_start_obs=0, Omega=0, fov=None, coords=None, resolution=64, chunk=-1):

@@ -174,8 +174,36 @@ class TrainStep(object):
         return cls(dtype, args, network.gradient_step_image, network.test_image, scale)
 
     @classmethod
-    def eht(cls, *a, **kw):
-        raise NotImplementedError('visibility-domain training (loss_fn_eht) is the next hot-path row (SURVEY 8f1)')
+    def eht_arrays(cls, t_frames, target, sigma, A, dtype='vis', scale=1.0):
+        """Training step on EHT observables from plain arrays: per frame the measurement `target`
+        (nt, nvis) (complex for 'vis'), its `sigma`, and the DFT matrices `A` (nt, nvis, H*W) or, for
+        'cphase', (nt, 3, nvis, H*W) (radians) -- what ehtim's chisqdata_<dtype> returns per frame
+        (optimization.py:237-257).  See ``observation.dft_matrix`` for a direct-DFT `A`."""
+        if dtype not in ('vis', 'amp', 'cphase'):
+            raise AttributeError('eht dtype ({}) not supported'.format(dtype))
+        args = TemporalBatchedArgs(t_frames, [np.asarray(target), np.asarray(sigma), np.asarray(A)])
+        return cls(dtype, args, network.gradient_step_eht, network.test_eht, scale)
+
+    @classmethod
+    def eht(cls, t_frames, obs, image_fov, image_size, chisqdata, pol='I', scale=1.0):
+        """Training step for an ehtim observation (optimization.py:219-268); needs the external ehtim
+        package to split the observation per frame and build (target, sigma, A)."""
+        try:
+            from ehtim.image import make_square
+        except ImportError as exc:
+            raise ImportError('TrainStep.eht needs ehtim; use TrainStep.eht_arrays with your own (target, sigma, A)') from exc
+        dtype = chisqdata.__name__.split('_')[-1]
+        for p in np.atleast_1d(pol):
+            if p not in ('I', 'Q', 'U'):
+                raise AttributeError('pol ({}) not in supported pol_types: I,Q,U'.format(p))
+        span = (t_frames[-1] - t_frames[0]).to('s').value
+        frames = obs.split_obs(t_gather=span / (len(t_frames) + 1))
+        prior = make_square(obs, image_size, image_fov)
+        per_pol = [[np.array(x) for x in zip(*[chisqdata(f, prior, mask=[], pol=p) for f in frames])] for p in np.atleast_1d(pol)]
+        target, sigma, A = (np.squeeze(np.stack([pp[i] for pp in per_pol], axis=1)) for i in range(3))
+        if dtype == 'cphase':                                   # ehtim closure phases are in degrees
+            target, sigma = np.deg2rad(target), np.deg2rad(sigma)
+        return cls.eht_arrays(t_frames, target, sigma, A, dtype, scale)
 
     @property
     def t_units(self):
@@ -192,7 +220,7 @@ class TemporalBatchedArgs(object):
             args = [args]
         self.num_frames = len(t_frames)
         assert all([self.num_frames == arg.shape[0] for arg in args])
-        self.host_args = [np.asarray(a, dtype=np.float32) for a in args]
+        self.host_args = [np.asarray(a, dtype=np.complex64 if np.iscomplexobj(a) else np.float32) for a in args]
         self.t_values = np.asarray(units.strip(t_frames), dtype=np.float64)
         self.args = self.host_args + [self.t_values]
         self.default_t_units = units.hr

@@ -137,6 +137,15 @@ int bhn_chi2_image(const float *images, const float *target, const float *sigma,
                    float scale, int32_t dtype, int32_t B, int32_t Sx, int64_t R, float *loss,
                    float *dimages, void *stream);
 
+/* loss_fn_eht (network.py:486-564): visibilities = A . image, then chi^2 of dtype 0 = 'vis' (complex
+ * target), 1 = 'amp', 2 = 'cphase' (closure phase of the product over the C axis).  images (N,R) with
+ * N = B*Sx planes; A complex64 interleaved (N,C,nvis,R), C = 1 for vis/amp; target (N,nvis) (complex
+ * interleaved for 'vis'); sigma (N,nvis); vis_ws: caller scratch of 2*N*C*nvis floats.  Writes
+ * loss[0] = scale*chi^2 and, unless NULL, dimages (N,R). */
+int bhn_chi2_eht(const float *images, const float *A, const float *target, const float *sigma, float scale,
+                 int32_t dtype, int32_t N, int32_t C, int32_t nvis, int64_t R, float *vis_ws, float *loss,
+                 float *dimages, void *stream);
+
 /* optax.adam + polynomial_schedule(power=1) as used by init_state (network.py:173-174, 621):
  * g' = g*grad_scale (the 1/ndev of pmean, network.py:620); t = 1-based update count. */
 int bhn_adam_step(float *params, const float *grads, float *m, float *v, int64_t n, int64_t t, float lr,

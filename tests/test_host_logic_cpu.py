@@ -104,8 +104,12 @@ def test_train_step_contract_and_total_movie_loss_chunking():
     assert both.num_losses == 2
     with pytest.raises(AttributeError, match='only hr units supported'):
         optimization.TrainStep('full', optimization.TemporalBatchedArgs(np.linspace(0, 1, 7) * units.s, [target]), fake_step, fake_step, 1.0)
-    with pytest.raises(NotImplementedError):
-        optimization.TrainStep.eht()
+    with pytest.raises(ImportError, match='ehtim'):          # external package; eht_arrays is the array-based entry
+        optimization.TrainStep.eht(t, None, 1e-10, 4, lambda *a, **k: None)
+    A = (np.ones((7, 5, 4)) + 1j * np.ones((7, 5, 4)))
+    eht = optimization.TrainStep.eht_arrays(t, np.zeros((7, 5), dtype=complex), np.ones((7, 5)), A, dtype='vis')
+    tgt, sig, Ab, tf = eht.args[0][np.array([0, 2])]
+    assert np.asarray(Ab).dtype == np.complex64 and np.asarray(tgt).dtype == np.complex64 and eht.dtype[0] == 'vis'
     fired = []
     log = optimization.LogFn(lambda opt: fired.append(opt.step), log_period=5)
     for s in (1, 2, 5, 7, 10):
