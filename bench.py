@@ -198,8 +198,15 @@ def main():
     dom = max(alg, key=lambda k: kern_ms[k])
     achieved = alg[dom] * pts / (kern_ms[dom] * 1e-3) / 1e12
     peak = PEAK_TFLOPS[args.mode]
+    traffic = None
+    try:      # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (profiles/)
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r1_pmc_traffic.json')))['kernels']
+        if H == 128 and G == 64 and args.frames_per_gpu == 8 and args.width == 256 and args.mode == 'bf16':
+            traffic = pmc.get(dom, {}).get('hbm_bytes')
+    except Exception:
+        pass
     roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
-                'frac': round(achieved / peak, 4), 'traffic': None,
+                'frac': round(achieved / peak, 4), 'traffic': traffic,
                 'kernel_ms': {k: round(v, 4) for k, v in kern_ms.items()},
                 'step_algorithmic_tflops': round(f_train * value * geom.active_fraction / 1e12 / world, 2)}
 
