@@ -176,7 +176,7 @@ def main():
         return float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
     lib = _hip.lib()
-    taped = eng.fits_tape(args.frames_per_gpu, geom.P)
+    taped = eng.fits_tape(args.frames_per_gpu, geom.P_eff)
     if taped:      # the kernels a training step runs: training forward (records the tape), delta chain, dW GEMM
         kern_ms = {'chain_kernel<MODE_FWD_TRAIN>': timed(lambda: eng.render_train(geom, tM0))}
         bwd = lambda: eng.render_bwd_tape(geom, tM0, dimg)
@@ -192,7 +192,7 @@ def main():
         kern_ms[name] = timed(bwd)
     lib.bhn_debug_set_bwd_stages(7)
     kern_ms['fused_fwd_kernel (inference)'] = timed(lambda: eng.render(geom, tM0))
-    pts = args.frames_per_gpu * geom.P * geom.active_fraction
+    pts = args.frames_per_gpu * geom.P * geom.visited_fraction     # points that go through the MLP
     f_fwd, f_chain, f_dw, f_train = mlp_flops(args.depth, args.width)
     alg = {fwd_name: f_fwd, chain_name: f_chain, 'dw_kernel': f_dw}
     dom = max(alg, key=lambda k: kern_ms[k])
@@ -208,7 +208,7 @@ def main():
     roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
                 'frac': round(achieved / peak, 4), 'traffic': traffic,
                 'kernel_ms': {k: round(v, 4) for k, v in kern_ms.items()},
-                'step_algorithmic_tflops': round(f_train * value * geom.active_fraction / 1e12 / world, 2)}
+                'step_algorithmic_tflops': round(f_train * value * geom.visited_fraction / 1e12 / world, 2)}
 
     # ---- stand-alone radiative-transfer scan (kgeo.radiative_trasfer, HBM-bound): achieved GB/s ---------
     # measured at the size SURVEY 8d quotes (config 3: 256x256 rays x 128 samples, B*S = 8*3 planes, ~1 GB)
@@ -231,7 +231,8 @@ def main():
         'config': {'workload': 'Tutorial3 image-plane recovery: %dx%d rays x %d samples, %d frames, %dx%d MLP, loss full'
                                % (H, W, G, nt, args.depth, args.width),
                    'frames_per_step': batch, 'frames_per_gpu': args.frames_per_gpu, 'parallelism': 'dp%d (time-frames)' % world,
-                   'active_fraction': round(geom.active_fraction, 4), 'loss': loss_now},
+                   'active_fraction': round(geom.active_fraction, 4), 'visited_fraction': round(geom.visited_fraction, 4),
+                   'loss': loss_now},
         'roofline': roofline,
         'rt_scan': rt_scan,
         'fwd_images_per_s': round(args.frames_per_gpu / (kern_ms['fused_fwd_kernel (inference)'] * 1e-3), 1),

@@ -191,9 +191,10 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
 #define RING_STEP_END(STORES) RG::template wait_prev<(STORES) + ES>(); lds_barrier(); cur = cur == 2 ? 0 : cur + 1;
 
     for (long long tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
-        const int b = (int)(tile / a.tiles_per_frame);
-        const long long p = (tile % a.tiles_per_frame) * (Pol::NWAVES * 32) + wv * 32 + pl;
-        const bool inb = p < a.P;
+        int b;
+        long long p;
+        bool inb;
+        tile_point<Pol::NWAVES>(a, tile, wv, pl, b, p, inb);
         const long long q = tile * Pol::NWAVES + wv;                     // 32-point group on the tape
         unsigned *mask_g = reinterpret_cast<unsigned *>(A.tape + A.t.mask_off) + q * (long long)(a.depth * MW * 64);
         float *e_g = reinterpret_cast<float *>(A.tape + A.t.e_off) + q * 32;

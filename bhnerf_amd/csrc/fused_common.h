@@ -89,6 +89,8 @@ struct FusedArgs {
     // geometry
     const float *x, *y, *z, *Omega, *t_geo, *w;
     const uint8_t *dom;
+    const int *groups;    // active 32-point groups (NULL = all)
+    long long n_groups;
     long long P, G, R;
     int Sx;               // max(S,1)
     // frames
@@ -226,6 +228,18 @@ DEVI void point_prologue(const FusedArgs &a, int b, long long p, bool inb, typen
             const float v1 = feat[16 * ks + phi16(1, j)];
             Pol::set(enc[ks], j, h ? v1 : v0);
         }
+}
+
+// tile -> (frame, point) mapping shared by all fused kernels: wave `wv` of tile `tile` owns the 32-point group
+// number (tile % tiles_per_frame) * NWAVES + wv of the (compacted) group list
+template <int NWAVES>
+DEVI void tile_point(const FusedArgs &a, long long tile, int wv, int pl, int &b, long long &p, bool &inb) {
+    b = (int)(tile / a.tiles_per_frame);
+    const long long gi = (tile % a.tiles_per_frame) * NWAVES + wv;
+    const bool gok = gi < a.n_groups;
+    const long long grp = gok ? (a.groups ? (long long)a.groups[gi] : gi) : 0;
+    p = grp * 32 + pl;
+    inb = gok && p < a.P;
 }
 
 // bias rows of output tile m as the initial accumulator: acc[r] = bias[32m + (r&3)+8(r>>2)+4h]

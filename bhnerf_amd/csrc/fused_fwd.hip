@@ -140,9 +140,10 @@ __global__ __launch_bounds__(Pol::NTHREADS) void fused_fwd_kernel(FusedArgs a) {
     int par = 0;
 
     for (long long tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
-        const int b = (int)(tile / a.tiles_per_frame);
-        const long long p = (tile % a.tiles_per_frame) * (Pol::NWAVES * 32) + wv * 32 + pl;
-        const bool inb = p < a.P;
+        int b;
+        long long p;
+        bool inb;
+        tile_point<Pol::NWAVES>(a, tile, wv, pl, b, p, inb);
         frag enc[2];
         bool live;
         point_prologue<Pol, DEG>(a, b, p, inb, enc, live);
@@ -248,8 +249,10 @@ int fused_fill_args(const bhn_model *m, int32_t mode, const void *packed, const 
     a->packed = (const char *)packed;
     a->fwd_off = (unsigned)L.fwd_off; a->bwd_off = (unsigned)L.bwd_off;
     a->bias_off = (unsigned)L.bias_off; a->wout_off = (unsigned)L.wout_off;
-    const long long pts_per_tile = (long long)nwaves * 32;
-    a->tiles_per_frame = (int)((a->P + pts_per_tile - 1) / pts_per_tile);
+    a->groups = reinterpret_cast<const int *>(geom->groups);
+    a->n_groups = geom->groups ? geom->n_groups : (a->P + 31) / 32;
+    BHN_CHECK_ARG(a->n_groups > 0 && a->n_groups <= (a->P + 31) / 32, "bad n_groups %lld", (long long)a->n_groups);
+    a->tiles_per_frame = (int)((a->n_groups + nwaves - 1) / nwaves);
     a->total_tiles = (long long)a->tiles_per_frame * a->B;
     return BHN_OK;
 }
@@ -298,6 +301,8 @@ extern "C" int bhn_predict_fwd(const bhn_model *m, int32_t mode, const void *pac
     int rc = fused_fill_args(m, mode, packed, geom, fr, false, &a, &s, nw);
     if (rc != BHN_OK) return rc;
     a.emission = emission;
+    if (geom->groups)   // points of skipped groups are outside the domain: emission 0
+        BHN_HIP(hipMemsetAsync(emission, 0, sizeof(float) * (size_t)a.B * a.P, (hipStream_t)stream));
     return mode == BHN_BF16 ? launch_fwd<PolBF16, false>(a, s.width, (hipStream_t)stream)
                             : launch_fwd<PolF32, false>(a, s.width, (hipStream_t)stream);
 }

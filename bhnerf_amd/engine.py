@@ -61,15 +61,36 @@ class RayGeometry:
             _hip.ptr(self.coords), _hip.ptr(g), _hip.ptr(dtau), _hip.ptr(Sigma), _hip.ptr(Jt), self.S, P,
             self.rmin, self.rmax, self.z_width, _hip.ptr(self.w), _hip.ptr(self.dom), _hip.stream_ptr(dev)))
         self.device = dev
+        # compaction of the static domain mask: the 32-point groups that contain an in-domain point
+        ngroups = (P + 31) // 32
+        pad = torch.zeros((ngroups * 32,), dtype=torch.uint8, device=dev)
+        pad[:P] = self.dom
+        active = pad.view(ngroups, 32).any(dim=1)
+        self.n_groups_total = ngroups
+        if bool(active.all()):
+            self.groups, self.n_groups = None, ngroups
+        else:
+            self.groups = torch.nonzero(active).reshape(-1).to(torch.int32).contiguous()
+            self.n_groups = max(int(self.groups.numel()), 1)
+            if self.groups.numel() == 0:                      # nothing inside the domain: keep one (masked) group
+                self.groups = torch.zeros((1,), dtype=torch.int32, device=dev)
+        self.P_eff = self.n_groups * 32                       # points the fused kernels / the tape visit per frame
 
     def c_struct(self):
         c = self.coords
         return _hip.bhn_geom(self.R, self.G, self.S, c[0].data_ptr(), c[1].data_ptr(), c[2].data_ptr(),
-                             self.Omega.data_ptr(), self.t_geo.data_ptr(), self.w.data_ptr(), self.dom.data_ptr())
+                             self.Omega.data_ptr(), self.t_geo.data_ptr(), self.w.data_ptr(), self.dom.data_ptr(),
+                             self.groups.data_ptr() if self.groups is not None else None, self.n_groups)
 
     @property
     def active_fraction(self):
+        """Fraction of ray samples inside the supervised domain (static mask)."""
         return float(self.dom.float().mean().item())
+
+    @property
+    def visited_fraction(self):
+        """Fraction of ray samples the fused kernels evaluate after 32-point group compaction."""
+        return self.P_eff / float(self.n_groups_total * 32)
 
 
 def frame_offsets(t_frames, t_start_obs, t_injection, GM_c3, device):
@@ -173,7 +194,7 @@ class FusedPredictor:
         assert dimages.dtype == torch.float32 and dimages.is_contiguous() and dimages.is_cuda
         if out is None:
             out = torch.empty((self.nparams,), dtype=torch.float32, device=self.device)
-        ws = self.workspace(int(tM0.numel()), geom.P)
+        ws = self.workspace(int(tM0.numel()), geom.P_eff)
         gs, fs = geom.c_struct(), self._frames(tM0)
         _hip.check(_hip.lib().bhn_render_bwd(C.byref(self.model), self.mode, _hip.ptr(self.packed), C.byref(gs),
                                              C.byref(fs), _hip.ptr(dimages), _hip.ptr(out), _hip.ptr(ws), ws.numel(),
@@ -192,7 +213,7 @@ class FusedPredictor:
         B = int(tM0.numel())
         if out is None:
             out = torch.empty((B, geom.Sx, geom.R), dtype=torch.float32, device=self.device)
-        ws = self.workspace(B, geom.P)
+        ws = self.workspace(B, geom.P_eff)
         gs, fs = geom.c_struct(), self._frames(tM0)
         _hip.check(_hip.lib().bhn_render_fwd_train(C.byref(self.model), self.mode, _hip.ptr(self.packed), C.byref(gs),
                                                    C.byref(fs), _hip.ptr(out), _hip.ptr(ws), ws.numel(),
@@ -204,7 +225,7 @@ class FusedPredictor:
         assert dimages.dtype == torch.float32 and dimages.is_contiguous() and dimages.is_cuda
         if out is None:
             out = torch.empty((self.nparams,), dtype=torch.float32, device=self.device)
-        ws = self.workspace(int(tM0.numel()), geom.P)
+        ws = self.workspace(int(tM0.numel()), geom.P_eff)
         gs, fs = geom.c_struct(), self._frames(tM0)
         _hip.check(_hip.lib().bhn_render_bwd_tape(C.byref(self.model), self.mode, _hip.ptr(self.packed), C.byref(gs),
                                                   C.byref(fs), _hip.ptr(dimages), _hip.ptr(out), _hip.ptr(ws), ws.numel(),

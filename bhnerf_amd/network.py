@@ -361,7 +361,7 @@ def _step_image(state, t_units, dtype, target, sigma, offset, t_frames, coords, 
     tM0, _ = _frame_offsets(t_frames, t_units, t_start_obs, t_injection, dev)
     B = int(tM0.numel())
     eng.pack(state.flat)
-    taped = train and eng.fits_tape(B, geom.P)      # record the tape while rendering: no recompute later
+    taped = train and eng.fits_tape(B, geom.P_eff)      # record the tape while rendering: no recompute later
     images = eng.render_train(geom, tM0) if taped else eng.render(geom, tM0)
     if eht:
         loss, dimg = engine.chi2_eht(images if geom.S else images[:, 0], offset, target, sigma, scale, dtype, want_grad=train)

@@ -56,6 +56,12 @@ typedef struct {
     const float *t_geo;   /* slow-light time per point (emission.py:200)      */
     const float *w;       /* (Sx,P) folded g^2*dtau*Sigma*J_s (kgeo.py:621, network.py:417) */
     const uint8_t *dom;   /* (P) 1 inside rmin<=r<=rmax,|z|<=z_width (emission.py:370-373)   */
+    /* Optional compaction of the static domain mask: ascending indices of the 32-point groups
+     * (points 32*i .. 32*i+31) that contain at least one in-domain point.  The fused kernels and the
+     * backward tape visit only these groups; every other point has emission 0 by emission.py:370-373.
+     * NULL = all ceil(P/32) groups. */
+    const int32_t *groups;
+    int64_t n_groups;
 } bhn_geom;
 
 /* Frames of one step.  tM0[b] = (t_frames[b]-t_start_obs)/GM_c3 - t_injection, float64, device

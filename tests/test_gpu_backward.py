@@ -222,7 +222,7 @@ def test_taped_training_path_equals_recompute_path(dev, golden, tag, mode):
     dimg = torch.randn((len(g['t_frames']), geom.Sx, geom.R), device=dev)
     img_ref = eng.render(geom, tM0).clone()
     grad_ref = eng.render_bwd(geom, tM0, dimg).clone()
-    assert eng.fits_tape(int(tM0.numel()), geom.P)
+    assert eng.fits_tape(int(tM0.numel()), geom.P_eff)
     img = eng.render_train(geom, tM0)
     grad = eng.render_bwd_tape(geom, tM0, dimg)
     assert torch.allclose(img, img_ref, rtol=1e-6, atol=1e-7 * float(img_ref.abs().max()))

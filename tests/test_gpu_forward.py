@@ -151,3 +151,31 @@ def test_fail_loud_on_cpu_tensors():
     from bhnerf_amd import _hip, kgeo
     with pytest.raises(_hip.HipError):
         kgeo.radiative_trasfer(torch.zeros(2, 3, 4), 1.0, 1.0, 1.0)
+
+
+def test_domain_compaction_skips_groups_but_not_results(dev):
+    """A thin-slab domain (as in the ALMA fits: rmin=6, rmax=20, z_width=4) leaves most 32-point groups
+    empty; the compacted kernels must still reproduce the oracle on every pixel and every emission."""
+    from bhnerf_amd import network, synthetic, units
+    from oracle import oracle_np as onp2
+    H, W, G, B = 12, 10, 64, 2
+    geo = synthetic.synthetic_geodesics(H, W, G, fov_M=40.0, inc_deg=12.0, seed=5)
+    rng = np.random.default_rng(2)
+    tree = onp2.he_uniform_params(rng, 4, 64, 21)
+    t_frames = np.array([0.2, 0.9])
+    pred = network.NeRF_Predictor(20.0, 6.0, 20.0, 4.0, net_width=64, mode='f32', device=dev)
+    rt = (geo['coords'], geo['Omega'], 1.0, geo['g'], geo['dtau'], geo['Sigma'], 0.0, geo['t_geos'], geo['t_injection'])
+    geom = pred.geometry(geo['coords'], geo['Omega'], geo['t_geos'], None, geo['g'], geo['dtau'], geo['Sigma'])
+    assert geom.groups is not None and geom.visited_fraction < 0.6 and geom.active_fraction < geom.visited_fraction
+    f64 = {k: np.asarray(v, dtype=np.float64) for k, v in geo.items() if not np.isscalar(v)}
+    tree64 = {'MLP_0': {k: {kk: vv.astype(np.float64) for kk, vv in v.items()} for k, v in tree['MLP_0'].items()}}
+    e_ref = onp2.predictor_apply(tree64, t_frames, f64['coords'], f64['Omega'], 0.0, f64['t_geos'], geo['t_injection'],
+                                 scale=20.0, rmin=6.0, rmax=20.0, z_width=4.0, net_depth=4)
+    img_ref = onp2.image_plane_prediction(e_ref, 1.0, f64['g'], f64['dtau'], f64['Sigma'])
+    e = pred.apply({'params': tree}, t_frames, units.hr, geo['coords'], geo['Omega'], 0.0, geo['t_geos'], geo['t_injection'])
+    with torch.no_grad():
+        img = network.image_plane_prediction(tree, pred.apply, t_frames, *rt, units.hr)
+    e = e.cpu().numpy()
+    assert ((e == 0) != (e_ref == 0)).mean() < 0.01
+    same = (e == 0) == (e_ref == 0)
+    assert relerr(e[same], e_ref[same]) < 1e-5 and relerr(img.cpu().numpy(), img_ref) < 2e-5
