@@ -1,0 +1,98 @@
+"""GPU tests of the reference-shaped driver API: Optimizer.run / checkpoints / total_movie_loss /
+sample_3d_grid / 'lc' light-curve fitting / generic predictor callables -- the usage contract of the
+tutorials and scripts on the HIP engine."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device('cuda:0')
+
+
+@pytest.fixture(scope='module')
+def problem(dev):
+    from bhnerf_amd import constants, network, synthetic, units
+    H = W = 16; G = 32; nt = 6
+    geo = synthetic.synthetic_geodesics(H, W, G, fov_M=16.0, seed=7, S=3)
+    t_frames = np.linspace(0, 0.6, nt)
+    rt = network.raytracing_args(dict(x=geo['coords'][0], y=geo['coords'][1], z=geo['coords'][2], dtau=geo['dtau'],
+                                      Sigma=geo['Sigma'], t=geo['t_geos'], g=geo['g']), geo['Omega'], geo['t_injection'],
+                                 0.0 * units.hr, J=geo['J'])
+    movie = synthetic.hotspot_movie(geo, t_frames, constants.GM_c3('hr'))                  # (nt,H,W) Stokes I
+    stokes = np.stack([movie * float(np.mean(geo['J'][s] / geo['J'][0])) for s in range(3)], axis=1)
+    return dict(geo=geo, rt=rt, t_frames=t_frames, movie=stokes, H=H, W=W, nt=nt)
+
+
+def test_lightcurve_fit_decreases_loss_and_checkpoints_resume(dev, problem, tmp_path):
+    """scripts/Fit_*.py flow: TrainStep.image(dtype='lc') with Stokes targets, Optimizer.run, checkpoint,
+    resume from the checkpoint directory, total_movie_loss with frames."""
+    from bhnerf_amd import network, optimization, units
+    p = problem
+    lc = p['movie'].sum(axis=(-1, -2))                                                     # (nt, 3) light curves
+    pred = network.NeRF_Predictor(8.0, 1.0, 8.0, 4.0, net_depth=4, net_width=64, mode='f32', device=dev)
+    step = optimization.TrainStep.image(p['t_frames'] * units.hr, lc, sigma=float(np.abs(lc).mean()) * 0.1, dtype='lc')
+    ckpt = str(tmp_path / 'run')
+    seen = []
+    opt = optimization.Optimizer({'num_iters': 30, 'lr_init': 2e-3, 'lr_final': 2e-4, 'seed': 1}, pred, p['rt'],
+                                 save_period=10, checkpoint_dir=ckpt, keep=2)
+    first = optimization.total_movie_loss(3, opt.state, step, p['rt'])
+    opt.run(3, step, p['rt'], log_fns=[optimization.LogFn(lambda o: seen.append((o.step, float(torch.as_tensor(o.loss).mean()))), 10)])
+    last, frames = optimization.total_movie_loss(3, opt.state, step, p['rt'], return_frames=True)
+    assert opt.state.step == 30 and [s for s, _ in seen] == [1, 10, 20, 30]
+    assert last < 0.7 * first, (first, last)
+    assert frames.shape == (p['nt'], 3, p['H'], p['W']) and np.isfinite(frames).all()
+    import os
+    assert sorted(os.listdir(ckpt)) == ['NeRF_Predictor_params.yml', 'checkpoint_20', 'checkpoint_30']    # keep=2
+    # resume: a new Optimizer on the same directory restores step, parameters and Adam moments
+    pred2 = network.NeRF_Predictor.from_yml(ckpt, mode='f32', device=dev)
+    opt2 = optimization.Optimizer({'num_iters': 5, 'lr_init': 2e-3, 'lr_final': 2e-4}, pred2, p['rt'], checkpoint_dir=ckpt)
+    assert opt2.state.step == 30 and torch.equal(opt2.state.flat, opt.state.flat) and torch.equal(opt2.state.m, opt.state.m)
+    opt2.run(3, step, p['rt'])
+    assert opt2.state.step == 35 and opt2.init_step == 31
+    with pytest.raises(AttributeError):
+        optimization.TrainStep.image(p['t_frames'] * units.hr, lc, dtype='nope')(opt.state, p['rt'], np.arange(3))
+
+
+def test_sample_3d_grid_and_generic_predictor_callable(dev, problem):
+    from bhnerf_amd import network, units
+    from oracle import oracle_np as onp
+    p = problem
+    pred = network.NeRF_Predictor(8.0, 0.0, 8.0, 100.0, net_depth=4, net_width=64, mode='f32', device=dev)
+    params = pred.init_params(p['rt'], seed=2)
+    vol = network.sample_3d_grid(pred.apply, params, fov=10.0, resolution=8)
+    assert vol.shape == (8, 8, 8) and (vol > 0).any()
+    vol2 = network.sample_3d_grid(pred.apply, params, fov=10.0, resolution=8, chunk=4)
+    assert np.array_equal(vol, vol2)
+    # oracle on the same grid (t=0, Omega=0 -> no warp): float64 restatement with the same weights
+    grid = np.linspace(-5, 5, 8)
+    coords = np.array(np.meshgrid(grid, grid, grid, indexing='ij'))
+    tree = {'MLP_0': {k: {kk: vv.cpu().numpy().astype(np.float64) for kk, vv in v.items()} for k, v in params['MLP_0'].items()}}
+    ref = onp.predictor_apply(tree, 0.0, coords, 0.0, 0.0, 0.0, 0.0, GM_c3=1.0, scale=8.0, rmin=0.0, rmax=8.0, z_width=100.0)
+    assert np.abs(vol - ref).max() < 1e-5 * ref.max()
+    with pytest.raises(AttributeError):
+        network.sample_3d_grid(pred.apply, params)
+    # any callable can stand in for the predictor: emission is integrated by the stand-alone kernel
+    e_fix = torch.rand((p['nt'],) + p['geo']['Omega'].shape, device=dev)
+    images = network.image_plane_prediction(None, lambda v, *a: e_fix, p['t_frames'], *p['rt'].values(), units.hr)
+    geo = p['geo']
+    ref = onp.image_plane_prediction(e_fix.cpu().numpy().astype(np.float64), geo['J'].astype(np.float64), geo['g'].astype(np.float64),
+                                     geo['dtau'].astype(np.float64), geo['Sigma'].astype(np.float64))
+    assert tuple(images.shape) == ref.shape and np.abs(images.cpu().numpy() - ref).max() < 1e-5 * np.abs(ref).max()
+
+
+def test_two_losses_take_sequential_adam_steps(dev, problem):
+    """TrainStep.__add__: each loss takes its own Adam step (optimization.py:175-178), they are not summed."""
+    from bhnerf_amd import network, optimization, units
+    p = problem
+    pred = network.NeRF_Predictor(8.0, 0.0, 8.0, 4.0, net_depth=4, net_width=32, mode='f32', device=dev)
+    full = optimization.TrainStep.image(p['t_frames'] * units.hr, p['movie'], dtype='full')
+    lc = optimization.TrainStep.image(p['t_frames'] * units.hr, p['movie'].sum(axis=(-1, -2)), dtype='lc', scale=0.5)
+    both = full + lc
+    state = pred.init_state(pred.init_params(p['rt']), num_iters=10)
+    loss, state, images = both(state, p['rt'], np.array([0, 2, 4]))
+    assert state.step == 2 and loss.shape == (1,) and images.shape == (1, 3, 3, p['H'], p['W'])
