@@ -102,13 +102,21 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device (no CPU fallback)')
+    # BHNERF_BENCH_ONE_DEVICE=1 (testing aid on a 1-GPU box): every rank uses cuda:0 and the gloo backend, so the
+    # multi-process path (frame sharding, gradient all-reduce, identical Adam) runs with the real kernels
+    one_dev = os.environ.get('BHNERF_BENCH_ONE_DEVICE') == '1'
+    if one_dev:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if one_dev:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     from bhnerf_amd import _hip, constants, engine, network, optimization, synthetic, units
     H = W = args.image
