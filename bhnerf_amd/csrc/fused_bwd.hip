@@ -55,6 +55,8 @@ struct BwdGeom {
     static constexpr int ROW_BYTES = 32 * Pol::ELEM_BYTES + 16;
     static constexpr int SCR_BYTES = 32 * ROW_BYTES;
     static constexpr int GROUP_BYTES = (2 * MT + 1) * TILE_BYTES;   // A tiles + h tiles + enc tile
+    // chain kernels: prefetch distance of the LDS-DMA weight ring (RING_DIST+1 buffers of one chunk)
+    static constexpr int RING_DIST = (Pol::ELEM_BYTES == 2) ? 4 : 2;
     // dW kernel, bf16: LDS-DMA ring of NBUF groups (counted vmcnt, raw s_barrier); f32: 2 buffers
     static constexpr int NBUF = (Pol::ELEM_BYTES == 2) ? ((160 * 1024) / GROUP_BYTES >= 4 ? 4 : 3) : 2;
     static constexpr int NPIECE = GROUP_BYTES / 1024;               // 1 KiB = one wave-wide 16-B DMA
@@ -154,9 +156,10 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
     constexpr int MW = (MT + 1) / 2;                                   // mask words per layer per lane
     const FusedArgs &a = A.f;
     const int edbg = (A.debug >> 6) & 3;           // measurement aid for emit_frags
+    const bool nomma = (A.debug >> 8) & 1;         // measurement aid: skip the hidden-layer / chain MFMAs
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *ring = smem;
-    float *bias_lds = reinterpret_cast<float *>(smem + 3 * CB);
+    float *bias_lds = reinterpret_cast<float *>(smem + (BG::RING_DIST + 1) * CB);
     float *wout_lds = bias_lds + (a.depth + 1) * W;
     char *scr_all = reinterpret_cast<char *>(wout_lds + W);
     unsigned *mask_all = reinterpret_cast<unsigned *>(scr_all + Pol::NWAVES * BG::SCR_BYTES);
@@ -173,22 +176,24 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
     const char *fwd = a.packed + a.fwd_off, *bwd = a.packed + a.bwd_off;
     const int depth_ = a.depth;
 #define chunk_src(seq_) chunk_source<MT, CB, MODE>((seq_), NSEQ, NCF, depth_, fwd, bwd)
-    // weight ring (3 LDS buffers, LDS-DMA, prefetch distance 2): step c issues chunk c+2, consumes chunk c,
-    // then waits for its own pieces of chunk c+1 with a counted vmcnt that leaves chunk c+2 and this
-    // step's tape stores in flight (vmcnt is in-order and counts stores: a plain wait on the prefetch
-    // would drain the tape stores of the previous step every time).
+    // weight ring (LDS-DMA, DIST+1 LDS buffers, prefetch distance DIST): step c issues chunk c+DIST, consumes
+    // chunk c, then waits for its own pieces of chunk c+1 with a counted vmcnt.  vmcnt is in-order and counts
+    // stores, so the wait also bounds how many tape stores may be pending: chunk c+1 was issued at the start
+    // of step c+1-DIST, and everything younger -- DIST-1 chunks (PPW pieces each) and the tape stores of DIST
+    // steps (>= ES each; this step's own count is STORES) -- may stay in flight.  HBM store latency (~3 us) x
+    // the store rate needs ~4 steps of stores in flight per wave; a distance-2 ring capped it at 2.
     using RG = DmaRing<CB, Pol::NWAVES>;
     constexpr int ES = (Pol::ELEM_BYTES == 2) ? 2 : 4;                 // global stores of one emit_frags
-    RG::issue(chunk_src(0), ring);
-    RG::issue(chunk_src(1), ring + CB);
-    RG::template wait_prev<0>();
+    constexpr int DIST = BG::RING_DIST, NB = DIST + 1;
+#pragma unroll
+    for (int j = 0; j < DIST; ++j) RG::issue(chunk_src(j), ring + j * CB);
+    RG::template wait_younger<RG::PPW * (DIST - 1)>();
     lds_barrier();
     int cur = 0;                                                       // ring slot of the chunk being consumed
-#define RING_STEP_BEGIN(seq) { const int nx = cur >= 1 ? cur - 1 : 2; RG::issue(chunk_src((seq) + 2), ring + nx * CB); } \
+#define RING_STEP_BEGIN(seq) { const int nx = cur >= 1 ? cur - 1 : NB - 1; RG::issue(chunk_src((seq) + DIST), ring + nx * CB); } \
     const char *ch = ring + cur * CB;
-// STORES = tape stores issued by this step after its DMA issue; every step is preceded (in-step or between
-// steps) by at least ES more stores that are younger than the chunk being waited for, so they may stay in flight
-#define RING_STEP_END(STORES) RG::template wait_prev<(STORES) + ES>(); lds_barrier(); cur = cur == 2 ? 0 : cur + 1;
+#define RING_STEP_END(STORES) RG::template wait_younger<(RG::PPW + ES) * (DIST - 1) + (STORES)>(); lds_barrier(); \
+    cur = cur == NB - 1 ? 0 : cur + 1;
 
     for (long long tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
         int b;
@@ -229,7 +234,8 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 RING_STEP_BEGIN(seq)
-                f32x16 acc = tile_matmul<W, Pol>(ch, act, enc, sk, bias_acc(bl, m, h));
+                f32x16 acc = bias_acc(bl, m, h);
+                if (!nomma) acc = tile_matmul<W, Pol>(ch, act, enc, sk, acc);
                 const unsigned mk = relu_pack<W, Pol>(acc, m, next);
                 emit_frags<Pol, BG::ROW_BYTES>(scr, hdst + m * BG::TILE_BYTES, next[2 * m], next[2 * m + 1], edbg);
                 unsigned *mwp = mask_w + (l * MW + (m >> 1)) * 64 + lane;
@@ -316,8 +322,10 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
             for (int m = 0; m < MT; ++m) {
                 RING_STEP_BEGIN(seq)
                 f32x16 acc = {};
+                if (!nomma) {
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) acc = Pol::mma(Pol::lds_frag(ch, ks, lane), dl[ks], acc);
+                } else acc[0] = Pol::get(dl[0], 0);
                 const unsigned mw = mask_w[((l - 1) * MW + (m >> 1)) * 64 + lane] >> ((m & 1) * 16);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = ((mw >> r) & 1) ? acc[r] : 0.f;
@@ -626,7 +634,7 @@ static thread_local int g_bwd_stages = 7;
 static thread_local int g_bwd_debug = 0;
 extern "C" int bhn_debug_set_bwd_stages(int32_t mask) {
     g_bwd_stages = mask & 7;
-    g_bwd_debug = (mask >> 3) & 0x1FF;    // bit 3: dW kernel without MFMA work, bit 4: without tape loads,
+    g_bwd_debug = (mask >> 3) & 0x7FF;    // bit 3: dW kernel without MFMA work, bit 4: without tape loads,
                                          // bits 5-8: run only dW job (value-1); bit 9: emit without global stores; bit 10: no emit
     return BHN_OK;
 }
@@ -736,7 +744,7 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
             return BHN_EINVAL;
         }
     }
-    const size_t lds_chain = 3 * PK::CHUNK_BYTES + (size_t)(depth + 1) * W * 4 + W * 4 + Pol::NWAVES * BG::SCR_BYTES +
+    const size_t lds_chain = (size_t)(BG::RING_DIST + 1) * PK::CHUNK_BYTES + (size_t)(depth + 1) * W * 4 + W * 4 + Pol::NWAVES * BG::SCR_BYTES +
                              (size_t)Pol::NWAVES * depth * ((BG::MT + 1) / 2) * 64 * 4;
     const size_t lds_dw = (size_t)BG::NBUF * BG::GROUP_BYTES;
     auto k_rec = chain_kernel<W, Pol, 3, MODE_RECOMPUTE>;

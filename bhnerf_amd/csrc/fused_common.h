@@ -307,12 +307,13 @@ struct DmaRing {
                                              (__attribute__((address_space(3))) void *)(dst + piece * 1024), 16, 0, 0);
         }
     }
-    // wait until this wave's pieces of the chunk issued one step ago have landed; YOUNGER = vector-memory
-    // operations this wave has issued since (the next chunk's PPW pieces + this step's tape stores).
-    // A smaller count than the true one is always safe (it only waits longer).
-    template <int STORES>
-    static DEVI void wait_prev() {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + STORES) : "memory");
+    // vmcnt retires in issue order and counts loads, stores and LDS-DMA alike: a chunk has landed once at
+    // most the operations issued AFTER its last piece are pending.  A smaller count than the true one is
+    // always safe (it only waits longer).
+    template <int YOUNGER>
+    static DEVI void wait_younger() {   // returns when at most YOUNGER of this wave's vector-memory ops are pending
+        static_assert(YOUNGER >= 0 && YOUNGER <= 63, "vmcnt is a 6-bit counter");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory");
     }
 };
 
