@@ -61,6 +61,8 @@ SIGNATURES = {
     'bhn_render_bwd_tape': (C.c_int, [_MP, _I32, _P, _GP, _FP, _P, _P, _P, _SZ, _P]),
     'bhn_chi2_image': (C.c_int, [_P, _P, _P, _P, _F, _I32, _I32, _I32, _I64, _P, _P, _P]),
     'bhn_chi2_eht': (C.c_int, [_P, _P, _P, _P, _F, _I32, _I32, _I32, _I32, _I64, _P, _P, _P, _P]),
+    'bhn_voxel_render_fwd': (C.c_int, [_GP, _FP, _P, _I32, _I32, _I32, _I64, C.POINTER(C.c_float), _P, _P]),
+    'bhn_trilinear': (C.c_int, [_P, _I64, _P, _I32, _I32, _I32, C.POINTER(C.c_float), _P, _P]),
     'bhn_adam_step': (C.c_int, [_P, _P, _P, _P, _I64, _I64, _F, _F, _F, _F, _F, _P]),
     'bhn_debug_set_bwd_stages': (C.c_int, [_I32]),
     'bhn_selftest': (C.c_int, [C.POINTER(_I32)]),

@@ -450,3 +450,120 @@ extern "C" int bhn_chi2_eht(const float *images, const float *A, const float *ta
     }
     return BHN_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// Voxel forward renderer: emission.image_plane_dynamics (emission.py:235-303) fused --
+// velocity warp (emission.py:143-211) -> trilinear sampling of a 3-D emission grid
+// (interpolate_coords, emission.py:213-233: scipy map_coordinates order=1, mode='constant', cval=0:
+// NaN or any index outside [0, n-1] gives 0) -> x J g^2 dtau Sigma -> sum over the ray (kgeo.py:621).
+// Gather-bound: the grid (<= a few MB) stays in L2, the geometry is streamed once per frame.
+// ------------------------------------------------------------------------------------------
+struct VoxelGrid {
+    const float *data;          // (nx, ny, nz) C-order, or (B, nx, ny, nz) when frame_stride != 0
+    long long frame_stride;
+    int nx, ny, nz;
+    float fx, fy, fz;           // extent of the grid along each axis (max - min of its coordinates)
+};
+
+__device__ __forceinline__ float trilinear(const VoxelGrid &v, const float *g, float x, float y, float z) {
+    // utils.world_to_image_coords (utils.py:160-166): index = (c + fov/2) / fov * (n - 1)
+    const float ix = (x + 0.5f * v.fx) / v.fx * (float)(v.nx - 1);
+    const float iy = (y + 0.5f * v.fy) / v.fy * (float)(v.ny - 1);
+    const float iz = (z + 0.5f * v.fz) / v.fz * (float)(v.nz - 1);
+    if (!(ix >= 0.f && ix <= (float)(v.nx - 1) && iy >= 0.f && iy <= (float)(v.ny - 1) && iz >= 0.f && iz <= (float)(v.nz - 1)))
+        return 0.f;                                              // also catches NaN (pre-injection)
+    const int x0 = min((int)ix, max(v.nx - 2, 0)), y0 = min((int)iy, max(v.ny - 2, 0)), z0 = min((int)iz, max(v.nz - 2, 0));
+    const int x1 = min(x0 + 1, v.nx - 1), y1 = min(y0 + 1, v.ny - 1), z1 = min(z0 + 1, v.nz - 1);
+    const float tx = ix - (float)x0, ty = iy - (float)y0, tz = iz - (float)z0;
+    const long long sx = (long long)v.ny * v.nz, sy = v.nz;
+    const float c000 = g[x0 * sx + y0 * sy + z0], c001 = g[x0 * sx + y0 * sy + z1];
+    const float c010 = g[x0 * sx + y1 * sy + z0], c011 = g[x0 * sx + y1 * sy + z1];
+    const float c100 = g[x1 * sx + y0 * sy + z0], c101 = g[x1 * sx + y0 * sy + z1];
+    const float c110 = g[x1 * sx + y1 * sy + z0], c111 = g[x1 * sx + y1 * sy + z1];
+    const float c00 = c000 + (c001 - c000) * tz, c01 = c010 + (c011 - c010) * tz;
+    const float c10 = c100 + (c101 - c100) * tz, c11 = c110 + (c111 - c110) * tz;
+    const float c0 = c00 + (c01 - c00) * ty, c1 = c10 + (c11 - c10) * ty;
+    return c0 + (c1 - c0) * tx;
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void voxel_render_kernel(bhn_geom geom, const double *__restrict__ tM0, int B, VoxelGrid v,
+                                                           float *__restrict__ images) {
+    constexpr int RPB = 256 / LPR;
+    const int sub = threadIdx.x % LPR;
+    const long long ray_b = (long long)blockIdx.x * RPB + threadIdx.x / LPR;       // (frame, ray)
+    const long long R = geom.R, G = geom.G, P = R * G;
+    const int Sx = geom.S > 0 ? geom.S : 1;
+    const bool ok = ray_b < (long long)B * R;
+    const int b = ok ? (int)(ray_b / R) : 0;
+    const long long ray = ok ? ray_b % R : 0;
+    const float *grid = v.data + (long long)b * v.frame_stride;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ok) {
+        const double t0 = tM0[b];
+        for (long long k = sub; k < G; k += LPR) {
+            const long long p = ray * G + k;
+            const double tM = t0 + (double)geom.t_geo[p];
+            float e = 0.f;
+            if (!(tM < 0.0)) {                                      // emission.py:204-205: NaN before injection -> 0
+                const double th = tM * (double)geom.Omega[p];
+                double s, c;
+                sincos(th, &s, &c);
+                const float x = geom.x[p], y = geom.y[p];
+                e = trilinear(v, grid, (float)(c * x + s * y), (float)(c * y - s * x), geom.z[p]);
+            }
+            if (e != 0.f)
+                for (int s = 0; s < Sx; ++s) acc[s] += geom.w[(long long)s * P + p] * e;
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) acc[s] += __shfl_xor(acc[s], o, 64);
+    if (ok && sub == 0)
+        for (int s = 0; s < Sx; ++s) images[((long long)b * Sx + s) * R + ray] = acc[s];
+}
+
+__global__ void trilinear_kernel(const float *__restrict__ pts, long long N, VoxelGrid v, float *__restrict__ out) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < N; i += (long long)gridDim.x * blockDim.x)
+        out[i] = trilinear(v, v.data, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+}
+
+static int voxel_grid_args(const float *grid, int32_t nx, int32_t ny, int32_t nz, int64_t frame_stride, const float *fov, VoxelGrid *v) {
+    BHN_CHECK_ARG(grid && fov, "null pointer");
+    BHN_CHECK_ARG(nx >= 1 && ny >= 1 && nz >= 1, "bad grid size %dx%dx%d", nx, ny, nz);
+    BHN_CHECK_ARG(fov[0] > 0.f && fov[1] > 0.f && fov[2] > 0.f, "grid extents must be positive");
+    v->data = grid; v->frame_stride = frame_stride; v->nx = nx; v->ny = ny; v->nz = nz;
+    v->fx = fov[0]; v->fy = fov[1]; v->fz = fov[2];
+    return BHN_OK;
+}
+
+extern "C" int bhn_voxel_render_fwd(const bhn_geom *geom, const bhn_frames *fr, const float *grid, int32_t nx, int32_t ny,
+                                    int32_t nz, int64_t frame_stride, const float *fov_host, float *images, void *stream) {
+    BHN_CHECK_ARG(geom && fr && images, "null pointer");
+    BHN_CHECK_ARG(geom->x && geom->y && geom->z && geom->Omega && geom->t_geo && geom->w, "null geometry array");
+    BHN_CHECK_ARG(geom->R > 0 && geom->G > 0 && geom->S >= 0 && geom->S <= 4 && fr->B > 0 && fr->tM0, "bad sizes");
+    VoxelGrid v;
+    int rc = voxel_grid_args(grid, nx, ny, nz, frame_stride, fov_host, &v);
+    if (rc != BHN_OK) return rc;
+    const long long rays = (long long)fr->B * geom->R;
+    const int lpr = geom->G >= 48 ? 32 : (geom->G >= 12 ? 16 : 4);
+    hipStream_t st = (hipStream_t)stream;
+    if (lpr == 32) hipLaunchKernelGGL((voxel_render_kernel<32>), dim3((unsigned)((rays + 7) / 8)), dim3(256), 0, st, *geom, fr->tM0, fr->B, v, images);
+    else if (lpr == 16) hipLaunchKernelGGL((voxel_render_kernel<16>), dim3((unsigned)((rays + 15) / 16)), dim3(256), 0, st, *geom, fr->tM0, fr->B, v, images);
+    else hipLaunchKernelGGL((voxel_render_kernel<4>), dim3((unsigned)((rays + 63) / 64)), dim3(256), 0, st, *geom, fr->tM0, fr->B, v, images);
+    BHN_HIP(hipGetLastError());
+    return BHN_OK;
+}
+
+extern "C" int bhn_trilinear(const float *points, int64_t N, const float *grid, int32_t nx, int32_t ny, int32_t nz,
+                             const float *fov_host, float *out, void *stream) {
+    BHN_CHECK_ARG(points && out && N > 0, "bad arguments");
+    VoxelGrid v;
+    int rc = voxel_grid_args(grid, nx, ny, nz, 0, fov_host, &v);
+    if (rc != BHN_OK) return rc;
+    const int blocks = (int)((N + 255) / 256 < 2048 ? (N + 255) / 256 : 2048);
+    hipLaunchKernelGGL(trilinear_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, points, (long long)N, v, out);
+    BHN_HIP(hipGetLastError());
+    return BHN_OK;
+}

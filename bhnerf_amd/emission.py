@@ -63,3 +63,89 @@ def fill_unsupervised_emission(emission, coords, rmin=0, rmax=np.inf, z_width=2.
     emission = xp.where(r_sq > rmax ** 2, fill, emission)
     emission = xp.where(abs(z) > z_width, fill, emission)
     return emission
+
+
+# ------------------------------------------------------------------------------------------------
+# Voxel forward renderer
+# ------------------------------------------------------------------------------------------------
+def _grid_of(emission):
+    """(values float32 ndarray, extents [fx,fy,fz]) of an xarray-like 3-D/4-D emission (``.dims`` + coordinate
+    arrays, the only things interpolate_coords uses: emission.py:229-230) or of a ``(array, fov)`` tuple."""
+    if isinstance(emission, tuple):
+        arr, fov = emission
+        fov = [float(fov)] * 3 if np.isscalar(fov) else [float(f) for f in fov]
+        return np.ascontiguousarray(arr, dtype=np.float32), fov
+    dims = list(emission.dims)[-3:]
+    fov = [float(np.max(np.asarray(emission[d])) - np.min(np.asarray(emission[d]))) for d in dims]
+    return np.ascontiguousarray(np.asarray(getattr(emission, 'data', emission)), dtype=np.float32), fov
+
+
+def interpolate_coords(emission, coords):
+    """Interpolate a 3-D emission field at world coordinates (emission.py:213-233): trilinear, zero
+    outside the grid.  coords (..., 3) NumPy -> NumPy via the HIP kernel when a GPU is present, else the
+    reference's own host path (scipy.ndimage.map_coordinates); torch device tensors -> device tensor."""
+    import ctypes as C
+    from . import _hip
+    arr, fov = _grid_of(emission)
+    if isinstance(coords, torch.Tensor) or torch.cuda.is_available():
+        dev = coords.device if isinstance(coords, torch.Tensor) else torch.device('cuda', torch.cuda.current_device())
+        pts = _hip.as_f32(coords, dev).reshape(-1, 3).contiguous()
+        grid = torch.as_tensor(arr, device=dev)
+        out = torch.empty((pts.shape[0],), dtype=torch.float32, device=dev)
+        _hip.check(_hip.lib().bhn_trilinear(_hip.ptr(pts), pts.shape[0], _hip.ptr(grid), *arr.shape[-3:], (C.c_float * 3)(*fov),
+                                            _hip.ptr(out), _hip.stream_ptr(dev)))
+        out = out.reshape(tuple(np.shape(coords)[:-1]))
+        return out if isinstance(coords, torch.Tensor) else out.cpu().numpy()
+    import scipy.ndimage
+    npix = arr.shape
+    idx = np.moveaxis(np.stack([(np.asarray(coords)[..., i] + fov[i] / 2.0) / fov[i] * (npix[i] - 1) for i in range(3)], -1), -1, 0)
+    return scipy.ndimage.map_coordinates(arr, idx, order=1, cval=0.)
+
+
+def image_plane_dynamics(emission_0, geos, Omega, t_frames, t_injection, J=1.0, t_start_obs=None, slow_light=True,
+                         doppler=True, rot_axis=[0, 0, 1], M=None):
+    """Image-plane movie of an initial 3-D emission advected by the velocity field (emission.py:235-303): warp ->
+    trilinear sampling -> x J -> radiative transfer, fused in one HIP kernel (``bhn_voxel_render_fwd``).
+    ``geos`` carries x, y, z, t, dtau, Sigma (and the Doppler factor ``g`` when ``doppler=True``: computing it
+    from the 4-velocity, kgeo.py:199-248, is outside this build).  Returns a NumPy movie (nt,[S],H,W)."""
+    import ctypes as C
+    from . import _hip, engine
+    if list(rot_axis) != [0, 0, 1]:
+        raise AttributeError('only equatorial-plane rotation (rot_axis=[0,0,1]) is supported')
+    get = (lambda k: geos[k]) if isinstance(geos, dict) else (lambda k: getattr(geos, k))
+    dev = torch.device('cuda', torch.cuda.current_device()) if torch.cuda.is_available() else None
+    if dev is None:
+        raise _hip.HipError('image_plane_dynamics runs on the HIP device only (no CPU fallback)')
+    coords = np.array([np.asarray(get(k), dtype=np.float32) for k in ('x', 'y', 'z')])
+    t_geos = np.asarray(get('t'), dtype=np.float32) if slow_light else 0.0            # emission.py:269
+    if doppler:
+        try:
+            g = np.asarray(get('g'), dtype=np.float32)
+        except (KeyError, AttributeError):
+            raise AttributeError('doppler=True needs the Doppler factor geos.g (kgeo.doppler_factor is not part of this build)')
+    else:
+        g = 1.0
+    if t_start_obs is None:                                                            # emission.py:274
+        t_start_obs = t_frames[0] if units.is_quantity(t_frames) else np.atleast_1d(t_frames)[0]
+    t_units = t_start_obs.unit if units.is_quantity(t_start_obs) else (t_frames.unit if units.is_quantity(t_frames) else None)
+    mass = constants.sgra_mass_msun if M is None else float(getattr(M, 'value', M))
+    GM_c3 = constants.GM_c3(t_units, mass) if t_units is not None else 1.0
+    tf = np.atleast_1d(np.asarray(units.strip(t_frames, t_units), dtype=np.float64))
+    t0 = float(np.asarray(units.strip(t_start_obs, t_units)))
+    Jn = None if (np.ndim(J) == 0 and float(J) == 1.0) else J
+    geom = engine.RayGeometry(coords, Omega, g, get('dtau'), get('Sigma'), t_geos, Jn, 0.0, np.inf, np.inf, dev)
+    arr, fov = _grid_of(emission_0)
+    if arr.ndim == 4 and arr.shape[0] != tf.size:
+        raise AttributeError('a 4-D emission needs one grid per frame')
+    grid = torch.as_tensor(arr, device=dev)
+    tM0 = engine.frame_offsets(tf, t0, t_injection, GM_c3, dev)
+    images = torch.empty((tf.size, geom.Sx, geom.R), dtype=torch.float32, device=dev)
+    gs, fs = geom.c_struct(), _hip.bhn_frames(int(tf.size), tM0.data_ptr())
+    nx, ny, nz = arr.shape[-3:]
+    _hip.check(_hip.lib().bhn_voxel_render_fwd(C.byref(gs), C.byref(fs), _hip.ptr(grid), nx, ny, nz,
+                                               nx * ny * nz if arr.ndim == 4 else 0, (C.c_float * 3)(*fov), _hip.ptr(images),
+                                               _hip.stream_ptr(dev)))
+    out = images.reshape((tf.size,) + ((geom.S,) if geom.S else ()) + geom.spatial).cpu().numpy()
+    if np.ndim(t_frames if not units.is_quantity(t_frames) else t_frames.value) == 0:
+        out = out[0]
+    return np.squeeze(out) if geom.S else out                                          # emission.py:299 squeeze quirk

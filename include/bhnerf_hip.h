@@ -152,6 +152,17 @@ int bhn_chi2_eht(const float *images, const float *A, const float *target, const
                  int32_t dtype, int32_t N, int32_t C, int32_t nvis, int64_t R, float *vis_ws, float *loss,
                  float *dimages, void *stream);
 
+/* Voxel forward renderer: emission.image_plane_dynamics (emission.py:235-303) fused: warp ->
+ * trilinear sampling of a 3-D emission grid (interpolate_coords, emission.py:213-233; scipy map_coordinates
+ * order=1, cval=0) -> x J g^2 dtau Sigma -> ray sum.  grid is (nx,ny,nz) C-order with frame_stride 0, or one
+ * grid per frame with frame_stride = nx*ny*nz; fov_host = 3 host floats, the coordinate extent of each grid
+ * axis (grid centred on 0 as utils.world_to_image_coords assumes).  geom->dom is not used (no domain fill in
+ * this function); images is (B,Sx,R).  bhn_trilinear: interpolate_coords alone, points (N,3) -> out (N). */
+int bhn_voxel_render_fwd(const bhn_geom *geom, const bhn_frames *fr, const float *grid, int32_t nx, int32_t ny,
+                         int32_t nz, int64_t frame_stride, const float *fov_host, float *images, void *stream);
+int bhn_trilinear(const float *points, int64_t N, const float *grid, int32_t nx, int32_t ny, int32_t nz,
+                  const float *fov_host, float *out, void *stream);
+
 /* optax.adam + polynomial_schedule(power=1) as used by init_state (network.py:173-174, 621):
  * g' = g*grad_scale (the 1/ndev of pmean, network.py:620); t = 1-based update count. */
 int bhn_adam_step(float *params, const float *grads, float *m, float *v, int64_t n, int64_t t, float lr,

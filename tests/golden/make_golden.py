@@ -268,6 +268,53 @@ def main():
              hparams=np.array([8.0, 2.5, 8.0, 4.0, 3, depth, width, 0.7]), J=(geo5['J'] if S else np.array(1.0)),
              **{k: geo5[k] for k in ('coords', 'Omega', 't_geos', 'g', 'dtau', 'Sigma')}, **out)
 
+    # G8: image_plane_dynamics / interpolate_coords (voxel forward renderer, emission.py:213-303) -----
+    class _Scalar(float):
+        data = property(lambda self: float(self))
+        def __sub__(self, other):
+            return _Scalar(float(self) - float(other))
+
+    class _Coord:
+        def __init__(self, v):
+            self.v = np.asarray(v)
+            self.size = self.v.size
+        def max(self):
+            return _Scalar(self.v.max())
+        def min(self):
+            return _Scalar(self.v.min())
+
+    class _FakeDataArray(np.ndarray):          # the three things interpolate_coords asks of an xarray.DataArray
+        def __new__(cls, arr, coords):
+            obj = np.asarray(arr).view(cls)
+            obj.dims = tuple(coords)
+            obj._coords = {k: _Coord(v) for k, v in coords.items()}
+            return obj
+        def __getitem__(self, key):
+            if isinstance(key, str):
+                return self._coords[key]
+            return np.asarray(self).__getitem__(key)
+
+    n = 9
+    ax = np.linspace(-6.0, 6.0, n)
+    gx, gy, gz = np.meshgrid(ax, ax, ax, indexing='ij')
+    vol = np.exp(-((gx - 3.0) ** 2 + (gy + 1.0) ** 2 + gz ** 2) / (2 * 1.2 ** 2)) + 0.1 * rng.uniform(size=gx.shape)
+    em0 = _FakeDataArray(vol, {'x': ax, 'y': ax, 'z': ax})
+    geo8 = geometry(rng, 4, 5, 12, S=3, rmax=7.0)
+    geos = types.SimpleNamespace(x=geo8['coords'][0], y=geo8['coords'][1], z=geo8['coords'][2], t=geo8['t_geos'],
+                                 dtau=geo8['dtau'], Sigma=geo8['Sigma'])
+    t_frames8 = np.array([0.0, 0.2, 0.55]) * units.hr
+    t_inj8 = -(1000.0 - 5.0)
+    dyn = emission.image_plane_dynamics(em0, geos, geo8['Omega'], t_frames8, t_inj8, J=1.0, doppler=False)
+    dyn_J = emission.image_plane_dynamics(em0, geos, geo8['Omega'], t_frames8, t_inj8, J=geo8['J'], doppler=False)
+    dyn_fast = emission.image_plane_dynamics(em0, geos, geo8['Omega'], t_frames8, t_inj8, J=1.0, slow_light=False,
+                                             doppler=False, t_start_obs=0.1 * units.hr)
+    pts = rng.uniform(-7.0, 7.0, (11, 3))
+    interp = emission.interpolate_coords(em0, pts)
+    save('g8_dynamics', volume=vol, axis=ax, t_frames=np.asarray(t_frames8.value), t_injection=t_inj8, J=geo8['J'],
+         images=np.nan_to_num(dyn, nan=0.0), images_J=np.nan_to_num(dyn_J, nan=0.0), images_fast=np.nan_to_num(dyn_fast, nan=0.0),
+         nan_count=np.isnan(dyn).sum(), points=pts, interp=interp,
+         **{k: geo8[k] for k in ('coords', 'Omega', 't_geos', 'dtau', 'Sigma')})
+
     # G7: loss_fn_eht (random complex A) --------------------------------------------------
     nt, H, W, nvis = 3, 4, 4, 7
     images = rng.uniform(0, 1, (nt, H, W))
