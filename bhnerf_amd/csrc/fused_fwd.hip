@@ -124,20 +124,29 @@ __global__ __launch_bounds__(Pol::NTHREADS) void fused_fwd_kernel(FusedArgs a) {
     using PK = Pack<W, Pol>;
     using frag = typename Pol::frag;
     constexpr int CB = PK::CHUNK_BYTES, MT = PK::MT, KS = PK::KS;
+    using RG = DmaRing<CB, Pol::NWAVES>;
+    constexpr int DIST = (Pol::ELEM_BYTES == 2) ? 4 : 2, NB = DIST + 1;     // LDS-DMA weight ring, see fused_bwd.hip
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *ring = smem;                                              // 2 x CB
-    float *bias_lds = reinterpret_cast<float *>(smem + 2 * CB);      // (depth+1) x W
+    char *ring = smem;                                              // NB x CB
+    float *bias_lds = reinterpret_cast<float *>(smem + NB * CB);     // (depth+1) x W
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 31, h = lane >> 5;
     for (int i = tid; i < (a.depth + 1) * W; i += Pol::NTHREADS)
         bias_lds[i] = reinterpret_cast<const float *>(a.packed + a.bias_off)[i];
 
     const char *fwd = a.packed + a.fwd_off;
-    Stager<CB, Pol::NTHREADS> stg;
-    stg.load(fwd);
-    stg.store(ring);
-    __syncthreads();
-    int par = 0;
+    const int NC = PK::fwd_chunks(a.depth);
+    auto chunk_src = [&](int seq) { while (seq >= NC) seq -= NC; return fwd + (size_t)seq * CB; };
+#pragma unroll
+    for (int j = 0; j < DIST; ++j) RG::issue(chunk_src(j), ring + j * CB);
+    RG::template wait_younger<RG::PPW * (DIST - 1)>();
+    lds_barrier();
+    int cur = 0;
+    // step c: issue chunk c+DIST, consume chunk c, wait for own pieces of chunk c+1 (the DIST-1 younger chunks
+    // stay in flight; the epilogue's stores/atomics and the prologue's loads only make the true count larger)
+#define STEP_BEGIN(seq) { const int nx = cur >= 1 ? cur - 1 : NB - 1; RG::issue(chunk_src((seq) + DIST), ring + nx * CB); } \
+    const char *ch = ring + cur * CB;
+#define STEP_END() RG::template wait_younger<RG::PPW * (DIST - 1)>(); lds_barrier(); cur = cur == NB - 1 ? 0 : cur + 1;
 
     for (long long tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
         int b;
@@ -149,10 +158,10 @@ __global__ __launch_bounds__(Pol::NTHREADS) void fused_fwd_kernel(FusedArgs a) {
         point_prologue<Pol, DEG>(a, b, p, inb, enc, live);
 
         frag act[KS], next[KS];
+        int seq = 0;
         // ---- layer 0 (chunk 0: fragment m*2+ks) -------------------------------------------
         {
-            stg.load(fwd + CB);
-            const char *ch = ring + par * CB;
+            STEP_BEGIN(seq)
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 f32x16 acc = bias_acc(bias_lds, m, h);
@@ -160,24 +169,20 @@ __global__ __launch_bounds__(Pol::NTHREADS) void fused_fwd_kernel(FusedArgs a) {
                 acc = Pol::mma(Pol::lds_frag(ch, 2 * m + 1, lane), enc[1], acc);
                 relu_pack<W, Pol>(acc, m, act);
             }
-            stg.store(ring + (par ^ 1) * CB);
-            __syncthreads();
-            par ^= 1;
+            STEP_END()
+            ++seq;
         }
         // ---- hidden layers 1..depth-1 -----------------------------------------------------
-        int q = 1;
         for (int l = 1; l < a.depth; ++l) {
             const bool sk = (a.skip_mask >> l) & 1;
             const float *bl = bias_lds + l * W;
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                stg.load(fwd + (size_t)(q + 1) * CB);
-                f32x16 acc = tile_matmul<W, Pol>(ring + par * CB, act, enc, sk, bias_acc(bl, m, h));
+                STEP_BEGIN(seq)
+                f32x16 acc = tile_matmul<W, Pol>(ch, act, enc, sk, bias_acc(bl, m, h));
                 relu_pack<W, Pol>(acc, m, next);
-                stg.store(ring + (par ^ 1) * CB);
-                __syncthreads();
-                par ^= 1;
-                ++q;
+                STEP_END()
+                ++seq;
             }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) act[ks] = next[ks];
@@ -185,12 +190,11 @@ __global__ __launch_bounds__(Pol::NTHREADS) void fused_fwd_kernel(FusedArgs a) {
         // ---- output layer (row 0 of the tile is the pre-activation) -----------------------
         float outv;
         {
-            stg.load(fwd);                                            // chunk 0 for the next tile
-            f32x16 acc = tile_matmul<W, Pol>(ring + par * CB, act, enc, false, bias_acc(bias_lds + a.depth * W, 0, h));
+            STEP_BEGIN(seq)
+            f32x16 acc = tile_matmul<W, Pol>(ch, act, enc, false, bias_acc(bias_lds + a.depth * W, 0, h));
             outv = acc[0];
-            stg.store(ring + (par ^ 1) * CB);
-            __syncthreads();
-            par ^= 1;
+            STEP_END()
+            ++seq;
         }
         // ---- epilogue: sigmoid(out - 10), masks (network.py:230-232) ----------------------
         float e = 0.f;
@@ -215,6 +219,8 @@ __global__ __launch_bounds__(Pol::NTHREADS) void fused_fwd_kernel(FusedArgs a) {
             }
         }
     }
+#undef STEP_BEGIN
+#undef STEP_END
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -260,7 +266,7 @@ int fused_fill_args(const bhn_model *m, int32_t mode, const void *packed, const 
 template <int W, class Pol, bool RENDER>
 static int launch_fwd_w(FusedArgs &a, hipStream_t st) {
     using PK = Pack<W, Pol>;
-    const size_t lds = 2 * PK::CHUNK_BYTES + (size_t)(a.depth + 1) * W * 4;
+    const size_t lds = (size_t)((Pol::ELEM_BYTES == 2 ? 4 : 2) + 1) * PK::CHUNK_BYTES + (size_t)(a.depth + 1) * W * 4;
     auto kern = fused_fwd_kernel<W, Pol, 3, RENDER>;
     static bool attr_done = false;
     static int occ = 1;
