@@ -39,84 +39,87 @@ def shard(xs):
     return one(xs)
 
 
-def total_movie_loss(batchsize, state, train_step, raytracing_args, return_frames=False):
-    """Chunk the movie into frame batches and sum the loss over all frames (optimization.py:14-66)."""
-    nt = train_step.args[0].num_frames
-    ndev = device_count()
+def _movie_chunks(nt, batchsize, ndev):
+    """Frame-index chunks of a whole-movie pass: full batches first, then one remainder chunk padded
+    (wrapping around the movie) to a multiple of the device count -- the split of optimization.py:42-46."""
     if nt % ndev:
         raise AttributeError('batch size should be an integer multiplication of the device number')
-    nt_tilde = nt - nt % batchsize
-    indices = np.array_split(np.arange(0, nt_tilde), nt_tilde / batchsize) if nt_tilde else []
-    nt_tilde1 = int(ndev * np.ceil(nt / ndev))
-    indices.append(np.arange(nt_tilde, nt_tilde1) % nt)
+    full = (nt // batchsize) * batchsize
+    chunks = [np.arange(lo, lo + batchsize) for lo in range(0, full, batchsize)]
+    padded_end = ndev * int(np.ceil(nt / ndev))
+    tail = np.arange(full, padded_end) % nt
+    return chunks + ([tail] if tail.size else [])
 
-    frames, total_loss = [], 0.0
-    for inds in indices:
-        if inds.size == 0:
-            break
+
+def total_movie_loss(batchsize, state, train_step, raytracing_args, return_frames=False):
+    """Loss of the whole movie in test mode, evaluated in frame batches that fit the GPUs; optionally also the
+    predicted frames (optimization.py:14-66).  Returns total_loss / nt [, frames (nt,[S],H,W) NumPy]."""
+    nt = train_step.args[0].num_frames
+    ndev = device_count()
+    polarised = not np.isscalar(np.atleast_1d(raytracing_args)[0]['J'])
+    total, movie = 0.0, []
+    for inds in _movie_chunks(nt, batchsize, ndev):
         loss, state, images = train_step(state, raytracing_args, inds, update_state=False)
-        total_loss += float(loss.sum())
-        if return_frames:
-            if ndev > 1:
-                import torch.distributed as dist
-                parts = [torch.empty_like(images) for _ in range(ndev)]
-                dist.all_gather(parts, images.contiguous())
-                images = torch.cat(parts, dim=0)
-            nlast = 2 if np.isscalar(np.atleast_1d(raytracing_args)[0]['J']) else 3
-            frames.append(images.reshape((-1,) + tuple(images.shape[-nlast:])).cpu().numpy())
-    output = total_loss / nt
-    if return_frames:
-        output = (output, np.concatenate(frames)[:nt])
-    return output
+        total += float(loss.sum())
+        if not return_frames:
+            continue
+        if ndev > 1:                                          # every rank rendered its slice of the chunk
+            import torch.distributed as dist
+            parts = [torch.empty_like(images) for _ in range(ndev)]
+            dist.all_gather(parts, images.contiguous())
+            images = torch.cat(parts, dim=0)
+        keep = 3 if polarised else 2                          # trailing ([S],H,W) axes of one frame
+        movie.append(images.reshape((-1,) + tuple(images.shape[-keep:])).cpu().numpy())
+    mean_loss = total / nt
+    return (mean_loss, np.concatenate(movie)[:nt]) if return_frames else mean_loss
 
 
 class Optimizer(object):
-    """Gradient-descent loop over the network parameters (optimization.py:68-143).
+    """Adam optimisation of the network parameters over random frame batches (optimization.py:68-143).
 
-    hparams: 'num_iters', 'lr_init' (1e-4), 'lr_final' (1e-6), 'lr_inject' (None), 'seed' (1)."""
+    hparams: 'num_iters'; optional 'lr_init' (1e-4), 'lr_final' (1e-6), 'lr_inject' (None, inert as in the
+    reference), 'seed' (1).  save_period < 0 saves only the final step; keep = checkpoints retained."""
 
     def __init__(self, hparams, predictor, raytracing_args, save_period=-1, checkpoint_dir='', keep=5):
-        self.step = 0
-        self.init_step = 0
         self.num_iters = hparams['num_iters']
-        self.checkpoint_dir = checkpoint_dir
-        self.save_period = self.num_iters if save_period < 0 else save_period
-        self.loss = np.inf
-        self.keep = keep
         self.seed = hparams.get('seed', 1)
-        params = predictor.init_params(raytracing_args, seed=self.seed)
-        self.state = predictor.init_state(params=params, num_iters=self.num_iters,
-                                          lr_init=hparams.get('lr_init', 1e-4), lr_final=hparams.get('lr_final', 1e-6),
-                                          lr_inject=hparams.get('lr_inject', None), checkpoint_dir=self.checkpoint_dir)
-        if checkpoint_dir != '' and network._world()[0] == 0:
-            predictor.save_params(checkpoint_dir)
+        self.checkpoint_dir, self.keep = checkpoint_dir, keep
+        self.save_period = save_period if save_period >= 0 else self.num_iters
+        self.step = self.init_step = 0
+        self.loss = np.inf
         self.log_fns = []
+        self.state = predictor.init_state(
+            params=predictor.init_params(raytracing_args, seed=self.seed), num_iters=self.num_iters,
+            lr_init=hparams.get('lr_init', 1e-4), lr_final=hparams.get('lr_final', 1e-6),
+            lr_inject=hparams.get('lr_inject', None), checkpoint_dir=checkpoint_dir)
+        if checkpoint_dir and network._world()[0] == 0:
+            predictor.save_params(checkpoint_dir)
 
     def log(self):
-        for log_fn in self.log_fns:
-            log_fn(self)
+        for fn in self.log_fns:
+            fn(self)
 
     def save_checkpoint(self):
-        if (self.checkpoint_dir != '') and ((self.step % self.save_period == 0) or (self.step == self.final_step)):
-            if network._world()[0] == 0:
-                os.makedirs(self.checkpoint_dir, exist_ok=True)
-                torch.save(self.state.state_dict(), os.path.join(self.checkpoint_dir, 'checkpoint_%d' % int(self.step)))
-                old = sorted((f for f in os.listdir(self.checkpoint_dir) if f.startswith('checkpoint_')
-                              and f.rsplit('_', 1)[-1].isdigit()), key=lambda f: int(f.rsplit('_', 1)[-1]))
-                for f in old[:-self.keep]:
-                    os.remove(os.path.join(self.checkpoint_dir, f))
+        due = self.step % self.save_period == 0 or self.step == self.final_step
+        if not (self.checkpoint_dir and due and network._world()[0] == 0):
+            return
+        os.makedirs(self.checkpoint_dir, exist_ok=True)
+        torch.save(self.state.state_dict(), os.path.join(self.checkpoint_dir, 'checkpoint_%d' % int(self.step)))
+        numbered = [f for f in os.listdir(self.checkpoint_dir) if f.startswith('checkpoint_') and f[11:].isdigit()]
+        for stale in sorted(numbered, key=lambda f: int(f[11:]))[:-self.keep]:
+            os.remove(os.path.join(self.checkpoint_dir, stale))
 
     def run(self, batchsize, train_step, raytracing_args, log_fns=[]):
+        """num_iters more steps from wherever the (possibly restored) state stands; Ctrl-C stops early."""
         self.init_step = int(self.state.step) + 1
         self.final_step = self.init_step + self.num_iters
         self.log_fns = list(np.atleast_1d(log_fns))
-        self.train_step = train_step
-        self.raytracing_args = raytracing_args
+        self.train_step, self.raytracing_args = train_step, raytracing_args
+        frames = train_step.args[0]
+        bar = tqdm(range(self.init_step, self.final_step), desc='iteration', disable=network._world()[0] != 0)
         try:
-            for self.step in tqdm(range(self.init_step, self.final_step), desc='iteration',
-                                  disable=network._world()[0] != 0):
-                batch_indices = train_step.args[0].sample(batchsize)
-                self.loss, self.state, images = train_step(self.state, raytracing_args, indices=batch_indices)
+            for self.step in bar:
+                self.loss, self.state, _ = train_step(self.state, raytracing_args, indices=frames.sample(batchsize))
                 self.log()
                 self.save_checkpoint()
         except KeyboardInterrupt:
@@ -143,21 +146,20 @@ class TrainStep(object):
         self.num_losses = self.dtype.size
 
     def __call__(self, state, raytracing_args, indices, update_state=True):
-        total_loss = 0.0
-        total_images = 0.0
-        raytracing_args = np.atleast_1d(raytracing_args)
+        """One pass over the losses.  Training picks ONE ray set at random (stochastic sub-pixel sampling,
+        optimization.py:169) and lets every loss take its own Adam step; testing averages over all ray sets."""
+        ray_sets = list(np.atleast_1d(raytracing_args))
         if update_state:
-            call_fn = self.grad_pmap
-            raytracing_args = [raytracing_args[np.random.choice(len(raytracing_args))]]
-        else:
-            call_fn = self.test_pmap
-        for rt_arg in raytracing_args:                       # sub-pixel ray sets (optimization.py:174)
-            for i in range(self.num_losses):
-                loss, state, images = call_fn[i](state, self.t_units, self.dtype[i], *self.args[i][indices],
-                                                 *rt_arg.values(), float(self.scale[i]))
-                total_loss = total_loss + loss / len(raytracing_args)
-                total_images = total_images + images / len(raytracing_args)
-        return total_loss, state, total_images
+            ray_sets = [ray_sets[np.random.choice(len(ray_sets))]]
+        fns = self.grad_pmap if update_state else self.test_pmap
+        loss_acc = images_acc = 0.0
+        for rt in ray_sets:
+            for k in range(self.num_losses):
+                loss, state, images = fns[k](state, self.t_units, self.dtype[k], *self.args[k][indices], *rt.values(),
+                                             float(self.scale[k]))
+                loss_acc = loss_acc + loss / len(ray_sets)
+                images_acc = images_acc + images / len(ray_sets)
+        return loss_acc, state, images_acc
 
     def __add__(self, other):
         return TrainStep(np.append(self.dtype, other.dtype), np.append(self.args, other.args),
