@@ -195,11 +195,33 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
 #define RING_STEP_END(STORES) RG::template wait_younger<(RG::PPW + ES) * (DIST - 1) + (STORES)>(); lds_barrier(); \
     cur = cur == NB - 1 ? 0 : cur + 1;
 
+    // inputs of the next tile are fetched one tile ahead (geometry for the forward modes; for MODE_CHAIN the
+    // recorded emission and dE = sum_s dimg * w, which only need the point index)
+    struct ChainIn { int b; long long p; bool inb; float e, dE; };
+    auto load_chain = [&](long long tile) {
+        ChainIn c;
+        c.b = 0; c.p = 0; c.inb = false; c.e = 0.f; c.dE = 0.f;
+        if (tile < a.total_tiles) {
+            tile_point<Pol::NWAVES>(a, tile, wv, pl, c.b, c.p, c.inb);
+            if (h == 0) c.e = (reinterpret_cast<const float *>(A.tape + A.t.e_off) + (tile * Pol::NWAVES + wv) * 32)[pl];
+            if (h == 0 && c.inb) {
+                const long long ray = c.p / a.G;
+                for (int s = 0; s < a.Sx; ++s)
+                    c.dE += a.dimages[((long long)c.b * a.Sx + s) * a.R + ray] * a.w[(long long)s * a.P + c.p];
+            }
+        }
+        return c;
+    };
+    PointIn nxt;
+    ChainIn cnxt;
+    if constexpr (MODE != MODE_CHAIN) nxt = load_point<Pol::NWAVES>(a, blockIdx.x, wv, pl);
+    else cnxt = load_chain(blockIdx.x);
     for (long long tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
-        int b;
-        long long p;
-        bool inb;
-        tile_point<Pol::NWAVES>(a, tile, wv, pl, b, p, inb);
+        const PointIn in = nxt;
+        const ChainIn cin = cnxt;
+        const int b = (MODE != MODE_CHAIN) ? in.b : cin.b;
+        const long long p = (MODE != MODE_CHAIN) ? in.p : cin.p;
+        const bool inb = (MODE != MODE_CHAIN) ? in.inb : cin.inb;
         const long long q = tile * Pol::NWAVES + wv;                     // 32-point group on the tape
         unsigned *mask_g = reinterpret_cast<unsigned *>(A.tape + A.t.mask_off) + q * (long long)(a.depth * MW * 64);
         float *e_g = reinterpret_cast<float *>(A.tape + A.t.e_off) + q * 32;
@@ -207,7 +229,8 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
         frag enc[2], act[KS], next[KS];
         bool live = false;
         if constexpr (MODE != MODE_CHAIN) {
-        point_prologue<Pol, DEG>(a, b, p, inb, enc, live);
+        point_prologue<Pol, DEG>(a, in, enc, live);
+        nxt = load_point<Pol::NWAVES>(a, tile + gridDim.x, wv, pl);
         // the encoded inputs are the B operand of dW_0 and of the skip layer
         emit_frags<Pol, BG::ROW_BYTES>(scr, A.tape + A.t.enc_off + q * BG::TILE_BYTES, enc[0], enc[1], edbg);
         // ---- forward, layer 0 ----------------------------------------------------------------
@@ -249,6 +272,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
         } else {
             // relu bits recorded by the training forward -> this wave's LDS stash
             for (int i = 0; i < a.depth * MW; ++i) mask_w[i * 64 + lane] = mask_g[i * 64 + lane];
+            cnxt = load_chain(tile + gridDim.x);
         }
         // ---- output layer -> e ; dE, dout -----------------------------------------------------
         float dout = 0.f;
@@ -261,7 +285,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
                 ++seq;
                 if (h == 0 && live) e = 1.f / (1.f + Pol::fexp(10.f - acc[0]));
             } else {
-                if (h == 0) e = e_g[pl];
+                e = cin.e;
             }
             if constexpr (MODE == MODE_FWD_TRAIN) {
                 // record what the delta chain needs, then the render epilogue of fused_fwd_kernel
@@ -283,10 +307,13 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
             } else {
                 float d = 0.f;
                 if (h == 0 && inb && e != 0.f) {
-                    const long long ray = p / a.G;
                     float dE = 0.f;
-                    for (int s = 0; s < a.Sx; ++s)
-                        dE += a.dimages[((long long)b * a.Sx + s) * a.R + ray] * a.w[(long long)s * a.P + p];
+                    if constexpr (MODE == MODE_CHAIN) dE = cin.dE;
+                    else {
+                        const long long ray = p / a.G;
+                        for (int s = 0; s < a.Sx; ++s)
+                            dE += a.dimages[((long long)b * a.Sx + s) * a.R + ray] * a.w[(long long)s * a.P + p];
+                    }
                     d = dE * e * (1.f - e);                            // sigmoid'(out-10) = e(1-e)
                 }
                 dout = __shfl(d, pl, 64);                               // both lane halves need it
@@ -499,14 +526,12 @@ DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
                     sbase[i] = srcE + (piece - PA - PH) * 1024;
                     sstride[i] = TB;
                 }
-                sbase[i] += lane * 16;
             }
             auto issue = [&](long long q, char *buf) {
                 q = q < q1 ? q : q1 - 1;
 #pragma unroll
                 for (int i = 0; i < PPW; ++i)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(sbase[i] + q * sstride[i]),
-                                                     (__attribute__((address_space(3))) void *)(buf + doff[i]), 16, 0, 0);
+                    dma_1k(sbase[i] + q * sstride[i], buf + doff[i]);
             };
             if (q0 < q1) {
 #pragma unroll

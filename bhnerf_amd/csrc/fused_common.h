@@ -34,6 +34,7 @@ struct PolBF16 {
     static constexpr int NTHREADS = NWAVES * 64;
     static constexpr int ELEM_BYTES = 2;
     static constexpr int FRAG_BYTES = 1024;     // 64 lanes x 8 bf16
+    static constexpr int LDS_PREFETCH = 4;      // A fragments in flight + 1 (tile_matmul)
     using frag = bf16x8;
     static DEVI frag zero() { frag f; for (int j = 0; j < 8; ++j) f[j] = (__bf16)0.f; return f; }
     static DEVI frag lds_frag(const char *chunk, int f, int lane) {
@@ -56,6 +57,7 @@ struct PolF32 {
     static constexpr int NTHREADS = NWAVES * 64;
     static constexpr int ELEM_BYTES = 4;
     static constexpr int FRAG_BYTES = 2048;     // 2 halves x 64 lanes x 4 f32
+    static constexpr int LDS_PREFETCH = 3;
     using frag = f32x8;
     static DEVI frag zero() { frag f; for (int j = 0; j < 8; ++j) f[j] = 0.f; return f; }
     static DEVI frag lds_frag(const char *chunk, int f, int lane) {
@@ -108,6 +110,7 @@ struct FusedArgs {
     // tiling
     int tiles_per_frame;
     long long total_tiles;
+    int debug;            // measurement builds only
 };
 
 // Packed-weight geometry for hidden width W
@@ -160,20 +163,57 @@ struct PointState {
     long long p;      // flat point index inside the frame
 };
 
+// tile -> (frame, point) mapping shared by all fused kernels: wave `wv` of tile `tile` owns the 32-point group
+// number (tile % tiles_per_frame) * NWAVES + wv of the (compacted) group list
+template <int NWAVES>
+DEVI void tile_point(const FusedArgs &a, long long tile, int wv, int pl, int &b, long long &p, bool &inb) {
+    b = (int)(tile / a.tiles_per_frame);
+    const long long gi = (tile % a.tiles_per_frame) * NWAVES + wv;
+    const bool gok = gi < a.n_groups;
+    const long long grp = gok ? (a.groups ? (long long)a.groups[gi] : gi) : 0;
+    p = grp * 32 + pl;
+    inb = gok && p < a.P;
+}
+
+// Raw per-point inputs of one tile.  They are loaded one tile AHEAD (the loads of tile i+1 are issued while
+// tile i runs its layers), so the ~2 us dependent-load latency at every tile start is hidden.
+struct PointIn {
+    int b;
+    long long p;
+    bool inb;
+    float x, y, z, om, tg, tm0;   // tm0 is unused; the frame offset stays in double (tM0d)
+    double tM0d;
+    bool dom;
+};
+
+template <int NG>
+DEVI PointIn load_point(const FusedArgs &a, long long tile, int gslot, int pl) {
+    PointIn q;
+    q.x = q.y = q.z = q.om = q.tg = q.tm0 = 0.f;
+    q.tM0d = 0.0;
+    q.dom = false;
+    q.b = 0; q.p = 0; q.inb = false;
+    if (tile < a.total_tiles) {
+        tile_point<NG>(a, tile, gslot, pl, q.b, q.p, q.inb);
+        q.tM0d = a.tM0[q.b];
+        if (q.inb) {
+            q.x = a.x[q.p]; q.y = a.y[q.p]; q.z = a.z[q.p]; q.om = a.Omega[q.p]; q.tg = a.t_geo[q.p];
+            q.dom = a.dom[q.p] != 0;
+        }
+    }
+    return q;
+}
+
 template <class Pol, int DEG>
-DEVI void point_prologue(const FusedArgs &a, int b, long long p, bool inb, typename Pol::frag (&enc)[2],
-                         bool &live) {
+DEVI void point_prologue(const FusedArgs &a, const PointIn &in, typename Pol::frag (&enc)[2], bool &live) {
     const int lane = threadIdx.x & 63;
     const int h = lane >> 5;
-    float x = 0.f, y = 0.f, z = 0.f, om = 0.f, tg = 0.f;
-    bool dom = false;
-    if (inb) {
-        x = a.x[p]; y = a.y[p]; z = a.z[p]; om = a.Omega[p]; tg = a.t_geo[p];
-        dom = a.dom[p] != 0;
-    }
+    const bool inb = in.inb;
+    const float x = in.x, y = in.y, z = in.z, om = in.om, tg = in.tg;
+    const bool dom = in.dom;
     // t_M = (t_frame - t_start_obs)/GM_c3 + t_geo - t_injection in double: the f32 reference loses
     // ~6e-5 here (|t_geo| ~ 1e3), the oracle is float64 (DESIGN.md "numerics").
-    const double tM = a.tM0[b] + (double)tg;
+    const double tM = in.tM0d + (double)tg;
     const bool pre = tM < 0.0;                                  // emission.py:204-205 -> NaN
     const double rev_d = tM * (double)om * 0.15915494309189535; // theta / (2 pi)
     const double fr = rev_d - floor(rev_d);
@@ -230,18 +270,6 @@ DEVI void point_prologue(const FusedArgs &a, int b, long long p, bool inb, typen
         }
 }
 
-// tile -> (frame, point) mapping shared by all fused kernels: wave `wv` of tile `tile` owns the 32-point group
-// number (tile % tiles_per_frame) * NWAVES + wv of the (compacted) group list
-template <int NWAVES>
-DEVI void tile_point(const FusedArgs &a, long long tile, int wv, int pl, int &b, long long &p, bool &inb) {
-    b = (int)(tile / a.tiles_per_frame);
-    const long long gi = (tile % a.tiles_per_frame) * NWAVES + wv;
-    const bool gok = gi < a.n_groups;
-    const long long grp = gok ? (a.groups ? (long long)a.groups[gi] : gi) : 0;
-    p = grp * 32 + pl;
-    inb = gok && p < a.P;
-}
-
 // bias rows of output tile m as the initial accumulator: acc[r] = bias[32m + (r&3)+8(r>>2)+4h]
 DEVI f32x16 bias_acc(const float *bias_lds, int m, int h) {
     f32x16 acc;
@@ -260,11 +288,23 @@ DEVI f32x16 tile_matmul(const char *chunk, const typename Pol::frag (&act)[W / 1
                         const typename Pol::frag (&enc)[2], bool with_enc, f32x16 acc) {
     const int lane = threadIdx.x & 63;
     constexpr int KS = W / 16;
+    // A fragments are read PF-1 k-steps ahead of the MFMA that consumes them (rotating register slots) so that
+    // the LDS latency overlaps the MFMAs of this wave, not only those of the SIMD's other wave; the scheduling
+    // fences keep the compiler from sinking the reads back to their uses (it minimises registers otherwise).
+    constexpr int PF = Pol::LDS_PREFETCH;
+    typename Pol::frag a[PF];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) acc = Pol::mma(Pol::lds_frag(chunk, ks, lane), act[ks], acc);
+    for (int i = 0; i < PF - 1; ++i) a[i] = Pol::lds_frag(chunk, i, lane);
+    __builtin_amdgcn_sched_barrier(0x6);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        if (ks + PF - 1 < KS + 2) a[(ks + PF - 1) % PF] = Pol::lds_frag(chunk, ks + PF - 1, lane);
+        acc = Pol::mma(a[ks % PF], act[ks], acc);
+        __builtin_amdgcn_sched_barrier(0x6);                               // VALU/SALU may cross, DS and MFMA may not
+    }
     if (with_enc) {
-        acc = Pol::mma(Pol::lds_frag(chunk, KS, lane), enc[0], acc);
-        acc = Pol::mma(Pol::lds_frag(chunk, KS + 1, lane), enc[1], acc);
+        acc = Pol::mma(a[KS % PF], enc[0], acc);
+        acc = Pol::mma(a[(KS + 1) % PF], enc[1], acc);
     }
     return acc;
 }
@@ -287,24 +327,34 @@ DEVI unsigned relu_pack(const f32x16 &acc, int m, typename Pol::frag (&next)[W /
 }
 
 // ---------------------------------------------------------------------------------------------
-// LDS-DMA weight ring: chunk c+2 is copied global -> LDS (global_load_lds_dwordx4, no registers)
+// LDS-DMA weight ring: chunk c+2 is copied global -> LDS (buffer_load_dwordx4 ... lds, no registers)
 // while chunk c is consumed; three buffers.  Every wave issues exactly PPW 1-KiB pieces per chunk
 // (tail waves re-issue the last piece) so that the counted vmcnt below is the same for all waves.
 // ---------------------------------------------------------------------------------------------
+// One wave copies 1 KiB global -> LDS without registers: lane i's 16 bytes land at dst + 16 i (src, dst wave-
+// uniform).  The MUBUF form (buffer_load_dwordx4 ... lds) is used on purpose: the compiler's waitcnt pass books
+// the FLAT form (global_load_lds_dwordx4) as a pending flat access and then degrades every later LDS wait to
+// lgkmcnt(0), which serialises the software-pipelined A-fragment reads in tile_matmul.
+DEVI void dma_1k(const char *src, char *dst) {
+    const unsigned long long u = reinterpret_cast<unsigned long long>(src);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    void *us = reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(us, 0, 1 << 20, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)dst, 16, (int)(threadIdx.x & 63) * 16, 0, 0, 0);
+}
+
 template <int CHUNK_BYTES, int NWAVES>
 struct DmaRing {
     static constexpr int NPIECE = CHUNK_BYTES / 1024;
     static constexpr int PPW = (NPIECE + NWAVES - 1) / NWAVES;
     static_assert(CHUNK_BYTES % 1024 == 0, "chunks are whole KiB");
     static DEVI void issue(const char *src, char *dst) {
-        const int lane = threadIdx.x & 63;
         const int wvu = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
             int piece = wvu + NWAVES * i;
             piece = piece < NPIECE ? piece : NPIECE - 1;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + piece * 1024 + lane * 16),
-                                             (__attribute__((address_space(3))) void *)(dst + piece * 1024), 16, 0, 0);
+            dma_1k(src + piece * 1024, dst + piece * 1024);
         }
     }
     // vmcnt retires in issue order and counts loads, stores and LDS-DMA alike: a chunk has landed once at

@@ -119,8 +119,11 @@ extern "C" int bhn_pack_weights(const bhn_model *m, int32_t mode, const float *p
 // ---------------------------------------------------------------------------------------------
 // forward kernel
 // ---------------------------------------------------------------------------------------------
-template <int W, class Pol, int DEG, bool RENDER>
+// DBG: measurement build (tools/dbg_fwd_ablate.py): a.debug bits knock out one cost at a time -- 1 hidden/output MFMAs,
+// 2 relu+pack, 4 weight DMA + its waits, 8 barriers, 16 posenc trig, 32 epilogue.  Results are then meaningless.
+template <int W, class Pol, int DEG, bool RENDER, bool DBG = false>
 __global__ __launch_bounds__(Pol::NTHREADS) void fused_fwd_kernel(FusedArgs a) {
+    const int dbg = DBG ? a.debug : 0;
     using PK = Pack<W, Pol>;
     using frag = typename Pol::frag;
     constexpr int CB = PK::CHUNK_BYTES, MT = PK::MT, KS = PK::KS;
@@ -144,20 +147,24 @@ __global__ __launch_bounds__(Pol::NTHREADS) void fused_fwd_kernel(FusedArgs a) {
     int cur = 0;
     // step c: issue chunk c+DIST, consume chunk c, wait for own pieces of chunk c+1 (the DIST-1 younger chunks
     // stay in flight; the epilogue's stores/atomics and the prologue's loads only make the true count larger)
-#define STEP_BEGIN(seq) { const int nx = cur >= 1 ? cur - 1 : NB - 1; RG::issue(chunk_src((seq) + DIST), ring + nx * CB); } \
+#define STEP_BEGIN(seq) if (!(dbg & 4)) { const int nx = cur >= 1 ? cur - 1 : NB - 1; RG::issue(chunk_src((seq) + DIST), ring + nx * CB); } \
     const char *ch = ring + cur * CB;
-#define STEP_END() RG::template wait_younger<RG::PPW * (DIST - 1)>(); lds_barrier(); cur = cur == NB - 1 ? 0 : cur + 1;
+#define STEP_END() if (!(dbg & 4)) RG::template wait_younger<RG::PPW * (DIST - 1)>(); if (!(dbg & 8)) lds_barrier(); cur = cur == NB - 1 ? 0 : cur + 1;
 
+    PointIn nxt = load_point<Pol::NWAVES>(a, blockIdx.x, wv, pl);
     for (long long tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
-        int b;
-        long long p;
-        bool inb;
-        tile_point<Pol::NWAVES>(a, tile, wv, pl, b, p, inb);
+        const PointIn in = nxt;
+        const int b = in.b;
+        const long long p = in.p;
+        const bool inb = in.inb;
         frag enc[2];
         bool live;
-        point_prologue<Pol, DEG>(a, b, p, inb, enc, live);
+        if (!(dbg & 16)) point_prologue<Pol, DEG>(a, in, enc, live);
+        else { live = in.dom; for (int j = 0; j < 8; ++j) { Pol::set(enc[0], j, in.x); Pol::set(enc[1], j, in.tg); } }
+        nxt = load_point<Pol::NWAVES>(a, tile + gridDim.x, wv, pl);      // next tile's inputs fly during this tile
 
         frag act[KS], next[KS];
+        if (DBG) for (int ks = 0; ks < KS; ++ks) next[ks] = act[ks] = Pol::zero();
         int seq = 0;
         // ---- layer 0 (chunk 0: fragment m*2+ks) -------------------------------------------
         {
@@ -179,8 +186,10 @@ __global__ __launch_bounds__(Pol::NTHREADS) void fused_fwd_kernel(FusedArgs a) {
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 STEP_BEGIN(seq)
-                f32x16 acc = tile_matmul<W, Pol>(ch, act, enc, sk, bias_acc(bl, m, h));
-                relu_pack<W, Pol>(acc, m, next);
+                f32x16 acc = bias_acc(bl, m, h);
+                if (!(dbg & 1)) acc = tile_matmul<W, Pol>(ch, act, enc, sk, acc);
+                if (!(dbg & 2)) relu_pack<W, Pol>(acc, m, next);
+                else Pol::set(next[2 * m], 0, acc[0]);
                 STEP_END()
                 ++seq;
             }
@@ -191,7 +200,8 @@ __global__ __launch_bounds__(Pol::NTHREADS) void fused_fwd_kernel(FusedArgs a) {
         float outv;
         {
             STEP_BEGIN(seq)
-            f32x16 acc = tile_matmul<W, Pol>(ch, act, enc, false, bias_acc(bias_lds + a.depth * W, 0, h));
+            f32x16 acc = bias_acc(bias_lds + a.depth * W, 0, h);
+            if (!(dbg & 1)) acc = tile_matmul<W, Pol>(ch, act, enc, false, acc);
             outv = acc[0];
             STEP_END()
             ++seq;
@@ -199,7 +209,9 @@ __global__ __launch_bounds__(Pol::NTHREADS) void fused_fwd_kernel(FusedArgs a) {
         // ---- epilogue: sigmoid(out - 10), masks (network.py:230-232) ----------------------
         float e = 0.f;
         if (h == 0 && live) e = 1.f / (1.f + Pol::fexp(10.f - outv));
-        if (!RENDER) {
+        if (dbg & 32) {
+            if (e == 12345.f) a.images[0] = e;
+        } else if (!RENDER) {
             if (h == 0 && inb) a.emission[(long long)b * a.P + p] = e;
         } else {
             // x J g^2 dtau Sigma and sum over the ray (network.py:415-419, kgeo.py:621); a 32-point
@@ -263,11 +275,11 @@ int fused_fill_args(const bhn_model *m, int32_t mode, const void *packed, const 
     return BHN_OK;
 }
 
-template <int W, class Pol, bool RENDER>
+template <int W, class Pol, bool RENDER, bool DBG = false>
 static int launch_fwd_w(FusedArgs &a, hipStream_t st) {
     using PK = Pack<W, Pol>;
     const size_t lds = (size_t)((Pol::ELEM_BYTES == 2 ? 4 : 2) + 1) * PK::CHUNK_BYTES + (size_t)(a.depth + 1) * W * 4;
-    auto kern = fused_fwd_kernel<W, Pol, 3, RENDER>;
+    auto kern = fused_fwd_kernel<W, Pol, 3, RENDER, DBG>;
     static bool attr_done = false;
     static int occ = 1;
     if (!attr_done) {
@@ -342,6 +354,10 @@ extern "C" int bhn_render_fwd(const bhn_model *m, int32_t mode, const void *pack
     if (rc != BHN_OK) return rc;
     a.images = images;
     BHN_HIP(hipMemsetAsync(images, 0, sizeof(float) * (size_t)a.B * a.Sx * a.R, (hipStream_t)stream));
+    if (mode == BHN_BF16 && s.width == 256 && (g_fwd_variant & 15) == 3) {     // ablation build, see fused_fwd_kernel
+        a.debug = g_fwd_variant >> 4;
+        return launch_fwd_w<256, PolBF16, true, true>(a, (hipStream_t)stream);
+    }
     return mode == BHN_BF16 ? launch_fwd<PolBF16, true>(a, s.width, (hipStream_t)stream)
                             : launch_fwd<PolF32, true>(a, s.width, (hipStream_t)stream);
 }

@@ -45,8 +45,9 @@ __global__ __launch_bounds__(Pol::NTHREADS) void fused_fwd2_kernel(FusedArgs a) 
         frag enc[NPT][2];
 #pragma unroll
         for (int t = 0; t < NPT; ++t) {
-            tile_point<Pol::NWAVES * NPT>(a, tile, wv * NPT + t, pl, b, p[t], inb[t]);
-            point_prologue<Pol, DEG>(a, b, p[t], inb[t], enc[t], live[t]);
+            const PointIn in = load_point<Pol::NWAVES * NPT>(a, tile, wv * NPT + t, pl);
+            b = in.b; p[t] = in.p; inb[t] = in.inb;
+            point_prologue<Pol, DEG>(a, in, enc[t], live[t]);
         }
         frag act[NPT][KS], next[NPT][KS];
         int seq = 0;

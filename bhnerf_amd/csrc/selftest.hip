@@ -2,7 +2,7 @@
 //   [0] v_mfma_f32_32x32x16_bf16 A/B/C maps   [1] v_mfma_f32_32x32x2_f32 maps
 //   [2] accumulator -> next B operand chaining (phi16 order), bf16     [3] same, f32
 //   [4] ds_read_b64_tr_b16 as a [k][n] -> B-operand transposed read
-//   [5]/[6] global_load_lds_dwordx4 (LDS-DMA) lane placement, destinations below / above 64 KiB
+//   [5]/[6] buffer_load_dwordx4 ... lds (LDS-DMA, dma_1k) lane placement, destinations below / above 64 KiB
 #include "fused_common.h"
 
 DEVI int ia(int i, int k) { return ((i * 3 + k * 5) % 7) - 3; }   // asymmetric integer operands
@@ -95,17 +95,16 @@ __global__ void selftest_kernel(int *res, short *dump) {
     }
 }
 
-// ---- [5],[6] LDS-DMA (global_load_lds_dwordx4): lane i's 16 bytes land at base + 16*i; destinations
+// ---- [5],[6] LDS-DMA (dma_1k: buffer_load_dwordx4 ... lds): lane i's 16 bytes land at base + 16*i; destinations
 //      below and above 64 KiB; counted vmcnt + barrier publish them to the other waves
 __global__ void selftest_dma_kernel(const unsigned *src, int *res) {
     extern __shared__ __attribute__((aligned(16))) char dsm[];
-    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nw = blockDim.x >> 6;
     // wave w copies KiB w of src to LDS offset 1024*w (low) and 96 KiB + 1024*w (high)
     for (int rep = 0; rep < 2; ++rep) {
         char *dst = dsm + (rep ? 96 * 1024 : 0) + wv * 1024;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(src) + wv * 1024 + lane * 16),
-                                         (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        dma_1k(reinterpret_cast<const char *>(src) + wv * 1024, dst);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
