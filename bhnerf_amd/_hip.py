@@ -66,6 +66,7 @@ SIGNATURES = {
     'bhn_adam_step': (C.c_int, [_P, _P, _P, _P, _I64, _I64, _F, _F, _F, _F, _F, _P]),
     'bhn_debug_set_bwd_stages': (C.c_int, [_I32]),
     'bhn_debug_set_fwd_variant': (C.c_int, [_I32]),
+    'bhn_debug_read': (C.c_int, [_P, C.c_size_t]),
     'bhn_selftest': (C.c_int, [C.POINTER(_I32)]),
 }
 

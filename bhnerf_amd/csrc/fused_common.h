@@ -34,7 +34,8 @@ struct PolBF16 {
     static constexpr int NTHREADS = NWAVES * 64;
     static constexpr int ELEM_BYTES = 2;
     static constexpr int FRAG_BYTES = 1024;     // 64 lanes x 8 bf16
-    static constexpr int LDS_PREFETCH = 4;      // A fragments in flight + 1 (tile_matmul)
+    static constexpr int LDS_PREFETCH = 4;      // A fragments in flight + 1 (tile_matmul, hidden_step); 8 measured no faster
+    static constexpr bool PHASE_LAG = false;    // RingState LAG: measured 5 % slower in the render kernel, off
     using frag = bf16x8;
     static DEVI frag zero() { frag f; for (int j = 0; j < 8; ++j) f[j] = (__bf16)0.f; return f; }
     static DEVI frag lds_frag(const char *chunk, int f, int lane) {
@@ -44,6 +45,11 @@ struct PolBF16 {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
     }
     static DEVI void set(frag &f, int j, float v) { f[j] = (__bf16)v; }
+    static DEVI float relu(float v) {           // one v_max (plain C gets a canonicalising second one from hipcc)
+        float q;
+        asm("v_max_f32 %0, 0, %1" : "=v"(q) : "v"(v));
+        return q;
+    }
     static DEVI float get(const frag &f, int j) { return (float)f[j]; }
     static DEVI float fsin_rev(float rev) { return __builtin_amdgcn_sinf(rev); }   // sin(2*pi*rev)
     static DEVI float fcos_rev(float rev) { return __builtin_amdgcn_cosf(rev); }
@@ -57,7 +63,8 @@ struct PolF32 {
     static constexpr int NTHREADS = NWAVES * 64;
     static constexpr int ELEM_BYTES = 4;
     static constexpr int FRAG_BYTES = 2048;     // 2 halves x 64 lanes x 4 f32
-    static constexpr int LDS_PREFETCH = 3;
+    static constexpr int LDS_PREFETCH = 2;
+    static constexpr bool PHASE_LAG = false;    // one wave per SIMD
     using frag = f32x8;
     static DEVI frag zero() { frag f; for (int j = 0; j < 8; ++j) f[j] = 0.f; return f; }
     static DEVI frag lds_frag(const char *chunk, int f, int lane) {
@@ -75,6 +82,7 @@ struct PolF32 {
         return c;
     }
     static DEVI void set(frag &f, int j, float v) { f[j] = v; }
+    static DEVI float relu(float v) { return v > 0.f ? v : 0.f; }
     static DEVI float get(const frag &f, int j) { return f[j]; }
     static DEVI float fexp(float x) { return expf(x); }
     static constexpr bool FAST_TRIG = false;
@@ -297,14 +305,11 @@ DEVI f32x16 tile_matmul(const char *chunk, const typename Pol::frag (&act)[W / 1
     for (int i = 0; i < PF - 1; ++i) a[i] = Pol::lds_frag(chunk, i, lane);
     __builtin_amdgcn_sched_barrier(0x6);
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        if (ks + PF - 1 < KS + 2) a[(ks + PF - 1) % PF] = Pol::lds_frag(chunk, ks + PF - 1, lane);
-        acc = Pol::mma(a[ks % PF], act[ks], acc);
+    for (int t = 0; t < KS + 2; ++t) {
+        if (t + PF - 1 < KS + 2) a[(t + PF - 1) % PF] = Pol::lds_frag(chunk, t + PF - 1, lane);
+        if (t < KS) acc = Pol::mma(a[t % PF], act[t], acc);
+        else if (with_enc) acc = Pol::mma(a[t % PF], enc[t - KS], acc);
         __builtin_amdgcn_sched_barrier(0x6);                               // VALU/SALU may cross, DS and MFMA may not
-    }
-    if (with_enc) {
-        acc = Pol::mma(a[KS % PF], enc[0], acc);
-        acc = Pol::mma(a[(KS + 1) % PF], enc[1], acc);
     }
     return acc;
 }
@@ -324,6 +329,100 @@ DEVI unsigned relu_pack(const f32x16 &acc, int m, typename Pol::frag (&next)[W /
             Pol::set(next[2 * m + s], j, pos ? v : 0.f);
         }
     return mask;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Software-pipelined ring steps (fused_fwd_kernel).  Three things that used to sit between the MFMA chains
+// of consecutive steps are folded INTO the chains, because the workgroup barrier keeps all eight waves in
+// lockstep and the SIMD's other wave is then in the same non-MFMA phase:
+//   * the first PF-1 A fragments of the NEXT chunk are read before the barrier (`ap`), so the first MFMA
+//     after it does not wait for LDS;
+//   * relu + repack of the PREVIOUS output tile (`pend`) runs in the shadow of this tile's first MFMAs;
+//   * the DMA issue for chunk c+DIST (scalar address math + buffer_load...lds) sits after MFMA 3.
+// The fences (sched_barrier 0) pin that order; hipcc otherwise sinks every LDS read to its use and hoists
+// the whole pack to the end of the layer.
+// ---------------------------------------------------------------------------------------------
+template <class Pol, int R0, int N>
+DEVI void pack_elems(const f32x16 &acc, typename Pol::frag &d0, typename Pol::frag &d1, unsigned &mask) {
+#pragma unroll
+    for (int r = R0; r < R0 + N; ++r) {
+        const float v = acc[r];
+        mask |= (v > 0.f) ? (1u << r) : 0u;                       // dead code unless the caller records relu bits
+        Pol::set(r < 8 ? d0 : d1, r & 7, Pol::relu(v));
+    }
+    // the packed registers are "used" here: without this the machine sinker moves the whole pack down to the
+    // next layer's first read of the fragment, i.e. out of the MFMA shadow it was placed in
+    if (R0 < 8) asm volatile("" : "+v"(d0));
+    if (R0 + N > 8) asm volatile("" : "+v"(d1));
+}
+
+template <class Pol>
+struct APipe {                                  // fragments 0..PF-2 of the chunk about to be consumed
+    static constexpr int N = Pol::LDS_PREFETCH - 1;
+    typename Pol::frag f[N];
+    f32x16 bias;                                // bias rows of the upcoming output tile (its initial accumulator)
+    DEVI void prime(const char *ch, const float *bias_tile) {
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int i = 0; i < N; ++i) f[i] = Pol::lds_frag(ch, i, lane);
+        bias = bias_acc(bias_tile, 0, lane >> 5);
+    }
+};
+
+// fragment `idx` of the stream "NF fragments of chunk ch, then chunk chn from its fragment 0"
+template <class Pol, int NF>
+DEVI typename Pol::frag stream_frag(const char *ch, const char *chn, int idx, int lane) {
+    return idx < NF ? Pol::lds_frag(ch, idx, lane) : Pol::lds_frag(chn, idx - NF, lane);
+}
+
+struct DmaJob {                                 // chunk to start copying in the middle of a step (src == nullptr: none)
+    const char *src;
+    char *dst;
+};
+
+// One hidden-layer (or output-layer) tile: acc += sum_ks A[ks] . src[ks] (+ enc block when with_enc), with the
+// pending tile `pend` packed into (pd0, pd1) during the first k-steps.  pd0/pd1 may be src[KS-2], src[KS-1]
+// (layer boundary): they are complete before k-step KS-2 reads them.
+template <int W, class Pol, class RG, bool PEND>
+DEVI f32x16 hidden_step(const char *ch, const char *chn, APipe<Pol> &ap, const typename Pol::frag (&src)[W / 16],
+                        const typename Pol::frag (&enc)[2], bool with_enc, const float *bias_next, const f32x16 &pend,
+                        typename Pol::frag &pd0, typename Pol::frag &pd1, unsigned &pmask, DmaJob dma, int dbg = 0) {
+    const int lane = threadIdx.x & 63;
+    constexpr int KS = W / 16, NF = KS + 2, PF = Pol::LDS_PREFETCH;
+    typename Pol::frag a[PF];
+#pragma unroll
+    for (int i = 0; i < PF - 1; ++i) a[i] = ap.f[i];
+    f32x16 acc = ap.bias;
+    const bool do_pack = PEND && !(dbg & 2), do_mma = !(dbg & 1);
+    if (do_pack && KS < 16) pack_elems<Pol, 0, 16>(pend, pd0, pd1, pmask);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < KS; ++t) {
+        a[(t + PF - 1) % PF] = stream_frag<Pol, NF>(ch, chn, t + PF - 1, lane);
+        if (do_mma) acc = Pol::mma(a[t % PF], src[t], acc);
+        if (do_pack && KS >= 16 && t < 8) {
+            if (t == 0) pack_elems<Pol, 0, 2>(pend, pd0, pd1, pmask);
+            if (t == 1) pack_elems<Pol, 2, 2>(pend, pd0, pd1, pmask);
+            if (t == 2) pack_elems<Pol, 4, 2>(pend, pd0, pd1, pmask);
+            if (t == 3) pack_elems<Pol, 6, 2>(pend, pd0, pd1, pmask);
+            if (t == 4) pack_elems<Pol, 8, 2>(pend, pd0, pd1, pmask);
+            if (t == 5) pack_elems<Pol, 10, 2>(pend, pd0, pd1, pmask);
+            if (t == 6) pack_elems<Pol, 12, 2>(pend, pd0, pd1, pmask);
+            if (t == 7) pack_elems<Pol, 14, 2>(pend, pd0, pd1, pmask);
+        }
+        if (t == (KS >= 16 ? 9 : 0) && dma.src) RG::issue(dma.src, dma.dst);
+        if (t == (KS >= 16 ? 11 : 0)) ap.bias = bias_acc(bias_next, 0, lane >> 5);   // next tile's bias, before the barrier
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int t = KS; t < NF; ++t) {
+        a[(t + PF - 1) % PF] = stream_frag<Pol, NF>(ch, chn, t + PF - 1, lane);
+        if (with_enc && do_mma) acc = Pol::mma(a[t % PF], enc[t - KS], acc);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int i = 0; i < PF - 1; ++i) ap.f[i] = a[(NF + i) % PF];
+    return acc;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -373,6 +472,124 @@ DEVI void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+}
+
+// ---------------------------------------------------------------------------------------------
+// Ring bookkeeping of the pipelined steps: chunk c is consumed from buffer `cur` while chunks c+1 .. c+DIST-1
+// are resident or in flight; step_end() waits for this wave's pieces of chunk c+2 (NOT c+1: the A-fragment
+// prefetch of the next step reads chunk c+2 before that step's barrier) and synchronises the workgroup.
+// ---------------------------------------------------------------------------------------------
+template <class RG, int CB, int DIST, bool LAG>
+struct RingState {
+    // LAG: the second wave of every SIMD (waves NWAVES/2..) consumes the ring ONE STEP BEHIND the first.  All
+    // waves still meet at every barrier, but the two waves of a SIMD are never in their per-tile VALU phases
+    // (warp + posenc prologue, sigmoid + ray-sum epilogue) at the same time: one wave's MFMAs cover the other's.
+    // Costs one more resident chunk and one idle step per wave.
+    static constexpr int NB = DIST + (LAG ? 2 : 1);
+    static_assert(DIST >= 2, "ring geometry");
+    char *ring;
+    const char *img;        // packed chunk sequence, NC chunks, consumed cyclically
+    int NC, cur, issue_c, dbg, lag;
+    static DEVI int wrap(int i) { return i < 0 ? i + NB : (i >= NB ? i - NB : i); }
+    DEVI const char *ch() const { return ring + wrap(cur - lag) * CB; }
+    DEVI const char *chn() const { return ring + wrap(cur - lag + 1) * CB; }
+    DEVI DmaJob job() {
+        if (dbg & 4) return DmaJob{nullptr, nullptr};
+        DmaJob j{img + (size_t)issue_c * CB, ring + wrap(cur - (LAG ? 2 : 1)) * CB};
+        issue_c = (issue_c + 1 == NC) ? 0 : issue_c + 1;
+        return j;
+    }
+    long long *ts;          // measurement builds: per-step time stamps (compute done, DMA wait done, barrier passed)
+    DEVI void step_end() {
+        long long t1 = 0, t2 = 0;
+        if (ts) t1 = __builtin_readcyclecounter();
+        if (!(dbg & 4)) RG::template wait_younger<RG::PPW * (DIST - 2)>();
+        if (ts) t2 = __builtin_readcyclecounter();
+        if (!(dbg & 8)) lds_barrier();
+        if (ts) {
+            const long long t3 = __builtin_readcyclecounter();
+            if ((threadIdx.x & 63) == 0) { ts[0] = t1; ts[1] = t3; }
+            (void)t2;
+            ts += 2;
+        }
+        cur = (cur == NB - 1) ? 0 : cur + 1;
+    }
+    DEVI void idle_step() {      // a step in which this wave consumes nothing (lagging waves: first; the others: last)
+        const DmaJob j = job();
+        if (j.src) RG::issue(j.src, j.dst);
+        step_end();
+    }
+    DEVI void start(char *ring_, const char *img_, int nc, int dbg_, int lag_) {
+        ring = ring_; img = img_; NC = nc; dbg = dbg_; cur = 0; issue_c = 0; lag = LAG ? lag_ : 0; ts = nullptr;
+#pragma unroll
+        for (int j = 0; j < DIST; ++j) {
+            RG::issue(img + (size_t)issue_c * CB, ring + j * CB);
+            issue_c = (issue_c + 1 == NC) ? 0 : issue_c + 1;
+        }
+        RG::template wait_younger<RG::PPW * (DIST - 2)>();
+        lds_barrier();
+    }
+};
+
+// layer 0 (chunk 0: fragment 2m+ks, B = enc[ks]); tile m-1 is packed into act behind the two MFMAs of tile m,
+// the last tile is left pending for the first hidden step.
+template <int W, class Pol, class RG, class RS>
+DEVI void layer0_step(RS &rs, APipe<Pol> &ap, const typename Pol::frag (&enc)[2], typename Pol::frag (&act)[W / 16],
+                      const float *bias_lds, int h, f32x16 &pend, unsigned (&masks)[W / 32]) {
+    const int lane = threadIdx.x & 63;
+    constexpr int KS = W / 16, MT = W / 32, NF = KS + 2, PF = Pol::LDS_PREFETCH;   // every chunk is a stream of KS+2 fragments;
+    const char *ch = rs.ch(), *chn = rs.chn();                                     // layer 0 uses the first KS of them
+    const DmaJob dj = rs.job();
+    typename Pol::frag a[PF];
+#pragma unroll
+    for (int i = 0; i < PF - 1; ++i) a[i] = ap.f[i];
+    f32x16 prev = {};
+    f32x16 acc = ap.bias;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const f32x16 nb = bias_acc(bias_lds + 32 * (m + 1), 0, h);       // tile m+1 (m = MT-1: first tile of layer 1)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int t = 2 * m + ks;
+            a[(t + PF - 1) % PF] = stream_frag<Pol, NF>(ch, chn, t + PF - 1, lane);
+            acc = Pol::mma(a[t % PF], enc[ks], acc);
+        }
+        if (m > 0) {
+            masks[m - 1] = 0;
+            pack_elems<Pol, 0, 16>(prev, act[2 * (m - 1)], act[2 * (m - 1) + 1], masks[m - 1]);
+        }
+        if (m == (MT > 1 ? 1 : 0) && dj.src) RG::issue(dj.src, dj.dst);
+        __builtin_amdgcn_sched_barrier(0);
+        prev = acc;
+        acc = nb;
+    }
+#pragma unroll
+    for (int t = KS; t < NF; ++t) a[(t + PF - 1) % PF] = stream_frag<Pol, NF>(ch, chn, t + PF - 1, lane);
+#pragma unroll
+    for (int i = 0; i < PF - 1; ++i) ap.f[i] = a[(NF + i) % PF];
+    ap.bias = acc;
+    pend = prev;
+    rs.step_end();
+}
+
+// hidden layer l: src -> dst.  On entry `pend` is the last tile of the previous layer (destination src[KS-2],
+// src[KS-1]); on exit it is this layer's last tile (destination dst[KS-2], dst[KS-1]).  masks[m] receives the
+// relu bits of the tile packed in step m (= tile m-1; m = 0: the previous layer's last tile).  bl = this layer's
+// bias rows; the rows of the next layer (or of the output layer) follow them at bl + W.
+template <int W, class Pol, class RG, class RS>
+DEVI void hidden_layer(RS &rs, APipe<Pol> &ap, typename Pol::frag (&src)[W / 16], typename Pol::frag (&dst)[W / 16],
+                       const typename Pol::frag (&enc)[2], bool sk, const float *bl, f32x16 &pend,
+                       unsigned (&masks)[W / 32]) {
+    constexpr int KS = W / 16, MT = W / 32;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const char *ch = rs.ch(), *chn = rs.chn();
+        const DmaJob dj = rs.job();
+        masks[m] = 0;
+        if (m == 0) pend = hidden_step<W, Pol, RG, true>(ch, chn, ap, src, enc, sk, bl + 32 * (m + 1), pend, src[KS - 2], src[KS - 1], masks[m], dj, rs.dbg);
+        else pend = hidden_step<W, Pol, RG, true>(ch, chn, ap, src, enc, sk, bl + 32 * (m + 1), pend, dst[2 * (m > 0 ? m - 1 : 0)], dst[2 * (m > 0 ? m - 1 : 0) + 1], masks[m], dj, rs.dbg);
+        rs.step_end();
+    }
 }
 
 // wave-level sum over the 32 lanes of each half (lanes 0-31 and 32-63 independently)

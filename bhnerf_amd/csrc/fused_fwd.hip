@@ -119,8 +119,11 @@ extern "C" int bhn_pack_weights(const bhn_model *m, int32_t mode, const float *p
 // ---------------------------------------------------------------------------------------------
 // forward kernel
 // ---------------------------------------------------------------------------------------------
-// DBG: measurement build (tools/dbg_fwd_ablate.py): a.debug bits knock out one cost at a time -- 1 hidden/output MFMAs,
+// DBG: measurement build (bit 128: per-wave time stamps [compute done, barrier passed] of the ring steps of one tile); (tools/dbg_fwd_ablate.py): a.debug bits knock out one cost at a time -- 1 hidden/output MFMAs,
 // 2 relu+pack, 4 weight DMA + its waits, 8 barriers, 16 posenc trig, 32 epilogue.  Results are then meaningless.
+#ifndef BHN_FWD_DIST
+#define BHN_FWD_DIST 4
+#endif
 template <int W, class Pol, int DEG, bool RENDER, bool DBG = false>
 __global__ __launch_bounds__(Pol::NTHREADS) void fused_fwd_kernel(FusedArgs a) {
     const int dbg = DBG ? a.debug : 0;
@@ -128,7 +131,9 @@ __global__ __launch_bounds__(Pol::NTHREADS) void fused_fwd_kernel(FusedArgs a) {
     using frag = typename Pol::frag;
     constexpr int CB = PK::CHUNK_BYTES, MT = PK::MT, KS = PK::KS;
     using RG = DmaRing<CB, Pol::NWAVES>;
-    constexpr int DIST = (Pol::ELEM_BYTES == 2) ? 4 : 2, NB = DIST + 1;     // LDS-DMA weight ring, see fused_bwd.hip
+    constexpr int DIST = (Pol::ELEM_BYTES == 2) ? BHN_FWD_DIST : 3;                    // LDS-DMA weight ring: chunks in flight
+    using RS = RingState<RG, CB, DIST, Pol::PHASE_LAG>;
+    constexpr int NB = RS::NB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *ring = smem;                                              // NB x CB
     float *bias_lds = reinterpret_cast<float *>(smem + NB * CB);     // (depth+1) x W
@@ -137,19 +142,12 @@ __global__ __launch_bounds__(Pol::NTHREADS) void fused_fwd_kernel(FusedArgs a) {
     for (int i = tid; i < (a.depth + 1) * W; i += Pol::NTHREADS)
         bias_lds[i] = reinterpret_cast<const float *>(a.packed + a.bias_off)[i];
 
-    const char *fwd = a.packed + a.fwd_off;
-    const int NC = PK::fwd_chunks(a.depth);
-    auto chunk_src = [&](int seq) { while (seq >= NC) seq -= NC; return fwd + (size_t)seq * CB; };
-#pragma unroll
-    for (int j = 0; j < DIST; ++j) RG::issue(chunk_src(j), ring + j * CB);
-    RG::template wait_younger<RG::PPW * (DIST - 1)>();
-    lds_barrier();
-    int cur = 0;
-    // step c: issue chunk c+DIST, consume chunk c, wait for own pieces of chunk c+1 (the DIST-1 younger chunks
-    // stay in flight; the epilogue's stores/atomics and the prologue's loads only make the true count larger)
-#define STEP_BEGIN(seq) if (!(dbg & 4)) { const int nx = cur >= 1 ? cur - 1 : NB - 1; RG::issue(chunk_src((seq) + DIST), ring + nx * CB); } \
-    const char *ch = ring + cur * CB;
-#define STEP_END() if (!(dbg & 4)) RG::template wait_younger<RG::PPW * (DIST - 1)>(); if (!(dbg & 8)) lds_barrier(); cur = cur == NB - 1 ? 0 : cur + 1;
+    // weight ring (LDS-DMA), software-pipelined steps: fused_common.h "Software-pipelined ring steps"
+    RS rs;
+    rs.start(ring, a.packed + a.fwd_off, PK::fwd_chunks(a.depth), dbg, (wv >= Pol::NWAVES / 2 && !(a.debug & 64)) ? 1 : 0);
+    if (rs.lag) rs.idle_step();
+    APipe<Pol> ap;
+    ap.prime(rs.ch(), bias_lds);
 
     PointIn nxt = load_point<Pol::NWAVES>(a, blockIdx.x, wv, pl);
     for (long long tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
@@ -162,49 +160,37 @@ __global__ __launch_bounds__(Pol::NTHREADS) void fused_fwd_kernel(FusedArgs a) {
         if (!(dbg & 16)) point_prologue<Pol, DEG>(a, in, enc, live);
         else { live = in.dom; for (int j = 0; j < 8; ++j) { Pol::set(enc[0], j, in.x); Pol::set(enc[1], j, in.tg); } }
         nxt = load_point<Pol::NWAVES>(a, tile + gridDim.x, wv, pl);      // next tile's inputs fly during this tile
+        float w0 = 0.f;                                                  // quadrature weight of s = 0, needed at the very end
+        if (RENDER && h == 0 && inb) w0 = a.w[p];
 
         frag act[KS], next[KS];
         if (DBG) for (int ks = 0; ks < KS; ++ks) next[ks] = act[ks] = Pol::zero();
-        int seq = 0;
-        // ---- layer 0 (chunk 0: fragment m*2+ks) -------------------------------------------
-        {
-            STEP_BEGIN(seq)
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                f32x16 acc = bias_acc(bias_lds, m, h);
-                acc = Pol::mma(Pol::lds_frag(ch, 2 * m, lane), enc[0], acc);
-                acc = Pol::mma(Pol::lds_frag(ch, 2 * m + 1, lane), enc[1], acc);
-                relu_pack<W, Pol>(acc, m, act);
-            }
-            STEP_END()
-            ++seq;
+        if (DBG) {      // bit 128: stamp the ring steps of this workgroup's 4th tile, waves 0 and NWAVES/2 -> a.emission
+            const bool on = (dbg & 128) && blockIdx.x == 0 && tile == blockIdx.x + 3 * (long long)gridDim.x;
+            rs.ts = on ? reinterpret_cast<long long *>(a.emission) + wv * 64 : nullptr;
         }
-        // ---- hidden layers 1..depth-1 -----------------------------------------------------
-        for (int l = 1; l < a.depth; ++l) {
-            const bool sk = (a.skip_mask >> l) & 1;
-            const float *bl = bias_lds + l * W;
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                STEP_BEGIN(seq)
-                f32x16 acc = bias_acc(bl, m, h);
-                if (!(dbg & 1)) acc = tile_matmul<W, Pol>(ch, act, enc, sk, acc);
-                if (!(dbg & 2)) relu_pack<W, Pol>(acc, m, next);
-                else Pol::set(next[2 * m], 0, acc[0]);
-                STEP_END()
-                ++seq;
-            }
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) act[ks] = next[ks];
-        }
-        // ---- output layer (row 0 of the tile is the pre-activation) -----------------------
+        f32x16 pend;
+        unsigned mk[MT];
+        layer0_step<W, Pol, RG>(rs, ap, enc, act, bias_lds, h, pend, mk);
+        // ---- hidden layers 1..depth-1, ping-pong act <-> next (no register copies) -------------
         float outv;
         {
-            STEP_BEGIN(seq)
-            f32x16 acc = bias_acc(bias_lds + a.depth * W, 0, h);
-            if (!(dbg & 1)) acc = tile_matmul<W, Pol>(ch, act, enc, false, acc);
+            // one copy of the layer code (the fully unrolled 3-layer body did not fit the instruction cache:
+            // every step then paid ~1000 cycles of instruction fetch); the price is 56 v_mov per layer
+#pragma nounroll
+            for (int l = 1; l < a.depth; ++l) {
+                hidden_layer<W, Pol, RG>(rs, ap, act, next, enc, (a.skip_mask >> l) & 1, bias_lds + l * W, pend, mk);
+#pragma unroll
+                for (int ks = 0; ks < KS - 2; ++ks) act[ks] = next[ks];      // the pending tile lands in act[KS-2], act[KS-1]
+            }
+            // ---- output layer (row 0 of the tile is the pre-activation) ------------------------
+            const char *ch = rs.ch(), *chn = rs.chn();
+            const DmaJob dj = rs.job();
+            unsigned m0 = 0;
+            const f32x16 acc = hidden_step<W, Pol, RG, true>(ch, chn, ap, act, enc, false, bias_lds /* next tile, layer 0 */,
+                                                             pend, act[KS - 2], act[KS - 1], m0, dj, dbg);
             outv = acc[0];
-            STEP_END()
-            ++seq;
+            rs.step_end();
         }
         // ---- epilogue: sigmoid(out - 10), masks (network.py:230-232) ----------------------
         float e = 0.f;
@@ -223,7 +209,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void fused_fwd_kernel(FusedArgs a) {
                 const long long r0 = __shfl(ray, first, 64);
                 const bool mine = (h == 0) && inb && (ray == r0);
                 for (int s = 0; s < a.Sx; ++s) {
-                    float v = (mine && e != 0.f) ? a.w[(long long)s * a.P + p] * e : 0.f;
+                    float v = (mine && e != 0.f) ? (s == 0 ? w0 : a.w[(long long)s * a.P + p]) * e : 0.f;
                     v = half_wave_sum(v);
                     if (lane == first) atomicAdd(a.images + ((long long)b * a.Sx + s) * a.R + r0, v);
                 }
@@ -231,8 +217,8 @@ __global__ __launch_bounds__(Pol::NTHREADS) void fused_fwd_kernel(FusedArgs a) {
             }
         }
     }
-#undef STEP_BEGIN
-#undef STEP_END
+    if (!rs.lag) rs.idle_step();                        // every wave runs the same number of ring steps (barriers)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may land after the workgroup has released its LDS
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -278,7 +264,7 @@ int fused_fill_args(const bhn_model *m, int32_t mode, const void *packed, const 
 template <int W, class Pol, bool RENDER, bool DBG = false>
 static int launch_fwd_w(FusedArgs &a, hipStream_t st) {
     using PK = Pack<W, Pol>;
-    const size_t lds = (size_t)((Pol::ELEM_BYTES == 2 ? 4 : 2) + 1) * PK::CHUNK_BYTES + (size_t)(a.depth + 1) * W * 4;
+    const size_t lds = (size_t)((Pol::ELEM_BYTES == 2 ? BHN_FWD_DIST : 3) + (Pol::PHASE_LAG ? 2 : 1)) * PK::CHUNK_BYTES + (size_t)(a.depth + 1) * W * 4;
     auto kern = fused_fwd_kernel<W, Pol, 3, RENDER, DBG>;
     static bool attr_done = false;
     static int occ = 1;
@@ -320,6 +306,13 @@ extern "C" int bhn_debug_set_fwd_variant(int32_t v) {
     g_fwd_variant = v;
     return BHN_OK;
 }
+static void *g_dbg_buf = nullptr;
+extern "C" int bhn_debug_read(void *dst_host, size_t bytes) {
+    BHN_CHECK_ARG(dst_host && bytes <= 4096, "bad debug read");
+    BHN_CHECK_ARG(g_dbg_buf, "no ablation launch has run");
+    BHN_HIP(hipMemcpy(dst_host, g_dbg_buf, bytes, hipMemcpyDeviceToHost));
+    return BHN_OK;
+}
 
 extern "C" int bhn_predict_fwd(const bhn_model *m, int32_t mode, const void *packed, const bhn_geom *geom,
                                const bhn_frames *fr, float *emission, void *stream) {
@@ -354,8 +347,14 @@ extern "C" int bhn_render_fwd(const bhn_model *m, int32_t mode, const void *pack
     if (rc != BHN_OK) return rc;
     a.images = images;
     BHN_HIP(hipMemsetAsync(images, 0, sizeof(float) * (size_t)a.B * a.Sx * a.R, (hipStream_t)stream));
+    a.debug = (g_fwd_variant >> 4) & 64;                                       // bit 64: no phase lag (A/B measurements)
     if (mode == BHN_BF16 && s.width == 256 && (g_fwd_variant & 15) == 3) {     // ablation build, see fused_fwd_kernel
-        a.debug = g_fwd_variant >> 4;
+        a.debug = g_fwd_variant >> 4;                                          // includes bit 64
+        if (!g_dbg_buf) {
+            BHN_HIP(hipMalloc(&g_dbg_buf, 4096));
+            BHN_HIP(hipMemset(g_dbg_buf, 0, 4096));
+        }
+        a.emission = reinterpret_cast<float *>(g_dbg_buf);
         return launch_fwd_w<256, PolBF16, true, true>(a, (hipStream_t)stream);
     }
     return mode == BHN_BF16 ? launch_fwd<PolBF16, true>(a, s.width, (hipStream_t)stream)

@@ -22,7 +22,14 @@ names = {0: 'full (debug build)', 1: '- MFMAs', 2: '- relu/pack', 4: '- weight D
          12: '- DMA - barriers', 3: '- MFMA - pack', 63: 'nothing left', 62: 'MFMAs only', 60: 'MFMA + pack only', 48: '- prologue - epilogue'}
 lib.bhn_debug_set_fwd_variant(1)
 print('%-24s %.3f ms' % ('production', timed(lambda: eng.render(geom, tM0))))
-for f, n in names.items():
-    lib.bhn_debug_set_fwd_variant(3 | (f << 4))
-    print('%-24s %.3f ms' % (n, timed(lambda: eng.render(geom, tM0))))
+lib.bhn_debug_set_fwd_variant(1 | (64 << 4))
+print('%-24s %.3f ms' % ('production, no phase lag', timed(lambda: eng.render(geom, tM0))))
+import os
+sel = names.items() if os.environ.get('ABLATE') else [(f, names[f]) for f in (0, 16, 32, 48, 1, 2)]
+for f, n in sel:
+    t = []
+    for nolag in (0, 64):
+        lib.bhn_debug_set_fwd_variant(3 | ((f | nolag) << 4))
+        t.append(timed(lambda: eng.render(geom, tM0)))
+    print('%-24s lag %.3f ms   no lag %.3f ms' % (n, t[0], t[1]))
 lib.bhn_debug_set_fwd_variant(1)

@@ -3,7 +3,7 @@
 //   mode 0: registers only, one dependent accumulator chain per wave
 //   mode 1: A fragment from LDS (ds_read_b128, 3 reads in flight), B in registers (= tile_matmul)
 //   mode 2: as 1, plus a workgroup barrier every 16 MFMAs (= one ring step)
-//   mode 3: as 2, plus 24 VALU ops per 16 MFMAs (relu + bf16 pack of one tile)
+//   mode 4: registers only, two independent accumulator chains per wave
 // build: hipcc -O3 --offload-arch=gfx950 tools/mfma_peak.hip -o gpurun_out/mfma_peak
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -26,6 +26,12 @@ __global__ __launch_bounds__(NW * 64) void k(float *out, int iters) {
         if (MODE == 0) {
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[(ks + 1) & 15], b[ks], acc, 0, 0, 0);
+        } else if (MODE == 4) {        // two independent accumulator chains per wave
+#pragma unroll
+            for (int ks = 0; ks < 16; ks += 2) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[(ks + 1) & 15], b[ks], acc, 0, 0, 0);
+                keep = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[(ks + 2) & 15], b[ks + 1], keep, 0, 0, 0);
+            }
         } else {
             bf16x8 a[4];
 #pragma unroll
@@ -84,11 +90,10 @@ void run(const char *name, int wg_per_cu) {
 int main() {
     run<0, 4>("regs only", 1);
     run<0, 8>("regs only", 1);
+    run<4, 4>("regs only, 2 chains/wave", 1);
+    run<4, 8>("regs only, 2 chains/wave", 1);
     run<1, 4>("A from LDS", 1);
     run<1, 8>("A from LDS", 1);
     run<2, 8>("A from LDS + barrier/16", 1);
-    run<3, 8>("A from LDS + barrier + pack", 1);
-    run<3, 4>("A from LDS + barrier + pack", 1);
-    run<3, 4>("A from LDS + barrier + pack 2wg", 2);
     return 0;
 }

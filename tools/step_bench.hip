@@ -1,0 +1,88 @@
+// Micro-benchmark (measurement only): the library's own hidden_step() in a loop, with features switched on
+// one at a time, to see which of them costs MFMA issue slots.  build on the GPU box:
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -Ibhnerf_amd/csrc -Iinclude tools/step_bench.hip -o /tmp/step_bench
+#include "fused_common.h"
+#include <cstdio>
+#include <cstring>
+
+// MODE bits: 1 pending-tile pack, 2 weight DMA, 4 phase lag
+template <int MODE>
+__global__ __launch_bounds__(512) void k(const char *img, float *out, int steps) {
+    using Pol = PolBF16;
+    constexpr int W = 256, KS = 16, CB = 18 * 1024, DIST = 4;
+    using RG = DmaRing<CB, 8>;
+    using RS = RingState<RG, CB, DIST, true>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *bias_lds = reinterpret_cast<float *>(smem + RS::NB * CB);
+    for (int i = threadIdx.x; i < 5 * W; i += 512) bias_lds[i] = 0.001f * i;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    RS rs;
+    rs.start(smem, img, 26, (MODE & 2) ? 0 : 4, ((MODE & 4) && wv >= 4) ? 1 : 0);
+    if (rs.lag) rs.idle_step();
+    APipe<Pol> ap;
+    ap.prime(rs.ch(), bias_lds);
+    Pol::frag act[KS], next[KS], enc[2];
+    for (int i = 0; i < KS; ++i)
+        for (int j = 0; j < 8; ++j) { act[i][j] = (__bf16)(0.37f * __sinf(1.7f * lane + 3.1f * i + 0.9f * j)); next[i][j] = act[i][j]; }
+    enc[0] = act[0]; enc[1] = act[1];
+    f32x16 pend = {};
+    unsigned mk[8];
+    for (int it = 0; it < steps; it += 16) {
+        hidden_layer<W, Pol, RG>(rs, ap, act, next, enc, false, bias_lds + W, pend, mk);
+        hidden_layer<W, Pol, RG>(rs, ap, next, act, enc, false, bias_lds + 2 * W, pend, mk);
+    }
+    if (!rs.lag) rs.idle_step();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float s = 0;
+    for (int j = 0; j < 16; ++j) s += pend[j];
+    for (int i = 0; i < KS; ++i) s += (float)act[i][0] + (float)next[i][3];
+    if (s == 12345.678f) out[threadIdx.x] = s + mk[0];
+}
+
+template <int MODE>
+void run(const char *name, bool random_weights) {
+    char *img;
+    float *d;
+    hipMalloc(&img, 26 * 18 * 1024);
+    hipMemset(img, 0, 26 * 18 * 1024);
+    if (random_weights) {      // bf16 values uniform in (-0.1, 0.1): MFMA power (and with it the clock) depends on the operand bits
+        static unsigned short h[26 * 9 * 1024];
+        unsigned x = 12345u;
+        for (auto &v : h) {
+            x = x * 1664525u + 1013904223u;
+            const float f = ((x >> 8) * (1.0f / 16777216.0f) - 0.5f) * 0.2f;
+            unsigned u; memcpy(&u, &f, 4);
+            v = (unsigned short)(u >> 16);
+        }
+        hipMemcpy(img, h, sizeof(h), hipMemcpyHostToDevice);
+    }
+    hipMalloc(&d, 4096);
+    const int steps = 16 * 400, grid = 256;
+    const size_t lds = 6 * 18 * 1024 + 5 * 256 * 4;
+    hipFuncSetAttribute((const void *)k<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    k<MODE><<<grid, 512, lds>>>(img, d, 32);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    k<MODE><<<grid, 512, lds>>>(img, d, steps);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double flops = (double)grid * 8 * steps * 16 * 32768.0;
+    printf("%s %-40s %.2f ms  %.0f TFLOP/s  %.0f ns per step\n", random_weights ? "random W" : "zero W  ", name, ms, flops / ms * 1e-9, ms * 1e6 / steps);
+    hipFree(d); hipFree(img);
+}
+
+int main() {
+    for (int r = 0; r < 2; ++r) {
+        run<0>("steps only (reads, MFMAs, barrier)", r);
+        run<1>("+ pack", r);
+        run<2>("+ DMA", r);
+        run<3>("+ pack + DMA", r);
+        run<7>("+ pack + DMA + lag", r);
+        run<4>("+ lag", r);
+    }
+    return 0;
+}
