@@ -29,6 +29,7 @@ struct BwdArgs {
     int wg_begin[BHN_MAX_LAYERS + 2];
     int accumulate;                            // 1: add to what the slabs already hold
     int debug;                                 // measurement aid: 1 skip MFMA work, 2 skip tape loads
+    long long *ts_buf;                         // measurement aid: ring-step time stamps (debug bit 9)
     float *dparams;
     long long kernel_off[BHN_MAX_LAYERS + 1], bias_off[BHN_MAX_LAYERS + 1];
     int in_dim[BHN_MAX_LAYERS + 1];
@@ -51,9 +52,6 @@ struct BwdGeom {
     static constexpr int NPW_ALL = (NTMAX + WCC - 1) / WCC;          // B tiles owned per wave
     static constexpr int NPASS = (NPW_ALL + 4) / 5;                    // <= 5 B tiles accumulated per sweep
     static constexpr int NPW = (NPW_ALL + NPASS - 1) / NPASS;
-    // wave-private transpose scratch of the chain kernel: [32 points][32 features] + row padding
-    static constexpr int ROW_BYTES = 32 * Pol::ELEM_BYTES + 16;
-    static constexpr int SCR_BYTES = 32 * ROW_BYTES;
     static constexpr int GROUP_BYTES = (2 * MT + 1) * TILE_BYTES;   // A tiles + h tiles + enc tile
     // chain kernels: prefetch distance of the LDS-DMA weight ring (RING_DIST+1 buffers of one chunk)
     static constexpr int RING_DIST = (Pol::ELEM_BYTES == 2) ? 4 : 2;
@@ -66,87 +64,167 @@ struct BwdGeom {
 // ---------------------------------------------------------------------------------------------
 // tile emission: 32x32 (feature x point) register tile -> fragment-ordered tape tile
 // ---------------------------------------------------------------------------------------------
-template <class Pol, int ROW_BYTES>
-DEVI void emit_frags(char *scr, char *dst, const typename Pol::frag &f0, const typename Pol::frag &f1, int dbg = 0) {
-    if (dbg & 2) return;                       // measurement aid: no emission at all
-    // f0/f1 = k-steps 0/1 of a 32-feature block in B-operand order: element j of f_s is feature
-    // 16s + 8(j>>2) + 4h + (j&3) of point (lane&31): elements 4c..4c+3 are 4 consecutive features.
-    const int lane = threadIdx.x & 63, pt = lane & 31, h = lane >> 5;
-    if constexpr (Pol::ELEM_BYTES == 2) {
-        typedef short s16x8 __attribute__((ext_vector_type(8)));
-        const s16x8 a0 = __builtin_bit_cast(s16x8, f0), a1 = __builtin_bit_cast(s16x8, f1);
+// Tile emission through the matrix core instead of LDS: the two B fragments of a 32-feature block are fed as the
+// A operand (rows = points) against identity fragments, D = H^T . I, and the accumulator then holds the tile with
+// its FEATURE on the lane and 16 points in the registers -- the operand layout of the dW GEMM (K = points).  Exact
+// (one product by 1.0 per output), no LDS traffic, no waits; the points of a tile end up in the fixed order
+// p = (r&3) + 8(r>>2) + 4(lane>>5), the same for every tile, which a sum over points does not care about.
+template <class Pol>
+struct TapeEmit {
+    // identity k-steps, one fragment pair in LDS (read when needed: holding them costs 8 registers the 4x256 bf16
+    // kernels do not have): element j of lane (n, h) is 1 where feature phi16(h,j)+16s == n
+    static constexpr int LDS_BYTES = 2 * Pol::FRAG_BYTES;
+    const char *table;
+    DEVI void init(char *lds) {         // call from every thread of the workgroup before the first barrier
+        table = lds;
+        if (threadIdx.x < 64) {
+            const int lane = threadIdx.x, n = lane & 31, h = lane >> 5;
+            typename Pol::frag id[2];
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+            for (int s = 0; s < 2; ++s) {
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                s16x4 pk;
+                for (int j = 0; j < 8; ++j) Pol::set(id[s], j, phi16(h, j) + 16 * s == n ? 1.f : 0.f);
+                if constexpr (Pol::ELEM_BYTES == 2) {
+                    *reinterpret_cast<typename Pol::frag *>(lds + s * Pol::FRAG_BYTES + lane * 16) = id[s];
+                } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) pk[e] = s ? a1[4 * c + e] : a0[4 * c + e];
-                *reinterpret_cast<s16x4 *>(scr + pt * ROW_BYTES + (16 * s + 8 * c + 4 * h) * 2) = pk;
+                    for (int hf = 0; hf < 2; ++hf) {
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = Pol::get(id[s], 4 * hf + e);
+                        *reinterpret_cast<f32x4 *>(lds + s * Pol::FRAG_BYTES + hf * 1024 + lane * 16) = v;
+                    }
+                }
             }
-        const int gi = lane >> 4, t16 = lane & 15, q4 = t16 >> 2, pp = t16 & 3;
-        const int n0 = 16 * (gi & 1);
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const char *ad = scr + (16 * s + 8 * (gi >> 1) + q4) * ROW_BYTES + (n0 + 4 * pp) * 2;
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)ad);
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(ad + 4 * ROW_BYTES));
-            s16x8 fr;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { fr[e] = lo[e]; fr[4 + e] = hi[e]; }
-            if (!(dbg & 1)) __builtin_nontemporal_store(fr, reinterpret_cast<s16x8 *>(dst + s * 1024 + lane * 16));   // streamed: read once, much later
-            else asm volatile("" ::"v"(fr));
         }
-    } else {
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                f32x4 pk;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) pk[e] = s ? Pol::get(f1, 4 * c + e) : Pol::get(f0, 4 * c + e);
-                *reinterpret_cast<f32x4 *>(scr + pt * ROW_BYTES + (16 * s + 8 * c + 4 * h) * 4) = pk;
-            }
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                f32x4 fr;
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    fr[e] = *reinterpret_cast<const float *>(scr + (16 * s + 8 * h + 4 * hf + e) * ROW_BYTES + pt * 4);
-                __builtin_nontemporal_store(fr, reinterpret_cast<f32x4 *>(dst + s * 2048 + hf * 1024 + lane * 16));
-            }
     }
-}
-
-template <int W, class Pol>
-DEVI void pack_tile(const f32x16 &v, int m, typename Pol::frag (&next)[W / 16]) {
+    DEVI void load_id(typename Pol::frag (&id)[2]) const {
+        const int lane = threadIdx.x & 63;
+        id[0] = Pol::lds_frag(table, 0, lane);
+        id[1] = Pol::lds_frag(table, 1, lane);
+    }
+    static DEVI f32x16 transpose(const typename Pol::frag &f0, const typename Pol::frag &f1, const typename Pol::frag (&id)[2]) {
+        f32x16 t = {};
+        t = Pol::mma(f0, id[0], t);
+        t = Pol::mma(f1, id[1], t);
+        return t;
+    }
+    static DEVI void store(char *dst, const f32x16 &t, int dbg) {
+        const int lane = threadIdx.x & 63;
+        typename Pol::frag o[2];
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) Pol::set(next[2 * m + s], j, v[8 * s + j]);
-}
+            for (int j = 0; j < 8; ++j) Pol::set(o[s], j, t[8 * s + j]);
+        if constexpr (Pol::ELEM_BYTES == 2) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                if (!(dbg & 1)) __builtin_nontemporal_store(o[s], reinterpret_cast<typename Pol::frag *>(dst + s * 1024 + lane * 16));
+                else asm volatile("" ::"v"(o[s]));
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = Pol::get(o[s], 4 * hf + e);
+                    __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(dst + s * 2048 + hf * 1024 + lane * 16));
+                }
+        }
+    }
+    DEVI void emit(char *dst, const typename Pol::frag &f0, const typename Pol::frag &f1, int dbg) const {
+        if (dbg & 2) return;
+        typename Pol::frag id[2];
+        load_id(id);
+        store(dst, transpose(f0, f1, id), dbg);
+    }
+};
 
+// Post object of the training kernels (fused_common.h "Software-pipelined ring steps"): finishes the PENDING
+// output tile in the MFMA shadows of the running step --
+//   k-steps 0..7   RELU: relu + relu bits (forward) / !RELU: apply the recorded relu bits `mask` (delta chain),
+//                  repack into the B fragments d0, d1 of the next layer
+//   k-step  6, 8   identity fragments from LDS; relu bits -> tape word (and the recompute kernel's LDS stash), two
+//                  transposing MFMAs
+//   k-step 12      bf16 convert + two 1 KiB non-temporal stores to the tape (after the step's DMA issue at k-step 9)
+template <class Pol, bool RELU>
+struct TapePost {
+    const f32x16 &pend;
+    typename Pol::frag &d0, &d1;
+    unsigned mask;
+    char *dst;
+    // RELU: the relu bits of two consecutive tiles share a tape word [group][layer][tile/2][lane]: `macc` carries the
+    // even tile's half to the odd tile's step, which stores the word; `stash` (recompute kernel only) is the same
+    // word in this wave's LDS stash for the delta chain of the same tile
+    unsigned *mword, *stash;
+    unsigned &macc;
+    bool hi, last;          // odd tile of the word / last tile of the layer (stores a half-filled word when MT is odd)
+    int edbg;
+    const TapeEmit<Pol> &em;
+    typename Pol::frag id[2];
+    f32x16 tr;
+    DEVI TapePost(const f32x16 &p, typename Pol::frag &a, typename Pol::frag &b, unsigned mask_in, const TapeEmit<Pol> &em_, char *dst_,
+                  unsigned *mword_, unsigned *stash_, unsigned &macc_, bool hi_, bool last_, int edbg_)
+        : pend(p), d0(a), d1(b), mask(mask_in), dst(dst_), mword(mword_), stash(stash_), macc(macc_), hi(hi_),
+          last(last_), edbg(edbg_), em(em_) {}
+    template <int R0, int N>
+    DEVI void elems() {
+        if constexpr (RELU) pack_elems<Pol, R0, N>(pend, d0, d1, mask);
+        else {
+#pragma unroll
+            for (int r = R0; r < R0 + N; ++r) Pol::set(r < 8 ? d0 : d1, r & 7, ((mask >> r) & 1) ? pend[r] : 0.f);
+            if (R0 < 8) asm volatile("" : "+v"(d0));
+            if (R0 + N > 8) asm volatile("" : "+v"(d1));
+        }
+    }
+    DEVI void bits_and_transpose() {
+        if constexpr (RELU) {
+            const unsigned word = hi ? (macc | (mask << 16)) : mask;
+            macc = word;
+            if (hi || last) {
+                if (mword) __builtin_nontemporal_store(word, mword);
+                if (stash) *stash = word;
+            }
+        }
+        if (!(edbg & 2)) tr = TapeEmit<Pol>::transpose(d0, d1, id);
+    }
+    DEVI void at(int t) {
+        if (t == 0) elems<0, 2>();
+        if (t == 1) elems<2, 2>();
+        if (t == 2) elems<4, 2>();
+        if (t == 3) elems<6, 2>();
+        if (t == 4) elems<8, 2>();
+        if (t == 5) elems<10, 2>();
+        if (t == 6) elems<12, 2>();
+        if (t == 7) elems<14, 2>();
+        if (t == 6 && !(edbg & 2)) em.load_id(id);
+        if (t == 8) bits_and_transpose();
+        if (t == 12 && !(edbg & 2)) TapeEmit<Pol>::store(dst, tr, edbg);
+    }
+    DEVI void all() {
+        elems<0, 16>();
+        if (!(edbg & 2)) em.load_id(id);
+        bits_and_transpose();
+        if (!(edbg & 2)) TapeEmit<Pol>::store(dst, tr, edbg);
+    }
+};
+
+void *bhn_debug_buffer();
 // ---------------------------------------------------------------------------------------------
 // chain kernel
 // ---------------------------------------------------------------------------------------------
-// weight-chunk stream of one tile: forward chunks 0..NCF-1, then the transposed chunks of hidden
-// layers depth-1 .. 1 (delta chain); wraps to the next tile's chunk 0
+#ifndef BHN_EXTRA_YS
+#define BHN_EXTRA_YS 0
+#endif
 enum { MODE_RECOMPUTE = 0, MODE_FWD_TRAIN = 1, MODE_CHAIN = 2 };
-
-template <int MT, int CB, int MODE>
-DEVI const char *chunk_source(int seq, int NSEQ, int NCF, int depth, const char *fwd, const char *bwd) {
-    while (seq >= NSEQ) seq -= NSEQ;
-    if (MODE != MODE_CHAIN && seq < NCF) return fwd + (size_t)seq * CB;
-    const int i = (MODE == MODE_CHAIN) ? seq : seq - NCF;
-    const int l = depth - 1 - i / MT, m = i % MT;
-    return bwd + (size_t)((l - 1) * MT + m) * CB;
-}
 
 // MODE_RECOMPUTE: forward recompute + delta chain in one kernel (any dimages, any workspace size).
 // MODE_FWD_TRAIN:  the training forward: render (images) AND record h tiles, relu bits and e on the tape.
 // MODE_CHAIN:      delta chain only, from the relu bits / e recorded by MODE_FWD_TRAIN.
+// Weight-chunk stream of one tile: forward chunks 0..NCF-1 (not in MODE_CHAIN), then the transposed chunks of
+// hidden layers depth-1 .. 1 (not in MODE_FWD_TRAIN); the ring wraps to the next tile's first chunk.
 template <int W, class Pol, int DEG, int MODE>
 __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
     using PK = Pack<W, Pol>;
@@ -154,54 +232,72 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
     using frag = typename Pol::frag;
     constexpr int CB = PK::CHUNK_BYTES, MT = PK::MT, KS = PK::KS;
     constexpr int MW = (MT + 1) / 2;                                   // mask words per layer per lane
+    constexpr int TB = BG::TILE_BYTES;
     const FusedArgs &a = A.f;
-    const int edbg = (A.debug >> 6) & 3;           // measurement aid for emit_frags
-    const bool nomma = (A.debug >> 8) & 1;         // measurement aid: skip the hidden-layer / chain MFMAs
+    const int edbg = (A.debug >> 6) & 3;           // measurement aid for the tape emission
+    const int sdbg = (A.debug >> 8) & 1;           // measurement aid: skip the hidden-layer / chain MFMAs
+    using RG = DmaRing<CB, Pol::NWAVES>;
+    constexpr int DIST = BG::RING_DIST;
+    using RS = RingState<RG, CB, DIST, false, MT>;
+    // stores guaranteed younger than chunk c+2 at the end of step c (RingState::step_end): every interval between
+    // two DMA issues holds the >= ES stores of one pending-tile emission; with >= 16 k-steps the running step's
+    // own emission (k-step 12) also follows its DMA issue (k-step 9)
+    constexpr int ES = (Pol::ELEM_BYTES == 2) ? 2 : 4;                 // global stores of one tile emission
+    constexpr int YS = ES * (DIST - 2) + ((KS >= 16 && Pol::ELEM_BYTES == 2) ? ES : 0) + BHN_EXTRA_YS;   // (f32 emits at k-step 8)
+    constexpr int YS0 = ES * (DIST - 2);                               // steps whose own stores precede their DMA issue
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *ring = smem;
-    float *bias_lds = reinterpret_cast<float *>(smem + (BG::RING_DIST + 1) * CB);
-    float *wout_lds = bias_lds + (a.depth + 1) * W;
-    char *scr_all = reinterpret_cast<char *>(wout_lds + W);
-    unsigned *mask_all = reinterpret_cast<unsigned *>(scr_all + Pol::NWAVES * BG::SCR_BYTES);
+    float *bias_lds = reinterpret_cast<float *>(smem + RS::NB * CB);  // (depth+1) x W, then one zero row
+    float *zero_lds = bias_lds + (a.depth + 1) * W;
+    float *wout_lds = zero_lds + 32;
+    char *id_lds = reinterpret_cast<char *>(wout_lds + W);
+    unsigned *mask_all = reinterpret_cast<unsigned *>(id_lds + TapeEmit<Pol>::LDS_BYTES);   // relu-bit stash, MODE_RECOMPUTE only
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 31, h = lane >> 5;
-    char *scr = scr_all + wv * BG::SCR_BYTES;
+    TapeEmit<Pol> em;
+    em.init(id_lds);
     unsigned *mask_w = mask_all + (size_t)wv * a.depth * MW * 64;       // [layer][word][lane]
     for (int i = tid; i < (a.depth + 1) * W; i += Pol::NTHREADS)
         bias_lds[i] = reinterpret_cast<const float *>(a.packed + a.bias_off)[i];
+    if (tid < 32) zero_lds[tid] = 0.f;
     for (int i = tid; i < W; i += Pol::NTHREADS) wout_lds[i] = reinterpret_cast<const float *>(a.packed + a.wout_off)[i];
 
-    const int NCF = PK::fwd_chunks(a.depth);
-    const int NSEQ = (MODE == MODE_FWD_TRAIN) ? NCF : (MODE == MODE_CHAIN) ? (a.depth - 1) * MT : NCF + (a.depth - 1) * MT;
-    const char *fwd = a.packed + a.fwd_off, *bwd = a.packed + a.bwd_off;
-    const int depth_ = a.depth;
-#define chunk_src(seq_) chunk_source<MT, CB, MODE>((seq_), NSEQ, NCF, depth_, fwd, bwd)
-    // weight ring (LDS-DMA, DIST+1 LDS buffers, prefetch distance DIST): step c issues chunk c+DIST, consumes
-    // chunk c, then waits for its own pieces of chunk c+1 with a counted vmcnt.  vmcnt is in-order and counts
-    // stores, so the wait also bounds how many tape stores may be pending: chunk c+1 was issued at the start
-    // of step c+1-DIST, and everything younger -- DIST-1 chunks (PPW pieces each) and the tape stores of DIST
-    // steps (>= ES each; this step's own count is STORES) -- may stay in flight.  HBM store latency (~3 us) x
-    // the store rate needs ~4 steps of stores in flight per wave; a distance-2 ring capped it at 2.
-    using RG = DmaRing<CB, Pol::NWAVES>;
-    constexpr int ES = (Pol::ELEM_BYTES == 2) ? 2 : 4;                 // global stores of one emit_frags
-    constexpr int DIST = BG::RING_DIST, NB = DIST + 1;
-#pragma unroll
-    for (int j = 0; j < DIST; ++j) RG::issue(chunk_src(j), ring + j * CB);
-    RG::template wait_younger<RG::PPW * (DIST - 1)>();
-    lds_barrier();
-    int cur = 0;                                                       // ring slot of the chunk being consumed
-#define RING_STEP_BEGIN(seq) { const int nx = cur >= 1 ? cur - 1 : NB - 1; RG::issue(chunk_src((seq) + DIST), ring + nx * CB); } \
-    const char *ch = ring + cur * CB;
-#define RING_STEP_END(STORES) RG::template wait_younger<(RG::PPW + ES) * (DIST - 1) + (STORES)>(); lds_barrier(); \
-    cur = cur == NB - 1 ? 0 : cur + 1;
+    const int NCF = (MODE == MODE_CHAIN) ? 0 : PK::fwd_chunks(a.depth);
+    const int NLB = (MODE == MODE_FWD_TRAIN) ? 0 : a.depth - 1;
+    const bool have_ring = NCF + NLB * MT > 0;
+    // first tile of the sequence starts with bias (forward) or zero (delta chain) accumulators
+    const float *first_bias = (MODE == MODE_CHAIN) ? zero_lds : bias_lds;
+    RS rs;
+    APipe<Pol> ap;
+    if (have_ring) {
+        rs.start(ring, a.packed + a.fwd_off, NCF, a.packed + a.bwd_off, NLB, sdbg ? 1 : 0, 0);
+        ap.prime(rs.ch(), first_bias);
+    } else {
+        __syncthreads();
+    }
 
     // inputs of the next tile are fetched one tile ahead (geometry for the forward modes; for MODE_CHAIN the
     // recorded emission and dE = sum_s dimg * w, which only need the point index)
-    struct ChainIn { int b; long long p; bool inb; float e, dE; };
+    // ... and the first relu-bit words: layer depth-1 (all of it, for gA_{depth-1}) and the first two words of the
+    // chain sequence (layers depth-2 .. 0, MW words each); the rest is fetched two words (four steps) ahead
+    struct ChainIn { int b; long long p; bool inb; float e, dE; unsigned mtop[MW], q0, q1; };
+    const int chain_words = (a.depth - 1) * MW;
+    auto chain_word = [&](const unsigned *mg, int j) -> unsigned {   // word j of the chain sequence of tape group mg
+        if (j >= chain_words) return 0u;
+        return __builtin_nontemporal_load(mg + ((a.depth - 2 - j / MW) * MW + j % MW) * 64 + lane);
+    };
     auto load_chain = [&](long long tile) {
         ChainIn c;
-        c.b = 0; c.p = 0; c.inb = false; c.e = 0.f; c.dE = 0.f;
+        c.b = 0; c.p = 0; c.inb = false; c.e = 0.f; c.dE = 0.f; c.q0 = c.q1 = 0u;
+#pragma unroll
+        for (int i = 0; i < MW; ++i) c.mtop[i] = 0u;
         if (tile < a.total_tiles) {
+            const unsigned *mg = reinterpret_cast<const unsigned *>(A.tape + A.t.mask_off) +
+                                 (tile * Pol::NWAVES + wv) * (long long)(a.depth * MW * 64);
+#pragma unroll
+            for (int i = 0; i < MW; ++i) c.mtop[i] = __builtin_nontemporal_load(mg + ((a.depth - 1) * MW + i) * 64 + lane);
+            c.q0 = chain_word(mg, 0);
+            c.q1 = chain_word(mg, 1);
             tile_point<Pol::NWAVES>(a, tile, wv, pl, c.b, c.p, c.inb);
             if (h == 0) c.e = (reinterpret_cast<const float *>(A.tape + A.t.e_off) + (tile * Pol::NWAVES + wv) * 32)[pl];
             if (h == 0 && c.inb) {
@@ -212,12 +308,13 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
         }
         return c;
     };
-    PointIn nxt;
+    // (the forward modes load their geometry at the tile start: a one-tile-ahead prefetch measured no faster and
+    // costs 12 registers the 4x256 kernel does not have)
     ChainIn cnxt;
-    if constexpr (MODE != MODE_CHAIN) nxt = load_point<Pol::NWAVES>(a, blockIdx.x, wv, pl);
-    else cnxt = load_chain(blockIdx.x);
+    if constexpr (MODE == MODE_CHAIN) cnxt = load_chain(blockIdx.x);
     for (long long tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
-        const PointIn in = nxt;
+        PointIn in;
+        if constexpr (MODE != MODE_CHAIN) in = load_point<Pol::NWAVES>(a, tile, wv, pl);
         const ChainIn cin = cnxt;
         const int b = (MODE != MODE_CHAIN) ? in.b : cin.b;
         const long long p = (MODE != MODE_CHAIN) ? in.p : cin.p;
@@ -225,150 +322,176 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
         const long long q = tile * Pol::NWAVES + wv;                     // 32-point group on the tape
         unsigned *mask_g = reinterpret_cast<unsigned *>(A.tape + A.t.mask_off) + q * (long long)(a.depth * MW * 64);
         float *e_g = reinterpret_cast<float *>(A.tape + A.t.e_off) + q * 32;
-        int seq = 0;
         frag enc[2], act[KS], next[KS];
         bool live = false;
+        float e = 0.f;
+        if (have_ring) rs.ts = (A.ts_buf && blockIdx.x == 0 && tile == 3 * (long long)gridDim.x) ? A.ts_buf + __builtin_amdgcn_readfirstlane(wv) * 64 : nullptr;
         if constexpr (MODE != MODE_CHAIN) {
-        point_prologue<Pol, DEG>(a, in, enc, live);
-        nxt = load_point<Pol::NWAVES>(a, tile + gridDim.x, wv, pl);
-        // the encoded inputs are the B operand of dW_0 and of the skip layer
-        emit_frags<Pol, BG::ROW_BYTES>(scr, A.tape + A.t.enc_off + q * BG::TILE_BYTES, enc[0], enc[1], edbg);
-        // ---- forward, layer 0 ----------------------------------------------------------------
-        {
-            RING_STEP_BEGIN(seq)
+            point_prologue<Pol, DEG>(a, in, enc, live);
+            // the encoded inputs are the B operand of dW_0 and of the skip layer
+            em.emit(A.tape + A.t.enc_off + q * TB, enc[0], enc[1], edbg);
+            // ---- forward, layer 0: tile m-1 is packed, recorded and emitted behind the MFMAs of tile m ------
+            const bool keep_stash = MODE == MODE_RECOMPUTE;          // the delta chain of the same tile reads the bits back
+            struct Tile0 {
+                const TapeEmit<Pol> &em;
+                char *dst;
+                unsigned *mword, *stash;
+                unsigned macc;
+                int edbg;
+                DEVI void tile(int m, const f32x16 &acc, frag &d0, frag &d1) {
+                    unsigned mk = 0;
+                    pack_elems<Pol, 0, 16>(acc, d0, d1, mk);
+                    macc = (m & 1) ? (macc | (mk << 16)) : mk;
+                    if (m & 1) {
+                        if (mword) __builtin_nontemporal_store(macc, mword + (m >> 1) * 64);
+                        if (stash) stash[(m >> 1) * 64] = macc;
+                    }
+                    em.emit(dst + (long long)m * TB, d0, d1, edbg);
+                }
+            } l0{em, A.tape + A.t.h_off[1] + q * MT * TB, MODE == MODE_FWD_TRAIN ? mask_g + lane : nullptr,
+                 keep_stash ? mask_w + lane : nullptr, 0u, edbg};
+            f32x16 pend;
+            layer0_step<W, Pol, RG, YS0>(rs, ap, enc, act, bias_lds, h, pend, l0);
+            // ---- hidden layers 1..depth-1 and the output layer: the pending tile is (l-1, MT-1) at m = 0 ------
+            int pl_layer = 0;                        // layer of the pending tile
+            unsigned macc = l0.macc;                 // relu bits of the even tile of the running mask word
+#pragma nounroll
+            for (int l = 1; l <= a.depth; ++l) {
+                const bool out = l == a.depth;
+                const bool sk = !out && ((a.skip_mask >> l) & 1);
+                const float *bl = bias_lds + l * W;
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                f32x16 acc = bias_acc(bias_lds, m, h);
-                acc = Pol::mma(Pol::lds_frag(ch, 2 * m, lane), enc[0], acc);
-                acc = Pol::mma(Pol::lds_frag(ch, 2 * m + 1, lane), enc[1], acc);
-                const unsigned mk = relu_pack<W, Pol>(acc, m, act);
-                emit_frags<Pol, BG::ROW_BYTES>(scr, A.tape + A.t.h_off[1] + (q * MT + m) * BG::TILE_BYTES, act[2 * m], act[2 * m + 1], edbg);
-                unsigned *mwp = mask_w + (0 * MW + (m >> 1)) * 64 + lane;
-                if (m & 1) *mwp |= mk << 16; else *mwp = mk;
+                for (int m = 0; m < MT; ++m) {
+                    if (out && m > 0) break;
+                    const char *ch = rs.ch(), *chn = rs.chn();
+                    const DmaJob dj = rs.job();
+                    const int pm = m == 0 ? MT - 1 : m - 1;           // pending tile (layer pl_layer)
+                    frag &d0 = m == 0 ? act[KS - 2] : next[2 * (m > 0 ? m - 1 : 0)];
+                    frag &d1 = m == 0 ? act[KS - 1] : next[2 * (m > 0 ? m - 1 : 0) + 1];
+                    const int widx = (pl_layer * MW + (pm >> 1)) * 64 + lane;
+                    TapePost<Pol, true> post(pend, d0, d1, 0u, em, A.tape + A.t.h_off[pl_layer + 1] + (q * MT + pm) * TB,
+                                                 MODE == MODE_FWD_TRAIN ? mask_g + widx : nullptr, keep_stash ? mask_w + widx : nullptr,
+                                                 macc, pm & 1, pm == MT - 1, edbg);
+                    // bias rows of the next tile: (l, m+1), or the first tile of the next sequence part
+                    const float *bn = (out || (m == MT - 1 && l + 1 > a.depth)) ? nullptr : bl + 32 * (m + 1);
+                    if (out) bn = (MODE == MODE_FWD_TRAIN) ? bias_lds : zero_lds;
+                    const f32x16 acc = ring_step<W, Pol, RG>(ch, chn, ap, act, enc, sk, bn, post, dj, sdbg);
+                    rs.template step_end<YS>();
+                    pend = acc;
+                    pl_layer = l;
+                    if (m == 0) pl_layer = l;                         // from here on the pending tiles are layer l's
+                }
+                if (!out) {
+#pragma unroll
+                    for (int ks = 0; ks < KS - 2; ++ks) act[ks] = next[ks];      // the pending tile lands in act[KS-2], act[KS-1]
+                }
             }
-            RING_STEP_END(ES)
-            ++seq;
-        }
-        // ---- hidden layers 1..depth-1 ---------------------------------------------------------
-        for (int l = 1; l < a.depth; ++l) {
-            const bool sk = (a.skip_mask >> l) & 1;
-            const float *bl = bias_lds + l * W;
-            char *hdst = A.tape + A.t.h_off[l + 1] + q * MT * BG::TILE_BYTES;
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                RING_STEP_BEGIN(seq)
-                f32x16 acc = bias_acc(bl, m, h);
-                if (!nomma) acc = tile_matmul<W, Pol>(ch, act, enc, sk, acc);
-                const unsigned mk = relu_pack<W, Pol>(acc, m, next);
-                emit_frags<Pol, BG::ROW_BYTES>(scr, hdst + m * BG::TILE_BYTES, next[2 * m], next[2 * m + 1], edbg);
-                unsigned *mwp = mask_w + (l * MW + (m >> 1)) * 64 + lane;
-                if (m & 1) *mwp |= mk << 16; else *mwp = mk;
-                RING_STEP_END(ES)
-                ++seq;
-            }
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) act[ks] = next[ks];
-        }
+            if (h == 0 && live) e = 1.f / (1.f + Pol::fexp(10.f - pend[0]));
         } else {
-            // relu bits recorded by the training forward -> this wave's LDS stash
-            for (int i = 0; i < a.depth * MW; ++i) mask_w[i * 64 + lane] = mask_g[i * 64 + lane];
             cnxt = load_chain(tile + gridDim.x);
+            e = cin.e;
         }
-        // ---- output layer -> e ; dE, dout -----------------------------------------------------
+        // ---- e ; dE, dout -----------------------------------------------------------------------
         float dout = 0.f;
-        {
-            float e = 0.f;
-            if constexpr (MODE != MODE_CHAIN) {
-                RING_STEP_BEGIN(seq)
-                f32x16 acc = tile_matmul<W, Pol>(ch, act, enc, false, bias_acc(bias_lds + a.depth * W, 0, h));
-                RING_STEP_END(0)
-                ++seq;
-                if (h == 0 && live) e = 1.f / (1.f + Pol::fexp(10.f - acc[0]));
-            } else {
-                e = cin.e;
-            }
-            if constexpr (MODE == MODE_FWD_TRAIN) {
-                // record what the delta chain needs, then the render epilogue of fused_fwd_kernel
-                for (int i = 0; i < a.depth * MW; ++i) mask_g[i * 64 + lane] = mask_w[i * 64 + lane];
-                if (h == 0) e_g[pl] = e;
-                const long long ray = inb ? p / a.G : -1;
-                unsigned long long rem = __ballot(h == 0 && inb);
-                while (rem) {
-                    const int first = __ffsll((long long)rem) - 1;
-                    const long long r0 = __shfl(ray, first, 64);
-                    const bool mine = (h == 0) && inb && (ray == r0);
-                    for (int s = 0; s < a.Sx; ++s) {
-                        float v = (mine && e != 0.f) ? a.w[(long long)s * a.P + p] * e : 0.f;
-                        v = half_wave_sum(v);
-                        if (lane == first) atomicAdd(a.images + ((long long)b * a.Sx + s) * a.R + r0, v);
-                    }
-                    rem &= ~__ballot(mine);
+        if constexpr (MODE == MODE_FWD_TRAIN) {
+            // record what the delta chain needs, then the render epilogue of fused_fwd_kernel
+            if (h == 0) e_g[pl] = e;
+            const long long ray = inb ? p / a.G : -1;
+            unsigned long long rem = __ballot(h == 0 && inb);
+            while (rem) {
+                const int first = __ffsll((long long)rem) - 1;
+                const long long r0 = __shfl(ray, first, 64);
+                const bool mine = (h == 0) && inb && (ray == r0);
+                for (int s = 0; s < a.Sx; ++s) {
+                    float v = (mine && e != 0.f) ? a.w[(long long)s * a.P + p] * e : 0.f;
+                    v = half_wave_sum(v);
+                    if (lane == first) atomicAdd(a.images + ((long long)b * a.Sx + s) * a.R + r0, v);
                 }
-            } else {
-                float d = 0.f;
-                if (h == 0 && inb && e != 0.f) {
-                    float dE = 0.f;
-                    if constexpr (MODE == MODE_CHAIN) dE = cin.dE;
-                    else {
-                        const long long ray = p / a.G;
-                        for (int s = 0; s < a.Sx; ++s)
-                            dE += a.dimages[((long long)b * a.Sx + s) * a.R + ray] * a.w[(long long)s * a.P + p];
-                    }
-                    d = dE * e * (1.f - e);                            // sigmoid'(out-10) = e(1-e)
-                }
-                dout = __shfl(d, pl, 64);                               // both lane halves need it
-                // dout as a 32x32 (feature x point) tile whose feature 0 is dout: the A operand of dW_out
-                frag d0 = Pol::zero(), d1 = Pol::zero();
-                Pol::set(d0, 0, h == 0 ? d : 0.f);
-                emit_frags<Pol, BG::ROW_BYTES>(scr, A.tape + A.t.dout_off + q * BG::TILE_BYTES, d0, d1, edbg);
+                rem &= ~__ballot(mine);
             }
+        } else {
+            float d = 0.f;
+            if (h == 0 && inb && e != 0.f) {
+                float dE = 0.f;
+                if constexpr (MODE == MODE_CHAIN) dE = cin.dE;
+                else {
+                    const long long ray = p / a.G;
+                    for (int s = 0; s < a.Sx; ++s)
+                        dE += a.dimages[((long long)b * a.Sx + s) * a.R + ray] * a.w[(long long)s * a.P + p];
+                }
+                d = dE * e * (1.f - e);                            // sigmoid'(out-10) = e(1-e)
+            }
+            dout = __shfl(d, pl, 64);                               // both lane halves need it
+            // dout as a 32x32 (feature x point) tile whose feature 0 is dout: the A operand of dW_out
+            frag d0 = Pol::zero(), d1 = Pol::zero();
+            Pol::set(d0, 0, h == 0 ? d : 0.f);
+            em.emit(A.tape + A.t.dout_off + q * TB, d0, d1, edbg);
         }
         if constexpr (MODE != MODE_FWD_TRAIN) {
-        // ---- gA_{depth-1} = wout * dout * relu'(a_{depth-1}) -----------------------------------
-        frag dl[KS];
-        {
-            char *gdst = A.tape + A.t.ga_off[a.depth - 1] + q * MT * BG::TILE_BYTES;
+            // ---- gA_{depth-1} = wout * dout * relu'(a_{depth-1}); its last tile stays pending ---------------
+            frag dl[KS];
+            f32x16 pend = {};
+            {
+                char *gdst = A.tape + A.t.ga_off[a.depth - 1] + q * MT * TB;
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const unsigned mw = mask_w[((a.depth - 1) * MW + (m >> 1)) * 64 + lane] >> ((m & 1) * 16);
-                f32x16 g;
+                for (int m = 0; m < MT; ++m) {
+                    const unsigned mw = ((MODE == MODE_CHAIN) ? cin.mtop[m >> 1] : mask_w[((a.depth - 1) * MW + (m >> 1)) * 64 + lane]) >>
+                                        ((m & 1) * 16);
+                    f32x16 g;
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const f32x4 wv4 = *reinterpret_cast<const f32x4 *>(wout_lds + 32 * m + 8 * g4 + 4 * h);
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const f32x4 wv4 = *reinterpret_cast<const f32x4 *>(wout_lds + 32 * m + 8 * g4 + 4 * h);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) g[4 * g4 + e] = ((mw >> (4 * g4 + e)) & 1) ? wv4[e] * dout : 0.f;
+                        for (int e4 = 0; e4 < 4; ++e4) g[4 * g4 + e4] = ((mw >> (4 * g4 + e4)) & 1) ? wv4[e4] * dout : 0.f;
+                    }
+                    if (m < MT - 1 || a.depth == 1) {
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) Pol::set(dl[2 * m + s2], j, g[8 * s2 + j]);
+                        em.emit(gdst + m * TB, dl[2 * m], dl[2 * m + 1], edbg);
+                    } else pend = g;
                 }
-                pack_tile<W, Pol>(g, m, dl);
-                emit_frags<Pol, BG::ROW_BYTES>(scr, gdst + m * BG::TILE_BYTES, dl[2 * m], dl[2 * m + 1], edbg);
             }
-        }
-        // ---- delta chain through hidden layers depth-1 .. 1 -----------------------------------
-        for (int l = a.depth - 1; l >= 1; --l) {
-            char *gdst = A.tape + A.t.ga_off[l - 1] + q * MT * BG::TILE_BYTES;
+            // ---- delta chain through hidden layers depth-1 .. 1: step (l, m) makes tile m of gA_{l-1} -------
+            int pnd_layer = a.depth - 1;             // layer of the pending gA tile
+            unsigned pnd_mask = 0xffffu;             // its relu bits (gA_{depth-1} is masked already)
+            unsigned mq0 = cin.q0, mq1 = cin.q1, mcur = 0u;          // MODE_CHAIN: relu-bit words in flight from the tape
+            unsigned no_acc = 0u;
+#pragma nounroll
+            for (int l = a.depth - 1; l >= 1; --l) {
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                RING_STEP_BEGIN(seq)
-                f32x16 acc = {};
-                if (!nomma) {
+                for (int m = 0; m < MT; ++m) {
+                    const char *ch = rs.ch(), *chn = rs.chn();
+                    const DmaJob dj = rs.job();
+                    const int pm = m == 0 ? MT - 1 : m - 1;
+                    frag &d0 = m == 0 ? dl[KS - 2] : next[2 * (m > 0 ? m - 1 : 0)];
+                    frag &d1 = m == 0 ? dl[KS - 1] : next[2 * (m > 0 ? m - 1 : 0) + 1];
+                    TapePost<Pol, false> post(pend, d0, d1, pnd_mask, em, A.tape + A.t.ga_off[pnd_layer] + (q * MT + pm) * TB,
+                                                  nullptr, nullptr, no_acc, false, false, edbg);
+                    if (MODE == MODE_CHAIN && !(m & 1)) {            // word (l-1, m/2): use the oldest, fetch two ahead
+                        mcur = mq0;
+                        mq0 = mq1;
+                        mq1 = chain_word(mask_g, (a.depth - 1 - l) * MW + (m >> 1) + 2);
+                    }
+                    const f32x16 acc = ring_step<W, Pol, RG>(ch, chn, ap, dl, enc, false,
+                                                             (l == 1 && m == MT - 1) ? first_bias : zero_lds, post, dj, sdbg);
+                    rs.template step_end<YS>();
+                    pend = acc;
+                    pnd_layer = l - 1;
+                    pnd_mask = ((MODE == MODE_CHAIN) ? mcur : mask_w[((l - 1) * MW + (m >> 1)) * 64 + lane]) >> ((m & 1) * 16);
+                }
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) acc = Pol::mma(Pol::lds_frag(ch, ks, lane), dl[ks], acc);
-                } else acc[0] = Pol::get(dl[0], 0);
-                const unsigned mw = mask_w[((l - 1) * MW + (m >> 1)) * 64 + lane] >> ((m & 1) * 16);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = ((mw >> r) & 1) ? acc[r] : 0.f;
-                pack_tile<W, Pol>(acc, m, next);
-                emit_frags<Pol, BG::ROW_BYTES>(scr, gdst + m * BG::TILE_BYTES, next[2 * m], next[2 * m + 1], edbg);
-                RING_STEP_END(ES)
-                ++seq;
+                for (int ks = 0; ks < KS - 2; ++ks) dl[ks] = next[ks];
             }
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) dl[ks] = next[ks];
-        }
+            if (a.depth > 1) {           // flush the last tile of gA_0 (no further step to hide it behind)
+                TapePost<Pol, false> post(pend, dl[KS - 2], dl[KS - 1], pnd_mask, em,
+                                              A.tape + A.t.ga_off[0] + (q * MT + MT - 1) * TB, nullptr, nullptr, no_acc, false, false, edbg);
+                post.all();
+            }
         }   // MODE != MODE_FWD_TRAIN
     }
-#undef RING_STEP_BEGIN
-#undef RING_STEP_END
-#undef chunk_src
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may land after the workgroup has released its LDS
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -659,7 +782,7 @@ static thread_local int g_bwd_stages = 7;
 static thread_local int g_bwd_debug = 0;
 extern "C" int bhn_debug_set_bwd_stages(int32_t mask) {
     g_bwd_stages = mask & 7;
-    g_bwd_debug = (mask >> 3) & 0x7FF;    // bit 3: dW kernel without MFMA work, bit 4: without tape loads,
+    g_bwd_debug = (mask >> 3) & 0xFFF;    // bit 12: ring-step time stamps of one tile (tools/dbg_chain_steps.py); bit 3: dW kernel without MFMA work, bit 4: without tape loads,
                                          // bits 5-8: run only dW job (value-1); bit 9: emit without global stores; bit 10: no emit
     return BHN_OK;
 }
@@ -769,7 +892,8 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
             return BHN_EINVAL;
         }
     }
-    const size_t lds_chain = (size_t)(BG::RING_DIST + 1) * PK::CHUNK_BYTES + (size_t)(depth + 1) * W * 4 + W * 4 + Pol::NWAVES * BG::SCR_BYTES +
+    // ring + bias rows + zero row + output weights + identity fragments + (recompute kernel) relu-bit stash
+    const size_t lds_chain = (size_t)(BG::RING_DIST + 1) * PK::CHUNK_BYTES + (size_t)(depth + 1) * W * 4 + 128 + W * 4 + 2 * Pol::FRAG_BYTES +
                              (size_t)Pol::NWAVES * depth * ((BG::MT + 1) / 2) * 64 * 4;
     const size_t lds_dw = (size_t)BG::NBUF * BG::GROUP_BYTES;
     auto k_rec = chain_kernel<W, Pol, 3, MODE_RECOMPUTE>;
@@ -798,6 +922,7 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
         tape_layout<W, Pol>(depth, A.f.total_tiles * Pol::NWAVES, &A.t);
         A.accumulate = pass > 0;
         A.debug = g_bwd_debug;
+        A.ts_buf = (g_bwd_debug & 512) ? reinterpret_cast<long long *>(bhn_debug_buffer()) : nullptr;
         long long grid = ncu;
         if (grid > A.f.total_tiles) grid = A.f.total_tiles;
         if (what == RUN_FWD_TRAIN) {

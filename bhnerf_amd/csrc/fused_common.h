@@ -380,38 +380,57 @@ struct DmaJob {                                 // chunk to start copying in the
     char *dst;
 };
 
-// One hidden-layer (or output-layer) tile: acc += sum_ks A[ks] . src[ks] (+ enc block when with_enc), with the
-// pending tile `pend` packed into (pd0, pd1) during the first k-steps.  pd0/pd1 may be src[KS-2], src[KS-1]
-// (layer boundary): they are complete before k-step KS-2 reads them.
-template <int W, class Pol, class RG, bool PEND>
-DEVI f32x16 hidden_step(const char *ch, const char *chn, APipe<Pol> &ap, const typename Pol::frag (&src)[W / 16],
-                        const typename Pol::frag (&enc)[2], bool with_enc, const float *bias_next, const f32x16 &pend,
-                        typename Pol::frag &pd0, typename Pol::frag &pd1, unsigned &pmask, DmaJob dma, int dbg = 0) {
+// Work folded into the MFMA shadows of a ring step ("Post" objects): at(t) is called right after MFMA t of the
+// step (t is a constant after unrolling) when the layer has >= 16 k-steps, all() before the first MFMA otherwise.
+struct NoPost {
+    DEVI void at(int) {}
+    DEVI void all() {}
+};
+
+// relu + repack of the pending output tile into its two B fragments (k-steps 0..7: two elements each).
+// d0/d1 may be the src[KS-2], src[KS-1] of the running step (layer boundary): complete before k-step KS-2.
+template <class Pol>
+struct PackPost {
+    const f32x16 &pend;
+    typename Pol::frag &d0, &d1;
+    unsigned mask;                              // relu bits of the pending tile (bit r: element r > 0)
+    DEVI PackPost(const f32x16 &p, typename Pol::frag &a, typename Pol::frag &b) : pend(p), d0(a), d1(b), mask(0) {}
+    DEVI void at(int t) {
+        if (t == 0) pack_elems<Pol, 0, 2>(pend, d0, d1, mask);
+        if (t == 1) pack_elems<Pol, 2, 2>(pend, d0, d1, mask);
+        if (t == 2) pack_elems<Pol, 4, 2>(pend, d0, d1, mask);
+        if (t == 3) pack_elems<Pol, 6, 2>(pend, d0, d1, mask);
+        if (t == 4) pack_elems<Pol, 8, 2>(pend, d0, d1, mask);
+        if (t == 5) pack_elems<Pol, 10, 2>(pend, d0, d1, mask);
+        if (t == 6) pack_elems<Pol, 12, 2>(pend, d0, d1, mask);
+        if (t == 7) pack_elems<Pol, 14, 2>(pend, d0, d1, mask);
+    }
+    DEVI void all() { pack_elems<Pol, 0, 16>(pend, d0, d1, mask); }
+};
+
+// One output tile of a hidden / output / delta-chain layer: acc = ap.bias + sum_ks A[ks] . src[ks] (+ the enc
+// block when with_enc), A streamed from the ring chunk `ch`; reads the head of the next chunk `chn` and the bias
+// rows `bias_next` of the next tile before returning (both consumed after the barrier).
+template <int W, class Pol, class RG, class Post>
+DEVI f32x16 ring_step(const char *ch, const char *chn, APipe<Pol> &ap, const typename Pol::frag (&src)[W / 16],
+                      const typename Pol::frag (&enc)[2], bool with_enc, const float *bias_next, Post &post, DmaJob dma,
+                      int dbg = 0) {
     const int lane = threadIdx.x & 63;
     constexpr int KS = W / 16, NF = KS + 2, PF = Pol::LDS_PREFETCH;
     typename Pol::frag a[PF];
 #pragma unroll
     for (int i = 0; i < PF - 1; ++i) a[i] = ap.f[i];
     f32x16 acc = ap.bias;
-    const bool do_pack = PEND && !(dbg & 2), do_mma = !(dbg & 1);
-    if (do_pack && KS < 16) pack_elems<Pol, 0, 16>(pend, pd0, pd1, pmask);
+    const bool do_post = !(dbg & 2), do_mma = !(dbg & 1);
+    if (do_post && KS < 16) post.all();
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < KS; ++t) {
         a[(t + PF - 1) % PF] = stream_frag<Pol, NF>(ch, chn, t + PF - 1, lane);
         if (do_mma) acc = Pol::mma(a[t % PF], src[t], acc);
-        if (do_pack && KS >= 16 && t < 8) {
-            if (t == 0) pack_elems<Pol, 0, 2>(pend, pd0, pd1, pmask);
-            if (t == 1) pack_elems<Pol, 2, 2>(pend, pd0, pd1, pmask);
-            if (t == 2) pack_elems<Pol, 4, 2>(pend, pd0, pd1, pmask);
-            if (t == 3) pack_elems<Pol, 6, 2>(pend, pd0, pd1, pmask);
-            if (t == 4) pack_elems<Pol, 8, 2>(pend, pd0, pd1, pmask);
-            if (t == 5) pack_elems<Pol, 10, 2>(pend, pd0, pd1, pmask);
-            if (t == 6) pack_elems<Pol, 12, 2>(pend, pd0, pd1, pmask);
-            if (t == 7) pack_elems<Pol, 14, 2>(pend, pd0, pd1, pmask);
-        }
+        if (do_post && KS >= 16) post.at(t);
         if (t == (KS >= 16 ? 9 : 0) && dma.src) RG::issue(dma.src, dma.dst);
-        if (t == (KS >= 16 ? 11 : 0)) ap.bias = bias_acc(bias_next, 0, lane >> 5);   // next tile's bias, before the barrier
+        if (t == (KS >= 16 ? 13 : 0)) ap.bias = bias_acc(bias_next, 0, lane >> 5);   // next tile's bias, before the barrier
         __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
@@ -479,37 +498,48 @@ DEVI void lds_barrier() {
 // are resident or in flight; step_end() waits for this wave's pieces of chunk c+2 (NOT c+1: the A-fragment
 // prefetch of the next step reads chunk c+2 before that step's barrier) and synchronises the workgroup.
 // ---------------------------------------------------------------------------------------------
-template <class RG, int CB, int DIST, bool LAG>
+template <class RG, int CB, int DIST, bool LAG, int MT = 1>
 struct RingState {
-    // LAG: the second wave of every SIMD (waves NWAVES/2..) consumes the ring ONE STEP BEHIND the first.  All
-    // waves still meet at every barrier, but the two waves of a SIMD are never in their per-tile VALU phases
-    // (warp + posenc prologue, sigmoid + ray-sum epilogue) at the same time: one wave's MFMAs cover the other's.
-    // Costs one more resident chunk and one idle step per wave.
+    // LAG (measured, not used): the second wave of every SIMD (waves NWAVES/2..) consumes the ring ONE STEP BEHIND
+    // the first, so that the two waves of a SIMD are never in their per-tile VALU phases at the same time.  Costs one
+    // more resident chunk and one idle step per wave; 5 % slower in the render kernel.
     static constexpr int NB = DIST + (LAG ? 2 : 1);
     static_assert(DIST >= 2, "ring geometry");
     char *ring;
-    const char *img;        // packed chunk sequence, NC chunks, consumed cyclically
-    int NC, cur, issue_c, dbg, lag;
+    // chunk sequence of one tile, consumed cyclically: NCA forward chunks (img_a, in order), then the transposed
+    // chunks of the delta chain (img_b): hidden layers nlb .. 1, MT chunks each, stored layer-major ascending
+    const char *img_a, *img_b;
+    int NC, NCA, nlb, cur, issue_c, dbg, lag;
+    long long *ts;          // measurement builds: per-step time stamps (compute done, barrier passed)
     static DEVI int wrap(int i) { return i < 0 ? i + NB : (i >= NB ? i - NB : i); }
     DEVI const char *ch() const { return ring + wrap(cur - lag) * CB; }
     DEVI const char *chn() const { return ring + wrap(cur - lag + 1) * CB; }
+    DEVI const char *next_src() {
+        const char *src;
+        if (issue_c < NCA) src = img_a + (size_t)issue_c * CB;
+        else {
+            const int i = issue_c - NCA;
+            src = img_b + (size_t)((nlb - 1 - i / MT) * MT + i % MT) * CB;
+        }
+        issue_c = (issue_c + 1 == NC) ? 0 : issue_c + 1;
+        return src;
+    }
     DEVI DmaJob job() {
         if (dbg & 4) return DmaJob{nullptr, nullptr};
-        DmaJob j{img + (size_t)issue_c * CB, ring + wrap(cur - (LAG ? 2 : 1)) * CB};
-        issue_c = (issue_c + 1 == NC) ? 0 : issue_c + 1;
-        return j;
+        return DmaJob{next_src(), ring + wrap(cur - (LAG ? 2 : 1)) * CB};
     }
-    long long *ts;          // measurement builds: per-step time stamps (compute done, DMA wait done, barrier passed)
+    // STORES: global stores this wave is GUARANTEED to have issued after the DMA pieces of chunk c+2 (issued in the
+    // middle of step c-2) other than the two younger chunks: vmcnt retires in order and counts stores, so they may
+    // stay in flight across the wait.  0 is always safe (it only waits for more).
+    template <int STORES = 0>
     DEVI void step_end() {
-        long long t1 = 0, t2 = 0;
+        long long t1 = 0;
         if (ts) t1 = __builtin_readcyclecounter();
-        if (!(dbg & 4)) RG::template wait_younger<RG::PPW * (DIST - 2)>();
-        if (ts) t2 = __builtin_readcyclecounter();
+        if (!(dbg & 4)) RG::template wait_younger<RG::PPW * (DIST - 2) + STORES>();
         if (!(dbg & 8)) lds_barrier();
         if (ts) {
             const long long t3 = __builtin_readcyclecounter();
             if ((threadIdx.x & 63) == 0) { ts[0] = t1; ts[1] = t3; }
-            (void)t2;
             ts += 2;
         }
         cur = (cur == NB - 1) ? 0 : cur + 1;
@@ -519,23 +549,30 @@ struct RingState {
         if (j.src) RG::issue(j.src, j.dst);
         step_end();
     }
-    DEVI void start(char *ring_, const char *img_, int nc, int dbg_, int lag_) {
-        ring = ring_; img = img_; NC = nc; dbg = dbg_; cur = 0; issue_c = 0; lag = LAG ? lag_ : 0; ts = nullptr;
+    DEVI void start(char *ring_, const char *a_, int nca, const char *b_, int nlb_, int dbg_, int lag_) {
+        ring = ring_; img_a = a_; img_b = b_; NCA = nca; nlb = nlb_; NC = nca + nlb_ * MT;
+        dbg = dbg_; cur = 0; issue_c = 0; lag = LAG ? lag_ : 0; ts = nullptr;
 #pragma unroll
-        for (int j = 0; j < DIST; ++j) {
-            RG::issue(img + (size_t)issue_c * CB, ring + j * CB);
-            issue_c = (issue_c + 1 == NC) ? 0 : issue_c + 1;
-        }
+        for (int j = 0; j < DIST; ++j) RG::issue(next_src(), ring + j * CB);
         RG::template wait_younger<RG::PPW * (DIST - 2)>();
         lds_barrier();
     }
 };
 
-// layer 0 (chunk 0: fragment 2m+ks, B = enc[ks]); tile m-1 is packed into act behind the two MFMAs of tile m,
-// the last tile is left pending for the first hidden step.
-template <int W, class Pol, class RG, class RS>
+// layer 0 (chunk 0: fragment 2m+ks, B = enc[ks]); tile m-1 is finished (l0.tile: relu + pack into act, and in
+// the training kernels mask + tape emission) behind the two MFMAs of tile m; the last tile is left pending for
+// the first hidden step.
+template <class Pol>
+struct PackTile0 {
+    DEVI void tile(int, const f32x16 &acc, typename Pol::frag &d0, typename Pol::frag &d1) {
+        unsigned mask = 0;
+        pack_elems<Pol, 0, 16>(acc, d0, d1, mask);
+    }
+};
+
+template <int W, class Pol, class RG, int STORES, class RS, class L0>
 DEVI void layer0_step(RS &rs, APipe<Pol> &ap, const typename Pol::frag (&enc)[2], typename Pol::frag (&act)[W / 16],
-                      const float *bias_lds, int h, f32x16 &pend, unsigned (&masks)[W / 32]) {
+                      const float *bias_lds, int h, f32x16 &pend, L0 &l0) {
     const int lane = threadIdx.x & 63;
     constexpr int KS = W / 16, MT = W / 32, NF = KS + 2, PF = Pol::LDS_PREFETCH;   // every chunk is a stream of KS+2 fragments;
     const char *ch = rs.ch(), *chn = rs.chn();                                     // layer 0 uses the first KS of them
@@ -554,10 +591,7 @@ DEVI void layer0_step(RS &rs, APipe<Pol> &ap, const typename Pol::frag (&enc)[2]
             a[(t + PF - 1) % PF] = stream_frag<Pol, NF>(ch, chn, t + PF - 1, lane);
             acc = Pol::mma(a[t % PF], enc[ks], acc);
         }
-        if (m > 0) {
-            masks[m - 1] = 0;
-            pack_elems<Pol, 0, 16>(prev, act[2 * (m - 1)], act[2 * (m - 1) + 1], masks[m - 1]);
-        }
+        if (m > 0) l0.tile(m - 1, prev, act[2 * (m > 0 ? m - 1 : 0)], act[2 * (m > 0 ? m - 1 : 0) + 1]);
         if (m == (MT > 1 ? 1 : 0) && dj.src) RG::issue(dj.src, dj.dst);
         __builtin_amdgcn_sched_barrier(0);
         prev = acc;
@@ -569,26 +603,24 @@ DEVI void layer0_step(RS &rs, APipe<Pol> &ap, const typename Pol::frag (&enc)[2]
     for (int i = 0; i < PF - 1; ++i) ap.f[i] = a[(NF + i) % PF];
     ap.bias = acc;
     pend = prev;
-    rs.step_end();
+    rs.template step_end<STORES>();
 }
 
 // hidden layer l: src -> dst.  On entry `pend` is the last tile of the previous layer (destination src[KS-2],
-// src[KS-1]); on exit it is this layer's last tile (destination dst[KS-2], dst[KS-1]).  masks[m] receives the
-// relu bits of the tile packed in step m (= tile m-1; m = 0: the previous layer's last tile).  bl = this layer's
-// bias rows; the rows of the next layer (or of the output layer) follow them at bl + W.
+// src[KS-1]); on exit it is this layer's last tile (destination dst[KS-2], dst[KS-1]).  bl = this layer's bias
+// rows; the rows of the next layer (or of the output layer) follow them at bl + W.
 template <int W, class Pol, class RG, class RS>
 DEVI void hidden_layer(RS &rs, APipe<Pol> &ap, typename Pol::frag (&src)[W / 16], typename Pol::frag (&dst)[W / 16],
-                       const typename Pol::frag (&enc)[2], bool sk, const float *bl, f32x16 &pend,
-                       unsigned (&masks)[W / 32]) {
+                       const typename Pol::frag (&enc)[2], bool sk, const float *bl, f32x16 &pend) {
     constexpr int KS = W / 16, MT = W / 32;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const char *ch = rs.ch(), *chn = rs.chn();
         const DmaJob dj = rs.job();
-        masks[m] = 0;
-        if (m == 0) pend = hidden_step<W, Pol, RG, true>(ch, chn, ap, src, enc, sk, bl + 32 * (m + 1), pend, src[KS - 2], src[KS - 1], masks[m], dj, rs.dbg);
-        else pend = hidden_step<W, Pol, RG, true>(ch, chn, ap, src, enc, sk, bl + 32 * (m + 1), pend, dst[2 * (m > 0 ? m - 1 : 0)], dst[2 * (m > 0 ? m - 1 : 0) + 1], masks[m], dj, rs.dbg);
+        PackPost<Pol> post(pend, m == 0 ? src[KS - 2] : dst[2 * (m > 0 ? m - 1 : 0)], m == 0 ? src[KS - 1] : dst[2 * (m > 0 ? m - 1 : 0) + 1]);
+        const f32x16 acc = ring_step<W, Pol, RG>(ch, chn, ap, src, enc, sk, bl + 32 * (m + 1), post, dj, rs.dbg);
         rs.step_end();
+        pend = acc;
     }
 }
 

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void fused_fwd_kernel(FusedArgs a) {
     constexpr int CB = PK::CHUNK_BYTES, MT = PK::MT, KS = PK::KS;
     using RG = DmaRing<CB, Pol::NWAVES>;
     constexpr int DIST = (Pol::ELEM_BYTES == 2) ? BHN_FWD_DIST : 3;                    // LDS-DMA weight ring: chunks in flight
-    using RS = RingState<RG, CB, DIST, Pol::PHASE_LAG>;
+    using RS = RingState<RG, CB, DIST, Pol::PHASE_LAG, MT>;
     constexpr int NB = RS::NB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *ring = smem;                                              // NB x CB
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void fused_fwd_kernel(FusedArgs a) {
 
     // weight ring (LDS-DMA), software-pipelined steps: fused_common.h "Software-pipelined ring steps"
     RS rs;
-    rs.start(ring, a.packed + a.fwd_off, PK::fwd_chunks(a.depth), dbg, (wv >= Pol::NWAVES / 2 && !(a.debug & 64)) ? 1 : 0);
+    rs.start(ring, a.packed + a.fwd_off, PK::fwd_chunks(a.depth), nullptr, 0, dbg, (wv >= Pol::NWAVES / 2 && !(a.debug & 64)) ? 1 : 0);
     if (rs.lag) rs.idle_step();
     APipe<Pol> ap;
     ap.prime(rs.ch(), bias_lds);
@@ -170,8 +170,8 @@ __global__ __launch_bounds__(Pol::NTHREADS) void fused_fwd_kernel(FusedArgs a) {
             rs.ts = on ? reinterpret_cast<long long *>(a.emission) + wv * 64 : nullptr;
         }
         f32x16 pend;
-        unsigned mk[MT];
-        layer0_step<W, Pol, RG>(rs, ap, enc, act, bias_lds, h, pend, mk);
+        PackTile0<Pol> l0;
+        layer0_step<W, Pol, RG, 0>(rs, ap, enc, act, bias_lds, h, pend, l0);
         // ---- hidden layers 1..depth-1, ping-pong act <-> next (no register copies) -------------
         float outv;
         {
@@ -179,16 +179,15 @@ __global__ __launch_bounds__(Pol::NTHREADS) void fused_fwd_kernel(FusedArgs a) {
             // every step then paid ~1000 cycles of instruction fetch); the price is 56 v_mov per layer
 #pragma nounroll
             for (int l = 1; l < a.depth; ++l) {
-                hidden_layer<W, Pol, RG>(rs, ap, act, next, enc, (a.skip_mask >> l) & 1, bias_lds + l * W, pend, mk);
+                hidden_layer<W, Pol, RG>(rs, ap, act, next, enc, (a.skip_mask >> l) & 1, bias_lds + l * W, pend);
 #pragma unroll
                 for (int ks = 0; ks < KS - 2; ++ks) act[ks] = next[ks];      // the pending tile lands in act[KS-2], act[KS-1]
             }
             // ---- output layer (row 0 of the tile is the pre-activation) ------------------------
             const char *ch = rs.ch(), *chn = rs.chn();
             const DmaJob dj = rs.job();
-            unsigned m0 = 0;
-            const f32x16 acc = hidden_step<W, Pol, RG, true>(ch, chn, ap, act, enc, false, bias_lds /* next tile, layer 0 */,
-                                                             pend, act[KS - 2], act[KS - 1], m0, dj, dbg);
+            PackPost<Pol> post(pend, act[KS - 2], act[KS - 1]);
+            const f32x16 acc = ring_step<W, Pol, RG>(ch, chn, ap, act, enc, false, bias_lds /* next tile, layer 0 */, post, dj, dbg);
             outv = acc[0];
             rs.step_end();
         }
@@ -307,6 +306,13 @@ extern "C" int bhn_debug_set_fwd_variant(int32_t v) {
     return BHN_OK;
 }
 static void *g_dbg_buf = nullptr;
+void *bhn_debug_buffer() {        // 4 KiB device scratch of the measurement builds (time stamps)
+    if (!g_dbg_buf) {
+        if (hipMalloc(&g_dbg_buf, 4096) != hipSuccess) return nullptr;
+        (void)hipMemset(g_dbg_buf, 0, 4096);
+    }
+    return g_dbg_buf;
+}
 extern "C" int bhn_debug_read(void *dst_host, size_t bytes) {
     BHN_CHECK_ARG(dst_host && bytes <= 4096, "bad debug read");
     BHN_CHECK_ARG(g_dbg_buf, "no ablation launch has run");
@@ -350,11 +356,8 @@ extern "C" int bhn_render_fwd(const bhn_model *m, int32_t mode, const void *pack
     a.debug = (g_fwd_variant >> 4) & 64;                                       // bit 64: no phase lag (A/B measurements)
     if (mode == BHN_BF16 && s.width == 256 && (g_fwd_variant & 15) == 3) {     // ablation build, see fused_fwd_kernel
         a.debug = g_fwd_variant >> 4;                                          // includes bit 64
-        if (!g_dbg_buf) {
-            BHN_HIP(hipMalloc(&g_dbg_buf, 4096));
-            BHN_HIP(hipMemset(g_dbg_buf, 0, 4096));
-        }
-        a.emission = reinterpret_cast<float *>(g_dbg_buf);
+        a.emission = reinterpret_cast<float *>(bhn_debug_buffer());
+        BHN_CHECK_ARG(a.emission, "no debug buffer");
         return launch_fwd_w<256, PolBF16, true, true>(a, (hipStream_t)stream);
     }
     return mode == BHN_BF16 ? launch_fwd<PolBF16, true>(a, s.width, (hipStream_t)stream)

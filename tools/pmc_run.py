@@ -1,0 +1,16 @@
+"""One training-forward, delta-chain, dW and inference-forward launch at config 2 (for rocprofv3 --pmc passes)."""
+import sys, numpy as np, torch
+sys.path.insert(0, '/root/repo')
+from bhnerf_amd import _hip, engine, network, synthetic, constants
+dev = torch.device('cuda:0')
+H = W = 128; G = 64; B = 8
+geo = synthetic.synthetic_geodesics(H, W, G)
+pred = network.NeRF_Predictor(8.0, 0.0, np.inf, np.inf, net_depth=4, net_width=256, mode='bf16', device=dev)
+eng = pred.engine()
+geom = pred.geometry(geo['coords'], geo['Omega'], geo['t_geos'], None, geo['g'], geo['dtau'], geo['Sigma'])
+flat = eng.flatten(network.MLP(4, 256).init(1, 21)); eng.pack(flat)
+tM0 = engine.frame_offsets(np.linspace(0, 1, B), 0.0, geo['t_injection'], constants.GM_c3('hr'), dev)
+dimg = torch.rand((B, 1, geom.R), device=dev) * 1e-3
+for _ in range(2):
+    eng.render_train(geom, tM0); eng.render_bwd_tape(geom, tM0, dimg); eng.render(geom, tM0)
+torch.cuda.synchronize()

@@ -17,7 +17,7 @@ __global__ __launch_bounds__(512) void k(const char *img, float *out, int steps)
     for (int i = threadIdx.x; i < 5 * W; i += 512) bias_lds[i] = 0.001f * i;
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     RS rs;
-    rs.start(smem, img, 26, (MODE & 2) ? 0 : 4, ((MODE & 4) && wv >= 4) ? 1 : 0);
+    rs.start(smem, img, 26, nullptr, 0, (MODE & 2) ? 0 : 4, ((MODE & 4) && wv >= 4) ? 1 : 0);
     if (rs.lag) rs.idle_step();
     APipe<Pol> ap;
     ap.prime(rs.ch(), bias_lds);
@@ -26,10 +26,10 @@ __global__ __launch_bounds__(512) void k(const char *img, float *out, int steps)
         for (int j = 0; j < 8; ++j) { act[i][j] = (__bf16)(0.37f * __sinf(1.7f * lane + 3.1f * i + 0.9f * j)); next[i][j] = act[i][j]; }
     enc[0] = act[0]; enc[1] = act[1];
     f32x16 pend = {};
-    unsigned mk[8];
+    unsigned mk[8] = {};
     for (int it = 0; it < steps; it += 16) {
-        hidden_layer<W, Pol, RG>(rs, ap, act, next, enc, false, bias_lds + W, pend, mk);
-        hidden_layer<W, Pol, RG>(rs, ap, next, act, enc, false, bias_lds + 2 * W, pend, mk);
+        hidden_layer<W, Pol, RG>(rs, ap, act, next, enc, false, bias_lds + W, pend);
+        hidden_layer<W, Pol, RG>(rs, ap, next, act, enc, false, bias_lds + 2 * W, pend);
     }
     if (!rs.lag) rs.idle_step();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
