@@ -185,9 +185,17 @@ def main():
 
     lib = _hip.lib()
     taped = eng.fits_tape(args.frames_per_gpu, geom.P_eff)
-    if taped:      # the kernels a training step runs: training forward (records the tape), delta chain, dW GEMM
-        kern_ms = {'chain_kernel<MODE_FWD_TRAIN>': timed(lambda: eng.render_train(geom, tM0))}
-        bwd = lambda: eng.render_bwd_tape(geom, tM0, dimg)
+    group = args.frames_per_gpu if taped else eng.tape_group(args.frames_per_gpu, geom.P_eff)
+    if group:      # the kernels a training step runs: training forward (records the tape), delta chain, dW GEMM --
+                   # over all frames at once, or frame group by frame group when the tape of all frames does not fit
+        slices = [slice(b0, min(b0 + group, args.frames_per_gpu)) for b0 in range(0, args.frames_per_gpu, group)]
+        def fwd_all():
+            for sl in slices:
+                eng.render_train(geom, tM0[sl])
+        def bwd():
+            for sl in slices:
+                eng.render_bwd_tape(geom, tM0[sl], dimg[sl])
+        kern_ms = {'chain_kernel<MODE_FWD_TRAIN>': timed(fwd_all)}
         names = (('chain_kernel<MODE_CHAIN>', 1), ('dw_kernel', 2), ('reduce_kernel', 4))
         fwd_name, chain_name = 'chain_kernel<MODE_FWD_TRAIN>', 'chain_kernel<MODE_CHAIN>'
     else:
@@ -222,6 +230,14 @@ def main():
         roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': PEAK_TFLOPS[args.mode],
                     'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_TFLOPS[args.mode], 4), 'traffic': traffic}
     roofline['kernel_ms'] = {k: round(v, 4) for k, v in kern_ms.items()}
+    try:      # matrix-pipe busy fraction of SIMD cycles from the committed SQ counter passes (profiles/r1_sq_summary.json)
+        sq = json.load(open(os.path.join(ROOT, 'profiles', 'r1_sq_summary.json')))['kernels']
+        if std:
+            tag = {', 1>': 'chain_kernel<MODE_FWD_TRAIN>', ', 2>': 'chain_kernel<MODE_CHAIN>', 'dw_kernel': 'dw_kernel',
+                   'fused_fwd_kernel': 'fused_fwd_kernel (inference)'}
+            roofline['mfma_busy_frac_pmc'] = {n: v['mfma_busy_frac'] for k, v in sq.items() for t, n in tag.items() if t in k}
+    except Exception:
+        pass
     roofline['mfma_tflops'] = {k: round(alg[k] * pts / (kern_ms[k] * 1e-3) / 1e12, 1) for k in alg}
     roofline['mfma_tflops']['fused_fwd_kernel (inference)'] = round(f_fwd * pts / (kern_ms['fused_fwd_kernel (inference)'] * 1e-3) / 1e12, 1)
     roofline['step_algorithmic_tflops'] = round(f_train * value * geom.visited_fraction / 1e12 / world, 2)
@@ -248,6 +264,7 @@ def main():
                                % (H, W, G, nt, args.depth, args.width),
                    'frames_per_step': batch, 'frames_per_gpu': args.frames_per_gpu, 'parallelism': 'dp%d (time-frames)' % world,
                    'active_fraction': round(geom.active_fraction, 4), 'visited_fraction': round(geom.visited_fraction, 4),
+                   'tape_frame_group': group,
                    'loss': loss_now},
         'roofline': roofline,
         'rt_scan': rt_scan,

@@ -14,6 +14,10 @@
 //   reduce_kernel sums the slabs of each layer's workgroups into the flat dparams (flax tree order).
 #include "fused_common.h"
 
+#ifndef BHN_TAPED_DIST
+#define BHN_TAPED_DIST 6
+#endif
+
 struct TapeLayout {
     long long NQ;                              // 32-point groups on the tape
     long long h_off[BHN_MAX_LAYERS + 1];       // h_l, l = 1..depth  (inputs of layer l)
@@ -54,7 +58,9 @@ struct BwdGeom {
     static constexpr int NPW = (NPW_ALL + NPASS - 1) / NPASS;
     static constexpr int GROUP_BYTES = (2 * MT + 1) * TILE_BYTES;   // A tiles + h tiles + enc tile
     // chain kernels: prefetch distance of the LDS-DMA weight ring (RING_DIST+1 buffers of one chunk)
-    static constexpr int RING_DIST = (Pol::ELEM_BYTES == 2) ? 4 : 2;
+    static constexpr int RING_DIST = (Pol::ELEM_BYTES == 2) ? 4 : 2;            // recompute kernel (LDS also holds the relu-bit stash)
+    static constexpr int RING_DIST_TAPED = (Pol::ELEM_BYTES == 2) ? BHN_TAPED_DIST : 3;   // training-forward / delta-chain kernels
+    template <int MODE> static constexpr int ring_dist() { return MODE == 0 ? RING_DIST : RING_DIST_TAPED; }
     // dW kernel, bf16: LDS-DMA ring of NBUF groups (counted vmcnt, raw s_barrier); f32: 2 buffers
     static constexpr int NBUF = (Pol::ELEM_BYTES == 2) ? ((160 * 1024) / GROUP_BYTES >= 4 ? 4 : 3) : 2;
     static constexpr int NPIECE = GROUP_BYTES / 1024;               // 1 KiB = one wave-wide 16-B DMA
@@ -237,7 +243,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
     const int edbg = (A.debug >> 6) & 3;           // measurement aid for the tape emission
     const int sdbg = (A.debug >> 8) & 1;           // measurement aid: skip the hidden-layer / chain MFMAs
     using RG = DmaRing<CB, Pol::NWAVES>;
-    constexpr int DIST = BG::RING_DIST;
+    constexpr int DIST = BG::template ring_dist<MODE>();
     using RS = RingState<RG, CB, DIST, false, MT>;
     // stores guaranteed younger than chunk c+2 at the end of step c (RingState::step_end): every interval between
     // two DMA issues holds the >= ES stores of one pending-tile emission; with >= 16 k-steps the running step's
@@ -892,9 +898,10 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
             return BHN_EINVAL;
         }
     }
-    // ring + bias rows + zero row + output weights + identity fragments + (recompute kernel) relu-bit stash
-    const size_t lds_chain = (size_t)(BG::RING_DIST + 1) * PK::CHUNK_BYTES + (size_t)(depth + 1) * W * 4 + 128 + W * 4 + 2 * Pol::FRAG_BYTES +
-                             (size_t)Pol::NWAVES * depth * ((BG::MT + 1) / 2) * 64 * 4;
+    // ring + bias rows + zero row + output weights + identity fragments; recompute kernel: + relu-bit stash
+    const size_t lds_fixed = (size_t)(depth + 1) * W * 4 + 128 + W * 4 + 2 * Pol::FRAG_BYTES;
+    const size_t lds_rec = (size_t)(BG::RING_DIST + 1) * PK::CHUNK_BYTES + lds_fixed + (size_t)Pol::NWAVES * depth * ((BG::MT + 1) / 2) * 64 * 4;
+    const size_t lds_taped = (size_t)(BG::RING_DIST_TAPED + 1) * PK::CHUNK_BYTES + lds_fixed;
     const size_t lds_dw = (size_t)BG::NBUF * BG::GROUP_BYTES;
     auto k_rec = chain_kernel<W, Pol, 3, MODE_RECOMPUTE>;
     auto k_fwd = chain_kernel<W, Pol, 3, MODE_FWD_TRAIN>;
@@ -908,7 +915,7 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
         BHN_HIP(hipFuncSetAttribute((const void *)kdw, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
-    BHN_CHECK_ARG(lds_chain <= 160 * 1024 && lds_dw <= 160 * 1024, "LDS budget exceeded (chain %zu, dw %zu)", lds_chain, lds_dw);
+    BHN_CHECK_ARG(lds_rec <= 160 * 1024 && lds_taped <= 160 * 1024 && lds_dw <= 160 * 1024, "LDS budget exceeded (chain %zu / %zu, dw %zu)", lds_rec, lds_taped, lds_dw);
     const int B_total = A.f.B;
     const double *tM0 = A.f.tM0;
     if (what == RUN_FWD_TRAIN)
@@ -926,13 +933,13 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
         long long grid = ncu;
         if (grid > A.f.total_tiles) grid = A.f.total_tiles;
         if (what == RUN_FWD_TRAIN) {
-            hipLaunchKernelGGL(k_fwd, dim3((unsigned)grid), dim3(Pol::NTHREADS), lds_chain, st, A);
+            hipLaunchKernelGGL(k_fwd, dim3((unsigned)grid), dim3(Pol::NTHREADS), lds_taped, st, A);
             BHN_HIP(hipGetLastError());
             continue;
         }
         if (g_bwd_stages & 1) {
-            if (what == RUN_BWD_TAPE) hipLaunchKernelGGL(k_chn, dim3((unsigned)grid), dim3(Pol::NTHREADS), lds_chain, st, A);
-            else hipLaunchKernelGGL(k_rec, dim3((unsigned)grid), dim3(Pol::NTHREADS), lds_chain, st, A);
+            if (what == RUN_BWD_TAPE) hipLaunchKernelGGL(k_chn, dim3((unsigned)grid), dim3(Pol::NTHREADS), lds_taped, st, A);
+            else hipLaunchKernelGGL(k_rec, dim3((unsigned)grid), dim3(Pol::NTHREADS), lds_rec, st, A);
         }
         BHN_HIP(hipGetLastError());
         if (g_bwd_stages & 2) hipLaunchKernelGGL(kdw, dim3((unsigned)A.wg_begin[depth + 1]), dim3(Pol::NTHREADS), lds_dw, st, A);

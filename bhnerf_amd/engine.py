@@ -208,6 +208,21 @@ class FusedPredictor:
         full = int(lib.bhn_render_bwd_workspace_bytes(C.byref(self.model), self.mode, B, P, self.device.index or 0))
         return 0 < full <= self.workspace(B, P).numel()
 
+    def tape_group(self, B, P):
+        """Largest number of frames (<= B) whose tape fits the workspace cap, 0 if not even one does: a training
+        step whose loss is a sum of per-frame terms then runs frame group by frame group on the recorded-tape
+        path instead of recomputing the forward (`bhn_render_bwd`)."""
+        lib = _hip.lib()
+        dev = self.device.index or 0
+        cap = getattr(self, 'max_workspace_bytes', None)
+        if cap is None:
+            cap = torch.cuda.get_device_properties(self.device).total_memory // 4
+        for nb in range(int(B), 0, -1):
+            need = int(lib.bhn_render_bwd_workspace_bytes(C.byref(self.model), self.mode, nb, P, dev))
+            if 0 < need <= cap:
+                return nb
+        return 0
+
     def render_train(self, geom, tM0, out=None):
         """Training forward: images (B,Sx,R) + tape recorded in the workspace (see render_bwd_tape)."""
         B = int(tM0.numel())

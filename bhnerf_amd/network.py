@@ -362,6 +362,31 @@ def _step_image(state, t_units, dtype, target, sigma, offset, t_frames, coords, 
     B = int(tM0.numel())
     eng.pack(state.flat)
     taped = train and eng.fits_tape(B, geom.P_eff)      # record the tape while rendering: no recompute later
+    group = eng.tape_group(B, geom.P_eff) if (train and not taped and not eht) else 0
+    if group:
+        # the tape of all B frames does not fit, but chi^2 is a sum of per-frame terms: frame groups on the taped path
+        tshape = (B, geom.Sx, geom.R) if dtype == 'full' else (B, geom.Sx)
+        tgt, sig, off = (_hip.as_f32(v, dev).reshape(tshape) for v in (target, sigma, offset))
+        images = torch.empty((B, geom.Sx, geom.R), dtype=torch.float32, device=dev)
+        n = eng.nparams
+        buf = state.grad
+        part = torch.empty((n,), dtype=torch.float32, device=dev)
+        loss = torch.zeros((1,), dtype=torch.float32, device=dev)
+        for b0 in range(0, B, group):
+            sl = slice(b0, min(b0 + group, B))
+            eng.render_train(geom, tM0[sl], out=images[sl])
+            lg, dimg = engine.chi2_image(images[sl], tgt[sl].contiguous(), sig[sl].contiguous(), off[sl].contiguous(), scale, dtype)
+            loss += lg
+            if b0 == 0:
+                eng.render_bwd_tape(geom, tM0[sl], dimg, out=buf[:n])
+            else:
+                eng.render_bwd_tape(geom, tM0[sl], dimg, out=part)
+                buf[:n] += part
+        rank, world = _world()
+        loss_vec = dp_allreduce(buf, n, loss, rank, world)
+        state.apply_gradients(buf[:n], grad_scale=1.0 / world)
+        out = images.reshape((1, B) + ((geom.S,) if geom.S else ()) + geom.spatial)
+        return loss_vec, state, out
     images = eng.render_train(geom, tM0) if taped else eng.render(geom, tM0)
     if eht:
         loss, dimg = engine.chi2_eht(images if geom.S else images[:, 0], offset, target, sigma, scale, dtype, want_grad=train)

@@ -151,6 +151,38 @@ def test_workspace_frame_chunking_is_equivalent(dev, golden):
     assert float(full.abs().max()) > 0
 
 
+@pytest.mark.parametrize('dt', ['full', 'lc'])
+def test_frame_group_taped_step_equals_full_step(dev, golden, dt):
+    """When the tape of all frames does not fit the workspace cap, gradient_step_image runs frame group by
+    frame group on the taped path (chi^2 is a sum of per-frame terms): same loss, images and parameters
+    as the all-frames step (f32; gradients are summed in a different order, hence the tolerance)."""
+    from bhnerf_amd import network, units, _hip
+    import ctypes as C
+    g = golden('g5_predict_e')
+    tg = targets(g, dt)
+    B = len(g['t_frames'])
+    assert B >= 2
+    res = []
+    for cap_frames in (None, 1):
+        pred, rt = device_setup(g, 'f32', dev)
+        eng = pred.engine()
+        if cap_frames is not None:      # cap = tape of exactly one frame
+            geom = pred.geometry(rt['coords'], rt['Omega'], rt['t_geos'], None, rt['g'], rt['dtau'], rt['Sigma'])
+            eng.max_workspace_bytes = int(_hip.lib().bhn_render_bwd_workspace_bytes(C.byref(eng.model), eng.mode, cap_frames,
+                                                                                      geom.P_eff, dev.index or 0))
+            assert not eng.fits_tape(B, geom.P_eff) and eng.tape_group(B, geom.P_eff) == cap_frames
+        state = pred.init_state(network.ParamTree(golden_tree(g)), num_iters=2, lr_init=1e-3, lr_final=1e-4)
+        for _ in range(2):
+            loss, state, images = network.gradient_step_image(
+                state, units.hr, dt, tg['target'], tg['sigma'], tg['offset'], g['t_frames'], rt['coords'], rt['Omega'],
+                rt['J'], rt['g'], rt['dtau'], rt['Sigma'], rt['t_start_obs'], rt['t_geos'], rt['t_injection'], 1.0)
+        res.append((loss.item(), images.clone(), state.flat.clone()))
+    (l0, i0, p0), (l1, i1, p1) = res
+    assert abs(l0 - l1) <= 1e-5 * abs(l0)
+    assert torch.allclose(i0, i1, rtol=1e-5, atol=1e-6 * float(i0.abs().max()))
+    assert torch.allclose(p0, p1, rtol=1e-4, atol=1e-6)
+
+
 @pytest.mark.parametrize('width,depth,S', [(256, 4, 0), (128, 4, 3), (64, 8, 2), (32, 6, 0)])
 def test_random_problem_f32_and_bf16(dev, width, depth, S):
     """Larger ragged problem (G=50 rays straddle wave tiles, several workgroup tiles, pre-injection

@@ -1,0 +1,62 @@
+#!/bin/bash
+# Everything under profiles/ comes from this script (run on the GPU box: gpurun -- bash tools/collect_profiles.sh):
+#   bench line, rocprofv3 --kernel-trace --stats of the same command, HBM traffic (FETCH_SIZE / WRITE_SIZE, separate
+#   passes) and SQ counter passes (MFMA busy, wave waits, LDS conflicts) of tools/pmc_run.py.
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/profiles
+mkdir -p $O
+python3 $R/bench.py > $O/bench_line.json 2> $O/bench.err
+rm -rf /tmp/kt; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o kt -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > /tmp/kt.log 2>&1
+cp $(find /tmp/kt -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pm_$c; rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pm_$c -o p -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /tmp/pm_$c.log 2>&1
+  cp $(find /tmp/pm_$c -name "*counter_collection.csv" | head -1) /tmp/pm_$c.csv
+done
+python3 - > $O/pmc_traffic.json <<'PY'
+import csv, json, collections
+out = collections.OrderedDict()
+names = {'Li1EEv7BwdArgs': 'chain_kernel<MODE_FWD_TRAIN>', 'Li2EEv7BwdArgs': 'chain_kernel<MODE_CHAIN>'}
+def short(k):
+    if 'chain_kernel' in k: return 'chain_kernel<MODE_FWD_TRAIN>' if ', 1>' in k else 'chain_kernel<MODE_CHAIN>' if ', 2>' in k else 'chain_kernel<MODE_RECOMPUTE>'
+    for n in ('dw_kernel', 'reduce_kernel', 'rt_kernel', 'adam_kernel', 'chi2_image_kernel', 'pack_weights_kernel'):
+        if n in k: return n
+    if 'fused_fwd_kernel' in k: return 'fused_fwd_kernel (inference)'
+    return None
+for c in ('FETCH_SIZE', 'WRITE_SIZE'):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open('/tmp/pm_%s.csv' % c)):
+        n = short(r['Kernel_Name'])
+        if n and r['Counter_Name'] == c: acc[n].append(float(r['Counter_Value']))
+    for n, v in acc.items():
+        out.setdefault(n, {})[c + '_KiB'] = round(sum(v) / len(v), 1)
+for n, d in out.items():
+    d['hbm_bytes'] = int((2 * d.get('FETCH_SIZE_KiB', 0) + d.get('WRITE_SIZE_KiB', 0)) * 1024)
+print(json.dumps({'note': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace) of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline`; averages per launch in KiB as reported; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 with the gfx950 correction (FETCH_SIZE reports half of wide coalesced reads, MI355X_MICROARCH.md HBM section)', 'kernels': out}, indent=1))
+PY
+bash $R/tools/pmc_collect.sh > /tmp/sq.log 2>&1
+cat $R/gpurun_out/pmc/pass*.txt > $O/sq_counters.txt
+python3 - $O/sq_counters.txt > $O/sq_summary.json <<'PY'
+import sys, json, re, collections
+k = None; d = collections.OrderedDict()
+for l in open(sys.argv[1]):
+    if not l.startswith(' '):
+        k = l.strip(); d.setdefault(k, {})
+    else:
+        m = re.match(r'\s+(\S+)\s+last (\S+)', l)
+        if m: d[k][m.group(1)] = float(m.group(2))
+out = collections.OrderedDict()
+for k, c in d.items():
+    try:
+        cu = c['SQ_BUSY_CU_CYCLES']
+        out[k] = {'mfma_busy_frac': round(c['SQ_VALU_MFMA_BUSY_CYCLES'] / (4 * cu), 3),      # 4 SIMDs per CU
+                  'valu_active_frac': round(4 * c['SQ_ACTIVE_INST_VALU'] / (4 * cu), 3),       # quad-cycle units
+                  'wave_wait_any_frac': round(c['SQ_WAIT_ANY'] / c['SQ_WAVE_CYCLES'], 3),
+                  'wave_wait_inst_frac': round(c['SQ_WAIT_INST_ANY'] / c['SQ_WAVE_CYCLES'], 3),
+                  'lds_bank_conflict_frac': round(c['SQ_LDS_BANK_CONFLICT'] / max(c['SQ_LDS_IDX_ACTIVE'], 1), 3),
+                  'cu_cycles_per_cu': round(cu / 256)}
+    except KeyError:
+        pass
+print(json.dumps({'note': 'from sq_counters.txt (rocprofv3 --pmc SQ_* passes of tools/pmc_run.py, one launch each): mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES) = fraction of SIMD cycles with the matrix pipe busy', 'kernels': out}, indent=1))
+PY
+ls -la $O
