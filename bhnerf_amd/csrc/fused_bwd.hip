@@ -1,12 +1,12 @@
 // Reverse of the fused render w.r.t. the MLP parameters (jax.value_and_grad of loss_fn_image,
 // network.py:617).  Three kernels (DESIGN.md "backward"):
 //
-//   chain_kernel  per 32-point wave tile: recompute the forward, dE = sum_s dimg*w, dout = dE*e*(1-e),
+//   chain_kernel  per 32-point wave tile: (re)compute the forward, dE = sum_s dimg*w, dout = dE*e*(1-e),
 //                 delta chain gA_{l-1} = (W_l gA_l) * relu'(a_{l-1}) with the same register-chained MFMA
-//                 structure as the forward.  Every 32x32 tile of h_l (layer inputs) and gA_l (gradients
-//                 w.r.t. pre-activations) is transposed through a wave-private LDS scratch
-//                 (ds_read_b64_tr_b16) and streamed to an HBM "tape" already in MFMA fragment order
-//                 [lane = feature][8 points].
+//                 structure and software-pipelined ring steps as the forward (fused_common.h).  Every 32x32
+//                 tile of h_l (layer inputs) and gA_l (gradients w.r.t. pre-activations) is transposed by two
+//                 MFMAs against identity fragments (TapeEmit) and streamed to an HBM "tape" already in MFMA
+//                 fragment order [lane = feature][8 points].
 //   dw_kernel     weight-gradient GEMMs dW_l^T[out x in] = sum_points gA_l^T . in_l with K = points:
 //                 a workgroup owns ONE layer's whole dW^T in registers (<= 288 KB) and streams its
 //                 share of the tape through LDS; bias gradients come from a constant ones B-fragment.
