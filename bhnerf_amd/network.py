@@ -19,7 +19,7 @@ import numpy as np
 import torch
 import yaml
 
-from . import _hip, constants, engine, units, utils
+from . import _hip, checkpoints, constants, engine, units, utils
 
 safe_sin = lambda x: (torch.sin(torch.remainder(x, 100 * np.pi)) if isinstance(x, torch.Tensor)
                       else np.sin(x % (100 * np.pi)))                       # network.py:16
@@ -113,14 +113,38 @@ class TrainState:
         self.step += 1
         return self
 
+    def to_state_dict(self):
+        """The state dict flax writes for TrainState.create(apply_fn, params, tx=optax.adam(schedule))
+        (network.py:171-182; checkpoints.py): step, params tree, Adam moments mu / nu as params-shaped trees."""
+        eng = self.predictor.engine()
+        tree = lambda flat: {k: {n: {q: a.cpu().numpy().copy() for q, a in d.items()} for n, d in layers.items()}
+                             for k, layers in eng.unflatten(flat).items()}
+        count = np.asarray(self.step, dtype=np.int32)
+        return {'step': count, 'params': tree(self.flat),
+                'opt_state': {'0': {'count': count, 'mu': tree(self.m), 'nu': tree(self.v)}, '1': {'count': count}}}
+
+    def from_state_dict(self, sd):
+        """Restore from a flax state dict (or from the torch.save dict of round-1 builds of this package)."""
+        if sd.get('_legacy'):
+            self.step = int(sd['step'])
+            self.flat.copy_(sd['params']); self.m.copy_(sd['m']); self.v.copy_(sd['v'])
+            return self
+        eng = self.predictor.engine()
+        self.flat.copy_(eng.flatten(sd['params']))
+        opt = sd.get('opt_state') or {}
+        adam = opt.get('0', opt) if isinstance(opt, dict) else {}
+        if 'mu' in adam and 'nu' in adam:
+            self.m.copy_(eng.flatten(adam['mu'])); self.v.copy_(eng.flatten(adam['nu']))
+        else:                                    # parameters only (e.g. a hand-written file): fresh moments
+            self.m.zero_(); self.v.zero_()
+        self.step = int(np.asarray(sd.get('step', adam.get('count', 0))))
+        return self
+
     def state_dict(self):
-        return {'step': self.step, 'params': self.flat.cpu(), 'm': self.m.cpu(), 'v': self.v.cpu()}
+        return self.to_state_dict()
 
     def load_state_dict(self, sd):
-        self.step = int(sd['step'])
-        self.flat.copy_(sd['params'])
-        self.m.copy_(sd['m'])
-        self.v.copy_(sd['v'])
+        return self.from_state_dict(sd)
 
 
 def _world():
@@ -196,9 +220,8 @@ class NeRF_Predictor:
         # (network.py:176-180, 235).
         flat = self.flat_params(params).clone()
         state = TrainState(self.apply, flat, self, num_iters, lr_init, lr_final)
-        ckpt = latest_checkpoint(checkpoint_dir)
-        if ckpt is not None:                                                   # network.py:185
-            state.load_state_dict(torch.load(ckpt, map_location='cpu'))
+        if checkpoint_dir:                                                     # network.py:185
+            state = checkpoints.restore_checkpoint(checkpoint_dir, state)
         return state
 
     def apply(self, variables, t_frames, t_units, coords, Omega, t_start_obs, t_geos, t_injection):
@@ -231,11 +254,7 @@ class NeRF_Predictor:
 
 
 def latest_checkpoint(checkpoint_dir):
-    if not checkpoint_dir:
-        return None
-    found = glob.glob(os.path.join(checkpoint_dir, 'checkpoint_*'))
-    found = [f for f in found if f.rsplit('_', 1)[-1].isdigit()]
-    return max(found, key=lambda f: int(f.rsplit('_', 1)[-1])) if found else None
+    return checkpoints.latest_checkpoint(checkpoint_dir) if checkpoint_dir else None
 
 
 def _frame_offsets(t_frames, t_units, t_start_obs, t_injection, device):
@@ -466,6 +485,35 @@ def sample_3d_grid(apply_fn, params, t_frame=0, t_start_obs=0, Omega=0, fov=None
         Omega_chunk = Omega if np.isscalar(Omega) else Omega[c * chunk:(c + 1) * chunk, :, :]
         emission.append(apply_fn({'params': params}, t_frame, t_units, coords_chunk, Omega_chunk, t_start_obs, 0.0, 0.0))
     return torch.cat(emission, dim=0).cpu().numpy()
+
+
+def sample_checkpoint_3d(checkpoint_dir, t_frame=0, t_start_obs=0, Omega=0, fov=None, coords=None, resolution=64, chunk=-1,
+                         **predictor_kw):
+    """sample_3d_grid of the newest checkpoint in ``checkpoint_dir`` (network.py:842-848)."""
+    predictor = NeRF_Predictor.from_yml(checkpoint_dir, **predictor_kw)
+    state = checkpoints.restore_checkpoint(checkpoint_dir, None)
+    if state is None:
+        raise FileNotFoundError('no checkpoint in {}'.format(checkpoint_dir))
+    if state.get('_legacy'):
+        params = ParamTree(predictor.engine().unflatten(_hip.as_f32(state['params'], predictor.engine().device)))
+    else:
+        params = state['params']
+    return sample_3d_grid(predictor.apply, params, t_frame, t_start_obs, Omega, fov, coords, resolution, chunk)
+
+
+def image_plane_checkpoint(raytracing_args, checkpoint_dir, t, rmin=0.0, rmax=np.inf, batchsize=20, **predictor_kw):
+    """Image-plane movie (nt, S, H, W) rendered from the newest checkpoint (network.py:896-906)."""
+    from . import optimization
+    predictor = NeRF_Predictor.from_yml(checkpoint_dir, **predictor_kw)
+    predictor.rmax = min(rmax, predictor.rmax)
+    predictor.rmin = max(rmin, predictor.rmin)
+    params = predictor.init_params(raytracing_args)
+    state = predictor.init_state(params, checkpoint_dir=checkpoint_dir)
+    first = raytracing_args[0] if isinstance(raytracing_args, (list, tuple)) else raytracing_args
+    num_stokes = np.shape(first['J'])[0]
+    train_step = optimization.TrainStep.image(t, np.zeros((len(t), num_stokes)), dtype='lc')
+    _, image_plane = optimization.total_movie_loss(batchsize, state, train_step, raytracing_args, return_frames=True)
+    return image_plane
 
 
 def raytracing_args(geos, Omega, t_injection, t_start_obs, J=1.0):

@@ -13,7 +13,7 @@ import os
 import numpy as np
 import torch
 
-from . import network, units
+from . import checkpoints, network, units
 
 try:  # progress bar is optional
     from tqdm.auto import tqdm
@@ -103,11 +103,8 @@ class Optimizer(object):
         due = self.step % self.save_period == 0 or self.step == self.final_step
         if not (self.checkpoint_dir and due and network._world()[0] == 0):
             return
-        os.makedirs(self.checkpoint_dir, exist_ok=True)
-        torch.save(self.state.state_dict(), os.path.join(self.checkpoint_dir, 'checkpoint_%d' % int(self.step)))
-        numbered = [f for f in os.listdir(self.checkpoint_dir) if f.startswith('checkpoint_') and f[11:].isdigit()]
-        for stale in sorted(numbered, key=lambda f: int(f[11:]))[:-self.keep]:
-            os.remove(os.path.join(self.checkpoint_dir, stale))
+        # the flax file format of the reference (optimization.py:118-121), see checkpoints.py
+        checkpoints.save_checkpoint(self.checkpoint_dir, self.state, int(self.step), keep=self.keep, overwrite=True)
 
     def run(self, batchsize, train_step, raytracing_args, log_fns=[]):
         """num_iters more steps from wherever the (possibly restored) state stands; Ctrl-C stops early."""
