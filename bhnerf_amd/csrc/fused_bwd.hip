@@ -14,6 +14,9 @@
 //   reduce_kernel sums the slabs of each layer's workgroups into the flat dparams (flax tree order).
 #include "fused_common.h"
 
+#ifndef BHN_JOB1_W
+#define BHN_JOB1_W 12
+#endif
 #ifndef BHN_TAPED_DIST
 #define BHN_TAPED_DIST 6
 #endif
@@ -23,6 +26,10 @@ struct TapeLayout {
     long long h_off[BHN_MAX_LAYERS + 1];       // h_l, l = 1..depth  (inputs of layer l)
     long long ga_off[BHN_MAX_LAYERS];          // gA_l, l = 0..depth-1
     long long enc_off, dout_off, mask_off, e_off, total;   // mask: relu bits [group][layer][word][lane]; e: [group][32] f32
+    // bf16: h_1 = relu(W_0^T enc + b_0) is NOT on the tape; the dW job of layer 1 recomputes it from the encoded
+    // inputs kept a second time in their forward (point-on-lane) fragment form -- 64 B instead of 512 B per point
+    long long encp_off;
+    int drop_h1;
 };
 
 struct BwdArgs {
@@ -251,6 +258,8 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
     constexpr int ES = (Pol::ELEM_BYTES == 2) ? 2 : 4;                 // global stores of one tile emission
     constexpr int YS = ES * (DIST - 2) + ((KS >= 16 && Pol::ELEM_BYTES == 2) ? ES : 0) + BHN_EXTRA_YS;   // (f32 emits at k-step 8)
     constexpr int YS0 = ES * (DIST - 2);                               // steps whose own stores precede their DMA issue
+    constexpr int YS_L1r = (KS >= 16) ? YS - (MODE == 0 ? 2 : 1) * ES : 0;      // first steps of layer 1 when h_1 is not emitted
+    constexpr int YS_L1 = YS_L1r > 0 ? YS_L1r : 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *ring = smem;
     float *bias_lds = reinterpret_cast<float *>(smem + RS::NB * CB);  // (depth+1) x W, then one zero row
@@ -336,6 +345,11 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
             point_prologue<Pol, DEG>(a, in, enc, live);
             // the encoded inputs are the B operand of dW_0 and of the skip layer
             em.emit(A.tape + A.t.enc_off + q * TB, enc[0], enc[1], edbg);
+            const bool drop_h1 = A.t.drop_h1;
+            if (drop_h1 && !(edbg & 2)) {        // ... and, as they are, the A operand from which dW_1 recomputes h_1
+                __builtin_nontemporal_store(enc[0], reinterpret_cast<frag *>(A.tape + A.t.encp_off + q * TB + lane * 16));
+                __builtin_nontemporal_store(enc[1], reinterpret_cast<frag *>(A.tape + A.t.encp_off + q * TB + Pol::FRAG_BYTES + lane * 16));
+            }
             // ---- forward, layer 0: tile m-1 is packed, recorded and emitted behind the MFMAs of tile m ------
             const bool keep_stash = MODE == MODE_RECOMPUTE;          // the delta chain of the same tile reads the bits back
             struct Tile0 {
@@ -352,9 +366,9 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
                         if (mword) __builtin_nontemporal_store(macc, mword + (m >> 1) * 64);
                         if (stash) stash[(m >> 1) * 64] = macc;
                     }
-                    em.emit(dst + (long long)m * TB, d0, d1, edbg);
+                    if (dst) em.emit(dst + (long long)m * TB, d0, d1, edbg);
                 }
-            } l0{em, A.tape + A.t.h_off[1] + q * MT * TB, MODE == MODE_FWD_TRAIN ? mask_g + lane : nullptr,
+            } l0{em, drop_h1 ? nullptr : A.tape + A.t.h_off[1] + q * MT * TB, MODE == MODE_FWD_TRAIN ? mask_g + lane : nullptr,
                  keep_stash ? mask_w + lane : nullptr, 0u, edbg};
             f32x16 pend;
             layer0_step<W, Pol, RG, YS0>(rs, ap, enc, act, bias_lds, h, pend, l0);
@@ -375,14 +389,20 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
                     frag &d0 = m == 0 ? act[KS - 2] : next[2 * (m > 0 ? m - 1 : 0)];
                     frag &d1 = m == 0 ? act[KS - 1] : next[2 * (m > 0 ? m - 1 : 0) + 1];
                     const int widx = (pl_layer * MW + (pm >> 1)) * 64 + lane;
+                    const bool no_h = drop_h1 && pl_layer == 0;     // layer 0's last tile: relu bits only
                     TapePost<Pol, true> post(pend, d0, d1, 0u, em, A.tape + A.t.h_off[pl_layer + 1] + (q * MT + pm) * TB,
                                                  MODE == MODE_FWD_TRAIN ? mask_g + widx : nullptr, keep_stash ? mask_w + widx : nullptr,
-                                                 macc, pm & 1, pm == MT - 1, edbg);
+                                                 macc, pm & 1, pm == MT - 1, no_h ? (edbg | 2) : edbg);
                     // bias rows of the next tile: (l, m+1), or the first tile of the next sequence part
                     const float *bn = (out || (m == MT - 1 && l + 1 > a.depth)) ? nullptr : bl + 32 * (m + 1);
                     if (out) bn = (MODE == MODE_FWD_TRAIN) ? bias_lds : zero_lds;
                     const f32x16 acc = ring_step<W, Pol, RG>(ch, chn, ap, act, enc, sk, bn, post, dj, sdbg);
-                    rs.template step_end<YS>();
+                    // without the h_1 emission the interval after this layer's first DMA issue holds no store: the
+                    // three step ends that count it allow one emission less in flight (small widths: none)
+                    // (the recompute kernel's layer-0 step stores nothing either: its relu bits stay in LDS)
+                    if (drop_h1 && l == 1 && m <= 2) rs.template step_end<YS_L1>();
+                    else if (drop_h1 && l == 1) rs.template step_end<(KS >= 16 ? YS : 0)>();
+                    else rs.template step_end<YS>();
                     pend = acc;
                     pl_layer = l;
                     if (m == 0) pl_layer = l;                         // from here on the pending tiles are layer l's
@@ -535,7 +555,7 @@ struct GroupStager {
 };
 
 // Job types of the dW kernel (compile-time so that the streaming loop is straight-line code)
-enum { JT_FIRST = 0, JT_HIDDEN = 1, JT_SKIP = 2, JT_OUT = 3 };
+enum { JT_FIRST = 0, JT_HIDDEN = 1, JT_SKIP = 2, JT_OUT = 3, JT_HIDDEN1 = 4 };   // HIDDEN1: layer 1 with h_1 recomputed from the encoded inputs
 
 template <int W, class Pol, int JT>
 DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
@@ -544,6 +564,7 @@ DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
     constexpr int MT = BG::MT, TB = BG::TILE_BYTES, GB = BG::GROUP_BYTES;
     constexpr int OFF_H = MT * TB, OFF_E = 2 * MT * TB;               // LDS group image [A][h][enc]
     constexpr bool out_job = JT == JT_OUT, has_h = JT != JT_FIRST, has_enc = (JT == JT_FIRST || JT == JT_SKIP);
+    constexpr bool make_h = JT == JT_HIDDEN1;       // the h tiles of the LDS group image are computed here, not DMA'd
     constexpr int mtA = out_job ? 1 : MT;                              // A tiles (gA rows; dout is 1 row)
     constexpr int nH = has_h ? MT : 0, nB = nH + (has_enc ? 1 : 0);    // B tiles; tile nB is the ones tile
     constexpr int NT = nB + 1;
@@ -558,8 +579,47 @@ DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
     const char *srcA = out_job ? A.tape + A.t.dout_off : A.tape + A.t.ga_off[out_job ? 0 : job];
     constexpr long long strideA = out_job ? TB : (long long)MT * TB;       // dout is one tile per group
     const char *srcH = has_h ? A.tape + A.t.h_off[job] : nullptr;
-    const char *srcE = A.tape + A.t.enc_off;
+    const char *srcE = A.tape + (make_h ? A.t.encp_off : A.t.enc_off);
     const int wr = wv % WRR, wc = wv / WRR;
+    // HIDDEN1: W_0 (the forward's layer-0 chunk: A-operand fragment 2m+ks of W_0^T = B-operand fragment of W_0) and
+    // b_0 behind the ring
+    char *w0_lds = smem + BG::NBUF * GB;
+    float *b0_lds = reinterpret_cast<float *>(w0_lds + 2 * MT * Pol::FRAG_BYTES);
+    if constexpr (make_h) {
+        const char *w0 = A.f.packed + A.f.fwd_off;
+        for (int i = tid; i < 2 * MT * Pol::FRAG_BYTES / 16; i += Pol::NTHREADS)
+            reinterpret_cast<u32x4 *>(w0_lds)[i] = reinterpret_cast<const u32x4 *>(w0)[i];
+        for (int i = tid; i < W; i += Pol::NTHREADS) b0_lds[i] = reinterpret_cast<const float *>(A.f.packed + A.f.bias_off)[i];
+    }
+    // h_1 tile `wv` of a group image from its encoded-input fragments: D[point][feature] = enc^T . W_0 + b_0.  Two
+    // phases so that the LDS reads fly during the dW MFMAs of the group being consumed.
+    struct HIn { frag e0, e1, w0, w1; float b; };
+    auto make_h_read = [&](const char *gp) {
+        HIn in;
+        in.e0 = Pol::lds_frag(gp + OFF_E, 0, lane); in.e1 = Pol::lds_frag(gp + OFF_E, 1, lane);
+        const int t = wv < MT ? wv : 0;
+        in.w0 = Pol::lds_frag(w0_lds, 2 * t, lane); in.w1 = Pol::lds_frag(w0_lds, 2 * t + 1, lane);
+        in.b = b0_lds[32 * t + (lane & 31)];
+        return in;
+    };
+    auto make_h_write = [&](char *gp, const HIn &in) {
+        if (wv < MT) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = in.b;
+            acc = Pol::mma(in.e0, in.w0, acc);
+            acc = Pol::mma(in.e1, in.w1, acc);
+            frag o[2];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) Pol::set(o[s2], j, Pol::relu(acc[8 * s2 + j]));
+            if constexpr (Pol::ELEM_BYTES == 2) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) *reinterpret_cast<frag *>(gp + OFF_H + wv * TB + s2 * Pol::FRAG_BYTES + lane * 16) = o[s2];
+            }
+        }
+    };
     const bool wave_works = wr * MPW < mtA;                            // output job: only the wr == 0 waves
     frag ones;
 #pragma unroll
@@ -632,7 +692,8 @@ DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
             // (q-1)%NBUF has been consumed; the counted wait leaves NBUF-2 younger groups in flight.
             // pieces (1 KiB = one wave-wide DMA) this job really needs: [A tiles | dout][h tiles][enc tile]
             constexpr int NBUF = BG::NBUF;
-            constexpr int PA = out_job ? TB / 1024 : MT * TB / 1024, PH = has_h ? MT * TB / 1024 : 0, PE = has_enc ? TB / 1024 : 0;
+            constexpr int PA = out_job ? TB / 1024 : MT * TB / 1024, PH = (has_h && !make_h) ? MT * TB / 1024 : 0,
+                          PE = (has_enc || make_h) ? TB / 1024 : 0;
             constexpr int NPJ = PA + PH + PE, PPW = (NPJ + Pol::NWAVES - 1) / Pol::NWAVES;
             const int wvu = __builtin_amdgcn_readfirstlane(wv);
             const char *sbase[PPW];
@@ -662,19 +723,35 @@ DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
                 for (int i = 0; i < PPW; ++i)
                     dma_1k(sbase[i] + q * sstride[i], buf + doff[i]);
             };
+            // HIDDEN1: the h tiles of group q+1 are computed while group q is consumed (one group less in flight:
+            // this job is MFMA-bound), so the loop-top barrier also publishes them and no latency chain is exposed
+            constexpr int INFLIGHT = make_h ? (NBUF >= 3 ? NBUF - 3 : 0) : NBUF - 2;
             if (q0 < q1) {
 #pragma unroll
                 for (int j = 0; j < NBUF - 1; ++j) issue(q0 + j, smem + j * GB);
+                if constexpr (make_h) {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * PPW) : "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    make_h_write(smem, make_h_read(smem));
+                }
                 int it = 0;
                 for (long long q = q0; q < q1; ++q) {
-                    if (!(A.debug & 2)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * PPW) : "memory");
+                    if (!(A.debug & 2)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT * PPW) : "memory");
+                    if constexpr (make_h) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's h-tile writes
                     __builtin_amdgcn_s_barrier();
                     asm volatile("" ::: "memory");      // the raw barrier is not a compiler fence: keep the
                                                          // DMA issue and the ds_reads below it
                     const int nx = (it == 0) ? NBUF - 1 : it - 1;
                     if (!(A.debug & 2)) issue(q + NBUF - 1, smem + nx * GB);
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    char *gnext = smem + ((it == NBUF - 1) ? 0 : it + 1) * GB;
+                    HIn hin;
+                    if constexpr (make_h) hin = make_h_read(gnext);
                     if (!(A.debug & 1) && wave_works) compute_group(smem + it * GB);
+                    if constexpr (make_h) {
+                        if (q + 1 < q1) make_h_write(gnext, hin);
+                    }
                     it = (it == NBUF - 1) ? 0 : it + 1;
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -735,7 +812,9 @@ __global__ __launch_bounds__(Pol::NTHREADS) void dw_kernel(BwdArgs A) {
     if (job == depth) dw_body<W, Pol, JT_OUT>(A, job, smem);
     else if (job == 0) dw_body<W, Pol, JT_FIRST>(A, job, smem);
     else if ((A.f.skip_mask >> job) & 1) dw_body<W, Pol, JT_SKIP>(A, job, smem);
-    else dw_body<W, Pol, JT_HIDDEN>(A, job, smem);
+    else if (job == 1 && A.t.drop_h1) {
+        if constexpr (Pol::ELEM_BYTES == 2) dw_body<W, Pol, JT_HIDDEN1>(A, job, smem);
+    } else dw_body<W, Pol, JT_HIDDEN>(A, job, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -794,13 +873,18 @@ extern "C" int bhn_debug_set_bwd_stages(int32_t mask) {
 }
 
 template <int W, class Pol>
-static void tape_layout(int depth, long long NQ, TapeLayout *t) {
+static void tape_layout(int depth, bool layer1_takes_enc, long long NQ, TapeLayout *t) {
     using BG = BwdGeom<W, Pol>;
     memset(t, 0, sizeof(*t));
     t->NQ = NQ;
+    t->drop_h1 = Pol::ELEM_BYTES == 2 && depth >= 2 && !layer1_takes_enc;
     long long off = 0;
     const long long per_tensor = NQ * BG::MT * (long long)BG::TILE_BYTES;
-    for (int l = 1; l <= depth; ++l) { t->h_off[l] = off; off += per_tensor; }
+    for (int l = 1; l <= depth; ++l) {
+        if (l == 1 && t->drop_h1) { t->h_off[l] = -1; continue; }
+        t->h_off[l] = off; off += per_tensor;
+    }
+    if (t->drop_h1) { t->encp_off = off; off += NQ * (long long)BG::TILE_BYTES; }
     for (int l = 0; l < depth; ++l) { t->ga_off[l] = off; off += per_tensor; }
     t->enc_off = off; off += NQ * (long long)BG::TILE_BYTES;
     t->dout_off = off; off += NQ * (long long)BG::TILE_BYTES;   // dout as an A tile: row 0 = dout, rows 1..31 zero
@@ -830,7 +914,10 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
     if (what == RUN_QUERY) {
         const long long tiles = (query_P + Pol::NWAVES * 32 - 1) / (Pol::NWAVES * 32) * query_B;
         TapeLayout t;
-        tape_layout<W, Pol>(m->net_depth, tiles * Pol::NWAVES, &t);
+        MlpShape sq;
+        const int rcq = bhn_mlp_shape(m, &sq);
+        if (rcq != BHN_OK) return rcq;
+        tape_layout<W, Pol>(sq.depth, sq.depth >= 2 && sq.skip_in[1], tiles * Pol::NWAVES, &t);
         *query_bytes = slab_bytes + (size_t)t.total;
         return BHN_OK;
     }
@@ -845,7 +932,8 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
     // frames per pass so that the tape fits the workspace (same layout function as the size query)
     const long long groups_per_frame = (long long)A.f.tiles_per_frame * Pol::NWAVES;
     TapeLayout t1;
-    tape_layout<W, Pol>(depth, groups_per_frame, &t1);
+    const bool l1enc = depth >= 2 && s.skip_in[1];
+    tape_layout<W, Pol>(depth, l1enc, groups_per_frame, &t1);
     if (workspace_bytes < slab_bytes + (size_t)t1.total) {
         bhn_set_error("render_bwd workspace too small: %zu bytes, need >= %zu (slabs %zu + one frame of tape %lld)",
                       workspace_bytes, slab_bytes + (size_t)t1.total, slab_bytes, t1.total);
@@ -854,7 +942,7 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
     long long fpp = 1;
     while (fpp < A.f.B) {
         TapeLayout tn;
-        tape_layout<W, Pol>(depth, groups_per_frame * (fpp + 1), &tn);
+        tape_layout<W, Pol>(depth, l1enc, groups_per_frame * (fpp + 1), &tn);
         if (slab_bytes + (size_t)tn.total > workspace_bytes) break;
         ++fpp;
     }
@@ -879,7 +967,9 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
         double work[BHN_MAX_LAYERS + 1], tot = 0;
         for (int l = 0; l <= depth; ++l) {
             const int mtA = (l == depth) ? 0 : BG::MT;
-            const int nB = (l >= 1 ? BG::MT : 0) + ((l == 0 || s.skip_in[l]) ? 1 : 0);
+            int nB = (l >= 1 ? BG::MT : 0) + ((l == 0 || s.skip_in[l]) ? 1 : 0);
+            if (l == 1 && t1.drop_h1) nB = BHN_JOB1_W;            // reads only the encoded inputs instead of h_1 but has the
+                                                                  // same MFMA work + the recompute: not byte-bound any more
             work[l] = (double)(mtA + nB) + 0.5;
             tot += work[l];
         }
@@ -902,7 +992,7 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
     const size_t lds_fixed = (size_t)(depth + 1) * W * 4 + 128 + W * 4 + 2 * Pol::FRAG_BYTES;
     const size_t lds_rec = (size_t)(BG::RING_DIST + 1) * PK::CHUNK_BYTES + lds_fixed + (size_t)Pol::NWAVES * depth * ((BG::MT + 1) / 2) * 64 * 4;
     const size_t lds_taped = (size_t)(BG::RING_DIST_TAPED + 1) * PK::CHUNK_BYTES + lds_fixed;
-    const size_t lds_dw = (size_t)BG::NBUF * BG::GROUP_BYTES;
+    const size_t lds_dw = (size_t)BG::NBUF * BG::GROUP_BYTES + (t1.drop_h1 ? (size_t)2 * BG::MT * Pol::FRAG_BYTES + W * 4 : 0);
     auto k_rec = chain_kernel<W, Pol, 3, MODE_RECOMPUTE>;
     auto k_fwd = chain_kernel<W, Pol, 3, MODE_FWD_TRAIN>;
     auto k_chn = chain_kernel<W, Pol, 3, MODE_CHAIN>;
@@ -926,7 +1016,7 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
         A.f.tM0 = tM0 + b0;
         A.f.dimages = dimages ? dimages + (long long)b0 * A.f.Sx * A.f.R : nullptr;
         A.f.total_tiles = (long long)A.f.tiles_per_frame * nb;
-        tape_layout<W, Pol>(depth, A.f.total_tiles * Pol::NWAVES, &A.t);
+        tape_layout<W, Pol>(depth, l1enc, A.f.total_tiles * Pol::NWAVES, &A.t);
         A.accumulate = pass > 0;
         A.debug = g_bwd_debug;
         A.ts_buf = (g_bwd_debug & 512) ? reinterpret_cast<long long *>(bhn_debug_buffer()) : nullptr;

@@ -45,11 +45,9 @@ struct PolBF16 {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
     }
     static DEVI void set(frag &f, int j, float v) { f[j] = (__bf16)v; }
-    static DEVI float relu(float v) {           // one v_max (plain C gets a canonicalising second one from hipcc)
-        float q;
-        asm("v_max_f32 %0, 0, %1" : "=v"(q) : "v"(v));
-        return q;
-    }
+    // one instruction (v_med3_f32; the plain C form gets a canonicalising second v_max from hipcc).  NOT inline asm:
+    // the hazard recogniser must see this VALU read of an MFMA result to insert the wait states gfx9 needs
+    static DEVI float relu(float v) { return __builtin_amdgcn_fmed3f(v, 0.f, __builtin_inff()); }
     static DEVI float get(const frag &f, int j) { return (float)f[j]; }
     static DEVI float fsin_rev(float rev) { return __builtin_amdgcn_sinf(rev); }   // sin(2*pi*rev)
     static DEVI float fcos_rev(float rev) { return __builtin_amdgcn_cosf(rev); }

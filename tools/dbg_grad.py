@@ -48,4 +48,4 @@ def run(width, depth, S, H=9, Wd=7, G=50, B=3):
             ['%.1e' % (ek[j:j + 32].max() / gmax) for j in range(0, ek.shape[0], 32)]))
 import sys as _s
 MODE = 'bf16'
-run(32, 4, 0); run(256, 4, 0)
+run(128, 4, 3); run(256, 4, 0)
