@@ -14,6 +14,9 @@
 //   reduce_kernel sums the slabs of each layer's workgroups into the flat dparams (flax tree order).
 #include "fused_common.h"
 
+#ifndef BHN_CHAIN_STAMPS
+#define BHN_CHAIN_STAMPS 0      // 1: ring-step time stamps in the chain kernels (tools/dbg_chain_steps.py needs this build)
+#endif
 #ifndef BHN_JOB1_W
 #define BHN_JOB1_W 12
 #endif
@@ -180,21 +183,22 @@ struct TapePost {
     f32x16 tr;
     DEVI TapePost(const f32x16 &p, typename Pol::frag &a, typename Pol::frag &b, unsigned mask_in, const TapeEmit<Pol> &em_, char *dst_,
                   unsigned *mword_, unsigned *stash_, unsigned &macc_, bool hi_, bool last_, int edbg_)
-        : pend(p), d0(a), d1(b), mask(mask_in), dst(dst_), mword(mword_), stash(stash_), macc(macc_), hi(hi_),
-          last(last_), edbg(edbg_), em(em_) {}
+        : pend(p), d0(a), d1(b), mask(RELU ? 0u : Pol::mask_spread(mask_in)), dst(dst_), mword(mword_), stash(stash_),
+          macc(macc_), hi(hi_), last(last_), edbg(edbg_), em(em_) {}
     template <int R0, int N>
     DEVI void elems() {
         if constexpr (RELU) pack_elems<Pol, R0, N>(pend, d0, d1, mask);
         else {
 #pragma unroll
-            for (int r = R0; r < R0 + N; ++r) Pol::set(r < 8 ? d0 : d1, r & 7, ((mask >> r) & 1) ? pend[r] : 0.f);
+            for (int r = R0; r < R0 + N; r += 2) Pol::mask_pair(r < 8 ? d0 : d1, (r & 7) >> 1, r >> 1, pend[r], pend[r + 1], mask);
             if (R0 < 8) asm volatile("" : "+v"(d0));
             if (R0 + N > 8) asm volatile("" : "+v"(d1));
         }
     }
     DEVI void bits_and_transpose() {
         if constexpr (RELU) {
-            const unsigned word = hi ? (macc | (mask << 16)) : mask;
+            const unsigned code = Pol::mask_code(mask);
+            const unsigned word = hi ? (macc | (code << 16)) : code;
             macc = word;
             if (hi || last) {
                 if (mword) __builtin_nontemporal_store(word, mword);
@@ -248,10 +252,10 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
     constexpr int TB = BG::TILE_BYTES;
     const FusedArgs &a = A.f;
     const int edbg = (A.debug >> 6) & 3;           // measurement aid for the tape emission
-    const int sdbg = (A.debug >> 8) & 1;           // measurement aid: skip the hidden-layer / chain MFMAs
+    constexpr int sdbg = 0;                        // (a run-time MFMA-skip flag put every MFMA in its own basic block)
     using RG = DmaRing<CB, Pol::NWAVES>;
     constexpr int DIST = BG::template ring_dist<MODE>();
-    using RS = RingState<RG, CB, DIST, false, MT>;
+    using RS = RingState<RG, CB, DIST, false, MT, BHN_CHAIN_STAMPS != 0>;
     // stores guaranteed younger than chunk c+2 at the end of step c (RingState::step_end): every interval between
     // two DMA issues holds the >= ES stores of one pending-tile emission; with >= 16 k-steps the running step's
     // own emission (k-step 12) also follows its DMA issue (k-step 9)
@@ -340,7 +344,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
         frag enc[2], act[KS], next[KS];
         bool live = false;
         float e = 0.f;
-        if (have_ring) rs.ts = (A.ts_buf && blockIdx.x == 0 && tile == 3 * (long long)gridDim.x) ? A.ts_buf + __builtin_amdgcn_readfirstlane(wv) * 64 : nullptr;
+        if (BHN_CHAIN_STAMPS && have_ring) rs.ts = (A.ts_buf && blockIdx.x == 0 && tile == 3 * (long long)gridDim.x) ? A.ts_buf + __builtin_amdgcn_readfirstlane(wv) * 64 : nullptr;
         if constexpr (MODE != MODE_CHAIN) {
             point_prologue<Pol, DEG>(a, in, enc, live);
             // the encoded inputs are the B operand of dW_0 and of the skip layer
@@ -361,6 +365,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
                 DEVI void tile(int m, const f32x16 &acc, frag &d0, frag &d1) {
                     unsigned mk = 0;
                     pack_elems<Pol, 0, 16>(acc, d0, d1, mk);
+                    mk = Pol::mask_code(mk);
                     macc = (m & 1) ? (macc | (mk << 16)) : mk;
                     if (m & 1) {
                         if (mword) __builtin_nontemporal_store(macc, mword + (m >> 1) * 64);
@@ -468,7 +473,10 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
                     for (int g4 = 0; g4 < 4; ++g4) {
                         const f32x4 wv4 = *reinterpret_cast<const f32x4 *>(wout_lds + 32 * m + 8 * g4 + 4 * h);
 #pragma unroll
-                        for (int e4 = 0; e4 < 4; ++e4) g[4 * g4 + e4] = ((mw >> (4 * g4 + e4)) & 1) ? wv4[e4] * dout : 0.f;
+                        for (int e4 = 0; e4 < 4; ++e4) {
+                            const int r = 4 * g4 + e4;                 // ReLU code: bit r/2 (even r) or 8 + r/2 (odd r)
+                            g[r] = ((mw >> ((r >> 1) + 8 * (r & 1))) & 1) ? wv4[e4] * dout : 0.f;
+                        }
                     }
                     if (m < MT - 1 || a.depth == 1) {
 #pragma unroll

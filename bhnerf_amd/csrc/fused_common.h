@@ -48,6 +48,35 @@ struct PolBF16 {
     // one instruction (v_med3_f32; the plain C form gets a canonicalising second v_max from hipcc).  NOT inline asm:
     // the hazard recogniser must see this VALU read of an MFMA result to insert the wait states gfx9 needs
     static DEVI float relu(float v) { return __builtin_amdgcn_fmed3f(v, 0.f, __builtin_inff()); }
+    // ReLU bits of a 32x32 tile, per lane a 16-bit code: bit k = element 2k is active, bit 8+k = element 2k+1
+    // (k = 0..7: the k-th packed dword of the tile's two B fragments).  While a tile is being packed the bits are
+    // kept "spread" (bit k and bit 16+k), which is what two-at-a-time operations on the packed dword produce:
+    //   relu_pair : dword = pack(relu(a), relu(b)); spread |= min_u16x2(dword, 1) << k        (5 VALU per pair)
+    //   mask_pair : dword = pack(a, b) & (((spread >> k) & 0x00010001) * 0xffff)              (5 VALU per pair)
+    // A bf16 result of +0 counts as inactive (an f32 pre-activation below 2^-133 would be active in exact arithmetic).
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    static DEVI void put_dword(frag &f, int i, unsigned u) {
+        u32x4 w = __builtin_bit_cast(u32x4, f);
+        w[i] = u;
+        f = __builtin_bit_cast(frag, w);
+    }
+    static DEVI void relu_pair(frag &f, int i, int k, float a, float b, unsigned &spread) {
+        const bf16x2 t = {(__bf16)relu(a), (__bf16)relu(b)};
+        const unsigned u = __builtin_bit_cast(unsigned, t);
+        put_dword(f, i, u);
+#ifndef BHN_NO_MASK
+        unsigned m;      // (plain VALU reading a VALU result: no hazard the compiler would have to know about; the
+                         //  generic elementwise min on u16x2 expands into ~10 compare/select instructions)
+        asm("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(u), "s"(0x00010001u));
+        spread |= m << k;
+#endif
+    }
+    static DEVI void mask_pair(frag &f, int i, int k, float a, float b, unsigned spread) {
+        const bf16x2 t = {(__bf16)a, (__bf16)b};
+        put_dword(f, i, __builtin_bit_cast(unsigned, t) & (((spread >> k) & 0x00010001u) * 0xffffu));
+    }
+    static DEVI unsigned mask_code(unsigned spread) { return (spread & 0xffu) | ((spread >> 8) & 0xff00u); }
+    static DEVI unsigned mask_spread(unsigned code) { return (code & 0xffu) | ((code & 0xff00u) << 8); }
     static DEVI float get(const frag &f, int j) { return (float)f[j]; }
     static DEVI float fsin_rev(float rev) { return __builtin_amdgcn_sinf(rev); }   // sin(2*pi*rev)
     static DEVI float fcos_rev(float rev) { return __builtin_amdgcn_cosf(rev); }
@@ -81,6 +110,16 @@ struct PolF32 {
     }
     static DEVI void set(frag &f, int j, float v) { f[j] = v; }
     static DEVI float relu(float v) { return v > 0.f ? v : 0.f; }
+    // same 16-bit ReLU code as PolBF16 (bit k = element 2k, bit 8+k = element 2k+1), exact `> 0`
+    static DEVI void relu_pair(frag &f, int i, int k, float a, float b, unsigned &code) {
+        f[2 * i] = relu(a); f[2 * i + 1] = relu(b);
+        code |= (a > 0.f ? 1u << k : 0u) | (b > 0.f ? 1u << (8 + k) : 0u);
+    }
+    static DEVI void mask_pair(frag &f, int i, int k, float a, float b, unsigned code) {
+        f[2 * i] = ((code >> k) & 1) ? a : 0.f; f[2 * i + 1] = ((code >> (8 + k)) & 1) ? b : 0.f;
+    }
+    static DEVI unsigned mask_code(unsigned code) { return code; }
+    static DEVI unsigned mask_spread(unsigned code) { return code; }
     static DEVI float get(const frag &f, int j) { return f[j]; }
     static DEVI float fexp(float x) { return expf(x); }
     static constexpr bool FAST_TRIG = false;
@@ -342,12 +381,10 @@ DEVI unsigned relu_pack(const f32x16 &acc, int m, typename Pol::frag (&next)[W /
 // ---------------------------------------------------------------------------------------------
 template <class Pol, int R0, int N>
 DEVI void pack_elems(const f32x16 &acc, typename Pol::frag &d0, typename Pol::frag &d1, unsigned &mask) {
+    static_assert(R0 % 2 == 0 && N % 2 == 0, "elements are packed in pairs");
 #pragma unroll
-    for (int r = R0; r < R0 + N; ++r) {
-        const float v = acc[r];
-        mask |= (v > 0.f) ? (1u << r) : 0u;                       // dead code unless the caller records relu bits
-        Pol::set(r < 8 ? d0 : d1, r & 7, Pol::relu(v));
-    }
+    for (int r = R0; r < R0 + N; r += 2)       // mask: spread ReLU bits (Pol::mask_code), dead code unless recorded
+        Pol::relu_pair(r < 8 ? d0 : d1, (r & 7) >> 1, r >> 1, acc[r], acc[r + 1], mask);
     // the packed registers are "used" here: without this the machine sinker moves the whole pack down to the
     // next layer's first read of the fragment, i.e. out of the MFMA shadow it was placed in
     if (R0 < 8) asm volatile("" : "+v"(d0));
@@ -496,7 +533,7 @@ DEVI void lds_barrier() {
 // are resident or in flight; step_end() waits for this wave's pieces of chunk c+2 (NOT c+1: the A-fragment
 // prefetch of the next step reads chunk c+2 before that step's barrier) and synchronises the workgroup.
 // ---------------------------------------------------------------------------------------------
-template <class RG, int CB, int DIST, bool LAG, int MT = 1>
+template <class RG, int CB, int DIST, bool LAG, int MT = 1, bool STAMPS = false>
 struct RingState {
     // LAG (measured, not used): the second wave of every SIMD (waves NWAVES/2..) consumes the ring ONE STEP BEHIND
     // the first, so that the two waves of a SIMD are never in their per-tile VALU phases at the same time.  Costs one
@@ -508,7 +545,7 @@ struct RingState {
     // chunks of the delta chain (img_b): hidden layers nlb .. 1, MT chunks each, stored layer-major ascending
     const char *img_a, *img_b;
     int NC, NCA, nlb, cur, issue_c, dbg, lag;
-    long long *ts;          // measurement builds: per-step time stamps (compute done, barrier passed)
+    long long *ts;          // STAMPS (measurement builds): per-step time stamps (compute done, barrier passed)
     static DEVI int wrap(int i) { return i < 0 ? i + NB : (i >= NB ? i - NB : i); }
     DEVI const char *ch() const { return ring + wrap(cur - lag) * CB; }
     DEVI const char *chn() const { return ring + wrap(cur - lag + 1) * CB; }
@@ -532,10 +569,10 @@ struct RingState {
     template <int STORES = 0>
     DEVI void step_end() {
         long long t1 = 0;
-        if (ts) t1 = __builtin_readcyclecounter();
+        if (STAMPS && ts) t1 = __builtin_readcyclecounter();
         if (!(dbg & 4)) RG::template wait_younger<RG::PPW * (DIST - 2) + STORES>();
         if (!(dbg & 8)) lds_barrier();
-        if (ts) {
+        if (STAMPS && ts) {
             const long long t3 = __builtin_readcyclecounter();
             if ((threadIdx.x & 63) == 0) { ts[0] = t1; ts[1] = t3; }
             ts += 2;

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void fused_fwd_kernel(FusedArgs a) {
     constexpr int CB = PK::CHUNK_BYTES, MT = PK::MT, KS = PK::KS;
     using RG = DmaRing<CB, Pol::NWAVES>;
     constexpr int DIST = (Pol::ELEM_BYTES == 2) ? BHN_FWD_DIST : 3;                    // LDS-DMA weight ring: chunks in flight
-    using RS = RingState<RG, CB, DIST, Pol::PHASE_LAG, MT>;
+    using RS = RingState<RG, CB, DIST, Pol::PHASE_LAG, MT, DBG>;
     constexpr int NB = RS::NB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *ring = smem;                                              // NB x CB

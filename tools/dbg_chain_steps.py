@@ -1,5 +1,6 @@
 """Per-ring-step time stamps (all 8 waves, one tile of workgroup 0) of the training-forward and delta-chain kernels
-at config 2: ticks spent computing and ticks waiting (DMA wait + barrier) per step.  bhn_debug_set_bwd_stages bit 12."""
+at config 2: ticks spent computing and ticks waiting (DMA wait + barrier) per step.  bhn_debug_set_bwd_stages bit 12.
+Needs the library built with the stamps compiled in:  make -C bhnerf_amd/csrc CXXFLAGS="... -DBHN_CHAIN_STAMPS=1"."""
 import sys, ctypes as C, numpy as np, torch
 sys.path.insert(0, '/root/repo')
 from bhnerf_amd import _hip, engine, network, synthetic, constants
