@@ -67,10 +67,8 @@ struct BwdGeom {
     static constexpr int NPASS = (NPW_ALL + 4) / 5;                    // <= 5 B tiles accumulated per sweep
     static constexpr int NPW = (NPW_ALL + NPASS - 1) / NPASS;
     static constexpr int GROUP_BYTES = (2 * MT + 1) * TILE_BYTES;   // A tiles + h tiles + enc tile
-    // chain kernels: prefetch distance of the LDS-DMA weight ring (RING_DIST+1 buffers of one chunk)
-    static constexpr int RING_DIST = (Pol::ELEM_BYTES == 2) ? 4 : 2;            // recompute kernel (LDS also holds the relu-bit stash)
-    static constexpr int RING_DIST_TAPED = (Pol::ELEM_BYTES == 2) ? BHN_TAPED_DIST : 3;   // training-forward / delta-chain kernels
-    template <int MODE> static constexpr int ring_dist() { return MODE == 0 ? RING_DIST : RING_DIST_TAPED; }
+    // chain kernels: prefetch distance of the LDS-DMA weight ring (RING_DIST_TAPED+1 buffers of one chunk)
+    static constexpr int RING_DIST_TAPED = (Pol::ELEM_BYTES == 2) ? BHN_TAPED_DIST : 3;
     // dW kernel, bf16: LDS-DMA ring of NBUF groups (counted vmcnt, raw s_barrier); f32: 2 buffers
     static constexpr int NBUF = (Pol::ELEM_BYTES == 2) ? ((160 * 1024) / GROUP_BYTES >= 4 ? 4 : 3) : 2;
     static constexpr int NPIECE = GROUP_BYTES / 1024;               // 1 KiB = one wave-wide 16-B DMA
@@ -162,7 +160,7 @@ struct TapeEmit {
 // output tile in the MFMA shadows of the running step --
 //   k-steps 0..7   RELU: relu + relu bits (forward) / !RELU: apply the recorded relu bits `mask` (delta chain),
 //                  repack into the B fragments d0, d1 of the next layer
-//   k-step  6, 8   identity fragments from LDS; relu bits -> tape word (and the recompute kernel's LDS stash), two
+//   k-step  6, 8   identity fragments from LDS; relu bits -> tape word, two
 //                  transposing MFMAs
 //   k-step 12      bf16 convert + two 1 KiB non-temporal stores to the tape (after the step's DMA issue at k-step 9)
 template <class Pol, bool RELU>
@@ -172,8 +170,7 @@ struct TapePost {
     unsigned mask;
     char *dst;
     // RELU: the relu bits of two consecutive tiles share a tape word [group][layer][tile/2][lane]: `macc` carries the
-    // even tile's half to the odd tile's step, which stores the word; `stash` (recompute kernel only) is the same
-    // word in this wave's LDS stash for the delta chain of the same tile
+    // even tile's half to the odd tile's step, which stores the word; `stash` (optional) is a second, LDS destination
     unsigned *mword, *stash;
     unsigned &macc;
     bool hi, last;          // odd tile of the word / last tile of the layer (stores a half-filled word when MT is odd)
@@ -235,13 +232,16 @@ void *bhn_debug_buffer();
 #ifndef BHN_EXTRA_YS
 #define BHN_EXTRA_YS 0
 #endif
-enum { MODE_RECOMPUTE = 0, MODE_FWD_TRAIN = 1, MODE_CHAIN = 2 };
+enum { MODE_FWD_TRAIN = 1, MODE_CHAIN = 2 };
 
-// MODE_RECOMPUTE: forward recompute + delta chain in one kernel (any dimages, any workspace size).
-// MODE_FWD_TRAIN:  the training forward: render (images) AND record h tiles, relu bits and e on the tape.
-// MODE_CHAIN:      delta chain only, from the relu bits / e recorded by MODE_FWD_TRAIN.
-// Weight-chunk stream of one tile: forward chunks 0..NCF-1 (not in MODE_CHAIN), then the transposed chunks of
-// hidden layers depth-1 .. 1 (not in MODE_FWD_TRAIN); the ring wraps to the next tile's first chunk.
+// MODE_FWD_TRAIN: the training forward: render (images, unless a.images is null) AND record h tiles, relu bits and
+//                 e on the tape.
+// MODE_CHAIN:     delta chain from the relu bits / e recorded by MODE_FWD_TRAIN.
+// bhn_render_bwd (gradient for arbitrary dimages, any workspace size) = both, frame group by frame group; a single
+// kernel doing both ("recompute" mode) needed the working sets of both halves in one register allocation and
+// spilled in its hot loop (12.8 ms vs 4.6 + 4.7 ms at config 2).
+// Weight-chunk stream of one tile: forward chunks 0..NCF-1 (MODE_FWD_TRAIN) or the transposed chunks of hidden
+// layers depth-1 .. 1 (MODE_CHAIN); the ring wraps to the next tile's first chunk.
 template <int W, class Pol, int DEG, int MODE>
 __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
     using PK = Pack<W, Pol>;
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
     const int edbg = (A.debug >> 6) & 3;           // measurement aid for the tape emission
     constexpr int sdbg = 0;                        // (a run-time MFMA-skip flag put every MFMA in its own basic block)
     using RG = DmaRing<CB, Pol::NWAVES>;
-    constexpr int DIST = BG::template ring_dist<MODE>();
+    constexpr int DIST = BG::RING_DIST_TAPED;
     using RS = RingState<RG, CB, DIST, false, MT, BHN_CHAIN_STAMPS != 0>;
     // stores guaranteed younger than chunk c+2 at the end of step c (RingState::step_end): every interval between
     // two DMA issues holds the >= ES stores of one pending-tile emission; with >= 16 k-steps the running step's
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
     constexpr int ES = (Pol::ELEM_BYTES == 2) ? 2 : 4;                 // global stores of one tile emission
     constexpr int YS = ES * (DIST - 2) + ((KS >= 16 && Pol::ELEM_BYTES == 2) ? ES : 0) + BHN_EXTRA_YS;   // (f32 emits at k-step 8)
     constexpr int YS0 = ES * (DIST - 2);                               // steps whose own stores precede their DMA issue
-    constexpr int YS_L1r = (KS >= 16) ? YS - (MODE == 0 ? 2 : 1) * ES : 0;      // first steps of layer 1 when h_1 is not emitted
+    constexpr int YS_L1r = (KS >= 16) ? YS - ES : 0;                   // first steps of layer 1 when h_1 is not emitted
     constexpr int YS_L1 = YS_L1r > 0 ? YS_L1r : 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *ring = smem;
@@ -270,12 +270,10 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
     float *zero_lds = bias_lds + (a.depth + 1) * W;
     float *wout_lds = zero_lds + 32;
     char *id_lds = reinterpret_cast<char *>(wout_lds + W);
-    unsigned *mask_all = reinterpret_cast<unsigned *>(id_lds + TapeEmit<Pol>::LDS_BYTES);   // relu-bit stash, MODE_RECOMPUTE only
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 31, h = lane >> 5;
     TapeEmit<Pol> em;
     em.init(id_lds);
-    unsigned *mask_w = mask_all + (size_t)wv * a.depth * MW * 64;       // [layer][word][lane]
     for (int i = tid; i < (a.depth + 1) * W; i += Pol::NTHREADS)
         bias_lds[i] = reinterpret_cast<const float *>(a.packed + a.bias_off)[i];
     if (tid < 32) zero_lds[tid] = 0.f;
@@ -355,7 +353,6 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
                 __builtin_nontemporal_store(enc[1], reinterpret_cast<frag *>(A.tape + A.t.encp_off + q * TB + Pol::FRAG_BYTES + lane * 16));
             }
             // ---- forward, layer 0: tile m-1 is packed, recorded and emitted behind the MFMAs of tile m ------
-            const bool keep_stash = MODE == MODE_RECOMPUTE;          // the delta chain of the same tile reads the bits back
             struct Tile0 {
                 const TapeEmit<Pol> &em;
                 char *dst;
@@ -373,8 +370,8 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
                     }
                     if (dst) em.emit(dst + (long long)m * TB, d0, d1, edbg);
                 }
-            } l0{em, drop_h1 ? nullptr : A.tape + A.t.h_off[1] + q * MT * TB, MODE == MODE_FWD_TRAIN ? mask_g + lane : nullptr,
-                 keep_stash ? mask_w + lane : nullptr, 0u, edbg};
+            } l0{em, drop_h1 ? nullptr : A.tape + A.t.h_off[1] + q * MT * TB, mask_g + lane,
+                 nullptr, 0u, edbg};
             f32x16 pend;
             layer0_step<W, Pol, RG, YS0>(rs, ap, enc, act, bias_lds, h, pend, l0);
             // ---- hidden layers 1..depth-1 and the output layer: the pending tile is (l-1, MT-1) at m = 0 ------
@@ -396,15 +393,14 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
                     const int widx = (pl_layer * MW + (pm >> 1)) * 64 + lane;
                     const bool no_h = drop_h1 && pl_layer == 0;     // layer 0's last tile: relu bits only
                     TapePost<Pol, true> post(pend, d0, d1, 0u, em, A.tape + A.t.h_off[pl_layer + 1] + (q * MT + pm) * TB,
-                                                 MODE == MODE_FWD_TRAIN ? mask_g + widx : nullptr, keep_stash ? mask_w + widx : nullptr,
+                                                 mask_g + widx, nullptr,
                                                  macc, pm & 1, pm == MT - 1, no_h ? (edbg | 2) : edbg);
                     // bias rows of the next tile: (l, m+1), or the first tile of the next sequence part
                     const float *bn = (out || (m == MT - 1 && l + 1 > a.depth)) ? nullptr : bl + 32 * (m + 1);
-                    if (out) bn = (MODE == MODE_FWD_TRAIN) ? bias_lds : zero_lds;
+                    if (out) bn = bias_lds;                           // next tile, layer 0
                     const f32x16 acc = ring_step<W, Pol, RG>(ch, chn, ap, act, enc, sk, bn, post, dj, sdbg);
                     // without the h_1 emission the interval after this layer's first DMA issue holds no store: the
                     // three step ends that count it allow one emission less in flight (small widths: none)
-                    // (the recompute kernel's layer-0 step stores nothing either: its relu bits stay in LDS)
                     if (drop_h1 && l == 1 && m <= 2) rs.template step_end<YS_L1>();
                     else if (drop_h1 && l == 1) rs.template step_end<(KS >= 16 ? YS : 0)>();
                     else rs.template step_end<YS>();
@@ -428,7 +424,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
             // record what the delta chain needs, then the render epilogue of fused_fwd_kernel
             if (h == 0) e_g[pl] = e;
             const long long ray = inb ? p / a.G : -1;
-            unsigned long long rem = __ballot(h == 0 && inb);
+            unsigned long long rem = a.images ? __ballot(h == 0 && inb) : 0ull;      // bhn_render_bwd: tape only
             while (rem) {
                 const int first = __ffsll((long long)rem) - 1;
                 const long long r0 = __shfl(ray, first, 64);
@@ -443,14 +439,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
         } else {
             float d = 0.f;
             if (h == 0 && inb && e != 0.f) {
-                float dE = 0.f;
-                if constexpr (MODE == MODE_CHAIN) dE = cin.dE;
-                else {
-                    const long long ray = p / a.G;
-                    for (int s = 0; s < a.Sx; ++s)
-                        dE += a.dimages[((long long)b * a.Sx + s) * a.R + ray] * a.w[(long long)s * a.P + p];
-                }
-                d = dE * e * (1.f - e);                            // sigmoid'(out-10) = e(1-e)
+                d = cin.dE * e * (1.f - e);                        // sigmoid'(out-10) = e(1-e)
             }
             dout = __shfl(d, pl, 64);                               // both lane halves need it
             // dout as a 32x32 (feature x point) tile whose feature 0 is dout: the A operand of dW_out
@@ -458,7 +447,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
             Pol::set(d0, 0, h == 0 ? d : 0.f);
             em.emit(A.tape + A.t.dout_off + q * TB, d0, d1, edbg);
         }
-        if constexpr (MODE != MODE_FWD_TRAIN) {
+        if constexpr (MODE == MODE_CHAIN) {
             // ---- gA_{depth-1} = wout * dout * relu'(a_{depth-1}); its last tile stays pending ---------------
             frag dl[KS];
             f32x16 pend = {};
@@ -466,8 +455,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
                 char *gdst = A.tape + A.t.ga_off[a.depth - 1] + q * MT * TB;
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
-                    const unsigned mw = ((MODE == MODE_CHAIN) ? cin.mtop[m >> 1] : mask_w[((a.depth - 1) * MW + (m >> 1)) * 64 + lane]) >>
-                                        ((m & 1) * 16);
+                    const unsigned mw = cin.mtop[m >> 1] >> ((m & 1) * 16);
                     f32x16 g;
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {
@@ -503,7 +491,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
                     frag &d1 = m == 0 ? dl[KS - 1] : next[2 * (m > 0 ? m - 1 : 0) + 1];
                     TapePost<Pol, false> post(pend, d0, d1, pnd_mask, em, A.tape + A.t.ga_off[pnd_layer] + (q * MT + pm) * TB,
                                                   nullptr, nullptr, no_acc, false, false, edbg);
-                    if (MODE == MODE_CHAIN && !(m & 1)) {            // word (l-1, m/2): use the oldest, fetch two ahead
+                    if (!(m & 1)) {                                  // word (l-1, m/2): use the oldest, fetch two ahead
                         mcur = mq0;
                         mq0 = mq1;
                         mq1 = chain_word(mask_g, (a.depth - 1 - l) * MW + (m >> 1) + 2);
@@ -513,7 +501,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
                     rs.template step_end<YS>();
                     pend = acc;
                     pnd_layer = l - 1;
-                    pnd_mask = ((MODE == MODE_CHAIN) ? mcur : mask_w[((l - 1) * MW + (m >> 1)) * 64 + lane]) >> ((m & 1) * 16);
+                    pnd_mask = mcur >> ((m & 1) * 16);
                 }
 #pragma unroll
                 for (int ks = 0; ks < KS - 2; ++ks) dl[ks] = next[ks];
@@ -523,7 +511,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
                                               A.tape + A.t.ga_off[0] + (q * MT + MT - 1) * TB, nullptr, nullptr, no_acc, false, false, edbg);
                 post.all();
             }
-        }   // MODE != MODE_FWD_TRAIN
+        }   // MODE_CHAIN
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may land after the workgroup has released its LDS
 }
@@ -996,24 +984,21 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
             return BHN_EINVAL;
         }
     }
-    // ring + bias rows + zero row + output weights + identity fragments; recompute kernel: + relu-bit stash
+    // ring + bias rows + zero row + output weights + identity fragments
     const size_t lds_fixed = (size_t)(depth + 1) * W * 4 + 128 + W * 4 + 2 * Pol::FRAG_BYTES;
-    const size_t lds_rec = (size_t)(BG::RING_DIST + 1) * PK::CHUNK_BYTES + lds_fixed + (size_t)Pol::NWAVES * depth * ((BG::MT + 1) / 2) * 64 * 4;
     const size_t lds_taped = (size_t)(BG::RING_DIST_TAPED + 1) * PK::CHUNK_BYTES + lds_fixed;
     const size_t lds_dw = (size_t)BG::NBUF * BG::GROUP_BYTES + (t1.drop_h1 ? (size_t)2 * BG::MT * Pol::FRAG_BYTES + W * 4 : 0);
-    auto k_rec = chain_kernel<W, Pol, 3, MODE_RECOMPUTE>;
     auto k_fwd = chain_kernel<W, Pol, 3, MODE_FWD_TRAIN>;
     auto k_chn = chain_kernel<W, Pol, 3, MODE_CHAIN>;
     auto kdw = dw_kernel<W, Pol>;
     static bool attr_done = false;
     if (!attr_done) {
-        BHN_HIP(hipFuncSetAttribute((const void *)k_rec, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         BHN_HIP(hipFuncSetAttribute((const void *)k_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         BHN_HIP(hipFuncSetAttribute((const void *)k_chn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         BHN_HIP(hipFuncSetAttribute((const void *)kdw, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
-    BHN_CHECK_ARG(lds_rec <= 160 * 1024 && lds_taped <= 160 * 1024 && lds_dw <= 160 * 1024, "LDS budget exceeded (chain %zu / %zu, dw %zu)", lds_rec, lds_taped, lds_dw);
+    BHN_CHECK_ARG(lds_taped <= 160 * 1024 && lds_dw <= 160 * 1024, "LDS budget exceeded (chain %zu, dw %zu)", lds_taped, lds_dw);
     const int B_total = A.f.B;
     const double *tM0 = A.f.tM0;
     if (what == RUN_FWD_TRAIN)
@@ -1036,8 +1021,11 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
             continue;
         }
         if (g_bwd_stages & 1) {
-            if (what == RUN_BWD_TAPE) hipLaunchKernelGGL(k_chn, dim3((unsigned)grid), dim3(Pol::NTHREADS), lds_taped, st, A);
-            else hipLaunchKernelGGL(k_rec, dim3((unsigned)grid), dim3(Pol::NTHREADS), lds_rec, st, A);
+            if (what == RUN_RECOMPUTE) {     // forward again (tape only: A.f.images is null), then the chain
+                hipLaunchKernelGGL(k_fwd, dim3((unsigned)grid), dim3(Pol::NTHREADS), lds_taped, st, A);
+                BHN_HIP(hipGetLastError());
+            }
+            hipLaunchKernelGGL(k_chn, dim3((unsigned)grid), dim3(Pol::NTHREADS), lds_taped, st, A);
         }
         BHN_HIP(hipGetLastError());
         if (g_bwd_stages & 2) hipLaunchKernelGGL(kdw, dim3((unsigned)A.wg_begin[depth + 1]), dim3(Pol::NTHREADS), lds_dw, st, A);

@@ -112,9 +112,9 @@ int bhn_render_fwd(const bhn_model *m, int32_t mode, const void *packed, const b
                    const bhn_frames *fr, float *images, void *stream);
 
 /* Reverse of bhn_render_fwd w.r.t. the parameters (jax.value_and_grad in network.py:617):
- * dimages (B,Sx,R) -> dparams (flat f32, overwritten).  Per 32-point tile the forward is recomputed
- * and the delta chain is run in registers; layer inputs and pre-activation gradients are streamed
- * to a fragment-ordered tape inside `workspace`, from which the weight-gradient GEMMs (K = points)
+ * dimages (B,Sx,R) -> dparams (flat f32, overwritten).  The training forward is run again (tape only)
+ * and then the delta chain, both register-chained per 32-point tile; layer inputs and pre-activation
+ * gradients are streamed to a fragment-ordered tape inside `workspace`, from which the weight-gradient GEMMs (K = points)
  * accumulate one layer per workgroup in registers; per-workgroup slabs are reduced at the end
  * (deterministic, no float atomics).  bhn_render_bwd_workspace_bytes(B,P) is the size that holds
  * all B frames at once; any workspace that holds the slabs plus ONE frame of tape is accepted and

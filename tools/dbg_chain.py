@@ -20,7 +20,10 @@ def timed(fn, reps=4):
 lib = _hip.lib()
 eng.render_train(geom, tM0); eng.render_bwd_tape(geom, tM0, dimg)
 print('inference fwd %.3f ms' % timed(lambda: eng.render(geom, tM0)))
-for name, bits in (('full', 0), ('emit w/o global stores', 1 << 9), ('no emit', 1 << 10), ('no MFMA, full emit', 1 << 11), ('no MFMA, no emit', (1 << 11) | (1 << 10))):
+lib.bhn_debug_set_bwd_stages(1)
+print('bhn_render_bwd, forward + chain stage %.3f ms' % timed(lambda: eng.render_bwd(geom, tM0, dimg)))
+lib.bhn_debug_set_bwd_stages(7)
+for name, bits in (('full', 0), ('emit w/o global stores', 1 << 9), ('no emit', 1 << 10)):
     lib.bhn_debug_set_bwd_stages(7 | bits)
     t1 = timed(lambda: eng.render_train(geom, tM0))
     lib.bhn_debug_set_bwd_stages(1 | bits)
