@@ -201,8 +201,8 @@ def main():
     else:
         kern_ms = {'fused_fwd_kernel': timed(lambda: eng.render(geom, tM0))}
         bwd = lambda: eng.render_bwd(geom, tM0, dimg)
-        names = (('chain_kernel<MODE_RECOMPUTE>', 1), ('dw_kernel', 2), ('reduce_kernel', 4))
-        fwd_name, chain_name = 'fused_fwd_kernel', 'chain_kernel<MODE_RECOMPUTE>'
+        names = (('chain_kernel<FWD_TRAIN+CHAIN> (bhn_render_bwd)', 1), ('dw_kernel', 2), ('reduce_kernel', 4))
+        fwd_name, chain_name = 'fused_fwd_kernel', 'chain_kernel<FWD_TRAIN+CHAIN> (bhn_render_bwd)'
     for name, mask in names:
         lib.bhn_debug_set_bwd_stages(mask)
         kern_ms[name] = timed(bwd)
@@ -210,7 +210,7 @@ def main():
     kern_ms['fused_fwd_kernel (inference)'] = timed(lambda: eng.render(geom, tM0))
     pts = args.frames_per_gpu * geom.P * geom.visited_fraction     # points that go through the MLP
     f_fwd, f_chain, f_dw, f_train = mlp_flops(args.depth, args.width)
-    alg = {fwd_name: f_fwd, chain_name: f_chain, 'dw_kernel': f_dw}
+    alg = {fwd_name: f_fwd, chain_name: f_chain + (0 if group else f_fwd), 'dw_kernel': f_dw}
     dom = max(alg, key=lambda k: kern_ms[k])
     # tape bytes per point the dW stream reads once: (h + gA tiles of every layer + enc + dout) / 32 points
     elem = 2 if args.mode == 'bf16' else 4
