@@ -212,9 +212,17 @@ def main():
     f_fwd, f_chain, f_dw, f_train = mlp_flops(args.depth, args.width)
     alg = {fwd_name: f_fwd, chain_name: f_chain + (0 if group else f_fwd), 'dw_kernel': f_dw}
     dom = max(alg, key=lambda k: kern_ms[k])
-    # tape bytes per point the dW stream reads once: (h + gA tiles of every layer + enc + dout) / 32 points
+    # tape bytes per point the dW stream reads once: per 32-point group and layer job the gA tiles (dout for
+    # the output layer) + the input tiles (encoded inputs for layer 0, for a skip layer in addition, and -- bf16 -- INSTEAD
+    # of h_1 for layer 1, which that job recomputes)
     elem = 2 if args.mode == 'bf16' else 4
-    tape_bpp = (2 * args.depth * (args.width // 32) + 2) * (32 * 32 * elem) / 32.0
+    mt = args.width // 32
+    skip_layer = args.depth // 2 + 1 if args.depth >= 4 else None          # the layer that consumes concat[h, enc] (do_skip)
+    tiles = (mt + 1) + (1 + mt)                                            # layer 0, output layer
+    for l in range(1, args.depth):
+        recomputed = l == 1 and args.mode == 'bf16' and l != skip_layer
+        tiles += mt + (1 if recomputed else mt) + (1 if l == skip_layer else 0)
+    tape_bpp = tiles * (32 * 32 * elem) / 32.0
     try:      # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (profiles/)
         pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r1_pmc_traffic.json')))['kernels']
         std = H == 128 and G == 64 and args.frames_per_gpu == 8 and args.width == 256 and args.mode == 'bf16' and not args.masked
