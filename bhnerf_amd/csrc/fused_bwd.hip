@@ -18,7 +18,7 @@
 #define BHN_CHAIN_STAMPS 0      // 1: ring-step time stamps in the chain kernels (tools/dbg_chain_steps.py needs this build)
 #endif
 #ifndef BHN_JOB1_W
-#define BHN_JOB1_W 12
+#define BHN_JOB1_W 12          // weight of the layer-1 dW job in B tiles at width 256 (measured optimum; scaled with the width)
 #endif
 #ifndef BHN_TAPED_DIST
 #define BHN_TAPED_DIST 6
@@ -606,10 +606,9 @@ DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
             acc = Pol::mma(in.e0, in.w0, acc);
             acc = Pol::mma(in.e1, in.w1, acc);
             frag o[2];
+            unsigned unused = 0;
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) Pol::set(o[s2], j, Pol::relu(acc[8 * s2 + j]));
+            for (int r = 0; r < 16; r += 2) Pol::relu_pair(o[r >> 3], (r & 7) >> 1, r >> 1, acc[r], acc[r + 1], unused);
             if constexpr (Pol::ELEM_BYTES == 2) {
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) *reinterpret_cast<frag *>(gp + OFF_H + wv * TB + s2 * Pol::FRAG_BYTES + lane * 16) = o[s2];
@@ -964,7 +963,7 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
         for (int l = 0; l <= depth; ++l) {
             const int mtA = (l == depth) ? 0 : BG::MT;
             int nB = (l >= 1 ? BG::MT : 0) + ((l == 0 || s.skip_in[l]) ? 1 : 0);
-            if (l == 1 && t1.drop_h1) nB = BHN_JOB1_W;            // reads only the encoded inputs instead of h_1 but has the
+            if (l == 1 && t1.drop_h1) nB = BHN_JOB1_W * BG::MT / 8;   // reads only the encoded inputs instead of h_1 but has the
                                                                   // same MFMA work + the recompute: not byte-bound any more
             work[l] = (double)(mtA + nB) + 0.5;
             tot += work[l];

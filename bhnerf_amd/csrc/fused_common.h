@@ -51,7 +51,7 @@ struct PolBF16 {
     // ReLU bits of a 32x32 tile, per lane a 16-bit code: bit k = element 2k is active, bit 8+k = element 2k+1
     // (k = 0..7: the k-th packed dword of the tile's two B fragments).  While a tile is being packed the bits are
     // kept "spread" (bit k and bit 16+k), which is what two-at-a-time operations on the packed dword produce:
-    //   relu_pair : dword = pack(relu(a), relu(b)); spread |= min_u16x2(dword, 1) << k        (5 VALU per pair)
+    //   relu_pair : dword = max_i16x2(pack(a, b), 0); spread |= min_u16x2(dword, 1) << k     (4 VALU per pair)
     //   mask_pair : dword = pack(a, b) & (((spread >> k) & 0x00010001) * 0xffff)              (5 VALU per pair)
     // A bf16 result of +0 counts as inactive (an f32 pre-activation below 2^-133 would be active in exact arithmetic).
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -61,8 +61,12 @@ struct PolBF16 {
         f = __builtin_bit_cast(frag, w);
     }
     static DEVI void relu_pair(frag &f, int i, int k, float a, float b, unsigned &spread) {
-        const bf16x2 t = {(__bf16)relu(a), (__bf16)relu(b)};
-        const unsigned u = __builtin_bit_cast(unsigned, t);
+        // round first, then clamp the two bf16 halves as signed 16-bit integers (sign bit set -> 0, -0 -> +0): one
+        // v_cvt_pk + one v_pk_max_i16 instead of two v_max per element (hipcc canonicalises before every max).
+        // Inline asm only on the VALU result of the convert, never on an MFMA accumulator (hazard, see relu()).
+        const bf16x2 t = {(__bf16)a, (__bf16)b};
+        unsigned u;
+        asm("v_pk_max_i16 %0, %1, 0" : "=v"(u) : "v"(__builtin_bit_cast(unsigned, t)));
         put_dword(f, i, u);
 #ifndef BHN_NO_MASK
         unsigned m;      // (plain VALU reading a VALU result: no hazard the compiler would have to know about; the
