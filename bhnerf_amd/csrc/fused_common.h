@@ -34,7 +34,7 @@ struct PolBF16 {
     static constexpr int NTHREADS = NWAVES * 64;
     static constexpr int ELEM_BYTES = 2;
     static constexpr int FRAG_BYTES = 1024;     // 64 lanes x 8 bf16
-    static constexpr int LDS_PREFETCH = 4;      // A fragments in flight + 1 (tile_matmul, hidden_step); 8 measured no faster
+    static constexpr int LDS_PREFETCH = 4;      // A fragments in flight + 1 (ring_step); 8 measured no faster
     static constexpr bool PHASE_LAG = false;    // RingState LAG: measured 5 % slower in the render kernel, off
     using frag = bf16x8;
     static DEVI frag zero() { frag f; for (int j = 0; j < 8; ++j) f[j] = (__bf16)0.f; return f; }
@@ -179,32 +179,6 @@ struct Pack {
 };
 
 // ---------------------------------------------------------------------------------------------
-// Double-buffered weight ring: global (L2) -> registers -> LDS, one barrier per chunk.
-// ---------------------------------------------------------------------------------------------
-template <int CHUNK_BYTES, int NTHREADS>
-struct Stager {
-    static constexpr int PIECES = (CHUNK_BYTES + NTHREADS * 16 - 1) / (NTHREADS * 16);
-    u32x4 st[PIECES];
-    // every thread always loads (the tail piece re-reads the last 16 bytes) so that st[] is fully
-    // initialised and stays in registers; only the store is guarded
-    DEVI void load(const char *src) {
-#pragma unroll
-        for (int i = 0; i < PIECES; ++i) {
-            int off = (i * NTHREADS + (int)threadIdx.x) * 16;
-            off = off < CHUNK_BYTES ? off : CHUNK_BYTES - 16;
-            st[i] = *reinterpret_cast<const u32x4 *>(src + off);
-        }
-    }
-    DEVI void store(char *dst) const {
-#pragma unroll
-        for (int i = 0; i < PIECES; ++i) {
-            const int off = (i * NTHREADS + (int)threadIdx.x) * 16;
-            if (off < CHUNK_BYTES) *reinterpret_cast<u32x4 *>(dst + off) = st[i];
-        }
-    }
-};
-
-// ---------------------------------------------------------------------------------------------
 // Per-point prologue: velocity warp (emission.py:200-210) + positional encoding (network.py:118-122)
 // ---------------------------------------------------------------------------------------------
 struct PointState {
@@ -331,47 +305,6 @@ DEVI f32x16 bias_acc(const float *bias_lds, int m, int h) {
     return acc;
 }
 
-// One 32-row output tile of a hidden layer: acc = bias + sum_ks A[ks] . act[ks] (+ enc block)
-template <int W, class Pol>
-DEVI f32x16 tile_matmul(const char *chunk, const typename Pol::frag (&act)[W / 16],
-                        const typename Pol::frag (&enc)[2], bool with_enc, f32x16 acc) {
-    const int lane = threadIdx.x & 63;
-    constexpr int KS = W / 16;
-    // A fragments are read PF-1 k-steps ahead of the MFMA that consumes them (rotating register slots) so that
-    // the LDS latency overlaps the MFMAs of this wave, not only those of the SIMD's other wave; the scheduling
-    // fences keep the compiler from sinking the reads back to their uses (it minimises registers otherwise).
-    constexpr int PF = Pol::LDS_PREFETCH;
-    typename Pol::frag a[PF];
-#pragma unroll
-    for (int i = 0; i < PF - 1; ++i) a[i] = Pol::lds_frag(chunk, i, lane);
-    __builtin_amdgcn_sched_barrier(0x6);
-#pragma unroll
-    for (int t = 0; t < KS + 2; ++t) {
-        if (t + PF - 1 < KS + 2) a[(t + PF - 1) % PF] = Pol::lds_frag(chunk, t + PF - 1, lane);
-        if (t < KS) acc = Pol::mma(a[t % PF], act[t], acc);
-        else if (with_enc) acc = Pol::mma(a[t % PF], enc[t - KS], acc);
-        __builtin_amdgcn_sched_barrier(0x6);                               // VALU/SALU may cross, DS and MFMA may not
-    }
-    return acc;
-}
-
-// relu + repack accumulator tile m into the next layer's B fragments 2m, 2m+1; returns the
-// 16-bit relu mask (bit r set where acc[r] > 0)
-template <int W, class Pol>
-DEVI unsigned relu_pack(const f32x16 &acc, int m, typename Pol::frag (&next)[W / 16]) {
-    unsigned mask = 0;
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float v = acc[8 * s + j];
-            const bool pos = v > 0.f;
-            mask |= pos ? (1u << (8 * s + j)) : 0u;
-            Pol::set(next[2 * m + s], j, pos ? v : 0.f);
-        }
-    return mask;
-}
-
 // ---------------------------------------------------------------------------------------------
 // Software-pipelined ring steps (fused_fwd_kernel).  Three things that used to sit between the MFMA chains
 // of consecutive steps are folded INTO the chains, because the workgroup barrier keeps all eight waves in
@@ -491,7 +424,7 @@ DEVI f32x16 ring_step(const char *ch, const char *chn, APipe<Pol> &ap, const typ
 // One wave copies 1 KiB global -> LDS without registers: lane i's 16 bytes land at dst + 16 i (src, dst wave-
 // uniform).  The MUBUF form (buffer_load_dwordx4 ... lds) is used on purpose: the compiler's waitcnt pass books
 // the FLAT form (global_load_lds_dwordx4) as a pending flat access and then degrades every later LDS wait to
-// lgkmcnt(0), which serialises the software-pipelined A-fragment reads in tile_matmul.
+// lgkmcnt(0), which serialises the software-pipelined A-fragment reads of ring_step.
 DEVI void dma_1k(const char *src, char *dst) {
     const unsigned long long u = reinterpret_cast<unsigned long long>(src);
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));

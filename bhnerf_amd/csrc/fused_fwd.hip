@@ -295,11 +295,8 @@ static int launch_fwd(FusedArgs &a, int width, hipStream_t st) {
     }
 }
 
-int launch_fwd2_bf16(const bhn_model *m, const void *packed, const bhn_geom *geom, const bhn_frames *fr, bool render,
-                     float *out, hipStream_t st);
-// 1 (default): 8 waves x 32 points.  2: wide-tile variant (4 waves x 64 points, fused_fwd2.hip) -- bit-identical
-// output but 17 % slower on MI355X (4.16 vs 3.56 ms at 4x256): at 508 registers hipcc cannot prefetch A fragments,
-// every ds_read latency is exposed.  Kept for A/B measurements only.
+// measurement aid: low 4 bits 1 = production kernel (default), 3 = ablation build of the 4x256 render kernel with the
+// flags of fused_fwd_kernel<DBG> in bits 4.. .  (Variant 2, a 4 waves x 64 points tile, was 17 % slower and is gone.)
 static thread_local int g_fwd_variant = 1;
 extern "C" int bhn_debug_set_fwd_variant(int32_t v) {
     g_fwd_variant = v;
@@ -325,10 +322,6 @@ extern "C" int bhn_predict_fwd(const bhn_model *m, int32_t mode, const void *pac
     FusedArgs a;
     MlpShape s;
     BHN_CHECK_ARG(emission, "null emission");
-    if (mode == BHN_BF16 && g_fwd_variant == 2 && m && packed && geom && fr) {
-        const int rc2 = launch_fwd2_bf16(m, packed, geom, fr, false, emission, (hipStream_t)stream);
-        if (rc2 != -1) return rc2;
-    }
     const int nw = (mode == BHN_BF16) ? PolBF16::NWAVES : PolF32::NWAVES;
     int rc = fused_fill_args(m, mode, packed, geom, fr, false, &a, &s, nw);
     if (rc != BHN_OK) return rc;
@@ -344,10 +337,6 @@ extern "C" int bhn_render_fwd(const bhn_model *m, int32_t mode, const void *pack
     FusedArgs a;
     MlpShape s;
     BHN_CHECK_ARG(images, "null images");
-    if (mode == BHN_BF16 && g_fwd_variant == 2 && m && packed && geom && fr) {
-        const int rc2 = launch_fwd2_bf16(m, packed, geom, fr, true, images, (hipStream_t)stream);
-        if (rc2 != -1) return rc2;
-    }
     const int nw = (mode == BHN_BF16) ? PolBF16::NWAVES : PolF32::NWAVES;
     int rc = fused_fill_args(m, mode, packed, geom, fr, true, &a, &s, nw);
     if (rc != BHN_OK) return rc;

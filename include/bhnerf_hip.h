@@ -171,8 +171,8 @@ int bhn_adam_step(float *params, const float *grads, float *m, float *v, int64_t
 /* Measurement aid (bench.py): run only some kernels of bhn_render_bwd on this thread.
  * bit 0 = chain kernel, bit 1 = dW GEMM kernel, bit 2 = slab reduction; default 7. */
 int bhn_debug_set_bwd_stages(int32_t mask);
-/* Measurement aid: bf16 forward kernel variant.  Low 4 bits: 1 = 8 waves x 32 points (default), 2 = 4 waves x
- * 64 points, 3 = ablation build of the 4x256 render kernel; bits 4.. = its ablation flags (fused_fwd.hip). */
+/* Measurement aid: bf16 forward kernel variant.  Low 4 bits: 1 = production kernel (default), 3 = ablation build
+ * of the 4x256 render kernel; bits 4.. = its ablation flags (fused_fwd.hip). */
 int bhn_debug_set_fwd_variant(int32_t variant);
 /* Measurement aid: copy the first `bytes` (<= 4096) of the ablation build's stamp buffer to the host. */
 int bhn_debug_read(void *dst_host, size_t bytes);
