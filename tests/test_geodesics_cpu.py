@@ -1,0 +1,178 @@
+"""Geodesic-side pre-compute: own Kerr ray tracer (bhnerf_amd/geodesics.py) and the NumPy restatement of
+bhnerf/kgeo.py:65-593 (bhnerf_amd/kgeo.py).  The reference's versions need xarray and the external kgeo package, so
+parity is unpinned; these tests hold the code to the invariants of the physics instead."""
+import numpy as np
+import pytest
+
+from bhnerf_amd import geodesics as G
+from bhnerf_amd import kgeo as K
+
+
+@pytest.fixture(scope='module')
+def geos():
+    return G.image_plane_geos(0.6, np.deg2rad(60.0), (-7.0, 7.0), (-7.0, 7.0), ngeo=40, num_alpha=6, num_beta=6)
+
+
+def test_constants_of_motion_and_layout(geos):
+    g = geos
+    assert g.r.shape == (6, 6, 40) and g.dims == {'alpha': 6, 'beta': 6, 'geo': 40}
+    assert g.lam.shape == (6, 6) and np.allclose(g.lam, -g.alpha * np.sin(g.inc))
+    assert np.allclose(g.eta, (g.alpha ** 2 - 0.36) * np.cos(g.inc) ** 2 + g.beta ** 2)
+    # (dr/dlambda)^2 = R(r), (dtheta/dlambda)^2 = Theta(theta) along every ray, relative to the scale of the potentials
+    assert (np.abs(g.vr ** 2 - g.R) / g.r ** 4).max() < 2e-3
+    assert (np.abs(g.vth ** 2 - g.Theta) / (g.eta + 0.36 + g.lam ** 2)[..., None]).max() < 2e-2
+    # samples are uniform in Mino time, time runs backwards from the observer, Sigma dtau is the affine step
+    assert np.allclose(np.diff(g.mino, axis=-1), -g.dtau[..., 1:]) and (g.dtau > 0).all()
+    assert (np.diff(g.t, axis=-1) < 0).all() and (g.t < 0).all()
+    assert np.allclose(np.diff(g.affine, axis=-1), -(g.Sigma * g.dtau)[..., 1:])
+    assert np.allclose(g.x ** 2 + g.y ** 2 + g.z ** 2, g.r ** 2)
+    Delta, Sigma, Xi, omega = G.kerr_functions(g.r, g.theta, 0.6)
+    assert np.allclose(g.Sigma, g.r ** 2 + 0.36 * np.cos(g.theta) ** 2) and np.allclose(g.Delta, Delta) and np.allclose(g.omega, omega)
+
+
+def test_flat_space_limit_gives_straight_lines_and_euclidean_travel_time():
+    inc = np.deg2rad(50.0)
+    g = G.image_plane_geos(0.0, inc, (2.0, 6.0), (-5.0, -3.0), ngeo=30, num_alpha=2, num_beta=2, distance=200.0, M=1e-9)
+    pts = np.stack([g.x, g.y, g.z], axis=-1)
+    obs = 200.0 * np.array([np.sin(inc), 0.0, np.cos(inc)])
+    for i in range(2):
+        for j in range(2):
+            p = pts[i, j]
+            d = p[-1] - p[0]
+            d /= np.linalg.norm(d)
+            off = (p - p[0]) - ((p - p[0]) @ d)[:, None] * d
+            assert np.abs(off).max() < 1e-3                                   # collinear
+            dist = np.linalg.norm(p - obs, axis=-1)
+            assert np.abs(-g.t[i, j] - dist).max() < 2e-3 * 200.0             # light-travel time = distance
+            # closest approach to the origin = impact parameter
+            b = np.hypot(g.alpha[i, j], g.beta[i, j])
+            t = -(p[0] @ d)
+            assert abs(np.linalg.norm(p[0] + t * d) - b) < 2e-3 * b
+
+
+def test_schwarzschild_shadow_radius():
+    """Rays with impact parameter below sqrt(27) M fall into the hole, above it they escape."""
+    bc = np.sqrt(27.0)
+    traj, last, _, _ = G.trace([bc - 0.05, bc + 0.05, 0.0, 0.0], [1e-6, 1e-6, bc - 0.05, bc + 0.05], 0.0, np.deg2rad(30.0))
+    r_end = traj[last, 1, np.arange(4)]
+    assert r_end[0] < 2.2 and r_end[2] < 2.2 and r_end[1] > 999.0 and r_end[3] > 999.0
+
+
+def test_equatorial_reflection_symmetry_at_edge_on():
+    g = G.image_plane_geos(0.8, 0.5 * np.pi, (-6.0, 6.0), (-5.0, 5.0), ngeo=25, num_alpha=3, num_beta=2)
+    assert np.allclose(g.r[:, 0], g.r[:, 1], rtol=1e-6, atol=1e-6)
+    assert np.allclose(g.theta[:, 0], np.pi - g.theta[:, 1], atol=1e-6)
+    assert np.allclose(g.t[:, 0], g.t[:, 1], rtol=1e-6, atol=1e-5)
+
+
+def _dot(gm, u, v):
+    return (gm.tt * u[..., 0] * v[..., 0] + gm.rr * u[..., 1] * v[..., 1] + gm.thth * u[..., 2] * v[..., 2] +
+            gm.phph * u[..., 3] * v[..., 3] + gm.tph * (u[..., 0] * v[..., 3] + u[..., 3] * v[..., 0]))
+
+
+def test_velocity_wave_vector_and_tetrads(geos):
+    g = geos
+    gm, gi = K.spacetime_metric(g), K.spacetime_inv_metric(g)
+    # metric times inverse metric (t-phi block)
+    assert np.allclose(gm.tt * gi.tt + gm.tph * gi.tph, 1.0) and np.allclose(gm.tt * gi.tph + gm.tph * gi.phph, 0.0, atol=1e-12)
+    assert np.allclose(gm.rr * gi.rr, 1.0) and np.allclose(gm.thth * gi.thth, 1.0)
+    Omega = 1.0 / (g.r ** 1.5 + g.spin)                                           # Keplerian
+    ok = g.r > 4.5                                                                # timelike circular orbits
+    u = K.azimuthal_velocity_vector(g, Omega)
+    assert u.shape == g.r.shape + (4,) and np.allclose(_dot(gm, u, u)[ok], -1.0)
+    k = K.wave_vector(g)
+    kk = gi.tt * k[..., 0] ** 2 + gi.rr * k[..., 1] ** 2 + gi.thth * k[..., 2] ** 2 + gi.phph * k[..., 3] ** 2 + 2 * gi.tph * k[..., 0] * k[..., 3]
+    inside = slice(1, -1)                  # np.gradient signs are one-sided at the two ends of a ray
+    assert (np.abs(kk) / np.abs(gi.tt * k[..., 0] ** 2))[..., inside].max() < 1e-9        # null
+    assert np.allclose(K.raise_or_lower_indices(gm, K.raise_or_lower_indices(gi, k)), k)
+    # orthonormal tetrads: g_{mu nu} e_a^mu e_b^nu = diag(-1, 1, 1, 1)
+    eta = np.diag([-1.0, 1.0, 1.0, 1.0])
+    e = K.fluid_frame_tetrad(g, u)
+    assert e.shape == g.r.shape + (4, 4)
+    for a in range(4):
+        for b in range(4):
+            assert np.allclose(_dot(gm, e[..., :, a], e[..., :, b])[ok], eta[a, b], atol=1e-9), (a, b)
+    # the boosted-ZAMO expressions (Gelles et al. 2021, A4) are written for the equatorial plane (Sigma = r^2)
+    r = np.linspace(2.5, 30.0, 12)
+    eq = G.Geodesics(r=r, theta=np.full_like(r, 0.5 * np.pi), M=1.0, spin=0.6)
+    eq['Delta'], eq['Sigma'], eq['Xi'], eq['omega'] = G.kerr_functions(r, eq.theta, 0.6)
+    gq = K.spacetime_metric(eq)
+    ez = K.zamo_frame_tetrad(eq, 0.3, 0.7)
+    for a in range(4):
+        for b in range(4):
+            assert np.allclose(_dot(gq, ez[..., :, a], ez[..., :, b]), eta[a, b], atol=1e-9), (a, b)
+    uz = K.zamo_frame_velocity(eq, 0.3, 0.7)
+    assert np.allclose(_dot(gq, uz, uz), -1.0) and np.allclose(ez[..., :, 0], uz)     # e_t is the observer's 4-velocity
+    u0 = K.zamo_frame_velocity(eq, 0.0, 0.0)
+    assert np.allclose(u0[..., 3] / u0[..., 0], eq.omega)                             # beta = 0: the ZAMO itself
+    assert np.allclose(K.transform_coordinates(u, np.broadcast_to(np.eye(4), u.shape + (4,)), 'lower')[ok], u[ok])
+    with pytest.raises(AttributeError):
+        K.transform_coordinates(u, np.eye(4), 'sideways')
+
+
+def test_doppler_factor_limits(geos):
+    g = geos
+    # static emitters: pure gravitational redshift g = sqrt(-g_tt)
+    u0 = K.azimuthal_velocity_vector(g, 0.0)
+    red = K.doppler_factor(g, u0)
+    out = g.r > 2.5                                                               # outside the ergosphere
+    assert np.allclose(red[out], np.sqrt(1.0 - 2.0 * g.r / g.Sigma)[out])
+    # far from the hole: the special-relativistic Doppler factor 1 / (gamma (1 - v.n))
+    far = G.image_plane_geos(0.0, np.deg2rad(60.0), (150.0, 200.0), (10.0, 20.0), ngeo=400, num_alpha=2, num_beta=2, distance=2000.0)
+    Omega = 1e-3
+    u = K.azimuthal_velocity_vector(far, Omega)
+    gd = K.doppler_factor(far, u)
+    pos = np.stack([far.x, far.y, far.z], axis=-1)
+    n = -np.gradient(pos, axis=-2)                                # photon direction of travel (samples run backwards)
+    n /= np.linalg.norm(n, axis=-1, keepdims=True)
+    v = Omega * np.stack([-far.y, far.x, np.zeros_like(far.x)], axis=-1)
+    sr = np.sqrt(1.0 - (v ** 2).sum(-1)) / (1.0 - (v * n).sum(-1))
+    sel = (far.r > 150.0) & (far.r < 400.0)
+    sel[..., :2] = False; sel[..., -2:] = False
+    assert sel.sum() > 20 and np.abs(gd / sr - 1.0)[sel].max() < 2e-2      # O(M/r) corrections
+    # superluminal rotation -> NaN -> fillna
+    big = K.azimuthal_velocity_vector(g, 10.0)
+    assert np.isnan(K.doppler_factor(g, big, fillna=False)).any()
+    assert not np.isnan(K.doppler_factor(g, big)).any() and (K.doppler_factor(g, big, fillna=0.0) == 0.0).any()
+
+
+def test_parallel_transport_stokes_factors(geos):
+    g = geos
+    Omega = 1.0 / (g.r ** 1.5 + g.spin)
+    u = K.azimuthal_velocity_vector(g, Omega)
+    dop = K.doppler_factor(g, u)
+    b = K.magnetic_field_fluid_frame(g, u, arad=0.0, avert=1.0, ator=0.0)
+    assert b.shape == g.r.shape + (3,)
+    ok = (g.r > 4.5)
+    ok[..., 0] = False; ok[..., -1] = False
+    J = K.parallel_transport(g, u, dop, b, Q_frac=0.3, V_frac=0.01, spectral_index=1)
+    assert J.shape == (4,) + g.r.shape
+    J3 = K.parallel_transport(g, u, dop, b, Q_frac=0.3, V_frac=0)
+    assert J3.shape == (3,) + g.r.shape and np.allclose(J3[:, ok], J[:3][:, ok])
+    # the transport only rotates the polarisation plane: |Q + iU| = Q_frac * I, and I > 0
+    assert (J[0][ok] > 0).all()
+    assert np.allclose(np.hypot(J[1], J[2])[ok], 0.3 * J[0][ok], rtol=1e-10)
+    # I = g^s |b|^(s+1) sinB^(s+1) with the reference's sinB = |k' x b| / |k'|^2 (k' = wave vector in the fluid frame)
+    bmag = np.sqrt((b ** 2).sum(-1))
+    kloc = K.transform_coordinates(K.wave_vector(g), K.fluid_frame_tetrad(g, u), 'upper')[..., 1:]
+    sinb = np.linalg.norm(np.cross(kloc, b), axis=-1) / (kloc ** 2).sum(-1)
+    assert np.allclose(J[0][ok], (dop * bmag ** 2 * sinb ** 2)[ok], rtol=1e-10)
+    # in the fluid frame the photon energy is E / g: |k'| = 1 / g
+    assert np.allclose(np.linalg.norm(kloc, axis=-1)[ok], 1.0 / dop[ok], rtol=1e-6)
+    Jz = K.parallel_transport_zamo(g, 0.3, 0.7, dop, K.magnetic_field_spherical(g, 0.0, 1.0, 0.0), Q_frac=0.2)
+    assert Jz.shape == (3,) + g.r.shape and np.allclose(np.hypot(Jz[1], Jz[2])[ok], 0.2 * Jz[0][ok], rtol=1e-10)
+    with pytest.raises(AttributeError):
+        K.parallel_transport(g, u, dop, b, Q_frac=1.5)
+
+
+def test_raytracing_args_takes_the_traced_geodesics(geos):
+    from bhnerf_amd import network, units
+    g = geos
+    Omega = 1.0 / (g.r ** 1.5 + g.spin)
+    u = K.azimuthal_velocity_vector(g, Omega)
+    geo = G.Geodesics(g)
+    geo['g'] = K.doppler_factor(g, u)
+    J = K.parallel_transport(g, u, geo['g'], K.magnetic_field_fluid_frame(g, u, 0.0, 1.0, 0.0), V_frac=0)
+    rt = network.raytracing_args(geo, Omega, 0.0, 0.0 * units.hr, J=np.nan_to_num(J))
+    assert list(rt)[:3] == ['coords', 'Omega', 'J'] or 'coords' in rt
+    assert np.shape(rt['coords']) == (3, 6, 6, 40) and np.shape(rt['J']) == (3, 6, 6, 40)
