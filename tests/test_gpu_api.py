@@ -117,3 +117,27 @@ def test_two_losses_take_sequential_adam_steps(dev, problem):
     state = pred.init_state(pred.init_params(p['rt']), num_iters=10)
     loss, state, images = both(state, p['rt'], np.array([0, 2, 4]))
     assert state.step == 2 and loss.shape == (1,) and images.shape == (1, 3, 3, p['H'], p['W'])
+
+
+def test_training_on_traced_kerr_geodesics(dev):
+    """f3 end to end: own ray tracer -> Doppler factor and Stokes factors -> raytracing_args -> polarised light-curve
+    fit steps on the HIP engine (the flow of scripts/Fit_*: kgeo.image_plane_geos, doppler_factor, parallel_transport)."""
+    from bhnerf_amd import kgeo, network, optimization, units
+    geos = kgeo.image_plane_geos(0.5, np.deg2rad(30.0), (-8.0, 8.0), (-8.0, 8.0), ngeo=32, num_alpha=8, num_beta=8)
+    Omega = 1.0 / (geos.r ** 1.5 + geos.spin)
+    umu = kgeo.azimuthal_velocity_vector(geos, Omega)
+    geos['g'] = kgeo.doppler_factor(geos, umu)
+    b = kgeo.magnetic_field_fluid_frame(geos, umu, arad=0.0, avert=1.0, ator=0.0)
+    J = np.nan_to_num(kgeo.parallel_transport(geos, umu, geos['g'], b, Q_frac=0.5, V_frac=0), posinf=0.0, neginf=0.0)
+    assert J.shape == (3, 8, 8, 32) and np.isfinite(geos['g']).all()
+    rt = network.raytracing_args(geos, np.nan_to_num(Omega), 0.0, 0.0 * units.hr, J=J)
+    t_frames = np.linspace(0.0, 0.5, 4) * units.hr
+    pred = network.NeRF_Predictor(8.0, 2.0, 8.0, 4.0, net_depth=4, net_width=64, mode='f32', device=dev)
+    target = np.abs(np.random.default_rng(0).standard_normal((4, 3))) * 1e-3
+    step = optimization.TrainStep.image(t_frames, target, sigma=1e-3, dtype='lc')
+    opt = optimization.Optimizer({'num_iters': 6, 'lr_init': 1e-3, 'lr_final': 1e-4}, pred, rt)
+    first = optimization.total_movie_loss(2, opt.state, step, rt)
+    opt.run(2, step, rt)
+    last, frames = optimization.total_movie_loss(2, opt.state, step, rt, return_frames=True)
+    assert np.isfinite(first) and np.isfinite(last) and frames.shape == (4, 3, 8, 8) and np.isfinite(frames).all()
+    assert opt.state.step == 6
