@@ -39,6 +39,115 @@ __global__ __launch_bounds__(512) void k(const char *img, float *out, int steps)
     if (s == 12345.678f) out[threadIdx.x] = s + mk[0];
 }
 
+// Wide variant: 4 waves x 64 points; every A fragment read from LDS feeds two MFMAs (two independent accumulator
+// chains per wave, one wave per SIMD).  Same MFMA work per workgroup step as the 8 x 32 kernel.
+template <class Pol, class RG>
+DEVI void wide_step(const char *ch, const char *chn, APipe<Pol> &ap, const typename Pol::frag (&s0)[16], const typename Pol::frag (&s1)[16],
+                    f32x16 &acc0, f32x16 &acc1, const float *bias_next, PackPost<Pol> &p0, PackPost<Pol> &p1, DmaJob dma) {
+    const int lane = threadIdx.x & 63;
+    constexpr int KS = 16, NF = 18, PF = Pol::LDS_PREFETCH;
+    typename Pol::frag a[PF];
+#pragma unroll
+    for (int i = 0; i < PF - 1; ++i) a[i] = ap.f[i];
+    acc0 = ap.bias; acc1 = ap.bias;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < KS; ++t) {
+        a[(t + PF - 1) % PF] = stream_frag<Pol, NF>(ch, chn, t + PF - 1, lane);
+        acc0 = Pol::mma(a[t % PF], s0[t], acc0);
+        acc1 = Pol::mma(a[t % PF], s1[t], acc1);
+        p0.at(t); p1.at(t);
+        if (t == 9 && dma.src) RG::issue(dma.src, dma.dst);
+        if (t == 13) ap.bias = bias_acc(bias_next, 0, lane >> 5);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int t = KS; t < NF; ++t) a[(t + PF - 1) % PF] = stream_frag<Pol, NF>(ch, chn, t + PF - 1, lane);
+#pragma unroll
+    for (int i = 0; i < PF - 1; ++i) ap.f[i] = a[(NF + i) % PF];
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void kw(const char *img, float *out, int steps) {
+    using Pol = PolBF16;
+    constexpr int W = 256, KS = 16, CB = 18 * 1024, DIST = 4, MT = 8;
+    using RG = DmaRing<CB, 4>;
+    using RS = RingState<RG, CB, DIST, false>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *bias_lds = reinterpret_cast<float *>(smem + RS::NB * CB);
+    for (int i = threadIdx.x; i < 5 * W; i += 256) bias_lds[i] = 0.001f * i;
+    const int lane = threadIdx.x & 63;
+    RS rs;
+    rs.start(smem, img, 26, nullptr, 0, (MODE & 2) ? 0 : 4, 0);
+    APipe<Pol> ap;
+    ap.prime(rs.ch(), bias_lds);
+    Pol::frag a0[KS], a1[KS], n0[KS], n1[KS];
+    for (int i = 0; i < KS; ++i)
+        for (int j = 0; j < 8; ++j) {
+            a0[i][j] = (__bf16)(0.37f * __sinf(1.7f * lane + 3.1f * i + 0.9f * j)); a1[i][j] = (__bf16)(0.31f * __cosf(1.3f * lane + 2.1f * i + 0.7f * j));
+            n0[i][j] = a0[i][j]; n1[i][j] = a1[i][j];
+        }
+    f32x16 pend0 = {}, pend1 = {};
+    auto layer = [&](Pol::frag (&s0)[KS], Pol::frag (&s1)[KS], Pol::frag (&d0)[KS], Pol::frag (&d1)[KS], const float *bl) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const char *ch = rs.ch(), *chn = rs.chn();
+            const DmaJob dj = rs.job();
+            PackPost<Pol> p0(pend0, m == 0 ? s0[KS - 2] : d0[2 * (m > 0 ? m - 1 : 0)], m == 0 ? s0[KS - 1] : d0[2 * (m > 0 ? m - 1 : 0) + 1]);
+            PackPost<Pol> p1(pend1, m == 0 ? s1[KS - 2] : d1[2 * (m > 0 ? m - 1 : 0)], m == 0 ? s1[KS - 1] : d1[2 * (m > 0 ? m - 1 : 0) + 1]);
+            f32x16 acc0, acc1;
+            wide_step<Pol, RG>(ch, chn, ap, s0, s1, acc0, acc1, bl + 32 * (m + 1), p0, p1, dj);
+            rs.step_end();
+            pend0 = acc0; pend1 = acc1;
+        }
+    };
+    for (int it = 0; it < steps; it += 16) {
+        layer(a0, a1, n0, n1, bias_lds + W);
+        layer(n0, n1, a0, a1, bias_lds + 2 * W);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float s = 0;
+    for (int j = 0; j < 16; ++j) s += pend0[j] + pend1[j];
+    for (int i = 0; i < KS; ++i) s += (float)a0[i][0] + (float)n0[i][3] + (float)a1[i][1] + (float)n1[i][2];
+    if (s == 12345.678f) out[threadIdx.x] = s;
+}
+
+template <int MODE>
+void runw(const char *name, bool random_weights) {
+    char *img;
+    float *d;
+    hipMalloc(&img, 26 * 18 * 1024);
+    hipMemset(img, 0, 26 * 18 * 1024);
+    if (random_weights) {
+        static unsigned short h[26 * 9 * 1024];
+        unsigned x = 12345u;
+        for (auto &v : h) {
+            x = x * 1664525u + 1013904223u;
+            const float f = ((x >> 8) * (1.0f / 16777216.0f) - 0.5f) * 0.2f;
+            unsigned u; memcpy(&u, &f, 4);
+            v = (unsigned short)(u >> 16);
+        }
+        hipMemcpy(img, h, sizeof(h), hipMemcpyHostToDevice);
+    }
+    hipMalloc(&d, 4096);
+    const int steps = 16 * 400, grid = 256;
+    const size_t lds = 6 * 18 * 1024 + 5 * 256 * 4;
+    hipFuncSetAttribute((const void *)kw<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    kw<MODE><<<grid, 256, lds>>>(img, d, 32);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    kw<MODE><<<grid, 256, lds>>>(img, d, steps);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double flops = (double)grid * 4 * 2 * steps * 16 * 32768.0;
+    printf("%s %-40s %.2f ms  %.0f TFLOP/s  %.0f ns per step\n", random_weights ? "random W" : "zero W  ", name, ms, flops / ms * 1e-9, ms * 1e6 / steps);
+    hipFree(d); hipFree(img);
+}
+
 template <int MODE>
 void run(const char *name, bool random_weights) {
     char *img;
@@ -83,6 +192,7 @@ int main() {
         run<3>("+ pack + DMA", r);
         run<7>("+ pack + DMA + lag", r);
         run<4>("+ lag", r);
+        runw<3>("wide 4x64: + pack + DMA", r);
     }
     return 0;
 }
