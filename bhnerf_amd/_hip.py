@@ -63,6 +63,9 @@ SIGNATURES = {
     'bhn_chi2_eht': (C.c_int, [_P, _P, _P, _P, _F, _I32, _I32, _I32, _I32, _I64, _P, _P, _P, _P]),
     'bhn_voxel_render_fwd': (C.c_int, [_GP, _FP, _P, _I32, _I32, _I32, _I64, C.POINTER(C.c_float), _P, _P]),
     'bhn_trilinear': (C.c_int, [_P, _I64, _P, _I32, _I32, _I32, C.POINTER(C.c_float), _P, _P]),
+    'bhn_grid_predict_fwd': (C.c_int, [_GP, _FP, _P, _I32, _F, _P, _P]),
+    'bhn_grid_render_fwd': (C.c_int, [_GP, _FP, _P, _I32, _F, _P, _P]),
+    'bhn_grid_render_bwd': (C.c_int, [_GP, _FP, _P, _I32, _F, _P, _P, _P]),
     'bhn_adam_step': (C.c_int, [_P, _P, _P, _P, _I64, _I64, _F, _F, _F, _F, _F, _P]),
     'bhn_debug_set_bwd_stages': (C.c_int, [_I32]),
     'bhn_debug_set_fwd_variant': (C.c_int, [_I32]),

@@ -567,3 +567,125 @@ extern "C" int bhn_trilinear(const float *points, int64_t N, const float *grid, 
     BHN_HIP(hipGetLastError());
     return BHN_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// GRID_Predictor (network.py:254-353): the emission is a learnable res^3 voxel grid -- warp -> voxel index
+// (u + scale)/(2 scale)(res - 1) -> trilinear sample (0 outside the grid: map_coordinates order 1, cval 0) ->
+// sigmoid(. - 10) -> domain fill -> 0 before the injection -> x w -> ray sum.  MODE 0: emission (B,P);
+// 1: images (B,Sx,R); 2: d loss / d grid from d loss / d images (float atomics into the res^3 grid, which is
+// L2-resident: 1 MB at res 64; not bitwise reproducible, unlike the MLP gradient).
+// ------------------------------------------------------------------------------------------
+template <int LPR, int MODE>
+__global__ __launch_bounds__(256) void grid_predictor_kernel(bhn_geom geom, const double *__restrict__ tM0, int B, VoxelGrid v,
+                                                             float *__restrict__ out, const float *__restrict__ dimages,
+                                                             float *__restrict__ dgrid) {
+    constexpr int RPB = 256 / LPR;
+    const int sub = threadIdx.x % LPR;
+    const long long ray_b = (long long)blockIdx.x * RPB + threadIdx.x / LPR;       // (frame, ray)
+    const long long R = geom.R, G = geom.G, P = R * G;
+    const int Sx = geom.S > 0 ? geom.S : 1;
+    const bool ok = ray_b < (long long)B * R;
+    const int b = ok ? (int)(ray_b / R) : 0;
+    const long long ray = ok ? ray_b % R : 0;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float dI[4] = {0.f, 0.f, 0.f, 0.f};
+    if (MODE == 2 && ok)
+        for (int s = 0; s < Sx; ++s) dI[s] = dimages[((long long)b * Sx + s) * R + ray];
+    if (ok) {
+        const double t0 = tM0[b];
+        const float nm1 = (float)(v.nx - 1);
+        for (long long k = sub; k < G; k += LPR) {
+            const long long p = ray * G + k;
+            const double tM = t0 + (double)geom.t_geo[p];
+            float e = 0.f;
+            float ix = 0.f, iy = 0.f, iz = 0.f;
+            bool inside = false;
+            if (!(tM < 0.0) && geom.dom[p]) {                       // emission.py:204-205, 370-373
+                const double th = tM * (double)geom.Omega[p];
+                double sn, cs;
+                sincos(th, &sn, &cs);
+                const float x = geom.x[p], y = geom.y[p];
+                const float ux = (float)(cs * x + sn * y), uy = (float)(cs * y - sn * x), uz = geom.z[p];
+                if (isfinite(ux) && isfinite(uy) && isfinite(uz)) {
+                    ix = (ux + 0.5f * v.fx) / v.fx * nm1; iy = (uy + 0.5f * v.fy) / v.fy * nm1; iz = (uz + 0.5f * v.fz) / v.fz * nm1;
+                    inside = ix >= 0.f && ix <= nm1 && iy >= 0.f && iy <= nm1 && iz >= 0.f && iz <= nm1;
+                    const float val = inside ? trilinear(v, v.data, ux, uy, uz) : 0.f;
+                    e = 1.f / (1.f + __expf(10.f - val));
+                }
+            }
+            if (MODE == 0) out[(long long)b * P + p] = e;
+            else if (MODE == 1) {
+                if (e != 0.f)
+                    for (int s = 0; s < Sx; ++s) acc[s] += geom.w[(long long)s * P + p] * e;
+            } else if (inside && e != 0.f) {
+                float dE = 0.f;
+                for (int s = 0; s < Sx; ++s) dE += dI[s] * geom.w[(long long)s * P + p];
+                const float d = dE * e * (1.f - e);
+                const int n = v.nx;
+                const int x0 = min((int)ix, max(n - 2, 0)), y0 = min((int)iy, max(n - 2, 0)), z0 = min((int)iz, max(n - 2, 0));
+                const int x1 = min(x0 + 1, n - 1), y1 = min(y0 + 1, n - 1), z1 = min(z0 + 1, n - 1);
+                const float tx = ix - (float)x0, ty = iy - (float)y0, tz = iz - (float)z0;
+                const long long sx = (long long)n * n, sy = n;
+                if (d != 0.f) {
+                    atomicAdd(dgrid + x0 * sx + y0 * sy + z0, d * (1.f - tx) * (1.f - ty) * (1.f - tz));
+                    atomicAdd(dgrid + x0 * sx + y0 * sy + z1, d * (1.f - tx) * (1.f - ty) * tz);
+                    atomicAdd(dgrid + x0 * sx + y1 * sy + z0, d * (1.f - tx) * ty * (1.f - tz));
+                    atomicAdd(dgrid + x0 * sx + y1 * sy + z1, d * (1.f - tx) * ty * tz);
+                    atomicAdd(dgrid + x1 * sx + y0 * sy + z0, d * tx * (1.f - ty) * (1.f - tz));
+                    atomicAdd(dgrid + x1 * sx + y0 * sy + z1, d * tx * (1.f - ty) * tz);
+                    atomicAdd(dgrid + x1 * sx + y1 * sy + z0, d * tx * ty * (1.f - tz));
+                    atomicAdd(dgrid + x1 * sx + y1 * sy + z1, d * tx * ty * tz);
+                }
+            }
+        }
+    }
+    if (MODE == 1) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int o = LPR / 2; o > 0; o >>= 1) acc[s] += __shfl_xor(acc[s], o, 64);
+        if (ok && sub == 0)
+            for (int s = 0; s < Sx; ++s) out[((long long)b * Sx + s) * R + ray] = acc[s];
+    }
+}
+
+template <int MODE>
+static int grid_predictor_launch(const bhn_geom *geom, const bhn_frames *fr, const float *grid, int32_t res, float scale, float *out,
+                                 const float *dimages, float *dgrid, void *stream) {
+    BHN_CHECK_ARG(geom && fr && grid, "null pointer");
+    BHN_CHECK_ARG(geom->x && geom->y && geom->z && geom->Omega && geom->t_geo && geom->dom, "null geometry array");
+    BHN_CHECK_ARG(MODE == 0 || geom->w, "render needs geom->w");
+    BHN_CHECK_ARG(geom->R > 0 && geom->G > 0 && geom->S >= 0 && geom->S <= 4 && fr->B > 0 && fr->tM0, "bad sizes");
+    BHN_CHECK_ARG(res >= 2 && res <= 1024 && scale > 0.f, "bad grid_res %d / scale %g", res, (double)scale);
+    const float fov[3] = {2.f * scale, 2.f * scale, 2.f * scale};
+    VoxelGrid v;
+    int rc = voxel_grid_args(grid, res, res, res, 0, fov, &v);
+    if (rc != BHN_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (MODE == 2) BHN_HIP(hipMemsetAsync(dgrid, 0, sizeof(float) * (size_t)res * res * res, st));
+    const long long rays = (long long)fr->B * geom->R;
+    const int lpr = geom->G >= 48 ? 32 : (geom->G >= 12 ? 16 : 4);
+    if (lpr == 32) hipLaunchKernelGGL((grid_predictor_kernel<32, MODE>), dim3((unsigned)((rays + 7) / 8)), dim3(256), 0, st, *geom, fr->tM0, fr->B, v, out, dimages, dgrid);
+    else if (lpr == 16) hipLaunchKernelGGL((grid_predictor_kernel<16, MODE>), dim3((unsigned)((rays + 15) / 16)), dim3(256), 0, st, *geom, fr->tM0, fr->B, v, out, dimages, dgrid);
+    else hipLaunchKernelGGL((grid_predictor_kernel<4, MODE>), dim3((unsigned)((rays + 63) / 64)), dim3(256), 0, st, *geom, fr->tM0, fr->B, v, out, dimages, dgrid);
+    BHN_HIP(hipGetLastError());
+    return BHN_OK;
+}
+
+extern "C" int bhn_grid_predict_fwd(const bhn_geom *geom, const bhn_frames *fr, const float *grid, int32_t res, float scale,
+                                    float *emission, void *stream) {
+    BHN_CHECK_ARG(emission, "null emission");
+    return grid_predictor_launch<0>(geom, fr, grid, res, scale, emission, nullptr, nullptr, stream);
+}
+
+extern "C" int bhn_grid_render_fwd(const bhn_geom *geom, const bhn_frames *fr, const float *grid, int32_t res, float scale,
+                                   float *images, void *stream) {
+    BHN_CHECK_ARG(images, "null images");
+    return grid_predictor_launch<1>(geom, fr, grid, res, scale, images, nullptr, nullptr, stream);
+}
+
+extern "C" int bhn_grid_render_bwd(const bhn_geom *geom, const bhn_frames *fr, const float *grid, int32_t res, float scale,
+                                   const float *dimages, float *dgrid, void *stream) {
+    BHN_CHECK_ARG(dimages && dgrid, "null pointer");
+    return grid_predictor_launch<2>(geom, fr, grid, res, scale, nullptr, dimages, dgrid, stream);
+}

@@ -262,6 +262,71 @@ class RenderFunction(torch.autograd.Function):
         return ctx.predictor.render_bwd(ctx.geom, ctx.tM0, dimages.contiguous()), None, None, None
 
 
+class GridEngine:
+    """GRID_Predictor (network.py:254-353) on the HIP kernels bhn_grid_*: the parameter vector IS the (res,res,res)
+    voxel grid.  Offers the subset of the FusedPredictor interface the training / rendering drivers use."""
+
+    def __init__(self, grid_res=64, scale=1.0, device='cuda'):
+        self.res, self.scale = int(grid_res), float(scale)
+        self.device = torch.device(device)
+        self.nparams = self.res ** 3
+        self.grid = None
+
+    def flatten(self, tree):
+        g = tree['grid'] if isinstance(tree, dict) else tree
+        g = _hip.as_f32(g, self.device)
+        if tuple(g.shape) != (self.res,) * 3:
+            raise ValueError('grid shape %s, expected %s' % (tuple(g.shape), (self.res,) * 3))
+        return g.reshape(-1).clone()
+
+    def unflatten(self, flat):
+        return {'grid': flat.view(self.res, self.res, self.res)}
+
+    def pack(self, flat):
+        _hip.require_device(flat)
+        assert flat.dtype == torch.float32 and flat.numel() == self.nparams and flat.is_contiguous()
+        self.grid = flat
+
+    def _frames(self, tM0):
+        assert tM0.dtype == torch.float64 and tM0.is_cuda and tM0.is_contiguous()
+        return _hip.bhn_frames(int(tM0.numel()), tM0.data_ptr())
+
+    def predict(self, geom, tM0):
+        out = torch.empty((int(tM0.numel()), geom.P), dtype=torch.float32, device=self.device)
+        gs, fs = geom.c_struct(), self._frames(tM0)
+        _hip.check(_hip.lib().bhn_grid_predict_fwd(C.byref(gs), C.byref(fs), _hip.ptr(self.grid), self.res, self.scale,
+                                                   _hip.ptr(out), _hip.stream_ptr(self.device)))
+        return out
+
+    def render(self, geom, tM0, out=None):
+        B = int(tM0.numel())
+        if out is None:
+            out = torch.empty((B, geom.Sx, geom.R), dtype=torch.float32, device=self.device)
+        gs, fs = geom.c_struct(), self._frames(tM0)
+        _hip.check(_hip.lib().bhn_grid_render_fwd(C.byref(gs), C.byref(fs), _hip.ptr(self.grid), self.res, self.scale,
+                                                  _hip.ptr(out), _hip.stream_ptr(self.device)))
+        return out
+
+    def render_bwd(self, geom, tM0, dimages, out=None):
+        assert dimages.dtype == torch.float32 and dimages.is_contiguous() and dimages.is_cuda
+        if out is None:
+            out = torch.empty((self.nparams,), dtype=torch.float32, device=self.device)
+        gs, fs = geom.c_struct(), self._frames(tM0)
+        _hip.check(_hip.lib().bhn_grid_render_bwd(C.byref(gs), C.byref(fs), _hip.ptr(self.grid), self.res, self.scale,
+                                                  _hip.ptr(dimages), _hip.ptr(out), _hip.stream_ptr(self.device)))
+        return out
+
+    # no tape: the "taped" route of the step driver is simply render + render_bwd
+    render_train = render
+    render_bwd_tape = render_bwd
+
+    def fits_tape(self, B, P):
+        return True
+
+    def tape_group(self, B, P):
+        return int(B)
+
+
 def chi2_image(images, target, sigma, offset, scale, dtype, want_grad=True):
     """loss_fn_image (network.py:476-484) on device -> (loss[1], dimages or None)."""
     code = {'full': 0, 'lc': 1}.get(dtype)

@@ -117,8 +117,8 @@ class TrainState:
         """The state dict flax writes for TrainState.create(apply_fn, params, tx=optax.adam(schedule))
         (network.py:171-182; checkpoints.py): step, params tree, Adam moments mu / nu as params-shaped trees."""
         eng = self.predictor.engine()
-        tree = lambda flat: {k: {n: {q: a.cpu().numpy().copy() for q, a in d.items()} for n, d in layers.items()}
-                             for k, layers in eng.unflatten(flat).items()}
+        host = lambda t: {k: host(v) for k, v in t.items()} if isinstance(t, dict) else t.cpu().numpy().copy()
+        tree = lambda flat: host(eng.unflatten(flat))
         count = np.asarray(self.step, dtype=np.int32)
         return {'step': count, 'params': tree(self.flat),
                 'opt_state': {'0': {'count': count, 'mu': tree(self.m), 'nu': tree(self.v)}, '1': {'count': count}}}
@@ -249,6 +249,47 @@ class NeRF_Predictor:
 
     @classmethod
     def from_yml(cls, directory, filename='NeRF_Predictor_params.yml', **kw):
+        params = yaml.safe_load(Path(directory).joinpath(filename).read_text())
+        return cls(**params, **kw)
+
+
+class GRID_Predictor(NeRF_Predictor):
+    """Emission as a learnable voxel grid (network.py:254-370): fields ``scale, rmin, rmax, z_width, grid_res``;
+    parameters ``{'grid': (res,res,res)}`` initialised to -10 (network.py:334).  Same driver interface as
+    NeRF_Predictor (``init_params / init_state / apply / save_params / from_yml``); kernels ``bhn_grid_*``."""
+
+    def __init__(self, scale=1.0, rmin=0.0, rmax=np.inf, z_width=np.inf, grid_res=64, *, device=None, mode='f32'):
+        self.scale, self.rmin, self.rmax, self.z_width, self.grid_res = scale, rmin, rmax, z_width, int(grid_res)
+        self.device, self.mode = device, 'f32'
+        self._engine, self._engine_key, self._geoms = None, None, OrderedDict()
+
+    def engine(self):
+        key = (self.scale, self.grid_res)
+        if self._engine is None or self._engine_key != key:
+            dev = torch.device(self.device) if self.device is not None else _default_device()
+            self._engine = engine.GridEngine(self.grid_res, self.scale, dev)
+            self._engine_key = key
+            self._geoms.clear()
+        return self._engine
+
+    def init_params(self, raytracing_args=None, seed=1):
+        eng = self.engine()
+        flat = torch.full((eng.nparams,), -10.0, dtype=torch.float32, device=eng.device)
+        tree = ParamTree(eng.unflatten(flat))
+        tree.flat = flat
+        return tree
+
+    def save_params(self, directory, filename='GRID_Predictor_params.yml'):
+        directory = Path(directory)
+        directory.mkdir(parents=True, exist_ok=True)
+        # (the reference's key list is the NeRF one, network.py:359, and so writes only these four; grid_res is added so
+        #  that from_yml can rebuild the predictor)
+        with open(directory.joinpath(filename), 'w') as f:
+            yaml.dump({k: (float(getattr(self, k)) if isinstance(getattr(self, k), (float, np.floating)) else getattr(self, k))
+                       for k in ('scale', 'rmin', 'rmax', 'z_width', 'grid_res')}, f)
+
+    @classmethod
+    def from_yml(cls, directory, filename='GRID_Predictor_params.yml', **kw):
         params = yaml.safe_load(Path(directory).joinpath(filename).read_text())
         return cls(**params, **kw)
 

@@ -163,6 +163,18 @@ int bhn_voxel_render_fwd(const bhn_geom *geom, const bhn_frames *fr, const float
 int bhn_trilinear(const float *points, int64_t N, const float *grid, int32_t nx, int32_t ny, int32_t nz,
                   const float *fov_host, float *out, void *stream);
 
+/* GRID_Predictor (network.py:254-353): the emission as a learnable (res,res,res) voxel grid sampled trilinearly at the
+ * velocity-warped points, index = (u + scale)/(2 scale)(res - 1), 0 outside the grid (map_coordinates order 1,
+ * cval 0), sigmoid(. - 10), domain fill (geom->dom), 0 before the injection.  predict: emission (B,P);
+ * render: images (B,Sx,R) as bhn_render_fwd; render_bwd: dgrid (res^3, overwritten) = d loss / d grid for the given
+ * d loss / d images (float atomics: not bitwise reproducible). */
+int bhn_grid_predict_fwd(const bhn_geom *geom, const bhn_frames *fr, const float *grid, int32_t res, float scale,
+                         float *emission, void *stream);
+int bhn_grid_render_fwd(const bhn_geom *geom, const bhn_frames *fr, const float *grid, int32_t res, float scale,
+                        float *images, void *stream);
+int bhn_grid_render_bwd(const bhn_geom *geom, const bhn_frames *fr, const float *grid, int32_t res, float scale,
+                        const float *dimages, float *dgrid, void *stream);
+
 /* optax.adam + polynomial_schedule(power=1) as used by init_state (network.py:173-174, 621):
  * g' = g*grad_scale (the 1/ndev of pmean, network.py:620); t = 1-based update count. */
 int bhn_adam_step(float *params, const float *grads, float *m, float *v, int64_t n, int64_t t, float lr,

@@ -211,3 +211,36 @@ def he_uniform_params(rng, net_depth, net_width, in_features, do_skip=True, out_
             'kernel': rng.uniform(-lim, lim, size=(fi, fo)).astype(dtype),
             'bias': np.zeros((fo,), dtype=dtype)}
     return {'MLP_0': tree}
+
+
+def map_coordinates_linear(grid, index):
+    """scipy / jax.scipy.ndimage.map_coordinates(grid, index, order=1, mode='constant', cval=0.0) restated:
+    `index` is (3, ...) in voxel units; samples whose index lies outside [0, n-1] on any axis (or is NaN) are 0."""
+    grid = np.asarray(grid)
+    ix, iy, iz = (np.asarray(index[i], dtype=np.float64) for i in range(3))
+    nx, ny, nz = grid.shape
+    inside = (ix >= 0) & (ix <= nx - 1) & (iy >= 0) & (iy <= ny - 1) & (iz >= 0) & (iz <= nz - 1)
+    ixc, iyc, izc = np.where(inside, ix, 0.0), np.where(inside, iy, 0.0), np.where(inside, iz, 0.0)
+    x0 = np.minimum(np.floor(ixc).astype(np.int64), max(nx - 2, 0)); x1 = np.minimum(x0 + 1, nx - 1)
+    y0 = np.minimum(np.floor(iyc).astype(np.int64), max(ny - 2, 0)); y1 = np.minimum(y0 + 1, ny - 1)
+    z0 = np.minimum(np.floor(izc).astype(np.int64), max(nz - 2, 0)); z1 = np.minimum(z0 + 1, nz - 1)
+    tx, ty, tz = ixc - x0, iyc - y0, izc - z0
+    out = ((grid[x0, y0, z0] * (1 - tz) + grid[x0, y0, z1] * tz) * (1 - ty) + (grid[x0, y1, z0] * (1 - tz) + grid[x0, y1, z1] * tz) * ty) * (1 - tx) + \
+          ((grid[x1, y0, z0] * (1 - tz) + grid[x1, y0, z1] * tz) * (1 - ty) + (grid[x1, y1, z0] * (1 - tz) + grid[x1, y1, z1] * tz) * ty) * tx
+    return np.where(inside, out, 0.0)
+
+
+def grid_predictor_apply(grid, t_frames, coords, Omega, t_start_obs, t_geos, t_injection, GM_c3=GM_C3_SGRA_HR, scale=1.0,
+                         rmin=0.0, rmax=np.inf, z_width=np.inf):
+    """GRID_Predictor.__call__ (network.py:306-353): warp -> where(valid, warped, 0) -> voxel index
+    (x + scale)/(2 scale) (res - 1) -> trilinear sample (0 outside the grid) -> sigmoid(. - 10) -> domain fill ->
+    0 where the warped x is not finite."""
+    grid = np.asarray(grid)
+    res = grid.shape[0]
+    warped = velocity_warp_coords(coords, Omega, t_frames, t_start_obs, t_geos, t_injection, GM_c3=GM_c3)
+    valid = np.isfinite(warped)
+    net_in = np.moveaxis(np.where(valid, warped, np.zeros_like(warped)), -1, 0)
+    index = (net_in + scale) / (2.0 * scale) * (res - 1.0)
+    emission = sigmoid(map_coordinates_linear(grid, index) - 10.0)
+    emission = fill_unsupervised_emission(emission, coords, rmin, rmax, z_width)
+    return np.where(valid[..., 0], emission, np.zeros_like(emission))

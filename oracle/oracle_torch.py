@@ -131,3 +131,35 @@ class CpuTrainer:
                 vhat = v / (1.0 - 0.999 ** t)
                 p.sub_(lr * mhat / (vhat.sqrt() + 1e-8))
         return loss, images
+
+
+def grid_loss_and_grad(grid, t_frames, geom, hp, target, sigma):
+    """chi^2 of the GRID_Predictor render (network.py:306-353 + kgeo.py:621 + network.py:476-480) and its gradient
+    w.r.t. the grid by torch.autograd (float64).  geom / hp as for CpuTrainer; `grid` (res,res,res) array."""
+    import numpy as np
+    g = torch.tensor(np.asarray(grid), dtype=torch.float64, requires_grad=True)
+    res = g.shape[0]
+    w = warp(geom['coords'], geom['Omega'], t_frames, geom['t_start_obs'], geom['t_geos'], geom['t_injection'], hp['GM_c3'])
+    valid = torch.isfinite(w)
+    u = torch.where(valid, w, torch.zeros_like(w))
+    idx = (u + hp['scale']) / (2.0 * hp['scale']) * (res - 1.0)
+    ix, iy, iz = idx[..., 0], idx[..., 1], idx[..., 2]
+    inside = (ix >= 0) & (ix <= res - 1) & (iy >= 0) & (iy <= res - 1) & (iz >= 0) & (iz <= res - 1)
+    z = torch.zeros_like(ix)
+    ixc, iyc, izc = torch.where(inside, ix, z), torch.where(inside, iy, z), torch.where(inside, iz, z)
+    hi = max(res - 2, 0)
+    x0 = torch.clamp(torch.floor(ixc).long(), max=hi); y0 = torch.clamp(torch.floor(iyc).long(), max=hi); z0 = torch.clamp(torch.floor(izc).long(), max=hi)
+    x1, y1, z1 = torch.clamp(x0 + 1, max=res - 1), torch.clamp(y0 + 1, max=res - 1), torch.clamp(z0 + 1, max=res - 1)
+    tx, ty, tz = ixc - x0, iyc - y0, izc - z0
+    val = ((g[x0, y0, z0] * (1 - tz) + g[x0, y0, z1] * tz) * (1 - ty) + (g[x0, y1, z0] * (1 - tz) + g[x0, y1, z1] * tz) * ty) * (1 - tx) + \
+          ((g[x1, y0, z0] * (1 - tz) + g[x1, y0, z1] * tz) * (1 - ty) + (g[x1, y1, z0] * (1 - tz) + g[x1, y1, z1] * tz) * ty) * tx
+    val = torch.where(inside, val, z)
+    e = torch.sigmoid(val - 10.0)
+    c = geom['coords']
+    r2 = (c ** 2).sum(0)
+    dom = (r2 >= hp['rmin'] ** 2) & (r2 <= hp['rmax'] ** 2) & (c[2].abs() <= hp['z_width'])
+    e = torch.where(dom & valid[..., 0], e, torch.zeros_like(e))
+    img = (geom['g'] ** 2 * e * geom['dtau'] * geom['Sigma']).sum(-1)
+    loss = (((img - target) / sigma) ** 2).sum()
+    loss.backward()
+    return loss.detach(), img.detach(), g.grad.detach()

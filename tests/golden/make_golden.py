@@ -57,12 +57,26 @@ sys.modules['jax.numpy'] = np
 jax.nn = _mod('jax.nn', initializers=types.SimpleNamespace(he_uniform=lambda: 'he_uniform'))
 jax.random = _mod('jax.random', PRNGKey=lambda s: s)
 jax.lax = _mod('jax.lax')
+import scipy.ndimage as _ndi  # noqa: E402
+# jax.scipy.ndimage.map_coordinates(input, coordinates, order, mode='constant', cval=0.0): SciPy's own function is the
+# algorithm JAX re-implements (order <= 1 only)
+jax.scipy = _mod('jax.scipy', ndimage=types.SimpleNamespace(
+    map_coordinates=lambda inp, coords, order, mode='constant', cval=0.0: _ndi.map_coordinates(inp, coords, order=order, mode=mode, cval=cval)))
+sys.modules['jax.scipy.ndimage'] = jax.scipy.ndimage
+
+
+_grid_param = []            # injected value of GRID_Predictor's `grid` parameter
 
 
 class _Module:
     def __init_subclass__(cls, **kw):
         super().__init_subclass__(**kw)
         dataclasses.dataclass(cls)
+
+    def param(self, name, init_fn, *init_args):      # flax: the stored parameter (here: the injected array)
+        value = _grid_param[0]
+        assert tuple(value.shape) == tuple(init_args[0]), (value.shape, init_args)
+        return value
 
 
 class _Dense:
@@ -151,7 +165,12 @@ def geometry(rng, H, W, G, S=None, rmax=8.0):
     return dict(coords=coords, Omega=Omega, t_geos=t_geos, g=g, dtau=dtau, Sigma=Sigma, J=J)
 
 
+ONLY = set(sys.argv[1:])       # optional: names of the fixtures to (re)write; default all
+
+
 def save(name, **arrays):
+    if ONLY and name not in ONLY:
+        return
     np.savez_compressed(os.path.join(OUT, name + '.npz'), **arrays)
     print('wrote', name, {k: np.shape(v) for k, v in arrays.items()})
 
@@ -334,6 +353,38 @@ def main():
         network.image_plane_prediction = orig_ipp
     save('g7_eht', images=images, A=A, A3=A3, target_vis=tv, target_amp=ta, target_cphase=tc, sigma=sv,
          scale=1.3, loss_vis=lv, loss_amp=la, loss_cphase=lc)
+
+    # G9: GRID_Predictor (network.py:254-353): learnable voxel grid, trilinear sampling (map_coordinates order 1, cval 0),
+    # sigmoid(. - 10), domain fill; own rng so that the fixtures above are unaffected ------------------------------------
+    rng9 = np.random.default_rng(909)
+    res = 7
+    geo9 = geometry(rng9, 5, 4, 10, S=None, rmax=7.0)
+    grid = rng9.uniform(6.0, 12.0, (res, res, res))                       # sigmoid(grid - 10) spans (0.02, 0.9)
+    t_frames9 = np.array([0.0, 0.25, 0.6])
+    t_inj9 = -(1000.0 - 7.0)                                             # part of the samples precede the injection
+    hp9 = dict(scale=6.0, rmin=1.5, rmax=6.5, z_width=3.0, grid_res=res)
+    pred9 = network.GRID_Predictor(**hp9)
+    _grid_param[:] = [grid]
+    em9 = pred9(t_frames9, units.hr, geo9['coords'], geo9['Omega'], 0.0, geo9['t_geos'], t_inj9)
+    img9 = kgeo.radiative_trasfer(em9, geo9['g'], geo9['dtau'], geo9['Sigma'])
+    target9 = rng9.uniform(0, 1.0, img9.shape); sigma9 = rng9.uniform(0.5, 2.0, img9.shape)
+    def chi2(gr):
+        _grid_param[:] = [gr]
+        e = pred9(t_frames9, units.hr, geo9['coords'], geo9['Omega'], 0.0, geo9['t_geos'], t_inj9)
+        im = kgeo.radiative_trasfer(e, geo9['g'], geo9['dtau'], geo9['Sigma'])
+        return float(np.sum(np.abs((im - target9) / sigma9) ** 2))
+    fd_idx, fd_val = [], []
+    flat_order = rng9.permutation(res ** 3)[:40]
+    for f in flat_order:
+        i = np.unravel_index(f, grid.shape)
+        h = 1e-5
+        gp, gm = grid.copy(), grid.copy()
+        gp[i] += h; gm[i] -= h
+        fd_idx.append(i); fd_val.append((chi2(gp) - chi2(gm)) / (2 * h))
+    save('g9_grid', grid=grid, hparams=np.array([hp9['scale'], hp9['rmin'], hp9['rmax'], hp9['z_width'], res]),
+         t_frames=t_frames9, t_injection=t_inj9, emission=em9, images=img9, target=target9, sigma=sigma9, loss=chi2(grid),
+         fd_idx=np.array(fd_idx), fd_val=np.array(fd_val), nonzero_fd=int((np.abs(np.array(fd_val)) > 0).sum()),
+         **{k: geo9[k] for k in ('coords', 'Omega', 't_geos', 'g', 'dtau', 'Sigma')})
 
 
 if __name__ == '__main__':

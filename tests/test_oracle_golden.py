@@ -149,3 +149,27 @@ def test_mlp_dims():
     assert [d[0] for d in onp.mlp_layer_dims(8, 256, 21)] == [21, 256, 256, 256, 256, 277, 256, 256, 256]
     n = sum(a * b + b for a, b in onp.mlp_layer_dims(4, 256, 21))
     assert n == 208641 and sum(a * b + b for a, b in onp.mlp_layer_dims(4, 128, 21)) == 55169
+
+
+def test_grid_predictor_golden(golden):
+    """GRID_Predictor.__call__ of the reference (network.py:306-353) vs the oracle: emission, images, chi^2 and its
+    finite-difference gradient w.r.t. 40 voxels (float64)."""
+    import torch
+    from oracle import oracle_torch as ot
+    g = golden('g9_grid')
+    sc, rmin, rmax, zw, res = g['hparams']
+    e = onp.grid_predictor_apply(g['grid'], g['t_frames'], g['coords'], g['Omega'], 0.0, g['t_geos'], float(g['t_injection']),
+                                 scale=sc, rmin=rmin, rmax=rmax, z_width=zw)
+    assert e.shape == g['emission'].shape and np.abs(e - g['emission']).max() < 1e-12
+    assert 0.05 < (e > 0).mean() < 0.5 and np.isclose(e[e > 0].min(), 1.0 / (1.0 + np.exp(10.0)), rtol=1e-6)   # valid points outside the grid
+    img = onp.radiative_trasfer(e, g['g'], g['dtau'], g['Sigma'])
+    assert np.abs(img - g['images']).max() < 1e-11
+    t = lambda v: torch.tensor(np.asarray(v, dtype=np.float64))
+    geom = dict(coords=t(g['coords']), Omega=t(g['Omega']), t_geos=t(g['t_geos']), g=t(g['g']), dtau=t(g['dtau']), Sigma=t(g['Sigma']),
+                t_start_obs=0.0, t_injection=float(g['t_injection']))
+    hp = dict(GM_c3=onp.GM_C3_SGRA_HR, scale=float(sc), rmin=float(rmin), rmax=float(rmax), z_width=float(zw))
+    loss, img_t, grad = ot.grid_loss_and_grad(g['grid'], t(g['t_frames']), geom, hp, t(g['target']), t(g['sigma']))
+    assert abs(loss.item() - float(g['loss'])) < 1e-9 * float(g['loss'])
+    assert int(g['nonzero_fd']) >= 10
+    for (i, j, k), fd in zip(g['fd_idx'], g['fd_val']):
+        assert abs(grad[i, j, k].item() - fd) <= 1e-6 * max(1.0, abs(fd)), ((i, j, k), grad[i, j, k].item(), fd)
