@@ -587,8 +587,8 @@ DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
             reinterpret_cast<u32x4 *>(w0_lds)[i] = reinterpret_cast<const u32x4 *>(w0)[i];
         for (int i = tid; i < W; i += Pol::NTHREADS) b0_lds[i] = reinterpret_cast<const float *>(A.f.packed + A.f.bias_off)[i];
     }
-    // h_1 tile `wv` of a group image from its encoded-input fragments: D[point][feature] = enc^T . W_0 + b_0.  Two
-    // phases so that the LDS reads fly during the dW MFMAs of the group being consumed.
+    // h_1 tile `wv` of a group image from its encoded-input fragments: D[point][feature] = enc^T . W_0 + b_0, in three
+    // phases (LDS reads, two MFMAs, relu + pack + LDS write) placed around the dW MFMAs of the group being consumed.
     struct HIn { frag e0, e1, w0, w1; float b; };
     auto make_h_read = [&](const char *gp) {
         HIn in;
@@ -598,13 +598,16 @@ DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
         in.b = b0_lds[32 * t + (lane & 31)];
         return in;
     };
-    auto make_h_write = [&](char *gp, const HIn &in) {
-        if (wv < MT) {
-            f32x16 acc;
+    auto make_h_mma = [&](const HIn &in) {
+        f32x16 acc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = in.b;
-            acc = Pol::mma(in.e0, in.w0, acc);
-            acc = Pol::mma(in.e1, in.w1, acc);
+        for (int r = 0; r < 16; ++r) acc[r] = in.b;
+        acc = Pol::mma(in.e0, in.w0, acc);
+        acc = Pol::mma(in.e1, in.w1, acc);
+        return acc;
+    };
+    auto make_h_write = [&](char *gp, const f32x16 &acc) {
+        if (wv < MT) {
             frag o[2];
             unsigned unused = 0;
 #pragma unroll
@@ -728,7 +731,7 @@ DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
                     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * PPW) : "memory");
                     __builtin_amdgcn_s_barrier();
                     asm volatile("" ::: "memory");
-                    make_h_write(smem, make_h_read(smem));
+                    make_h_write(smem, make_h_mma(make_h_read(smem)));
                 }
                 int it = 0;
                 for (long long q = q0; q < q1; ++q) {
@@ -741,11 +744,13 @@ DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
                     if (!(A.debug & 2)) issue(q + NBUF - 1, smem + nx * GB);
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     char *gnext = smem + ((it == NBUF - 1) ? 0 : it + 1) * GB;
-                    HIn hin;
-                    if constexpr (make_h) hin = make_h_read(gnext);
+                    // the next group's h tile: LDS reads and the two MFMAs ahead of this group's dW MFMAs, relu / pack /
+                    // LDS write behind them (the MFMA result is long done by then: no exposed MFMA -> VALU latency)
+                    f32x16 hacc = {};
+                    if constexpr (make_h) hacc = make_h_mma(make_h_read(gnext));
                     if (!(A.debug & 1) && wave_works) compute_group(smem + it * GB);
                     if constexpr (make_h) {
-                        if (q + 1 < q1) make_h_write(gnext, hin);
+                        if (q + 1 < q1) make_h_write(gnext, hacc);
                     }
                     it = (it == NBUF - 1) ? 0 : it + 1;
                 }
