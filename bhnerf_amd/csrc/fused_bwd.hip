@@ -69,7 +69,7 @@ struct BwdGeom {
     static constexpr int GROUP_BYTES = (2 * MT + 1) * TILE_BYTES;   // A tiles + h tiles + enc tile
     // chain kernels: prefetch distance of the LDS-DMA weight ring (RING_DIST_TAPED+1 buffers of one chunk)
     static constexpr int RING_DIST_TAPED = (Pol::ELEM_BYTES == 2) ? BHN_TAPED_DIST : 3;
-    // dW kernel, bf16: LDS-DMA ring of NBUF groups (counted vmcnt, raw s_barrier); f32: 2 buffers
+    // dW kernel: LDS-DMA ring of NBUF groups (counted vmcnt, raw s_barrier); f32: 2 buffers
     static constexpr int NBUF = (Pol::ELEM_BYTES == 2) ? ((160 * 1024) / GROUP_BYTES >= 4 ? 4 : 3) : 2;
     static constexpr int NPIECE = GROUP_BYTES / 1024;               // 1 KiB = one wave-wide 16-B DMA
     static constexpr int PPW = (NPIECE + Pol::NWAVES - 1) / Pol::NWAVES;
@@ -519,37 +519,6 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
 // ---------------------------------------------------------------------------------------------
 // dW kernel
 // ---------------------------------------------------------------------------------------------
-// global -> registers -> LDS copy of one 32-point group image [A tiles][h tiles][enc tile]
-template <int UNITS, int NTHREADS, int OFF_H, int OFF_E, int AH_BYTES, int TB>
-struct GroupStager {
-    static constexpr int PIECES = (UNITS + NTHREADS - 1) / NTHREADS;
-    u32x4 st[PIECES];
-    bool out_job, has_h;
-    const char *srcA, *srcH, *srcE;
-    DEVI void load(long long q) {
-#pragma unroll
-        for (int i = 0; i < PIECES; ++i) {
-            int u = i * NTHREADS + (int)threadIdx.x;
-            u = u < UNITS ? u : UNITS - 1;
-            const int off = u * 16;
-            const char *src;
-            if (off < OFF_H) {
-                if (out_job) src = srcA + q * (long long)TB + (off % TB);      // dout: one tile per group
-                else src = srcA + q * (long long)AH_BYTES + off;
-            } else if (off < OFF_E) src = has_h ? srcH + q * (long long)AH_BYTES + (off - OFF_H) : srcE + q * TB;
-            else src = srcE + q * TB + (off - OFF_E);
-            st[i] = *reinterpret_cast<const u32x4 *>(src);
-        }
-    }
-    DEVI void store(char *dst) const {
-#pragma unroll
-        for (int i = 0; i < PIECES; ++i) {
-            const int u = i * NTHREADS + (int)threadIdx.x;
-            if (u < UNITS) *reinterpret_cast<u32x4 *>(dst + u * 16) = st[i];
-        }
-    }
-};
-
 // Job types of the dW kernel (compile-time so that the streaming loop is straight-line code)
 enum { JT_FIRST = 0, JT_HIDDEN = 1, JT_SKIP = 2, JT_OUT = 3, JT_HIDDEN1 = 4 };   // HIDDEN1: layer 1 with h_1 recomputed from the encoded inputs
 
@@ -685,7 +654,9 @@ DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-        if constexpr (Pol::ELEM_BYTES == 2) {
+        {
+            // (f32: 2 buffers -- the DMA of group q+1 runs under the MFMAs of group q, which at 8 MFMAs per fragment
+            //  pair are several times longer than an HBM round trip)
             // LDS-DMA ring: group q+NBUF-1 is issued right after the barrier that proves buffer
             // (q-1)%NBUF has been consumed; the counted wait leaves NBUF-2 younger groups in flight.
             // pieces (1 KiB = one wave-wide DMA) this job really needs: [A tiles | dout][h tiles][enc tile]
@@ -755,26 +726,6 @@ DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
                     it = (it == NBUF - 1) ? 0 : it + 1;
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-        } else {
-            // f32 (parity mode): plain double buffer through registers, no overlap
-            constexpr int UNITS = GB / 16;
-            GroupStager<UNITS, Pol::NTHREADS, OFF_H, OFF_E, MT * TB, TB> gs;
-            gs.out_job = out_job; gs.has_h = has_h; gs.srcA = srcA; gs.srcH = srcH; gs.srcE = srcE;
-            if (q0 < q1) {
-                gs.load(q0);
-                gs.store(smem);
-            }
-            __syncthreads();
-            int par = 0;
-            for (long long q = q0; q < q1; ++q) {
-                if (wave_works) compute_group(smem + par * GB);
-                if (q + 1 < q1) {
-                    gs.load(q + 1);
-                    gs.store(smem + (par ^ 1) * GB);
-                }
-                __syncthreads();
-                par ^= 1;
             }
         }
         // ---- flush this pass's partial dW^T tiles: slab[(m*NTMAX+n)][r/4][lane][r%4] ------------
