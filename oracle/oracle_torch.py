@@ -106,7 +106,7 @@ class CpuTrainer:
         G, hp = self.geom, self.hp
         e = predictor(self.k, self.b, t_frames, G['coords'], G['Omega'], G['t_start_obs'], G['t_geos'],
                       G['t_injection'], hp['GM_c3'], hp['scale'], hp['rmin'], hp['rmax'], hp['z_width'],
-                      hp.get('posenc_deg', 3), hp['net_depth'])
+                      hp.get('posenc_deg', 3), hp['net_depth'], hp.get('do_skip', True))
         return render(e, G.get('J'), G['g'], G['dtau'], G['Sigma'])
 
     def loss_and_grad(self, t_frames, target, sigma, offset, scale, dtype):

@@ -259,3 +259,57 @@ def test_taped_training_path_equals_recompute_path(dev, golden, tag, mode):
     grad = eng.render_bwd_tape(geom, tM0, dimg)
     assert torch.allclose(img, img_ref, rtol=1e-6, atol=1e-7 * float(img_ref.abs().max()))
     assert torch.equal(grad, grad_ref)
+
+
+@pytest.mark.parametrize('depth', [2, 3, 5])
+def test_networks_without_skip_connection(dev, depth):
+    """do_skip=False with depths outside the reference's 4/6/8 (two hidden layers: the layer-1 weight-gradient job
+    that recomputes h_1 is also the last hidden layer): images and gradient vs the oracle.  (Depth 1 is rejected.)"""
+    from bhnerf_amd import network, units, _hip
+    with pytest.raises(_hip.HipError):
+        network.NeRF_Predictor(8.0, net_depth=1, net_width=64, do_skip=False, device=dev).engine()
+    rng = np.random.default_rng(100 + depth)
+    H, Wd, G, B, width = 6, 5, 40, 2, 64
+    alpha, beta = np.meshgrid(np.linspace(-7, 7, H), np.linspace(-7, 7, Wd), indexing='ij')
+    s = np.linspace(-9.0, 9.0, G)
+    coords = np.stack([alpha[..., None] * np.ones(G), beta[..., None] * 0.5 + s * 0.8, -beta[..., None] * 0.8 + s * 0.5])
+    r = np.sqrt((coords ** 2).sum(0)) + 0.3
+    f32r = lambda v: np.asarray(v, dtype=np.float32).astype(np.float64)
+    geo = {k: f32r(v) for k, v in dict(coords=coords, Omega=1.0 / (r ** 1.5 + 0.1), t_geos=-(1000.0 - (s + 9.0)) * np.ones_like(r),
+                                        g=rng.uniform(0.6, 1.4, r.shape), Sigma=r ** 2, dtau=(s[1] - s[0]) / r ** 2).items()}
+    t_frames = np.array([0.1, 0.7]); t_inj = -(1000.0 - 3.0)
+    tree = onp.he_uniform_params(rng, depth, width, 21, do_skip=False, dtype=np.float32)
+    for i in range(depth + 1):
+        d = tree['MLP_0']['Dense_%d' % i]
+        d['kernel'] = d['kernel'].astype(np.float64); d['bias'] = f32r(rng.uniform(-0.1, 0.1, d['bias'].shape))
+    tree['MLP_0']['Dense_%d' % depth]['bias'] = tree['MLP_0']['Dense_%d' % depth]['bias'] + 9.0
+    t64 = lambda x: torch.tensor(np.asarray(x, dtype=np.float64))
+    ks, bs = ot.tree_to_lists(tree, torch.float64)
+    geom_t = dict(coords=t64(geo['coords']), Omega=t64(geo['Omega']), t_geos=t64(geo['t_geos']), g=t64(geo['g']), dtau=t64(geo['dtau']),
+                  Sigma=t64(geo['Sigma']), J=None, t_start_obs=0.0, t_injection=t_inj)
+    hp = dict(GM_c3=onp.GM_C3_SGRA_HR, scale=8.0, rmin=2.0, rmax=8.0, z_width=4.0, posenc_deg=3, net_depth=depth, do_skip=False)
+    tr = ot.CpuTrainer(ks, bs, geom_t, hp)
+    target = rng.uniform(0, 1e-2, (B, H, Wd)); sigma = rng.uniform(0.5, 2.0, (B, H, Wd)); offset = np.zeros((B, H, Wd))
+    loss_ref, img_ref, grads_ref = tr.loss_and_grad(t64(t_frames), t64(target), t64(sigma), t64(offset), 1.0, 'full')
+    n = len(tr.k)
+    gref = np.concatenate([np.concatenate([grads_ref[i].numpy().ravel(), grads_ref[n + i].numpy().ravel()]) for i in range(n)])
+    assert np.abs(gref).max() > 0
+    f = lambda k: np.ascontiguousarray(geo[k].astype(np.float32))
+    for mode in ('f32', 'bf16'):
+        pred = network.NeRF_Predictor(8.0, 2.0, 8.0, 4.0, net_depth=depth, net_width=width, do_skip=False, mode=mode, device=dev)
+        params = pred.engine().flatten(tree).requires_grad_(True)
+        ptree = network.ParamTree(); ptree.flat = params
+        loss, [images] = network.loss_fn_image(ptree, pred.apply, target, sigma, offset, t_frames, f('coords'), f('Omega'), 1.0, f('g'),
+                                               f('dtau'), f('Sigma'), 0.0, f('t_geos'), t_inj, 1.0, units.hr, 'full')
+        loss.backward()
+        ierr = np.abs(images.detach().cpu().numpy().reshape(img_ref.shape) - img_ref.numpy()).max() / img_ref.abs().max().item()
+        assert ierr < {'f32': 1e-5, 'bf16': 3e-2}[mode], (mode, ierr)
+        assert l2err(params.grad.cpu().numpy(), gref) < L2TOL[mode], (mode, l2err(params.grad.cpu().numpy(), gref))
+        # the taped route of the same gradient
+        eng = pred.engine()
+        geom = pred.geometry(f('coords'), f('Omega'), f('t_geos'), None, f('g'), f('dtau'), f('Sigma'))
+        tM0, _ = network._frame_offsets(t_frames, units.hr, 0.0, t_inj, dev)
+        eng.pack(params.detach())
+        dimg = torch.rand((B, 1, geom.R), device=dev)
+        eng.render_train(geom, tM0)
+        assert torch.equal(eng.render_bwd_tape(geom, tM0, dimg), eng.render_bwd(geom, tM0, dimg))
