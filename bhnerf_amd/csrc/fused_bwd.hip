@@ -21,7 +21,7 @@
 #define BHN_JOB1_W 12          // weight of the layer-1 dW job in B tiles at width 256 (measured optimum; scaled with the width)
 #endif
 #ifndef BHN_TAPED_DIST
-#define BHN_TAPED_DIST 6
+#define BHN_TAPED_DIST 6         // weight chunks in flight in the training-forward / delta-chain kernels (bf16; 4 measured 2 % slower)
 #endif
 
 struct TapeLayout {
@@ -229,9 +229,6 @@ void *bhn_debug_buffer();
 // ---------------------------------------------------------------------------------------------
 // chain kernel
 // ---------------------------------------------------------------------------------------------
-#ifndef BHN_EXTRA_YS
-#define BHN_EXTRA_YS 0
-#endif
 enum { MODE_FWD_TRAIN = 1, MODE_CHAIN = 2 };
 
 // MODE_FWD_TRAIN: the training forward: render (images, unless a.images is null) AND record h tiles, relu bits and
@@ -260,7 +257,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
     // two DMA issues holds the >= ES stores of one pending-tile emission; with >= 16 k-steps the running step's
     // own emission (k-step 12) also follows its DMA issue (k-step 9)
     constexpr int ES = (Pol::ELEM_BYTES == 2) ? 2 : 4;                 // global stores of one tile emission
-    constexpr int YS = ES * (DIST - 2) + ((KS >= 16 && Pol::ELEM_BYTES == 2) ? ES : 0) + BHN_EXTRA_YS;   // (f32 emits at k-step 8)
+    constexpr int YS = ES * (DIST - 2) + ((KS >= 16 && Pol::ELEM_BYTES == 2) ? ES : 0);   // (f32 emits at k-step 8)
     constexpr int YS0 = ES * (DIST - 2);                               // steps whose own stores precede their DMA issue
     constexpr int YS_L1r = (KS >= 16) ? YS - ES : 0;                   // first steps of layer 1 when h_1 is not emitted
     constexpr int YS_L1 = YS_L1r > 0 ? YS_L1r : 0;

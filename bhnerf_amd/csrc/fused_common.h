@@ -68,12 +68,10 @@ struct PolBF16 {
         unsigned u;
         asm("v_pk_max_i16 %0, %1, 0" : "=v"(u) : "v"(__builtin_bit_cast(unsigned, t)));
         put_dword(f, i, u);
-#ifndef BHN_NO_MASK
         unsigned m;      // (plain VALU reading a VALU result: no hazard the compiler would have to know about; the
                          //  generic elementwise min on u16x2 expands into ~10 compare/select instructions)
         asm("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(u), "s"(0x00010001u));
         spread |= m << k;
-#endif
     }
     static DEVI void mask_pair(frag &f, int i, int k, float a, float b, unsigned spread) {
         const bf16x2 t = {(__bf16)a, (__bf16)b};
@@ -354,10 +352,6 @@ struct DmaJob {                                 // chunk to start copying in the
 
 // Work folded into the MFMA shadows of a ring step ("Post" objects): at(t) is called right after MFMA t of the
 // step (t is a constant after unrolling) when the layer has >= 16 k-steps, all() before the first MFMA otherwise.
-struct NoPost {
-    DEVI void at(int) {}
-    DEVI void all() {}
-};
 
 // relu + repack of the pending output tile into its two B fragments (k-steps 0..7: two elements each).
 // d0/d1 may be the src[KS-2], src[KS-1] of the running step (layer boundary): complete before k-step KS-2.
