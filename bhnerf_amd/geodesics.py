@@ -19,8 +19,8 @@ inclination ``i`` (Bardeen 1973).  The second-order form ``r'' = R'(r)/2``, ``θ
 from the observer with classical RK4 — no sign bookkeeping at the turning points; away from them the radial
 velocity is re-derived from ``R(r)`` after every step — with a per-ray step
 ``dλ = h (1 + r/r_c) / r²`` (radial steps of ≈ h(1 + r/r_c): a few hundredths of M near the hole, geometric far away), until the ray falls
-through the horizon or is back at the observer's radius.  Every ray is then resampled at ``ngeo`` points uniform in
-Mino time, which is where ``dtau`` (the Mino step) of the radiative-transfer integrand ``g² · dtau · Σ`` comes from.
+through the horizon or is back at the observer's radius (finished rays are compacted away).  A second pass with the
+now known total Mino time of every ray writes its ``ngeo`` samples, uniform in Mino time, as the steps cross them, which is where ``dtau`` (the Mino step) of the radiative-transfer integrand ``g² · dtau · Σ`` comes from.
 """
 import numpy as np
 
@@ -67,61 +67,101 @@ def _rhs(y, a, lam, eta, M):
     return np.stack([vr, vth, dph, dt, ar, ath])
 
 
-def trace(alpha, beta, spin, inclination, distance=1000.0, M=1.0, h=0.02, r_c=5.0, max_steps=200000):
-    """Integrate one geodesic per (alpha, beta) backwards from the observer.  Returns the dense trajectories
-    ``(mino, r, theta, phi, t, vr, vth)`` as arrays ``(nsteps, nrays)`` and the index of each ray's last valid step."""
-    alpha = np.asarray(alpha, dtype=np.float64).ravel()
-    beta = np.asarray(beta, dtype=np.float64).ravel()
-    a = float(spin) * M
-    inc = float(inclination)
-    if not (0.0 < inc <= 0.5 * np.pi + 1e-12):
-        raise ValueError('inclination must be in (0, pi/2]')
+def _initial_state(alpha, beta, a, inc, distance, M):
     lam = -alpha * np.sin(inc)
     eta = (alpha ** 2 - a ** 2) * np.cos(inc) ** 2 + beta ** 2
     r0 = np.full_like(alpha, float(distance))
     th0 = np.full_like(alpha, inc)
     vr0 = -np.sqrt(np.clip(radial_potential(r0, a, lam, eta, M), 0.0, None))            # inwards, back in time
     vth0 = -np.sign(beta) * np.sqrt(np.clip(angular_potential(th0, a, lam, eta), 0.0, None))
-    y = np.stack([r0, th0, np.zeros_like(r0), np.zeros_like(r0), vr0, vth0])
+    return np.stack([r0, th0, np.zeros_like(r0), np.zeros_like(r0), vr0, vth0]), lam, eta
+
+
+def _integrate(alpha, beta, spin, inclination, distance, M, h, r_c, max_steps, targets=None):
+    """RK4 over all rays with the finished ones compacted away.  Without ``targets``: returns each ray's final Mino
+    time and state.  With ``targets`` (n, ngeo) increasing Mino times: returns the states interpolated at them,
+    shape (7, n, ngeo) with rows (mino, r, theta, phi, t, vr, vth)."""
+    alpha = np.asarray(alpha, dtype=np.float64).ravel()
+    beta = np.asarray(beta, dtype=np.float64).ravel()
+    a = float(spin) * M
+    inc = float(inclination)
+    if not (0.0 < inc <= 0.5 * np.pi + 1e-12):
+        raise ValueError('inclination must be in (0, pi/2]')
+    n = alpha.size
+    y, lam, eta = _initial_state(alpha, beta, a, inc, distance, M)
     r_hor = M + np.sqrt(max(M * M - a * a, 0.0))
-    alive = np.ones(alpha.shape, dtype=bool)
-    mino = np.zeros_like(alpha)
-    traj = [np.concatenate([mino[None], y])]
-    last = np.zeros(alpha.shape, dtype=np.int64)
+    idx = np.arange(n)                                   # rays still being integrated (compacted)
+    mino = np.zeros(n)
+    end_mino, end_y = np.zeros(n), y.copy()
+    out = nxt = None
+    if targets is not None:
+        ngeo = targets.shape[1]
+        out = np.zeros((7, n, ngeo))
+        nxt = np.zeros(n, dtype=np.int64)                # next sample of every ray (global indexing)
     for step in range(1, max_steps + 1):
-        # (the centrifugal term of Θ is stiff next to the poles: up to 20x smaller steps there)
-        dl = np.where(alive, h * (1.0 + y[0] / r_c) / y[0] ** 2 * np.clip((np.sin(y[1]) / 0.25) ** 2, 0.05, 1.0), 0.0)
-        k1 = _rhs(y, a, lam, eta, M)
-        k2 = _rhs(y + 0.5 * dl * k1, a, lam, eta, M)
-        k3 = _rhs(y + 0.5 * dl * k2, a, lam, eta, M)
-        k4 = _rhs(y + dl * k3, a, lam, eta, M)
+        lm, et = lam[idx], eta[idx]
+        # (the centrifugal term of Theta is stiff next to the poles: up to 20x smaller steps there)
+        dl = h * (1.0 + y[0] / r_c) / y[0] ** 2 * np.clip((np.sin(y[1]) / 0.25) ** 2, 0.05, 1.0)
+        k1 = _rhs(y, a, lm, et, M)
+        k2 = _rhs(y + 0.5 * dl * k1, a, lm, et, M)
+        k3 = _rhs(y + 0.5 * dl * k2, a, lm, et, M)
+        k4 = _rhs(y + dl * k3, a, lm, et, M)
         y_new = y + dl / 6.0 * (k1 + 2.0 * k2 + 2.0 * k3 + k4)
-        # keep the first integral (dr/dλ)² = R(r): far from the hole dr/dλ ~ r² ~ 1e6 and a relative RK4 error of
-        # 1e-10 there is an absolute error of 1e2 in (dr/dλ)² at the turning point; away from turning points the
-        # velocity is therefore re-derived from the potential (sign kept), near them the second-order form runs free
-        Rn = radial_potential(y_new[0], a, lam, eta, M)
-        far = Rn > 1e-2 * y_new[0] ** 4
-        y_new[4] = np.where(far, np.sign(y_new[4]) * np.sqrt(np.abs(Rn)), y_new[4])
-        Tn = angular_potential(y_new[1], a, lam, eta)
-        farth = Tn > 1e-2 * (eta + a * a + lam ** 2)
-        y_new[5] = np.where(farth, np.sign(y_new[5]) * np.sqrt(np.abs(Tn)), y_new[5])
-        captured = alive & ~(y_new[0] > r_hor * 1.02)         # (also catches a NaN): the step is not taken, the ray ends here
-        ok = alive & ~captured
-        y = np.where(ok, y_new, y)
-        mino = np.where(ok, mino + dl, mino)
-        last = np.where(ok, step, last)
-        escaped = (y[0] > distance) & (y[4] > 0.0)
-        alive = ok & ~escaped
-        traj.append(np.concatenate([mino[None], y]))
-        if not alive.any():
-            break
+        # keep the first integrals (dr/dlambda)^2 = R(r), (dtheta/dlambda)^2 = Theta(theta): far from the hole dr/dlambda ~ r^2 ~
+        # 1e6 and a relative RK4 error of 1e-10 there is an absolute error of 1e2 in (dr/dlambda)^2 at the turning point; away
+        # from turning points the velocities are therefore re-derived from the potentials (sign kept), near them the
+        # second-order form runs free
+        Rn = radial_potential(y_new[0], a, lm, et, M)
+        y_new[4] = np.where(Rn > 1e-2 * y_new[0] ** 4, np.sign(y_new[4]) * np.sqrt(np.abs(Rn)), y_new[4])
+        Tn = angular_potential(y_new[1], a, lm, et)
+        y_new[5] = np.where(Tn > 1e-2 * (et + a * a + lm ** 2), np.sign(y_new[5]) * np.sqrt(np.abs(Tn)), y_new[5])
+        captured = ~(y_new[0] > r_hor * 1.02)              # (also catches a NaN): the step is not taken, the ray ends here
+        mino_new = mino + dl
+        if targets is not None:                            # samples crossed by this step: linear in Mino time
+            ok = ~captured
+            while True:
+                g_idx = idx
+                k = np.minimum(nxt[g_idx], ngeo - 1)
+                tgt = targets[g_idx, k]
+                hit = ok & (nxt[g_idx] < ngeo) & (tgt <= mino_new)
+                if not hit.any():
+                    break
+                w = ((tgt - mino) / np.where(dl > 0, dl, 1.0))[hit]
+                rows = g_idx[hit]
+                out[0, rows, k[hit]] = tgt[hit]
+                out[1:, rows, k[hit]] = y[:, hit] * (1.0 - w) + y_new[:, hit] * w
+                nxt[rows] += 1
+        y = np.where(captured, y, y_new)
+        mino = np.where(captured, mino, mino_new)
+        done = captured | ((y[0] > distance) & (y[4] > 0.0))
+        if done.any():
+            rows = idx[done]
+            end_mino[rows], end_y[:, rows] = mino[done], y[:, done]
+            keep = ~done
+            idx, y, mino = idx[keep], y[:, keep], mino[keep]
+            if idx.size == 0:
+                break
     else:
         raise RuntimeError('geodesic integration did not terminate in %d steps' % max_steps)
-    return np.stack(traj), last, lam, eta
+    if targets is None:
+        return end_mino, end_y, lam, eta
+    # rounding can leave the very last sample (target = end of the ray) unwritten: it is the end state
+    miss = nxt < ngeo
+    for j in np.nonzero(miss)[0]:
+        out[0, j, nxt[j]:] = end_mino[j]
+        out[1:, j, nxt[j]:] = end_y[:, j, None]
+    return out, lam, eta
+
+
+def trace(alpha, beta, spin, inclination, distance=1000.0, M=1.0, h=0.02, r_c=5.0, max_steps=400000):
+    """Integrate one geodesic per (alpha, beta) backwards from the observer until it is captured or has escaped.
+    Returns ``(mino_end, state_end, lam, eta)`` with ``state_end`` rows ``(r, theta, phi, t, vr, vth)`` (phi and t of
+    the forward equations: negate them for the backward ray)."""
+    return _integrate(alpha, beta, spin, inclination, distance, M, h, r_c, max_steps)
 
 
 def image_plane_geos(spin, inclination, alpha_range, beta_range, ngeo=100, num_alpha=64, num_beta=64, distance=1000.0,
-                     E=1.0, M=1.0, randomize_subpixel_rays=False, verbose=False, h=0.02, chunk=4096):
+                     E=1.0, M=1.0, randomize_subpixel_rays=False, verbose=False, h=0.02, chunk=65536):
     """Kerr geodesics for the whole image plane (signature of ``bhnerf.kgeo.image_plane_geos``, kgeo.py:6-63).
 
     Returns a ``Geodesics`` record with arrays of shape ``(num_alpha, num_beta, ngeo)`` (per-ray constants
@@ -142,15 +182,12 @@ def image_plane_geos(spin, inclination, alpha_range, beta_range, ngeo=100, num_a
     bf = np.where(bf == 0.0, 1e-9, bf)
     for c0 in range(0, n, chunk):
         sl = slice(c0, min(c0 + chunk, n))
-        traj, last, lam, eta = trace(af[sl], bf[sl], spin, inclination, distance, M, h)
+        mino_end, _, lam, eta = _integrate(af[sl], bf[sl], spin, inclination, distance, M, h, 5.0, 400000)
         lam_all[sl], eta_all[sl] = lam, eta
-        mino_end = traj[last, 0, np.arange(last.size)]
         target = (np.arange(1, ngeo + 1)[None, :] / float(ngeo)) * mino_end[:, None]            # uniform in Mino time
-        for j in range(last.size):                       # per-ray 1-D interpolation on its own Mino grid
-            m = traj[:last[j] + 1, 0, j]
-            for name, row in (('r', 1), ('theta', 2), ('phi', 3), ('t', 4), ('vr', 5), ('vth', 6)):
-                out[name][c0 + j] = np.interp(target[j], m, traj[:last[j] + 1, row, j])
-            out['mino'][c0 + j] = target[j]
+        samp, _, _ = _integrate(af[sl], bf[sl], spin, inclination, distance, M, h, 5.0, 400000, targets=target)
+        for row, name in enumerate(('mino', 'r', 'theta', 'phi', 't', 'vr', 'vth')):
+            out[name][sl] = samp[row]
         if verbose:
             print('traced rays %d-%d of %d' % (c0, sl.stop, n))
     shape3 = (num_alpha, num_beta, ngeo)

@@ -53,8 +53,8 @@ def test_flat_space_limit_gives_straight_lines_and_euclidean_travel_time():
 def test_schwarzschild_shadow_radius():
     """Rays with impact parameter below sqrt(27) M fall into the hole, above it they escape."""
     bc = np.sqrt(27.0)
-    traj, last, _, _ = G.trace([bc - 0.05, bc + 0.05, 0.0, 0.0], [1e-6, 1e-6, bc - 0.05, bc + 0.05], 0.0, np.deg2rad(30.0))
-    r_end = traj[last, 1, np.arange(4)]
+    _, y_end, _, _ = G.trace([bc - 0.05, bc + 0.05, 0.0, 0.0], [1e-6, 1e-6, bc - 0.05, bc + 0.05], 0.0, np.deg2rad(30.0))
+    r_end = y_end[0]
     assert r_end[0] < 2.2 and r_end[2] < 2.2 and r_end[1] > 999.0 and r_end[3] > 999.0
 
 
