@@ -687,7 +687,7 @@ DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
                 q = q < q1 ? q : q1 - 1;
 #pragma unroll
                 for (int i = 0; i < PPW; ++i)
-                    dma_1k(sbase[i] + q * sstride[i], buf + doff[i]);
+                    dma_1k<true>(sbase[i] + q * sstride[i], buf + doff[i]);
             };
             // HIDDEN1: the h tiles of group q+1 are computed while group q is consumed (one group less in flight:
             // this job is MFMA-bound), so the loop-top barrier also publishes them and no latency chain is exposed

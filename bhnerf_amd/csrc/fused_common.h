@@ -419,12 +419,15 @@ DEVI f32x16 ring_step(const char *ch, const char *chn, APipe<Pol> &ap, const typ
 // uniform).  The MUBUF form (buffer_load_dwordx4 ... lds) is used on purpose: the compiler's waitcnt pass books
 // the FLAT form (global_load_lds_dwordx4) as a pending flat access and then degrades every later LDS wait to
 // lgkmcnt(0), which serialises the software-pipelined A-fragment reads of ring_step.
+// STREAM: cache policy `nt` for bytes that one CU reads exactly once (the tape in the dW kernel); never for the
+// weight ring, which every CU re-reads from L2.
+template <bool STREAM = false>
 DEVI void dma_1k(const char *src, char *dst) {
     const unsigned long long u = reinterpret_cast<unsigned long long>(src);
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
     void *us = reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo);
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(us, 0, 1 << 20, 0x00020000);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)dst, 16, (int)(threadIdx.x & 63) * 16, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)dst, 16, (int)(threadIdx.x & 63) * 16, 0, 0, STREAM ? 2 : 0);
 }
 
 template <int CHUNK_BYTES, int NWAVES>
