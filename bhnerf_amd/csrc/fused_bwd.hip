@@ -255,9 +255,11 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
     using RS = RingState<RG, CB, DIST, false, MT, BHN_CHAIN_STAMPS != 0>;
     // stores guaranteed younger than chunk c+2 at the end of step c (RingState::step_end): every interval between
     // two DMA issues holds the >= ES stores of one pending-tile emission; with >= 16 k-steps the running step's
-    // own emission (k-step 12) also follows its DMA issue (k-step 9)
+    // own emission (k-step 12) also follows its DMA issue (k-step 9).  The DMA pieces of the DIST-2 younger chunks
+    // cancel out of the balance, so only this store count has to be a lower bound (relu-bit words, epilogue stores and
+    // prefetch loads only add slack); the exceptions are the steps right after a layer-0 step without h_1 emission.
     constexpr int ES = (Pol::ELEM_BYTES == 2) ? 2 : 4;                 // global stores of one tile emission
-    constexpr int YS = ES * (DIST - 2) + ((KS >= 16 && Pol::ELEM_BYTES == 2) ? ES : 0);   // (f32 emits at k-step 8)
+    constexpr int YS = ES * (DIST - 2) + ((KS >= 16 && Pol::ELEM_BYTES == 2) ? ES : 0);   // (f32: kept conservative)
     constexpr int YS0 = ES * (DIST - 2);                               // steps whose own stores precede their DMA issue
     constexpr int YS_L1r = (KS >= 16) ? YS - ES : 0;                   // first steps of layer 1 when h_1 is not emitted
     constexpr int YS_L1 = YS_L1r > 0 ? YS_L1r : 0;
