@@ -149,3 +149,19 @@ def image_plane_dynamics(emission_0, geos, Omega, t_frames, t_injection, J=1.0, 
     if np.ndim(t_frames if not units.is_quantity(t_frames) else t_frames.value) == 0:
         out = out[0]
     return np.squeeze(out) if geom.S else out                                          # emission.py:299 squeeze quirk
+
+
+def rotate_evpa(stokes, angle, axis=0):
+    """Rotate the electric-vector position angle by ``angle`` [rad]: ``Q + iU -> exp(2i angle) (Q + iU)``
+    (emission.py:395-407).  The Stokes axis holds (Q, U), (I, Q, U) or (I, Q, U, V); I and V are unchanged."""
+    stokes = np.asarray(stokes)
+    n = stokes.shape[axis]
+    if n not in (2, 3, 4):
+        raise AttributeError('Shape of stokes vector along axis={} not supported'.format(axis))
+    q = 0 if n == 2 else 1
+    moved = np.moveaxis(stokes, axis, 0)
+    c, s = np.cos(2.0 * angle), np.sin(2.0 * angle)
+    out = np.array(moved, dtype=np.result_type(moved.dtype, np.float64), copy=True)
+    out[q] = c * moved[q] - s * moved[q + 1]
+    out[q + 1] = s * moved[q] + c * moved[q + 1]
+    return np.moveaxis(out, 0, axis)

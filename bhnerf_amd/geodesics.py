@@ -34,6 +34,14 @@ class Geodesics(dict):
     def dims(self):
         return {'alpha': self['r'].shape[0], 'beta': self['r'].shape[1], 'geo': self['r'].shape[2]}
 
+    def fillna(self, value):
+        """Copy with the NaNs of every floating array replaced (``xarray.Dataset.fillna``, used by alma.py:43)."""
+        out = Geodesics()
+        for k, v in self.items():
+            arr = np.asarray(v)
+            out[k] = np.where(np.isnan(arr), value, arr) if arr.dtype.kind == 'f' and arr.ndim else v
+        return out
+
 
 def kerr_functions(r, theta, spin, M=1.0):
     """Δ, Σ, Ξ and the frame-dragging frequency ω of the Kerr metric (spin in units of M)."""

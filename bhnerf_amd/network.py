@@ -558,14 +558,28 @@ def image_plane_checkpoint(raytracing_args, checkpoint_dir, t, rmin=0.0, rmax=np
 
 
 def raytracing_args(geos, Omega, t_injection, t_start_obs, J=1.0):
-    """Ordered dict of the non-optimised ray-tracing arguments (network.py:850-894).  ``geos`` is
-    any mapping/object with x, y, z, dtau, Sigma, t and the Doppler factor ``g``; computing g from
-    the 4-velocity (kgeo.py:199-248) is outside the hot path."""
+    """Ordered dict of the non-optimised ray-tracing arguments (network.py:850-894).
+
+    ``geos`` is any mapping/object with x, y, z, dtau, Sigma, t.  When it is a traced geodesic record
+    (``kgeo.image_plane_geos``: r, theta, affine, potentials, constants of motion) the Doppler factor is derived from
+    the azimuthal 4-velocity of ``Omega`` as the reference does (network.py:875-876); a pre-computed table may carry
+    its own ``g`` instead."""
+    from . import kgeo
     get = (lambda k: geos[k]) if isinstance(geos, dict) else (lambda k: getattr(geos, k))
-    try:
+
+    def has(k):
+        try:
+            get(k)
+            return True
+        except (KeyError, AttributeError):
+            return False
+
+    if all(has(k) for k in ('r', 'theta', 'affine', 'R', 'Theta', 'Delta', 'Xi', 'lam', 'E', 'M', 'spin')):
+        gfac = kgeo.doppler_factor(geos, kgeo.azimuthal_velocity_vector(geos, Omega))
+    elif has('g'):
         gfac = get('g')
-    except (KeyError, AttributeError):
-        raise AttributeError('geos must carry the Doppler factor "g" (kgeo.doppler_factor is not part of this build)')
+    else:
+        raise AttributeError('geos must be a traced geodesic record (kgeo.image_plane_geos) or carry the Doppler factor "g"')
     f32 = lambda v: np.ascontiguousarray(np.asarray(v, dtype=np.float32))
     return OrderedDict({
         'coords': f32(np.array([get('x'), get('y'), get('z')])),

@@ -98,7 +98,7 @@ _mod('flax.training.checkpoints')
 _mod('optax')
 _mod('xarray')
 _mod('kgeo', __all__=[])
-_mod('tqdm'); _mod('tqdm.auto', tqdm=lambda x, **k: x)
+_mod('tqdm'); _mod('tqdm.auto', tqdm=lambda x, **k: x); _mod('tqdm.contrib', tzip=lambda *a, **k: zip(*a))
 _mod('tensorboardX', SummaryWriter=object)
 
 pkg = types.ModuleType('bhnerf')
@@ -385,6 +385,21 @@ def main():
          t_frames=t_frames9, t_injection=t_inj9, emission=em9, images=img9, target=target9, sigma=sigma9, loss=chi2(grid),
          fd_idx=np.array(fd_idx), fd_val=np.array(fd_val), nonzero_fd=int((np.abs(np.array(fd_val)) > 0).sum()),
          **{k: geo9[k] for k in ('coords', 'Omega', 't_geos', 'g', 'dtau', 'Sigma')})
+
+    # G10: emission.rotate_evpa (emission.py:395-407) and alma.preprocess_data (alma.py:9-25) on a synthetic two-scan
+    # light-curve table (the csv is rebuilt from the stored columns by the test) ------------------------------------------
+    import pandas as pd, tempfile
+    alma = _load('alma')
+    rng10 = np.random.default_rng(1010)
+    s2, s3, s4 = rng10.standard_normal((2, 5)), rng10.standard_normal((6, 3, 4)), rng10.standard_normal((3, 2, 4))
+    tt = np.concatenate([9.0 + np.arange(500) * 4 / 3600.0, 9.0 + 0.62 + np.arange(450) * 4 / 3600.0])
+    lc = pd.DataFrame({'time': tt, 'I': rng10.uniform(2, 3, tt.size), 'Q': rng10.standard_normal(tt.size), 'U': rng10.standard_normal(tt.size)})
+    with tempfile.TemporaryDirectory() as d:
+        lc.to_csv(os.path.join(d, 'lc.csv'))
+        target10, t10 = alma.preprocess_data(os.path.join(d, 'lc.csv'), 12, 0.25, 0.08, 31.0, -17.5, t_start=9.07, t_end=10.0)
+    save('g10_alma', s2=s2, s3=s3, s4=s4, rot2=emission.rotate_evpa(s2, 0.37), rot3=emission.rotate_evpa(s3, -1.2, axis=1),
+         rot4=emission.rotate_evpa(s4, 2.9, axis=2), lc_time=tt, lc_I=lc['I'].values, lc_Q=lc['Q'].values, lc_U=lc['U'].values,
+         pre_args=np.array([12, 0.25, 0.08, 31.0, -17.5, 9.07, 10.0]), pre_target=target10, pre_t_hr=np.asarray(t10.to('hr').value))
 
 
 if __name__ == '__main__':

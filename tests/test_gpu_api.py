@@ -141,3 +141,26 @@ def test_training_on_traced_kerr_geodesics(dev):
     last, frames = optimization.total_movie_loss(2, opt.state, step, rt, return_frames=True)
     assert np.isfinite(first) and np.isfinite(last) and frames.shape == (4, 3, 8, 8) and np.isfinite(frames).all()
     assert opt.state.step == 6
+
+
+def test_alma_chi2_from_checkpoint(dev, tmp_path):
+    """alma.get_raytracing_args -> Optimizer (polarised 'lc' fit) -> alma.chi2_lightcurves / chi2_df (alma.py:66-117)."""
+    import os
+    from bhnerf_amd import alma, network, optimization, units
+    params = dict(num_alpha=8, num_beta=8, fov_M=16.0, z_width=4.0, rmin='ISCO', Q_frac=0.5,
+                  b_consts=dict(arad=0.0, avert=1.0, ator=0.0), Omega_dir='cw', t_start_obs=9.5)
+    rt = alma.get_raytracing_args(np.deg2rad(25.0), 0.2, params)
+    t = (9.5 + np.linspace(0.0, 0.5, 5)) * units.hr
+    data = np.abs(np.random.default_rng(3).standard_normal((5, 3))) * 1e-2
+    ckpt = str(tmp_path / 'inc_25.0_seed_0')
+    pred = network.NeRF_Predictor(8.0, 2.0, 8.0, 4.0, net_depth=4, net_width=64, mode='f32', device=dev)
+    step = optimization.TrainStep.image(t, data, sigma=1e-2, dtype='lc')
+    opt = optimization.Optimizer({'num_iters': 4, 'lr_init': 1e-3, 'lr_final': 1e-4}, pred, rt, save_period=4, checkpoint_dir=ckpt)
+    opt.run(5, step, rt)
+    assert os.path.exists(os.path.join(ckpt, 'checkpoint_4'))
+    chi2 = alma.chi2_lightcurves(rt, ckpt, t, data, sigma=1e-2, batchsize=5, mode='f32', device=dev)
+    _, frames = optimization.total_movie_loss(5, opt.state, step, rt, return_frames=True)
+    want = np.sum(((frames.sum(axis=(-1, -2)) - data) / 1e-2) ** 2) / 5
+    assert np.isfinite(chi2) and abs(chi2 - want) <= 1e-5 * abs(want)
+    df = alma.chi2_df([25.0, 35.0], 0.2, [0], params, str(tmp_path / 'inc_{}_seed_{}'), t, data, sigma=1e-2, final_step=4)
+    assert np.isnan(df.loc[35.0, 'seed 0']) and np.isfinite(df.loc[25.0, 'seed 0'])
