@@ -263,3 +263,95 @@ class LogFn(object):
         if self.log_period > 0:
             if (optimizer.step == 1) or ((optimizer.step % self.log_period) == 0):
                 self.log_fn(optimizer)
+
+
+class SummaryWriter(object):
+    """Training-log writer with the methods the reference's drivers use (optimization.py:304-347, a subclass of
+    ``tensorboardX.SummaryWriter`` there).  tensorboardX is used when it is installed; otherwise scalars go to
+    ``<logdir>/scalars.jsonl`` (one ``{"tag", "value", "step"}`` object per line), image batches to
+    ``<logdir>/<tag>_<step>.npy`` and figures to ``<logdir>/<tag>_<step>.png`` -- plain files, no event protocol."""
+
+    def __init__(self, logdir=None, comment='', **kwargs):
+        self.logdir = logdir or os.path.join('runs', comment or 'bhnerf')
+        self._tb = None
+        try:
+            import tensorboardX
+            self._tb = tensorboardX.SummaryWriter(self.logdir, comment, **kwargs)
+        except ImportError:
+            os.makedirs(self.logdir, exist_ok=True)
+
+    def _path(self, tag, step, ext):
+        path = os.path.join(self.logdir, '%s_%s.%s' % (tag.replace('/', '_'), step, ext))
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        return path
+
+    def add_scalar(self, tag, scalar_value, global_step=None):
+        if self._tb is not None:
+            return self._tb.add_scalar(tag, scalar_value, global_step)
+        import json
+        with open(os.path.join(self.logdir, 'scalars.jsonl'), 'a') as f:
+            f.write(json.dumps({'tag': tag, 'value': float(scalar_value), 'step': None if global_step is None else int(global_step)}) + '\n')
+
+    def add_images(self, tag, img_tensor, global_step=None, dataformats='NCHW'):
+        if self._tb is not None:
+            return self._tb.add_images(tag, img_tensor, global_step, dataformats=dataformats)
+        np.save(self._path(tag, global_step, 'npy'), np.asarray(img_tensor))
+
+    def add_figure(self, tag, figure, global_step=None, close=True):
+        if self._tb is not None:
+            return self._tb.add_figure(tag, figure, global_step, close)
+        figure.savefig(self._path(tag, global_step, 'png'))
+        if close:
+            import matplotlib.pyplot as plt
+            plt.close(figure)
+
+    def flush(self):
+        if self._tb is not None:
+            self._tb.flush()
+
+    def close(self):
+        if self._tb is not None:
+            self._tb.close()
+
+    def recovery_3d(self, fov, vis_res=64, emission_true=None):
+        """Log function for ``Optimizer.run(log_fns=...)``: samples the network on a ``vis_res``^3 grid of width ``fov``
+        (or on the grid of ``emission_true``: an array with 1-D ``x, y, z`` coordinate attributes) and logs its slices,
+        plus mse / psnr against the truth (optimization.py:310-329)."""
+        from . import utils
+        if emission_true is not None:
+            axes = [np.linspace(float(c[0]), float(c[-1]), n) for c, n in
+                    zip((emission_true.x, emission_true.y, emission_true.z), emission_true.shape[:3])]
+            truth = np.asarray(getattr(emission_true, 'data', emission_true))
+        else:
+            axes = [np.linspace(-fov / 2.0, fov / 2.0, vis_res)] * 3
+        vis_coords = np.array(np.meshgrid(*axes, indexing='ij'))
+
+        def log_fn(opt):
+            grid = network.sample_3d_grid(opt.state.apply_fn, opt.params, coords=vis_coords)
+            self.add_images('emission/estimate', utils.intensity_to_nchw(grid), global_step=opt.step, dataformats='NCWH')
+            if emission_true is not None:
+                self.add_scalar('emission/mse', utils.mse(truth, grid), global_step=opt.step)
+                self.add_scalar('emission/psnr', utils.psnr(truth, grid), global_step=opt.step)
+        return log_fn
+
+    def plot_lc_datafit(self, opt, name, train_step, target, stokes, t_frames=None, batchsize=20):
+        """Figure of the estimated against the target Stokes light curves, and the log10 data-fit scalar
+        (optimization.py:331-347).  One of the sub-pixel ray sets is drawn at random, as in the reference."""
+        import matplotlib
+        matplotlib.use('Agg', force=False)
+        import matplotlib.pyplot as plt
+        rt = opt.raytracing_args
+        if isinstance(rt, (list, tuple)):
+            rt = rt[np.random.choice(len(rt))]
+        loss, movie = total_movie_loss(batchsize, opt.state, train_step, rt, return_frames=True)
+        lc_est = np.asarray(movie).sum(axis=(-1, -2))
+        target = np.asarray(target)
+        t = np.arange(len(target)) if t_frames is None else np.asarray(getattr(t_frames, 'value', t_frames))
+        fig, axes = plt.subplots(1, len(stokes), figsize=(4 * len(stokes), 3), squeeze=False)
+        for k, (ax, s) in enumerate(zip(axes[0], stokes)):
+            ax.plot(t, target[:, k] if target.ndim > 1 else target, label='True')
+            ax.plot(t, lc_est[:, k] if lc_est.ndim > 1 else lc_est, 'rx', label='Estimate')
+            ax.set_title(s)
+            ax.legend()
+        self.add_figure('lightcurve/{}'.format(name), fig, global_step=opt.step)
+        self.add_scalar('datafit/{}'.format(name), np.log10(np.mean(loss)), global_step=opt.step)

@@ -40,3 +40,31 @@ def rotation_matrix(axis, angle, use_jax=False):
     if xp is torch:
         return torch.stack([torch.stack(r) for r in rows])
     return np.array(rows)
+
+
+def mse(true, est):
+    """Mean squared error (utils.py:9)."""
+    return float(np.mean((np.asarray(true) - np.asarray(est)) ** 2))
+
+
+def psnr(true, est):
+    """Peak signal-to-noise ratio in dB relative to ``max(true)`` (utils.py:11)."""
+    return float(10.0 * np.log10(np.max(true) ** 2 / mse(true, est)))
+
+
+def world_to_image_coords(coords, fov, npix, use_jax=False):
+    """World coordinates in ``[-fov/2, fov/2]`` -> fractional pixel indices ``[0, npix-1]`` per axis (utils.py:160-166)."""
+    xp = _xp(coords)
+    return xp.stack([(coords[..., i] + fov[i] / 2.0) / fov[i] * (npix[i] - 1) for i in range(coords.shape[-1])], -1)
+
+
+def intensity_to_nchw(intensity, cmap='viridis', gamma=0.5):
+    """Colour-mapped slices of a 3-D intensity volume for image logging (utils.py:168-193): min-max normalised,
+    gamma-corrected, RGB from the matplotlib colour map; the volume axes (0, 1, 2) + colour become axes (3, 2, 0, 1)."""
+    import matplotlib
+    intensity = np.asarray(intensity, dtype=np.float64)
+    lo, hi = intensity.min(), intensity.max()
+    with np.errstate(invalid='ignore', divide='ignore'):
+        normed = ((intensity - lo) / (hi - lo)) ** gamma
+    rgb = matplotlib.colormaps[cmap](normed)[..., :3]
+    return np.moveaxis(rgb, (0, 1, 2, 3), (3, 2, 0, 1))

@@ -397,7 +397,12 @@ def main():
     with tempfile.TemporaryDirectory() as d:
         lc.to_csv(os.path.join(d, 'lc.csv'))
         target10, t10 = alma.preprocess_data(os.path.join(d, 'lc.csv'), 12, 0.25, 0.08, 31.0, -17.5, t_start=9.07, t_end=10.0)
-    save('g10_alma', s2=s2, s3=s3, s4=s4, rot2=emission.rotate_evpa(s2, 0.37), rot3=emission.rotate_evpa(s3, -1.2, axis=1),
+    vol = rng10.uniform(0, 2, (4, 5, 6)); vol_est = vol + 0.1 * rng10.standard_normal(vol.shape)
+    wc = rng10.uniform(-4, 4, (7, 3))
+    extra = dict(vol=vol, vol_est=vol_est, nchw=utils.intensity_to_nchw(vol), nchw_g1=utils.intensity_to_nchw(vol, 'magma', 1.0),
+                 mse=utils.mse(vol, vol_est), psnr=utils.psnr(vol, vol_est), wc=wc,
+                 wc_img=utils.world_to_image_coords(wc, (8.0, 8.0, 10.0), (16, 16, 20)))
+    save('g10_alma', **extra, s2=s2, s3=s3, s4=s4, rot2=emission.rotate_evpa(s2, 0.37), rot3=emission.rotate_evpa(s3, -1.2, axis=1),
          rot4=emission.rotate_evpa(s4, 2.9, axis=2), lc_time=tt, lc_I=lc['I'].values, lc_Q=lc['Q'].values, lc_U=lc['U'].values,
          pre_args=np.array([12, 0.25, 0.08, 31.0, -17.5, 9.07, 10.0]), pre_target=target10, pre_t_hr=np.asarray(t10.to('hr').value))
 

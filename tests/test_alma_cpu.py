@@ -128,3 +128,26 @@ def test_against_reference_golden(tmp_path):
     assert target.shape == gold['pre_target'].shape
     assert np.allclose(target, gold['pre_target'], rtol=1e-12, atol=1e-14)
     assert np.allclose(np.asarray(t_frames.to('hr').value), gold['pre_t_hr'], rtol=1e-14)
+
+
+def test_logging_helpers_against_reference_golden(tmp_path):
+    """utils.mse / psnr / intensity_to_nchw / world_to_image_coords (utils.py:9-11, 160-193) against fixture g10."""
+    import json
+    import os
+    from bhnerf_amd import optimization, utils
+    gold = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'g10_alma.npz'))
+    assert utils.mse(gold['vol'], gold['vol_est']) == pytest.approx(float(gold['mse']), rel=1e-14)
+    assert utils.psnr(gold['vol'], gold['vol_est']) == pytest.approx(float(gold['psnr']), rel=1e-14)
+    assert np.allclose(utils.world_to_image_coords(gold['wc'], (8.0, 8.0, 10.0), (16, 16, 20)), gold['wc_img'], rtol=1e-14)
+    nchw = utils.intensity_to_nchw(gold['vol'])
+    assert nchw.shape == gold['nchw'].shape == (6, 3, 5, 4) and np.allclose(nchw, gold['nchw'], atol=1e-12)
+    assert np.allclose(utils.intensity_to_nchw(gold['vol'], 'magma', 1.0), gold['nchw_g1'], atol=1e-12)
+    # file-backed writer (tensorboardX is not installed here)
+    w = optimization.SummaryWriter(str(tmp_path / 'log'))
+    w.add_scalar('datafit/x', 0.5, global_step=3)
+    w.add_images('emission/estimate', nchw, global_step=3, dataformats='NCWH')
+    w.close()
+    if w._tb is None:
+        rec = [json.loads(l) for l in open(tmp_path / 'log' / 'scalars.jsonl')]
+        assert rec == [{'tag': 'datafit/x', 'value': 0.5, 'step': 3}]
+        assert np.array_equal(np.load(tmp_path / 'log' / 'emission_estimate_3.npy'), nchw)

@@ -164,3 +164,28 @@ def test_alma_chi2_from_checkpoint(dev, tmp_path):
     assert np.isfinite(chi2) and abs(chi2 - want) <= 1e-5 * abs(want)
     df = alma.chi2_df([25.0, 35.0], 0.2, [0], params, str(tmp_path / 'inc_{}_seed_{}'), t, data, sigma=1e-2, final_step=4)
     assert np.isnan(df.loc[35.0, 'seed 0']) and np.isfinite(df.loc[25.0, 'seed 0'])
+
+
+def test_summary_writer_log_functions(dev, problem, tmp_path):
+    """SummaryWriter.recovery_3d / plot_lc_datafit as used by the fit scripts (optimization.py:310-347)."""
+    import json
+    import types
+    from bhnerf_amd import network, optimization, units
+    p = problem
+    lc = p['movie'].sum(axis=(-1, -2))
+    pred = network.NeRF_Predictor(8.0, 1.0, 8.0, 4.0, net_depth=4, net_width=64, mode='f32', device=dev)
+    step = optimization.TrainStep.image(p['t_frames'] * units.hr, lc, sigma=float(np.abs(lc).mean()) * 0.1, dtype='lc')
+    opt = optimization.Optimizer({'num_iters': 4, 'lr_init': 1e-3, 'lr_final': 1e-4}, pred, p['rt'])
+    writer = optimization.SummaryWriter(str(tmp_path / 'tb'))
+    ax = np.linspace(-5.0, 5.0, 6)
+    truth = types.SimpleNamespace(x=ax, y=ax, z=ax, data=np.full((6, 6, 6), 0.1), shape=(6, 6, 6))   # xarray-like volume
+    opt.run(3, step, p['rt'], log_fns=[optimization.LogFn(writer.recovery_3d(10.0, emission_true=truth), 2),
+                                       optimization.LogFn(writer.recovery_3d(10.0, vis_res=8), 4)])
+    writer.plot_lc_datafit(opt, 'stokes', step, lc, ['I', 'Q', 'U'], p['t_frames'], batchsize=3)
+    writer.close()
+    if writer._tb is None:
+        recs = [json.loads(l) for l in open(tmp_path / 'tb' / 'scalars.jsonl')]
+        tags = [(r['tag'], r['step']) for r in recs]
+        assert ('emission/mse', 1) in tags and ('emission/psnr', 4) in tags and ('datafit/stokes', 4) in tags
+        assert np.load(tmp_path / 'tb' / 'emission_estimate_4.npy').shape in ((8, 3, 8, 8), (6, 3, 6, 6))
+        assert (tmp_path / 'tb' / 'lightcurve_stokes_4.png').stat().st_size > 1000
