@@ -1,0 +1,130 @@
+"""BASELINE configs 3 and 5 at full size -- the polarised (Stokes I, Q, U) light-curve recoveries:
+
+* config 3: 256 x 256 rays x 128 samples, 8 frames per step, 4x256 MLP, rmin = isco_pro(0.94), fov 40 M;
+* config 5: 64 x 64 rays x 100 samples, 8 frames per step, 4x128 MLP, scale = rmax = 20, rmin = 6, z_width = 4
+  (scripts/Fit_ALMA_LP_Apr11_SgrA_Flare.yaml).
+
+Checked through size-independent properties: the f64 oracle on a random subset of rays (rays are independent), the
+'lc' chi-square and its parameter gradient through the reference-shaped API on the full geometry against (i) the other
+backward route (bhn_render_bwd, bitwise) and (ii) linearity in the light-curve residual.
+
+Tolerances: f32 mode 1e-5 relative on images (north-star parity); bf16 mode 2e-2 of the per-Stokes image maximum."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle_np as onp
+
+pytestmark = pytest.mark.gpu
+B = 8
+CONFIGS = {
+    'config3': dict(H=256, W=256, G=128, width=256, fov=40.0, inc=60.0, spin=0.94, rmin=2.024, rmax=20.0, z_width=4.0),
+    'config5': dict(H=64, W=64, G=100, width=128, fov=40.0, inc=12.0, spin=0.0, rmin=6.0, rmax=20.0, z_width=4.0),
+}
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device('cuda:0')
+
+
+def make_problem(name, dev):
+    from bhnerf_amd import constants, engine, synthetic
+    c = CONFIGS[name]
+    geo = synthetic.synthetic_geodesics(c['H'], c['W'], c['G'], fov_M=c['fov'], inc_deg=c['inc'], spin=c['spin'], S=3, seed=3)
+    t_frames = np.linspace(0.0, 1.7, 128)[:B]
+    rng = np.random.default_rng(21)
+    tree = onp.he_uniform_params(rng, 4, c['width'], 21, dtype=np.float32)
+    for i in range(5):
+        d = tree['MLP_0']['Dense_%d' % i]
+        d['bias'] = rng.uniform(-0.05, 0.05, d['bias'].shape).astype(np.float32)
+    tree['MLP_0']['Dense_4']['bias'] = tree['MLP_0']['Dense_4']['bias'] + 9.0
+    tM0 = engine.frame_offsets(t_frames, 0.0, geo['t_injection'], constants.GM_c3('hr'), dev)
+    return dict(c=c, geo=geo, t_frames=t_frames, tree=tree, tM0=tM0, GM_c3=constants.GM_c3('hr'))
+
+
+def setup(p, mode, dev):
+    from bhnerf_amd import network
+    c, geo = p['c'], p['geo']
+    pred = network.NeRF_Predictor(c['rmax'], c['rmin'], c['rmax'], c['z_width'], net_depth=4, net_width=c['width'], mode=mode, device=dev)
+    eng = pred.engine()
+    geom = pred.geometry(geo['coords'], geo['Omega'], geo['t_geos'], geo['J'], geo['g'], geo['dtau'], geo['Sigma'])
+    eng.pack(eng.flatten(p['tree']))
+    return pred, eng, geom
+
+
+def oracle_images(p, rays):
+    c, geo = p['c'], p['geo']
+    G = c['G']
+    sub = lambda v: v.reshape((-1, G))[rays].reshape(12, 8, G).astype(np.float64)
+    coords = np.stack([sub(geo['coords'][i]) for i in range(3)])
+    J = np.stack([sub(geo['J'][s]) for s in range(3)])
+    tree = {'MLP_0': {k: {kk: np.asarray(vv, dtype=np.float64) for kk, vv in v.items()} for k, v in p['tree']['MLP_0'].items()}}
+    e = onp.predictor_apply(tree, p['t_frames'], coords, sub(geo['Omega']), 0.0, sub(geo['t_geos']), float(geo['t_injection']),
+                            GM_c3=p['GM_c3'], scale=c['rmax'], rmin=c['rmin'], rmax=c['rmax'], z_width=c['z_width'])
+    return onp.image_plane_prediction(e, J, sub(geo['g']), sub(geo['dtau']), sub(geo['Sigma'])).reshape(B, 3, 96)
+
+
+@pytest.mark.parametrize('name', ['config5', 'config3'])
+def test_polarised_forward_against_oracle_on_a_ray_subset(dev, name):
+    p = make_problem(name, dev)
+    c = p['c']
+    rays = np.random.default_rng(31).choice(c['H'] * c['W'], size=96, replace=False)
+    ref = oracle_images(p, rays)
+    assert np.abs(ref).max() > 0
+    for mode, tol in (('f32', 1e-5), ('bf16', 2e-2)):
+        pred, eng, geom = setup(p, mode, dev)
+        images = eng.render(geom, p['tM0'])                                              # (B, 3, R)
+        assert images.shape == (B, 3, c['H'] * c['W'])
+        got = images[:, :, torch.as_tensor(rays, device=dev)].cpu().numpy()
+        for s in range(3):
+            err = np.abs(got[:, s] - ref[:, s]).max() / np.abs(ref[:, s]).max()
+            assert err <= tol, (mode, s, err)
+        del images, eng, geom, pred
+        torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize('name', ['config5', 'config3'])
+def test_polarised_lightcurve_gradient_properties(dev, name):
+    """'lc' chi-square of all three Stokes light curves on the full geometry (bf16): reference-shaped training step,
+    both backward routes bitwise equal, gradient linear in the residual."""
+    from bhnerf_amd import network, optimization, units
+    p = make_problem(name, dev)
+    c, geo = p['c'], p['geo']
+    pred, eng, geom = setup(p, 'bf16', dev)
+    tM0 = p['tM0']
+    images = eng.render(geom, tM0)
+    lc = images.sum(dim=-1)                                                             # (B, 3)
+    gen = torch.Generator(device=dev).manual_seed(4)
+    r1 = (torch.rand((B, 3), device=dev, generator=gen) - 0.5) * lc.abs().max()
+    r2 = (torch.rand((B, 3), device=dev, generator=gen) - 0.5) * lc.abs().max()
+    bcast = lambda r: r[:, :, None].expand(B, 3, geom.R).contiguous()                    # d chi2 / d image of an 'lc' loss
+    g1 = eng.render_bwd(geom, tM0, bcast(r1)).clone()
+    assert torch.equal(eng.render_bwd(geom, tM0, bcast(r1)), g1)                       # reproducible, no float atomics
+    g2 = eng.render_bwd(geom, tM0, bcast(r2)).clone()
+    g12 = eng.render_bwd(geom, tM0, bcast(0.5 * r1 - 2.0 * r2)).clone()
+    scale = float(torch.maximum(g1.abs().max(), g2.abs().max()))
+    assert scale > 0 and float((g12 - (0.5 * g1 - 2.0 * g2)).abs().max()) <= 2e-2 * 2.5 * scale
+    # the taped route (whole batch when the tape fits, frame groups otherwise) gives the bits of bhn_render_bwd
+    group = B if eng.fits_tape(B, geom.P_eff) else eng.tape_group(B, geom.P_eff)
+    acc = torch.zeros_like(g1)
+    d = bcast(r1)
+    for b0 in range(0, B, group):
+        sl = slice(b0, min(b0 + group, B))
+        eng.render_train(geom, tM0[sl])
+        acc += eng.render_bwd_tape(geom, tM0[sl], d[sl].contiguous())
+    assert float((acc - g1).abs().max()) <= 1e-4 * scale
+    del images, acc, g12, g2, d
+    torch.cuda.empty_cache()
+    # the reference-shaped step on the same problem: loss equals the chi-square of the rendered light curves
+    rt = network.raytracing_args(dict(x=geo['coords'][0], y=geo['coords'][1], z=geo['coords'][2], dtau=geo['dtau'], Sigma=geo['Sigma'],
+                                      t=geo['t_geos'], g=geo['g']), geo['Omega'], geo['t_injection'], 0.0 * units.hr, J=geo['J'])
+    target = (lc * 0.9).cpu().numpy()
+    sigma = float(lc.abs().mean()) * 0.1
+    step = optimization.TrainStep.image(p['t_frames'] * units.hr, target, sigma=sigma, dtype='lc')
+    opt = optimization.Optimizer({'num_iters': 2, 'lr_init': 1e-4, 'lr_final': 1e-4}, pred, rt)
+    opt.state.flat.copy_(eng.flatten(p['tree']).to(opt.state.flat))
+    loss, _, frames = step(opt.state, rt, np.arange(B), update_state=False)
+    want = float((((lc - torch.as_tensor(target, device=dev)) / sigma) ** 2).sum())
+    assert abs(float(torch.as_tensor(loss).sum()) - want) <= 2e-2 * want
