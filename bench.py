@@ -218,10 +218,15 @@ def main():
     elem = 2 if args.mode == 'bf16' else 4
     mt = args.width // 32
     skip_layer = args.depth // 2 + 1 if args.depth >= 4 else None          # the layer that consumes concat[h, enc] (do_skip)
-    tiles = (mt + 1) + (1 + mt)                                            # layer 0, output layer
+    # bf16, depth >= 3: gA_{depth-1} is not on the tape either -- the job of layer depth-1 reads the h_depth tiles instead
+    # (rebuilds gA from them, W_out and dout) and makes the output layer's row from the same tiles: no output-layer job
+    rides = args.mode == 'bf16' and args.depth >= 3
+    tiles = (mt + 1) + (0 if rides else 1 + mt)                            # layer 0, output layer
     for l in range(1, args.depth):
         recomputed = l == 1 and args.mode == 'bf16' and l != skip_layer
         tiles += mt + (1 if recomputed else mt) + (1 if l == skip_layer else 0)
+        if rides and l == args.depth - 1:
+            tiles += 1.5                                                   # dout tile + the 1 KiB piece with the f32 dout
     tape_bpp = tiles * (32 * 32 * elem) / 32.0
     try:      # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (profiles/)
         pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r1_pmc_traffic.json')))['kernels']

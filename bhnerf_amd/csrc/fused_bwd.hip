@@ -20,6 +20,9 @@
 #ifndef BHN_JOB1_W
 #define BHN_JOB1_W 12          // weight of the layer-1 dW job in B tiles at width 256 (measured optimum; scaled with the width)
 #endif
+#ifndef BHN_JOBL_W
+#define BHN_JOBL_W 6           // extra weight (in tiles) of the layer depth-1 dW job when it rebuilds gA_{depth-1} and carries the output row
+#endif
 #ifndef BHN_TAPED_DIST
 #define BHN_TAPED_DIST 6         // weight chunks in flight in the training-forward / delta-chain kernels (bf16; 4 measured 2 % slower)
 #endif
@@ -33,6 +36,12 @@ struct TapeLayout {
     // inputs kept a second time in their forward (point-on-lane) fragment form -- 64 B instead of 512 B per point
     long long encp_off;
     int drop_h1;
+    // bf16, depth >= 3: gA_{depth-1} = relu'(a_{depth-1}) * W_out * dout is NOT on the tape either; the dW job of layer
+    // depth-1 rebuilds it from the h_depth tiles (relu bits = "!= 0"), W_out and dout kept in f32 behind the dout
+    // tile, and also makes dW_out from the same h_depth tiles (no separate output-layer job): -1 KB per point of
+    // tape traffic (chain write + dW read of gA_{depth-1}, second dW read of h_depth)
+    int drop_ga;
+    long long dout_stride;                     // bytes per group of the dout region: tile (+ 32 f32 when drop_ga)
 };
 
 struct BwdArgs {
@@ -56,7 +65,7 @@ struct BwdGeom {
     static constexpr int MT = W / 32;
     static constexpr int TILE_BYTES = 2 * Pol::FRAG_BYTES;          // 32 features x 32 points
     static constexpr int NTMAX = MT + 2;                            // h tiles + enc tile + ones tile
-    static constexpr int SLAB_FLOATS = MT * NTMAX * 1024;
+    static constexpr int SLAB_FLOATS = (MT + 1) * NTMAX * 1024;     // row MT: the output layer's row when it rides on job depth-1
     // wave grid of the dW kernel
     static constexpr int WR = (MT >= 4) ? 4 : MT;
     static constexpr int WC = Pol::NWAVES / WR >= 1 ? Pol::NWAVES / WR : 1;
@@ -67,6 +76,7 @@ struct BwdGeom {
     static constexpr int NPASS = (NPW_ALL + 4) / 5;                    // <= 5 B tiles accumulated per sweep
     static constexpr int NPW = (NPW_ALL + NPASS - 1) / NPASS;
     static constexpr int GROUP_BYTES = (2 * MT + 1) * TILE_BYTES;   // A tiles + h tiles + enc tile
+    static constexpr int GROUP_BYTES_LAST = GROUP_BYTES + TILE_BYTES + 1024;   // + dout tile + f32 dout piece (dw_body LAST)
     // chain kernels: prefetch distance of the LDS-DMA weight ring (RING_DIST_TAPED+1 buffers of one chunk)
     static constexpr int RING_DIST_TAPED = (Pol::ELEM_BYTES == 2) ? BHN_TAPED_DIST : 3;
     // dW kernel: LDS-DMA ring of NBUF groups (counted vmcnt, raw s_barrier); f32: 2 buffers
@@ -444,13 +454,16 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
             // dout as a 32x32 (feature x point) tile whose feature 0 is dout: the A operand of dW_out
             frag d0 = Pol::zero(), d1 = Pol::zero();
             Pol::set(d0, 0, h == 0 ? d : 0.f);
-            em.emit(A.tape + A.t.dout_off + q * TB, d0, d1, edbg);
+            char *dgrp = A.tape + A.t.dout_off + q * A.t.dout_stride;
+            em.emit(dgrp, d0, d1, edbg);
+            if (A.t.drop_ga && h == 0 && !(edbg & 2)) __builtin_nontemporal_store(d, reinterpret_cast<float *>(dgrp + TB) + pl);
         }
         if constexpr (MODE == MODE_CHAIN) {
             // ---- gA_{depth-1} = wout * dout * relu'(a_{depth-1}); its last tile stays pending ---------------
             frag dl[KS];
             f32x16 pend = {};
             {
+                const bool keep_ga = !A.t.drop_ga;                    // else the dW kernel rebuilds gA_{depth-1}
                 char *gdst = A.tape + A.t.ga_off[a.depth - 1] + q * MT * TB;
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
@@ -470,7 +483,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
                         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
                             for (int j = 0; j < 8; ++j) Pol::set(dl[2 * m + s2], j, g[8 * s2 + j]);
-                        em.emit(gdst + m * TB, dl[2 * m], dl[2 * m + 1], edbg);
+                        if (keep_ga) em.emit(gdst + m * TB, dl[2 * m], dl[2 * m + 1], edbg);
                     } else pend = g;
                 }
             }
@@ -488,8 +501,9 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
                     const int pm = m == 0 ? MT - 1 : m - 1;
                     frag &d0 = m == 0 ? dl[KS - 2] : next[2 * (m > 0 ? m - 1 : 0)];
                     frag &d1 = m == 0 ? dl[KS - 1] : next[2 * (m > 0 ? m - 1 : 0) + 1];
+                    const bool no_ga = A.t.drop_ga && pnd_layer == a.depth - 1;     // gA_{depth-1}'s last tile: not recorded
                     TapePost<Pol, false> post(pend, d0, d1, pnd_mask, em, A.tape + A.t.ga_off[pnd_layer] + (q * MT + pm) * TB,
-                                                  nullptr, nullptr, no_acc, false, false, edbg);
+                                                  nullptr, nullptr, no_acc, false, false, no_ga ? (edbg | 2) : edbg);
                     if (!(m & 1)) {                                  // word (l-1, m/2): use the oldest, fetch two ahead
                         mcur = mq0;
                         mq0 = mq1;
@@ -497,7 +511,11 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
                     }
                     const f32x16 acc = ring_step<W, Pol, RG>(ch, chn, ap, dl, enc, false,
                                                              (l == 1 && m == MT - 1) ? first_bias : zero_lds, post, dj, sdbg);
-                    rs.template step_end<YS>();
+                    // without the gA_{depth-1} emissions the intervals around this layer's first DMA issue hold one
+                    // emission less: the step ends whose window reaches back to it count one less (small widths: none)
+                    if (A.t.drop_ga && l == a.depth - 1 && m <= 4) rs.template step_end<YS_L1>();
+                    else if (A.t.drop_ga && l == a.depth - 1) rs.template step_end<(KS >= 16 ? YS : 0)>();
+                    else rs.template step_end<YS>();
                     pend = acc;
                     pnd_layer = l - 1;
                     pnd_mask = mcur >> ((m & 1) * 16);
@@ -521,12 +539,19 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
 // Job types of the dW kernel (compile-time so that the streaming loop is straight-line code)
 enum { JT_FIRST = 0, JT_HIDDEN = 1, JT_SKIP = 2, JT_OUT = 3, JT_HIDDEN1 = 4 };   // HIDDEN1: layer 1 with h_1 recomputed from the encoded inputs
 
-template <int W, class Pol, int JT>
+// LAST (layer depth-1 when TapeLayout::drop_ga): the A region of the group image holds the h_depth tiles, from which
+// the A fragments gA_{depth-1} = (h_depth != 0) * W_out * dout are rebuilt (same f32 product and rounding as the
+// delta-chain kernel), and which are also the B operand of the output layer's row dW_out = sum dout . h_depth
+// (A = the dout tile) -- slab row MT, no separate output job.  Group image [h_depth][h_{depth-1}][enc][dout tile][f32 dout].
+template <int W, class Pol, int JT, bool LAST = false>
 DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
     using BG = BwdGeom<W, Pol>;
     using frag = typename Pol::frag;
-    constexpr int MT = BG::MT, TB = BG::TILE_BYTES, GB = BG::GROUP_BYTES;
+    static_assert(!LAST || (Pol::ELEM_BYTES == 2 && (JT == JT_HIDDEN || JT == JT_SKIP)), "LAST: bf16 hidden / skip job");
+    constexpr int MT = BG::MT, TB = BG::TILE_BYTES;
     constexpr int OFF_H = MT * TB, OFF_E = 2 * MT * TB;               // LDS group image [A][h][enc]
+    constexpr int OFF_D = BG::GROUP_BYTES, OFF_D32 = OFF_D + TB;      // LAST: [dout tile][1 KiB piece starting with 32 f32 dout]
+    constexpr int GB = LAST ? BG::GROUP_BYTES_LAST : BG::GROUP_BYTES;
     constexpr bool out_job = JT == JT_OUT, has_h = JT != JT_FIRST, has_enc = (JT == JT_FIRST || JT == JT_SKIP);
     constexpr bool make_h = JT == JT_HIDDEN1;       // the h tiles of the LDS group image are computed here, not DMA'd
     constexpr int mtA = out_job ? 1 : MT;                              // A tiles (gA rows; dout is 1 row)
@@ -540,8 +565,9 @@ DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
     const int nwg = A.wg_begin[job + 1] - A.wg_begin[job];
     const int kb = blockIdx.x - A.wg_begin[job];
     const long long q0 = A.t.NQ * kb / nwg, q1 = A.t.NQ * (kb + 1) / nwg;
-    const char *srcA = out_job ? A.tape + A.t.dout_off : A.tape + A.t.ga_off[out_job ? 0 : job];
-    constexpr long long strideA = out_job ? TB : (long long)MT * TB;       // dout is one tile per group
+    const char *srcA = out_job ? A.tape + A.t.dout_off : (LAST ? A.tape + A.t.h_off[job + 1] : A.tape + A.t.ga_off[out_job ? 0 : job]);
+    const long long strideA = out_job ? A.t.dout_stride : (long long)MT * TB;       // dout is one tile per group
+    const char *srcD = A.tape + A.t.dout_off;
     const char *srcH = has_h ? A.tape + A.t.h_off[job] : nullptr;
     const char *srcE = A.tape + (make_h ? A.t.encp_off : A.t.enc_off);
     const int wr = wv % WRR, wc = wv / WRR;
@@ -590,6 +616,23 @@ DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
     frag ones;
 #pragma unroll
     for (int j = 0; j < 8; ++j) Pol::set(ones, j, 1.f);
+    // LAST: W_out of this lane's feature in each of the wave's A tiles; the output row's tiles are shared out over the
+    // waves that hold the same A tiles (A tile mi -> the wave with wc == mi % WCC), its bias column goes to one wave
+    constexpr int MO = (MPW + WCC - 1) / WCC;
+    float wout_r[MPW];
+    f32x16 acc_o[MO], acc_b = {};
+    const bool bias_wave = LAST && wr == WRR - 1 && wc == WCC - 1;
+    if constexpr (LAST) {
+#pragma unroll
+        for (int mi = 0; mi < MPW; ++mi) {
+            const int f = 32 * (wr * MPW + mi) + (lane & 31);
+            wout_r[mi] = f < W ? reinterpret_cast<const float *>(A.f.packed + A.f.wout_off)[f] : 0.f;
+        }
+#pragma unroll
+        for (int o = 0; o < MO; ++o)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc_o[o][r] = 0.f;
+    }
     float *slab = A.f.slabs + (long long)blockIdx.x * BG::SLAB_FLOATS;
 
     for (int pass = 0; pass < NPASS; ++pass) {
@@ -634,11 +677,47 @@ DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
             constexpr int NTOT = 2 * NPW, AHEAD = (Pol::ELEM_BYTES == 2) ? 2 : 1;
             frag af[2][MPW];
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
+            for (int s = 0; s < 2; ++s) {
+                f32x4 da = {}, db = {};
+                frag ad = {};
+                if constexpr (LAST) {
+                    // dout of this lane's eight points of k-step s: tape point order p = (j&3) + 8(j>>2) + 16s + 4(lane>>5)
+                    const float *d32 = reinterpret_cast<const float *>(gp + OFF_D32) + 16 * s + 4 * (lane >> 5);
+                    da = *reinterpret_cast<const f32x4 *>(d32);
+                    db = *reinterpret_cast<const f32x4 *>(d32 + 8);
+                    ad = Pol::lds_frag(gp + OFF_D, s, lane);
+                }
 #pragma unroll
                 for (int mi = 0; mi < MPW; ++mi) {
                     af[s][mi] = Pol::lds_frag(gp + (wr * MPW + mi) * TB, s, lane);
+                    if constexpr (LAST) {
+                        if (pass == 0 && (mi % WCC) == wc) acc_o[mi / WCC] = Pol::mma(ad, af[s][mi], acc_o[mi / WCC]);
+                        const u32x4 raw = __builtin_bit_cast(u32x4, af[s][mi]);
+                        u32x4 ga;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            // (W_out * dout) of two points: v_pk_mul_f32 + v_cvt_pk_bf16_f32; relu'(a) from h >= 0 (bf16 halves
+                            // <= 0x7f80): + 0x7fff sets the half's sign bit iff h != 0 without a carry, >> 15 (packed,
+                            // arithmetic) spreads it.  Two compiler traps on the way here: inline asm (v_pk_min_u16) wrote
+                            // into registers the output-row MFMA issued just before was still reading as SrcB (opaque to
+                            // the hazard recogniser: wrong dW_out), and "(0 - h) >> 15" on the four dwords as i16x2 vectors
+                            // was combined by hipcc 7.2 into ONE mask for all four dwords (wrong dW_{depth-1}).
+                            typedef float f32x2 __attribute__((ext_vector_type(2)));
+                            typedef short i16x2 __attribute__((ext_vector_type(2)));
+                            const f32x2 dd = {i < 2 ? da[2 * i] : db[2 * i - 4], i < 2 ? da[2 * i + 1] : db[2 * i - 3]};
+                            const f32x2 pr = dd * wout_r[mi];
+                            const typename Pol::bf16x2 t = {(__bf16)pr[0], (__bf16)pr[1]};
+                            const unsigned sgn = raw[i] + 0x7fff7fffu;
+                            const i16x2 on = __builtin_bit_cast(i16x2, sgn) >> (i16x2){15, 15};
+                            ga[i] = __builtin_bit_cast(unsigned, t) & __builtin_bit_cast(unsigned, on);
+                        }
+                        af[s][mi] = __builtin_bit_cast(frag, ga);
+                    }
                 }
+                if constexpr (LAST) {
+                    if (pass == 0 && bias_wave) acc_b = Pol::mma(ad, ones, acc_b);
+                }
+            }
             frag bq[AHEAD + 1];
 #pragma unroll
             for (int t = 0; t < AHEAD && t < NTOT; ++t) bq[t] = load_b(gp, t);
@@ -661,8 +740,8 @@ DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
             // pieces (1 KiB = one wave-wide DMA) this job really needs: [A tiles | dout][h tiles][enc tile]
             constexpr int NBUF = BG::NBUF;
             constexpr int PA = out_job ? TB / 1024 : MT * TB / 1024, PH = (has_h && !make_h) ? MT * TB / 1024 : 0,
-                          PE = (has_enc || make_h) ? TB / 1024 : 0;
-            constexpr int NPJ = PA + PH + PE, PPW = (NPJ + Pol::NWAVES - 1) / Pol::NWAVES;
+                          PE = (has_enc || make_h) ? TB / 1024 : 0, PD = LAST ? TB / 1024 + 1 : 0;
+            constexpr int NPJ = PA + PH + PE + PD, PPW = (NPJ + Pol::NWAVES - 1) / Pol::NWAVES;
             const int wvu = __builtin_amdgcn_readfirstlane(wv);
             const char *sbase[PPW];
             long long sstride[PPW];
@@ -679,10 +758,14 @@ DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
                     doff[i] = OFF_H + (piece - PA) * 1024;
                     sbase[i] = srcH + (piece - PA) * 1024;
                     sstride[i] = (long long)MT * TB;
-                } else {
+                } else if (piece < PA + PH + PE) {
                     doff[i] = OFF_E + (piece - PA - PH) * 1024;
                     sbase[i] = srcE + (piece - PA - PH) * 1024;
                     sstride[i] = TB;
+                } else {                                                // LAST: dout tile, then the piece that starts with f32 dout
+                    doff[i] = OFF_D + (piece - PA - PH - PE) * 1024;
+                    sbase[i] = srcD + (piece - PA - PH - PE) * 1024;
+                    sstride[i] = A.t.dout_stride;
                 }
             }
             auto issue = [&](long long q, char *buf) {
@@ -750,6 +833,28 @@ DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
                 }
             }
     }
+    if constexpr (LAST) {       // the output layer's row: slab row MT, column tiles = h_depth tiles, then the bias tile
+        auto flush_tile = [&](int n, const f32x16 &t) {
+            float *tp = slab + (long long)(MT * BG::NTMAX + n) * 1024;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = t[4 * g4 + e];
+                f32x4 *dst = reinterpret_cast<f32x4 *>(tp + g4 * 256 + lane * 4);
+                if (A.accumulate) {
+                    const f32x4 old = *dst;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += old[e];
+                }
+                *dst = v;
+            }
+        };
+#pragma unroll
+        for (int mi = 0; mi < MPW; ++mi)
+            if ((mi % WCC) == wc && wr * MPW + mi < MT) flush_tile(wr * MPW + mi, acc_o[mi / WCC]);
+        if (bias_wave) flush_tile(MT, acc_b);
+    }
 }
 
 template <int W, class Pol>
@@ -761,7 +866,12 @@ __global__ __launch_bounds__(Pol::NTHREADS) void dw_kernel(BwdArgs A) {
     if ((A.debug >> 2) && (A.debug >> 2) - 1 != job) return;
     if (job == depth) dw_body<W, Pol, JT_OUT>(A, job, smem);
     else if (job == 0) dw_body<W, Pol, JT_FIRST>(A, job, smem);
-    else if ((A.f.skip_mask >> job) & 1) dw_body<W, Pol, JT_SKIP>(A, job, smem);
+    else if (job == depth - 1 && A.t.drop_ga) {
+        if constexpr (Pol::ELEM_BYTES == 2) {
+            if ((A.f.skip_mask >> job) & 1) dw_body<W, Pol, JT_SKIP, true>(A, job, smem);
+            else dw_body<W, Pol, JT_HIDDEN, true>(A, job, smem);
+        }
+    } else if ((A.f.skip_mask >> job) & 1) dw_body<W, Pol, JT_SKIP>(A, job, smem);
     else if (job == 1 && A.t.drop_h1) {
         if constexpr (Pol::ELEM_BYTES == 2) dw_body<W, Pol, JT_HIDDEN1>(A, job, smem);
     } else dw_body<W, Pol, JT_HIDDEN>(A, job, smem);
@@ -797,9 +907,12 @@ __global__ void reduce_kernel(BwdArgs A) {
         else if (l == 0) { n = 0; col = kin; }
         else if (kin < W) { n = kin >> 5; col = kin & 31; }
         else { n = nH; col = kin - W; }
-        const long long idx = (long long)(m * BG::NTMAX + n) * 1024 + (r >> 2) * 256 + (col + 32 * hh) * 4 + (r & 3);
+        // the output layer's row rides on the job of layer depth-1 (slab row MT) when gA_{depth-1} is not on the tape
+        const bool rides = l == depth && A.t.drop_ga;
+        const int jl = rides ? depth - 1 : l;
+        const long long idx = (long long)((rides ? MT : m) * BG::NTMAX + n) * 1024 + (r >> 2) * 256 + (col + 32 * hh) * 4 + (r & 3);
         float sum = 0.f;
-        for (int wg = A.wg_begin[l]; wg < A.wg_begin[l + 1]; ++wg) sum += A.f.slabs[(long long)wg * BG::SLAB_FLOATS + idx];
+        for (int wg = A.wg_begin[jl]; wg < A.wg_begin[jl + 1]; ++wg) sum += A.f.slabs[(long long)wg * BG::SLAB_FLOATS + idx];
         A.dparams[t] = sum;
     }
 }
@@ -835,9 +948,14 @@ static void tape_layout(int depth, bool layer1_takes_enc, long long NQ, TapeLayo
         t->h_off[l] = off; off += per_tensor;
     }
     if (t->drop_h1) { t->encp_off = off; off += NQ * (long long)BG::TILE_BYTES; }
-    for (int l = 0; l < depth; ++l) { t->ga_off[l] = off; off += per_tensor; }
+    t->drop_ga = Pol::ELEM_BYTES == 2 && depth >= 3;
+    for (int l = 0; l < depth; ++l) {
+        if (l == depth - 1 && t->drop_ga) { t->ga_off[l] = -1; continue; }
+        t->ga_off[l] = off; off += per_tensor;
+    }
     t->enc_off = off; off += NQ * (long long)BG::TILE_BYTES;
-    t->dout_off = off; off += NQ * (long long)BG::TILE_BYTES;   // dout as an A tile: row 0 = dout, rows 1..31 zero
+    t->dout_stride = BG::TILE_BYTES + (t->drop_ga ? 128 : 0);   // dout as an A tile: row 0 = dout, rows 1..31 zero (+ f32 dout)
+    t->dout_off = off; off += NQ * t->dout_stride;
     t->mask_off = off; off += NQ * (long long)depth * ((BG::MT + 1) / 2) * 256;
     t->e_off = off; off += NQ * 128;
     t->total = (long long)align_up((size_t)off + 1024, 256);     // +1 KiB: the last dout piece is DMA'd as a full KiB
@@ -859,7 +977,8 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
     using BG = BwdGeom<W, Pol>;
     using PK = Pack<W, Pol>;
     const int ncu = bhn_num_cus(device);
-    const int grid_dw = ncu;                                           // one dW workgroup per CU
+    static const int grid_override = getenv("BHN_DEBUG_DW_GRID") ? atoi(getenv("BHN_DEBUG_DW_GRID")) : 0;
+    const int grid_dw = grid_override > 0 ? grid_override : ncu;        // one dW workgroup per CU
     const size_t slab_bytes = align_up((size_t)grid_dw * BG::SLAB_FLOATS * 4, 256);
     if (what == RUN_QUERY) {
         const long long tiles = (query_P + Pol::NWAVES * 32 - 1) / (Pol::NWAVES * 32) * query_B;
@@ -915,12 +1034,15 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
     // proportion to the bytes it reads per 32-point group (A tiles + B tiles), not to its MFMA count
     {
         double work[BHN_MAX_LAYERS + 1], tot = 0;
+        const int last_job = t1.drop_ga ? depth - 1 : depth;       // drop_ga: the output row rides on layer depth-1's job
         for (int l = 0; l <= depth; ++l) {
             const int mtA = (l == depth) ? 0 : BG::MT;
             int nB = (l >= 1 ? BG::MT : 0) + ((l == 0 || s.skip_in[l]) ? 1 : 0);
-            if (l == 1 && t1.drop_h1) nB = BHN_JOB1_W * BG::MT / 8;   // reads only the encoded inputs instead of h_1 but has the
+            if (l == 1 && t1.drop_h1) nB = (getenv("BHN_DEBUG_JOB1_W") ? atoi(getenv("BHN_DEBUG_JOB1_W")) : BHN_JOB1_W) * BG::MT / 8;   // reads only the encoded inputs instead of h_1 but has the
                                                                   // same MFMA work + the recompute: not byte-bound any more
             work[l] = (double)(mtA + nB) + 0.5;
+            if (l == depth - 1 && t1.drop_ga) work[l] += getenv("BHN_DEBUG_JOBL_W") ? atof(getenv("BHN_DEBUG_JOBL_W")) : BHN_JOBL_W;    // + dout pieces, the rebuild of gA and the output row
+            if (l > last_job) work[l] = 0;
             tot += work[l];
         }
         int used = 0;
@@ -928,8 +1050,9 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
         for (int l = 0; l <= depth; ++l) {
             int n = (int)(grid_dw * work[l] / tot);
             if (n < 1) n = 1;
-            if (l == depth) n = grid_dw - used;
+            if (l == last_job) n = grid_dw - used;
             if (n < 1) n = 1;
+            if (l > last_job) n = 0;
             used += n;
             A.wg_begin[l + 1] = used;
         }
@@ -941,7 +1064,8 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
     // ring + bias rows + zero row + output weights + identity fragments
     const size_t lds_fixed = (size_t)(depth + 1) * W * 4 + 128 + W * 4 + 2 * Pol::FRAG_BYTES;
     const size_t lds_taped = (size_t)(BG::RING_DIST_TAPED + 1) * PK::CHUNK_BYTES + lds_fixed;
-    const size_t lds_dw = (size_t)BG::NBUF * BG::GROUP_BYTES + (t1.drop_h1 ? (size_t)2 * BG::MT * Pol::FRAG_BYTES + W * 4 : 0);
+    size_t lds_dw = (size_t)BG::NBUF * BG::GROUP_BYTES + (t1.drop_h1 ? (size_t)2 * BG::MT * Pol::FRAG_BYTES + W * 4 : 0);
+    if (t1.drop_ga && (size_t)BG::NBUF * BG::GROUP_BYTES_LAST > lds_dw) lds_dw = (size_t)BG::NBUF * BG::GROUP_BYTES_LAST;
     auto k_fwd = chain_kernel<W, Pol, 3, MODE_FWD_TRAIN>;
     auto k_chn = chain_kernel<W, Pol, 3, MODE_CHAIN>;
     auto kdw = dw_kernel<W, Pol>;
