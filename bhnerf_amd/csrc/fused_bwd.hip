@@ -21,7 +21,7 @@
 #define BHN_JOB1_W 12          // weight of the layer-1 dW job in B tiles at width 256 (measured optimum; scaled with the width)
 #endif
 #ifndef BHN_JOBL_W
-#define BHN_JOBL_W 6           // extra weight (in tiles) of the layer depth-1 dW job when it rebuilds gA_{depth-1} and carries the output row
+#define BHN_JOBL_W 6           // extra weight (in tiles at width 256, scaled with the width) of the layer depth-1 dW job when it rebuilds gA_{depth-1} and carries the output row
 #endif
 #ifndef BHN_TAPED_DIST
 #define BHN_TAPED_DIST 6         // weight chunks in flight in the training-forward / delta-chain kernels (bf16; 4 measured 2 % slower)
@@ -1041,7 +1041,7 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
             if (l == 1 && t1.drop_h1) nB = (getenv("BHN_DEBUG_JOB1_W") ? atoi(getenv("BHN_DEBUG_JOB1_W")) : BHN_JOB1_W) * BG::MT / 8;   // reads only the encoded inputs instead of h_1 but has the
                                                                   // same MFMA work + the recompute: not byte-bound any more
             work[l] = (double)(mtA + nB) + 0.5;
-            if (l == depth - 1 && t1.drop_ga) work[l] += getenv("BHN_DEBUG_JOBL_W") ? atof(getenv("BHN_DEBUG_JOBL_W")) : BHN_JOBL_W;    // + dout pieces, the rebuild of gA and the output row
+            if (l == depth - 1 && t1.drop_ga) work[l] += (getenv("BHN_DEBUG_JOBL_W") ? atof(getenv("BHN_DEBUG_JOBL_W")) : BHN_JOBL_W) * BG::MT / 8.0;    // + dout pieces, the rebuild of gA and the output row
             if (l > last_job) work[l] = 0;
             tot += work[l];
         }

@@ -7,10 +7,11 @@ if len(sys.argv) > 1:
     dev = torch.device('cuda:0')
     H = W = 128; G = 64; B = 8
     geo = synthetic.synthetic_geodesics(H, W, G)
-    pred = network.NeRF_Predictor(8.0, 0.0, np.inf, np.inf, net_depth=4, net_width=256, mode='bf16', device=dev)
+    WID, DEP = int(os.environ.get('WIDTH', 256)), int(os.environ.get('DEPTH', 4))
+    pred = network.NeRF_Predictor(8.0, 0.0, np.inf, np.inf, net_depth=DEP, net_width=WID, mode='bf16', device=dev)
     eng = pred.engine()
     geom = pred.geometry(geo['coords'], geo['Omega'], geo['t_geos'], None, geo['g'], geo['dtau'], geo['Sigma'])
-    flat = eng.flatten(network.MLP(4, 256).init(1, 21)); eng.pack(flat)
+    flat = eng.flatten(network.MLP(DEP, WID).init(1, 21)); eng.pack(flat)
     tM0 = engine.frame_offsets(np.linspace(0, 1, B), 0.0, geo['t_injection'], constants.GM_c3('hr'), dev)
     dimg = torch.rand((B, 1, geom.R), device=dev) * 1e-3
     def timed(fn, reps=4):
@@ -27,8 +28,8 @@ if len(sys.argv) > 1:
         print('grid', os.environ.get('BHN_DEBUG_DW_GRID', 'ncu'), name, '%.3f ms' % timed(lambda: eng.render_bwd(geom, tM0, dimg)), flush=True)
 else:
     if os.environ.get('SWEEP') == 'jobs':
-        for jl in ['1.5', '4', '6', '8', '10', '12']:
-            for j1 in ['12', '14']:
+        for jl in os.environ.get('JL', '1.5 4 6 8 10 12').split():
+            for j1 in os.environ.get('J1', '12 14').split():
                 print('JOBL_W', jl, 'JOB1_W', j1, flush=True)
                 subprocess.run([sys.executable, os.path.abspath(__file__), 'run'], env=dict(os.environ, BHN_DEBUG_JOBL_W=jl, BHN_DEBUG_JOB1_W=j1))
     else:
