@@ -106,8 +106,8 @@ def image_plane_dynamics(emission_0, geos, Omega, t_frames, t_injection, J=1.0, 
                          doppler=True, rot_axis=[0, 0, 1], M=None):
     """Image-plane movie of an initial 3-D emission advected by the velocity field (emission.py:235-303): warp ->
     trilinear sampling -> x J -> radiative transfer, fused in one HIP kernel (``bhn_voxel_render_fwd``).
-    ``geos`` carries x, y, z, t, dtau, Sigma (and the Doppler factor ``g`` when ``doppler=True``: computing it
-    from the 4-velocity, kgeo.py:199-248, is outside this build).  Returns a NumPy movie (nt,[S],H,W)."""
+    ``geos`` carries x, y, z, t, dtau, Sigma; with ``doppler=True`` the Doppler factor is derived from traced geodesics
+    (kgeo.azimuthal_velocity_vector / doppler_factor) or taken from ``geos.g``.  Returns a NumPy movie (nt,[S],H,W)."""
     import ctypes as C
     from . import _hip, engine
     if list(rot_axis) != [0, 0, 1]:
@@ -119,10 +119,19 @@ def image_plane_dynamics(emission_0, geos, Omega, t_frames, t_injection, J=1.0, 
     coords = np.array([np.asarray(get(k), dtype=np.float32) for k in ('x', 'y', 'z')])
     t_geos = np.asarray(get('t'), dtype=np.float32) if slow_light else 0.0            # emission.py:269
     if doppler:
-        try:
+        def has(k):
+            try:
+                get(k)
+                return True
+            except (KeyError, AttributeError):
+                return False
+        if all(has(k) for k in ('r', 'theta', 'affine', 'R', 'Theta', 'Delta', 'Xi', 'lam', 'E', 'M', 'spin')):
+            from . import kgeo                                                       # emission.py:281-282
+            g = np.asarray(kgeo.doppler_factor(geos, kgeo.azimuthal_velocity_vector(geos, Omega)), dtype=np.float32)
+        elif has('g'):
             g = np.asarray(get('g'), dtype=np.float32)
-        except (KeyError, AttributeError):
-            raise AttributeError('doppler=True needs the Doppler factor geos.g (kgeo.doppler_factor is not part of this build)')
+        else:
+            raise AttributeError('doppler=True needs traced geodesics (kgeo.image_plane_geos) or a Doppler factor geos.g')
     else:
         g = 1.0
     if t_start_obs is None:                                                            # emission.py:274

@@ -21,6 +21,26 @@ except Exception:  # pragma: no cover
     tqdm = lambda x, **kw: x
 
 
+class HostReadable(torch.Tensor):
+    """Device tensor that NumPy can read.  The reference's drivers log ``np.log10(np.mean(opt.loss))`` on a JAX device
+    array (scripts/Fit_ALMA_LP_Apr11_SgrA_Flare.py); ``Optimizer.loss`` stays on the GPU (no per-step sync) and is copied
+    to the host only when NumPy asks for it."""
+
+    def __array__(self, dtype=None, copy=None):
+        host = self.detach().as_subclass(torch.Tensor).cpu().numpy()
+        return host.astype(dtype) if dtype is not None else host
+
+    def __array_wrap__(self, array, context=None, return_scalar=False):     # results of NumPy ufuncs stay NumPy
+        return array[()] if return_scalar or np.ndim(array) == 0 else array
+
+    def mean(self, *args, axis=None, out=None, **kw):       # np.mean(x) calls x.mean(axis=None, dtype=None, out=None)
+        if axis is not None:
+            kw['dim'] = axis
+        if kw.get('dtype', 0) is None:
+            kw.pop('dtype')
+        return super().mean(*args, **kw)
+
+
 def device_count():
     """Number of data-parallel workers (the reference's jax.device_count())."""
     return network._world()[1]
@@ -116,7 +136,8 @@ class Optimizer(object):
         bar = tqdm(range(self.init_step, self.final_step), desc='iteration', disable=network._world()[0] != 0)
         try:
             for self.step in bar:
-                self.loss, self.state, _ = train_step(self.state, raytracing_args, indices=frames.sample(batchsize))
+                loss, self.state, _ = train_step(self.state, raytracing_args, indices=frames.sample(batchsize))
+                self.loss = loss.as_subclass(HostReadable) if isinstance(loss, torch.Tensor) else loss
                 self.log()
                 self.save_checkpoint()
         except KeyboardInterrupt:

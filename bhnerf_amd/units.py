@@ -54,6 +54,29 @@ except Exception:  # astropy absent (this image): minimal stand-in
         def __sub__(self, other):
             return Quantity(np.asarray(self.value) - np.asarray(other.to(self.unit).value), self.unit)
 
+        def __add__(self, other):
+            return Quantity(np.asarray(self.value) + np.asarray(other.to(self.unit).value), self.unit)
+
+        def __mul__(self, factor):
+            return Quantity(np.asarray(self.value) * factor, self.unit)
+
+        __rmul__ = __mul__
+
+        def _cmp(self, other, op):
+            return op(np.asarray(self.value), np.asarray(other.to(self.unit).value))
+
+        def __le__(self, other):
+            return self._cmp(other, np.less_equal)
+
+        def __lt__(self, other):
+            return self._cmp(other, np.less)
+
+        def __ge__(self, other):
+            return self._cmp(other, np.greater_equal)
+
+        def __gt__(self, other):
+            return self._cmp(other, np.greater)
+
         def __repr__(self):
             return '<Quantity %s %s>' % (self.value, self.unit)
 

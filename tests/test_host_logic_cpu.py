@@ -141,3 +141,17 @@ def test_schedule_and_checkpoint_helpers(tmp_path):
     pred.save_params(str(tmp_path))
     again = network.NeRF_Predictor.from_yml(str(tmp_path))
     assert (again.scale, again.rmin, again.rmax, again.z_width, again.net_width, again.posenc_deg) == (20.0, 6.0, 20.0, 4.0, 128, 3)
+
+
+def test_quantity_arithmetic_and_loss_readable_by_numpy():
+    """What the reference's fit scripts do with times and with ``opt.loss`` (scripts/Fit_ALMA_LP_Apr11_SgrA_Flare.py:66-69, 98)."""
+    import torch
+    from bhnerf_amd import optimization
+    t = np.array([9.4, 10.2, 11.5]) * units.hr
+    split = 9.33 * units.hr + 103.0 * units.min
+    assert np.array_equal(np.asarray(t <= split), [True, True, False]) and np.array_equal(np.asarray(t > split), [False, False, True])
+    assert len(t[np.asarray(t <= split)]) == 2
+    assert float((t[1] - t[0]).to('min').value) == pytest.approx(48.0)
+    loss = torch.tensor([10.0, 1000.0]).as_subclass(optimization.HostReadable)
+    assert float(np.log10(np.mean(loss))) == pytest.approx(np.log10(505.0))
+    assert np.asarray(loss).tolist() == [10.0, 1000.0] and float(torch.as_tensor(loss).mean()) == 505.0
