@@ -174,3 +174,26 @@ def rotate_evpa(stokes, angle, axis=0):
     out[q] = c * moved[q] - s * moved[q + 1]
     out[q + 1] = s * moved[q] + c * moved[q + 1]
     return np.moveaxis(out, 0, axis)
+
+
+def generate_hotspot_xr(resolution, rot_axis, rot_angle, orbit_radius, std, r_isco, fov, std_clip=np.inf, normalize=True):
+    """Gaussian hotspot at angle ``rot_angle`` of a circular orbit of radius ``orbit_radius`` about ``rot_axis``
+    (emission.py:10-60), as a ``utils.Volume``; ``normalize`` divides by the volume integral."""
+    if orbit_radius < r_isco:
+        raise AttributeError('hotspot center ({}) is is within r_isco: {}'.format(orbit_radius, r_isco))
+    resolution = np.atleast_1d(resolution)
+    center = orbit_radius * np.array([np.cos(rot_angle), np.sin(rot_angle)])
+    if len(resolution) != 2:
+        axis = np.asarray(rot_axis, dtype=np.float64)
+        axis = axis / np.sqrt((axis ** 2).sum())
+        z_axis = np.array([0.0, 0.0, 1.0])
+        tilt_axis = np.cross(z_axis, axis)                 # rotation taking the z axis onto the orbit axis
+        if np.sqrt((tilt_axis ** 2).sum()) < 1e-5:
+            tilt_axis = z_axis
+        tilt = utils.rotation_matrix(tilt_axis, np.arccos(np.dot(axis, z_axis)))
+        center = np.matmul(np.asarray(tilt), np.append(center, 0.0))
+    vol = utils.gaussian_xr(resolution, center, std, fov=fov, std_clip=std_clip)
+    if normalize:
+        vol = utils.Volume(vol.data / vol.integrate(list(vol.dims) if len(resolution) == 2 else ['x', 'y', 'z']), vol.coords, vol.dims, vol.attrs)
+    vol.attrs.update(rot_axis=rot_axis)
+    return vol

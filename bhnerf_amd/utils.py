@@ -68,3 +68,70 @@ def intensity_to_nchw(intensity, cmap='viridis', gamma=0.5):
         normed = ((intensity - lo) / (hi - lo)) ** gamma
     rgb = matplotlib.colormaps[cmap](normed)[..., :3]
     return np.moveaxis(rgb, (0, 1, 2, 3), (3, 2, 0, 1))
+
+
+class Volume(np.ndarray):
+    """Gridded field with named axes -- the parts of ``xarray.DataArray`` this package and the reference's drivers touch
+    (xarray is not a dependency): ``dims``, coordinate arrays by name (``vol['x']``, ``vol.x``), ``data``, ``attrs``,
+    ``integrate``.  Accepted wherever the reference takes an emission DataArray (``emission.image_plane_dynamics``,
+    ``interpolate_coords``, ``SummaryWriter.recovery_3d``)."""
+
+    def __new__(cls, data, coords, dims, attrs=None):
+        obj = np.asarray(data).view(cls)
+        obj.dims, obj.coords, obj.attrs = tuple(dims), {d: np.asarray(coords[d]) for d in dims}, dict(attrs or {})
+        return obj
+
+    def __array_finalize__(self, src):
+        self.dims = getattr(src, 'dims', ())
+        self.coords = getattr(src, 'coords', {})
+        self.attrs = dict(getattr(src, 'attrs', {}))
+
+    def __getitem__(self, key):
+        if isinstance(key, str):
+            return self.coords[key]
+        out = super().__getitem__(key)
+        return out.view(np.ndarray) if isinstance(out, Volume) else out       # a slice no longer matches the coordinates
+
+    def __getattr__(self, name):                     # vol.x, vol.y, vol.z
+        coords = self.__dict__.get('coords', {})
+        if name in coords:
+            return coords[name]
+        raise AttributeError(name)
+
+    @property
+    def data(self):
+        return self.view(np.ndarray)
+
+    def integrate(self, dims):
+        """Trapezoidal integral over the named axes (``DataArray.integrate``)."""
+        out = self.view(np.ndarray)
+        for d in sorted((self.dims.index(d) for d in np.atleast_1d(dims)), reverse=True):
+            out = (np.trapezoid if hasattr(np, 'trapezoid') else np.trapz)(out, self.coords[self.dims[d]], axis=d)
+        return out
+
+
+def linspace_xr(num, start=-0.5, stop=0.5, endpoint=True, units='unitless'):
+    """Coordinates ``x[, y[, z]]`` linearly spaced over ``[start, stop]`` (utils.py:15-46), as a ``{dim: array}`` dict."""
+    return {d: np.linspace(start, stop, int(n), endpoint=endpoint) for d, n in zip(('x', 'y', 'z'), np.atleast_1d(num))}
+
+
+def gaussian_xr(resolution, center, std, fov=(1.0, 'unitless'), std_clip=np.inf):
+    """Gaussian blob on a regular grid of extent ``fov[0]`` centred on the origin (utils.py:48-95); values below
+    ``exp(-std_clip^2 / 2)`` are zeroed.  3-D: dims (x, y, z); 2-D: dims (y, x) as in the reference."""
+    resolution = np.atleast_1d(resolution)
+    std = (std,) * 3 if np.isscalar(std) else tuple(std)
+    if len(resolution) != len(center):
+        raise AttributeError('resolution and center should have same length {} != {}'.format(len(resolution), len(center)))
+    grid = linspace_xr(resolution, start=-fov[0] / 2.0, stop=fov[0] / 2.0, units=fov[1])
+    if len(resolution) == 3:
+        dims = ('x', 'y', 'z')
+        arg = (((grid['x'] - center[0]) / std[0]) ** 2)[:, None, None] + (((grid['y'] - center[1]) / std[1]) ** 2)[None, :, None] \
+            + (((grid['z'] - center[2]) / std[2]) ** 2)[None, None, :]
+    elif len(resolution) == 2:
+        dims = ('y', 'x')
+        arg = (((grid['y'] - center[1]) / std[1]) ** 2)[:, None] + (((grid['x'] - center[0]) / std[0]) ** 2)[None, :]
+    else:
+        raise AttributeError
+    data = np.exp(-0.5 * arg)
+    data = np.where(data > np.exp(-0.5 * std_clip ** 2), data, 0.0)
+    return Volume(data, grid, dims, dict(fov=fov, std=std, center=center, std_clip=std_clip))

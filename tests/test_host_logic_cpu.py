@@ -155,3 +155,32 @@ def test_quantity_arithmetic_and_loss_readable_by_numpy():
     loss = torch.tensor([10.0, 1000.0]).as_subclass(optimization.HostReadable)
     assert float(np.log10(np.mean(loss))) == pytest.approx(np.log10(505.0))
     assert np.asarray(loss).tolist() == [10.0, 1000.0] and float(torch.as_tensor(loss).mean()) == 505.0
+
+
+def test_gaussian_volume_and_hotspot_generator():
+    """utils.gaussian_xr / emission.generate_hotspot_xr (utils.py:48-95, emission.py:10-60) on the xarray-free Volume."""
+    from bhnerf_amd import emission, utils as U
+    vol = U.gaussian_xr([33, 33, 33], (1.0, -2.0, 0.5), 1.5, fov=(16.0, 'GM/c^2'))
+    assert vol.dims == ('x', 'y', 'z') and vol.shape == (33, 33, 33) and np.allclose(vol.x, np.linspace(-8, 8, 33))
+    i, j, k = np.unravel_index(np.argmax(vol.data), vol.shape)
+    assert (vol.x[i], vol.y[j], vol.z[k]) == (1.0, -2.0, 0.5) and vol.data.max() == 1.0
+    assert np.isclose(vol.data[i + 3, j, k], np.exp(-0.5 * (1.5 / 1.5) ** 2))                   # 3 cells = 1.5 M = 1 std
+    clipped = U.gaussian_xr([33, 33, 33], (0.0, 0.0, 0.0), 1.0, fov=(16.0, 'GM/c^2'), std_clip=2.0)
+    assert clipped.data.min() == 0.0 and (clipped.data[clipped.data > 0] > np.exp(-2.0)).all()
+    img = U.gaussian_xr([9, 17], (0.25, -0.25), (0.1, 0.2))
+    assert img.dims == ('y', 'x') and img.shape == (17, 9)                      # resolution = (nx, ny)
+    with pytest.raises(AttributeError):
+        U.gaussian_xr([9, 9, 9], (0.0, 0.0), 1.0)
+    # hotspot on the orbit, rotated about the axis; unit volume integral
+    hs = emission.generate_hotspot_xr([65, 65, 65], [0, 0, 1], np.pi / 2, 5.0, 0.8, 3.0, (20.0, 'GM/c^2'))
+    assert np.isclose(hs.integrate(['x', 'y', 'z']), 1.0)
+    i, j, k = np.unravel_index(np.argmax(hs.data), hs.shape)
+    assert abs(hs.x[i]) < 0.2 and abs(hs.y[j] - 5.0) < 0.2 and abs(hs.z[k]) < 0.2
+    tilted = emission.generate_hotspot_xr([65, 65, 65], [1, 0, 0], 0.0, 5.0, 0.8, 3.0, (20.0, 'GM/c^2'), normalize=False)
+    c = tilted.attrs['center']
+    assert np.isclose(np.dot(c, [1, 0, 0]), 0.0, atol=1e-12) and np.isclose(np.linalg.norm(c), 5.0)   # orbit plane is normal to the axis
+    with pytest.raises(AttributeError):
+        emission.generate_hotspot_xr([9, 9, 9], [0, 0, 1], 0.0, 2.0, 0.5, 3.0, (20.0, 'M'))
+    # the volume is accepted where the reference takes a DataArray
+    arr, fov = emission._grid_of(hs)
+    assert arr.shape == (65, 65, 65) and fov == [20.0, 20.0, 20.0]
