@@ -91,3 +91,22 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith(('.py', '.hip', '.h', '.cpp')):
                 text = open(os.path.join(dirpath, f)).read()
                 assert 'import oracle' not in text and 'from oracle' not in text, f
+
+
+def test_inline_asm_results_do_not_land_in_live_mfma_sources(lib):
+    """tools/check_asm_hazard.py on the built objects: an inline-asm VALU write into a source register of the most recent
+    MFMA is invisible to hipcc's hazard recogniser (measured wrong results for SrcB on gfx950)."""
+    import importlib.util
+    import shutil
+    from bhnerf_amd import _hip
+    if not os.path.exists('/opt/rocm/lib/llvm/bin/llvm-objdump'):
+        pytest.skip('llvm-objdump not available')
+    spec = importlib.util.spec_from_file_location('check_asm_hazard', os.path.join(ROOT, 'tools', 'check_asm_hazard.py'))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    objs = [os.path.join(_hip.CSRC, f) for f in ('fused_fwd.o', 'fused_bwd.o')]
+    assert all(os.path.exists(o) for o in objs)
+    assert chk.violations(objs) == []
+    # the scanner itself: a write into SrcB right after the MFMA is reported, one into an unrelated register is not
+    fake = '0000 <k>:\n\tv_mfma_f32_32x32x16_bf16 v[2:17], v[20:23], v[30:33], v[2:17] // 0\n\tv_pk_min_u16 v31, v5, s0 // 1\n\tv_pk_max_i16 v40, v5, 0 // 2\n'
+    assert [(w, d) for _, w, d, _ in chk.scan(fake)] == [('B', 1)]
