@@ -52,7 +52,7 @@ struct PolBF16 {
     // (k = 0..7: the k-th packed dword of the tile's two B fragments).  While a tile is being packed the bits are
     // kept "spread" (bit k and bit 16+k), which is what two-at-a-time operations on the packed dword produce:
     //   relu_pair : dword = max_i16x2(pack(a, b), 0); spread |= min_u16x2(dword, 1) << k     (4 VALU per pair)
-    //   mask_pair : dword = pack(a, b) & (((spread >> k) & 0x00010001) * 0xffff)              (5 VALU per pair)
+    //   mask_pair : dword = pack(a, b) & pk_ashr15(spread << (15 - k))                       (4 VALU per pair)
     // A bf16 result of +0 counts as inactive (an f32 pre-activation below 2^-133 would be active in exact arithmetic).
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
     static DEVI void put_dword(frag &f, int i, unsigned u) {
@@ -74,8 +74,12 @@ struct PolBF16 {
         spread |= m << k;
     }
     static DEVI void mask_pair(frag &f, int i, int k, float a, float b, unsigned spread) {
+        // bits k and 16+k of `spread` moved to the sign bits of the two halves, spread by a packed arithmetic >> 15
+        // (v_lshlrev_b32 + v_pk_ashrrev_i16: one VALU less than mask-and-multiply)
+        typedef short i16x2 __attribute__((ext_vector_type(2)));
         const bf16x2 t = {(__bf16)a, (__bf16)b};
-        put_dword(f, i, __builtin_bit_cast(unsigned, t) & (((spread >> k) & 0x00010001u) * 0xffffu));
+        const i16x2 on = __builtin_bit_cast(i16x2, spread << (15 - k)) >> (i16x2){15, 15};
+        put_dword(f, i, __builtin_bit_cast(unsigned, t) & __builtin_bit_cast(unsigned, on));
     }
     static DEVI unsigned mask_code(unsigned spread) { return (spread & 0xffu) | ((spread >> 8) & 0xff00u); }
     static DEVI unsigned mask_spread(unsigned code) { return (code & 0xffu) | ((code & 0xff00u) << 8); }
