@@ -9,6 +9,18 @@
 
 #define BHN_MAX_LAYERS 9   // net_depth <= 8 hidden layers + the output layer
 #define BHN_ENC_PAD 32     // encoded input (3 + 6*deg <= 27) padded to one 32-feature block
+#define BHN_DEG_MAX 4      // posenc degrees 0..4 share ONE kernel-side slot layout of the 32-feature block:
+                           //   [0..2] u | [3 + 3i + k] sin(2^i u_k) | [15 + 3i + k] cos(2^i u_k),  i < deg
+// reference feature index (network.py:118-122: [u | sin block (3 deg) | cos block (3 deg)]) of kernel slot q, or -1
+static inline __host__ __device__ int bhn_enc_slot_feature(int q, int deg) {
+    if (q < 3 + 3 * deg) return q;
+    if (q >= 3 + 3 * BHN_DEG_MAX && q < 3 + 3 * BHN_DEG_MAX + 3 * deg) return 3 + 3 * deg + (q - 3 - 3 * BHN_DEG_MAX);
+    return -1;
+}
+// kernel slot of reference feature index f (0 <= f < 3 + 6 deg)
+static inline __host__ __device__ int bhn_enc_feature_slot(int f, int deg) {
+    return f < 3 + 3 * deg ? f : 3 + 3 * BHN_DEG_MAX + (f - 3 - 3 * deg);
+}
 
 void bhn_set_error(const char *fmt, ...);
 
@@ -35,6 +47,7 @@ struct MlpShape {
     int depth;                  // hidden layers
     int width;                  // hidden width (multiple of 32)
     int F;                      // encoded input features 3 + 6*deg (network.py:118-122)
+    int deg;                    // posenc degree (0..BHN_DEG_MAX)
     int skip_in[BHN_MAX_LAYERS];   // 1 if layer l takes concat[h, enc] as input (network.py:59-61)
     int in_dim[BHN_MAX_LAYERS];    // true fan-in of layer l (l = depth is the output layer)
     int64_t kernel_off[BHN_MAX_LAYERS], bias_off[BHN_MAX_LAYERS];

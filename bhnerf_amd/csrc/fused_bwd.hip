@@ -904,9 +904,9 @@ __global__ void reduce_kernel(BwdArgs A) {
         const int nH = has_h ? MT : 0, nB = nH + (has_enc ? 1 : 0);
         int n, col;
         if (is_bias) { n = nB; col = 0; }
-        else if (l == 0) { n = 0; col = kin; }
+        else if (l == 0) { n = 0; col = bhn_enc_feature_slot(kin, A.f.deg); }
         else if (kin < W) { n = kin >> 5; col = kin & 31; }
-        else { n = nH; col = kin - W; }
+        else { n = nH; col = bhn_enc_feature_slot(kin - W, A.f.deg); }
         // the output layer's row rides on the job of layer depth-1 (slab row MT) when gA_{depth-1} is not on the tape
         const bool rides = l == depth && A.t.drop_ga;
         const int jl = rides ? depth - 1 : l;

@@ -162,6 +162,7 @@ struct FusedArgs {
     int tiles_per_frame;
     long long total_tiles;
     int debug;            // measurement builds only
+    int deg;              // posenc degree 0..BHN_DEG_MAX (run time: only the prologue and the weight packing depend on it)
 };
 
 // Packed-weight geometry for hidden width W
@@ -262,27 +263,31 @@ DEVI void point_prologue(const FusedArgs &a, const PointIn &in, typename Pol::fr
         u[k] = valid[k] ? u[k] / a.scale : 0.f;                  // network.py:227,229
     }
     live = inb && dom && valid[0];                               // emission.py:370-373, network.py:232
-    // encoded features, canonical order [u | sin(2^i u_c) i-major | cos(2^i u_c)] (network.py:118-122)
+    // encoded features in the kernel's slot layout [u | sin(2^i u_k) at 3+3i+k | cos(2^i u_k) at 15+3i+k], i < deg
+    // (common.h; bhn_pack_weights puts the reference's rows [u | sin block | cos block], network.py:118-122, on these
+    // slots, unused slots meet zero weight rows).  The degree is a run-time argument: a wave-uniform branch per octave.
     float feat[BHN_ENC_PAD];
 #pragma unroll
     for (int q = 0; q < BHN_ENC_PAD; ++q) feat[q] = 0.f;
 #pragma unroll
     for (int k = 0; k < 3; ++k) feat[k] = u[k];
 #pragma unroll
-    for (int i = 0; i < DEG; ++i) {
+    for (int i = 0; i < BHN_DEG_MAX; ++i) {
+        if (i < a.deg) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const float arg = u[k] * (float)(1 << i);
-            float sv, cv;
-            if (Pol::FAST_TRIG) {
-                const float rev = __builtin_amdgcn_fractf(arg * 0.15915494309189535f);
-                sv = __builtin_amdgcn_sinf(rev);
-                cv = __builtin_amdgcn_cosf(rev);
-            } else {
-                sincosf(arg, &sv, &cv);
+            for (int k = 0; k < 3; ++k) {
+                const float arg = u[k] * (float)(1 << i);
+                float sv, cv;
+                if (Pol::FAST_TRIG) {
+                    const float rev = __builtin_amdgcn_fractf(arg * 0.15915494309189535f);
+                    sv = __builtin_amdgcn_sinf(rev);
+                    cv = __builtin_amdgcn_cosf(rev);
+                } else {
+                    sincosf(arg, &sv, &cv);
+                }
+                feat[3 + 3 * i + k] = sv;
+                feat[3 + 3 * BHN_DEG_MAX + 3 * i + k] = cv;
             }
-            feat[3 + 3 * i + k] = sv;
-            feat[3 + 3 * DEG + 3 * i + k] = cv;
         }
     }
 #pragma unroll

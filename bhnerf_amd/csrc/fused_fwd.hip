@@ -73,7 +73,8 @@ __global__ void pack_weights_kernel(PackArgs a) {
             if (c == 0) {                                   // layer 0: frag = m*2 + ks
                 if (f < 2 * MT) {
                     const int m = f >> 1, q = 16 * (f & 1) + ph;
-                    if (q < s.F) v = a.params[s.kernel_off[0] + (long long)q * W + 32 * m + i];
+                    const int fe = bhn_enc_slot_feature(q, s.deg);
+                    if (fe >= 0) v = a.params[s.kernel_off[0] + (long long)fe * W + 32 * m + i];
                 }
             } else if (c == a.L.n_fwd - 1) {                // output layer, only row 0 is real
                 if (f < KS && i == 0) v = a.params[s.kernel_off[D] + 16 * f + ph];
@@ -83,7 +84,8 @@ __global__ void pack_weights_kernel(PackArgs a) {
                     v = a.params[s.kernel_off[l] + (long long)(16 * f + ph) * W + 32 * m + i];
                 } else if (s.skip_in[l]) {
                     const int q = 16 * (f - KS) + ph;
-                    if (q < s.F) v = a.params[s.kernel_off[l] + (long long)(W + q) * W + 32 * m + i];
+                    const int fe = bhn_enc_slot_feature(q, s.deg);
+                    if (fe >= 0) v = a.params[s.kernel_off[l] + (long long)(W + fe) * W + 32 * m + i];
                 }
             }
         } else {
@@ -229,10 +231,6 @@ int fused_fill_args(const bhn_model *m, int32_t mode, const void *packed, const 
     BHN_CHECK_ARG(mode == BHN_F32 || mode == BHN_BF16, "bad mode %d", mode);
     int rc = bhn_mlp_shape(m, s);
     if (rc != BHN_OK) return rc;
-    if (m->posenc_deg != 3) {
-        bhn_set_error("fused kernels are instantiated for posenc_deg=3 only (got %d)", m->posenc_deg);
-        return BHN_EUNSUPPORTED;
-    }
     BHN_CHECK_ARG(geom->R > 0 && geom->G > 0 && geom->S >= 0 && geom->S <= 4, "bad geometry sizes");
     BHN_CHECK_ARG(geom->x && geom->y && geom->z && geom->Omega && geom->t_geo && geom->dom, "null geometry array");
     BHN_CHECK_ARG(!need_w || geom->w, "render needs geom->w");
@@ -242,6 +240,7 @@ int fused_fill_args(const bhn_model *m, int32_t mode, const void *packed, const 
     packed_layout(*s, mode, &L);
     memset(a, 0, sizeof(*a));
     a->depth = s->depth;
+    a->deg = s->deg;
     for (int l = 0; l <= s->depth; ++l) a->skip_mask |= s->skip_in[l] << l;
     a->scale = m->scale;
     a->x = geom->x; a->y = geom->y; a->z = geom->z; a->Omega = geom->Omega; a->t_geo = geom->t_geo;

@@ -45,6 +45,7 @@ int bhn_mlp_shape(const bhn_model *m, MlpShape *s) {
     s->depth = m->net_depth;
     s->width = m->net_width;
     s->F = 3 + 6 * m->posenc_deg;
+    s->deg = m->posenc_deg;
     const int skip_layer = m->net_depth / 2;
     int cur = s->F;
     int64_t off = 0;

@@ -183,10 +183,12 @@ def test_frame_group_taped_step_equals_full_step(dev, golden, dt):
     assert torch.allclose(p0, p1, rtol=1e-4, atol=1e-6)
 
 
-@pytest.mark.parametrize('width,depth,S', [(256, 4, 0), (128, 4, 3), (64, 8, 2), (32, 6, 0)])
-def test_random_problem_f32_and_bf16(dev, width, depth, S):
+@pytest.mark.parametrize('width,depth,S,deg', [(256, 4, 0, 3), (128, 4, 3, 3), (64, 8, 2, 3), (32, 6, 0, 3),
+                                               (128, 4, 0, 0), (256, 4, 3, 1), (64, 4, 0, 2), (128, 4, 2, 4)])
+def test_random_problem_f32_and_bf16(dev, width, depth, S, deg):
     """Larger ragged problem (G=50 rays straddle wave tiles, several workgroup tiles, pre-injection
-    and out-of-domain samples) against the float64 oracle."""
+    and out-of-domain samples) against the float64 oracle; positional-encoding degrees 0..4 (network.py:98-122,
+    `NeRF_Predictor.posenc_deg`)."""
     from bhnerf_amd import network, units
     rng = np.random.default_rng(width + depth)
     H, Wd, G, B = 9, 7, 50, 3
@@ -208,13 +210,13 @@ def test_random_problem_f32_and_bf16(dev, width, depth, S):
     f32r = lambda v: np.asarray(v, dtype=np.float32).astype(np.float64)
     geo = {k: f32r(v) for k, v in geo.items()}
     J = f32r(J) if S else None
-    tree = onp.he_uniform_params(rng, depth, width, 21, dtype=np.float32)
+    tree = onp.he_uniform_params(rng, depth, width, 3 + 6 * deg, dtype=np.float32)
     for i in range(depth + 1):
         d = tree['MLP_0']['Dense_%d' % i]
         d['kernel'] = d['kernel'].astype(np.float64)
         d['bias'] = f32r(rng.uniform(-0.1, 0.1, d['bias'].shape))
     g = dict(geo, J=(J if S else np.array(1.0)), t_frames=t_frames, t_start_obs=0.0, t_injection=t_inj,
-             hparams=np.array([8.0, 2.5, 8.0, 4.0, 3, depth, width, 1.0]))
+             hparams=np.array([8.0, 2.5, 8.0, 4.0, deg, depth, width, 1.0]))
     for i in range(depth + 1):
         g['kernel%d' % i] = tree['MLP_0']['Dense_%d' % i]['kernel']; g['bias%d' % i] = tree['MLP_0']['Dense_%d' % i]['bias']
     tr, t = oracle_trainer(g)
