@@ -184,16 +184,62 @@ def generate_hotspot_xr(resolution, rot_axis, rot_angle, orbit_radius, std, r_is
     resolution = np.atleast_1d(resolution)
     center = orbit_radius * np.array([np.cos(rot_angle), np.sin(rot_angle)])
     if len(resolution) != 2:
-        axis = np.asarray(rot_axis, dtype=np.float64)
-        axis = axis / np.sqrt((axis ** 2).sum())
-        z_axis = np.array([0.0, 0.0, 1.0])
-        tilt_axis = np.cross(z_axis, axis)                 # rotation taking the z axis onto the orbit axis
-        if np.sqrt((tilt_axis ** 2).sum()) < 1e-5:
-            tilt_axis = z_axis
-        tilt = utils.rotation_matrix(tilt_axis, np.arccos(np.dot(axis, z_axis)))
-        center = np.matmul(np.asarray(tilt), np.append(center, 0.0))
+        center = np.matmul(_tilt_to_axis(rot_axis), np.append(center, 0.0))
     vol = utils.gaussian_xr(resolution, center, std, fov=fov, std_clip=std_clip)
     if normalize:
         vol = utils.Volume(vol.data / vol.integrate(list(vol.dims) if len(resolution) == 2 else ['x', 'y', 'z']), vol.coords, vol.dims, vol.attrs)
     vol.attrs.update(rot_axis=rot_axis)
     return vol
+
+
+def _tilt_to_axis(rot_axis):
+    """Rotation taking the z axis onto ``rot_axis`` (the orbit-plane tilt of emission.py:46-52, 85-91)."""
+    axis = np.asarray(rot_axis, dtype=np.float64)
+    axis = axis / np.sqrt((axis ** 2).sum())
+    z_axis = np.array([0.0, 0.0, 1.0])
+    tilt_axis = np.cross(z_axis, axis)
+    if np.sqrt((tilt_axis ** 2).sum()) < 1e-5:
+        tilt_axis = z_axis
+    return np.asarray(utils.rotation_matrix(tilt_axis, np.arccos(np.dot(axis, z_axis))))
+
+
+def generate_tube_xr(resolution, rot_axis, phi_start, phi_end, orbit_radius, std, r_isco, fov, std_clip=np.inf, normalize=True):
+    """Arc of Gaussian blobs along the orbit between the angles ``phi_start`` and ``phi_end`` in steps of 0.015 rad
+    (emission.py:62-117), as a ``utils.Volume``."""
+    if orbit_radius < r_isco:
+        raise AttributeError('hotspot center ({}) is is within r_isco: {}'.format(orbit_radius, r_isco))
+    tilt = _tilt_to_axis(rot_axis)
+    total, vol = 0.0, None
+    for phi in np.arange(phi_start, phi_end, 0.015):
+        center = np.matmul(tilt, [orbit_radius * np.cos(phi), orbit_radius * np.sin(phi), 0.0])
+        vol = utils.gaussian_xr(resolution, center, std, fov=fov, std_clip=std_clip)
+        total = total + vol.data
+    if vol is None:
+        raise AttributeError('empty angle range [{}, {})'.format(phi_start, phi_end))
+    out = utils.Volume(total, vol.coords, vol.dims, dict(fov=fov, std=vol.attrs['std'], std_clip=std_clip))
+    if normalize:
+        out = utils.Volume(out.data / out.integrate(['x', 'y', 'z']), out.coords, out.dims, out.attrs)
+    out.attrs.update(rot_axis=rot_axis, phi_start=phi_start, phi_end=phi_end)
+    return out
+
+
+def propogate_flatspace_emission(emission_0, Omega_3D, t_frames, t_start_obs=None, rot_axis=[0, 0, 1], M=None):
+    """3-D movie of an initial emission sheared by the velocity field on its own grid -- no ray tracing, no light
+    travel time (emission.py:305-341): warp of the grid points, then trilinear sampling of ``emission_0``."""
+    x, y, z = np.meshgrid(emission_0.x, emission_0.y, emission_0.z, indexing='ij')
+    t0 = (t_frames[0] if units.is_quantity(t_frames) else np.atleast_1d(t_frames)[0]) if t_start_obs is None else t_start_obs
+    kw = {} if M is None else {'M': M}
+    warped = velocity_warp_coords(coords=[x, y, z], Omega=Omega_3D, t_frames=t_frames, t_start_obs=t0, t_geos=0,
+                                  t_injection=0, rot_axis=rot_axis, **kw)
+    return interpolate_coords(emission_0, warped)
+
+
+def normalize_stokes(movie, I_flux, P_flux, V_flux=None):
+    """Scale a Stokes movie (nt, S, H, W) in place to a mean total flux ``I_flux`` and a mean linearly polarised flux
+    ``P_flux`` of the light curves (emission.py:387-393)."""
+    dolp = np.sqrt(np.sum(movie[:, 1:].sum(axis=(-1, -2)) ** 2, axis=1)).mean()
+    movie[:, 0] *= I_flux / movie[:, 0].sum(axis=(-1, -2)).mean()
+    movie[:, 1:3] *= P_flux / dolp
+    if V_flux is not None:
+        movie[:, 3] *= V_flux / movie[:, 3].sum(axis=(-1, -2)).mean()
+    return movie

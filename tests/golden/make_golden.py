@@ -402,6 +402,9 @@ def main():
     extra = dict(vol=vol, vol_est=vol_est, nchw=utils.intensity_to_nchw(vol), nchw_g1=utils.intensity_to_nchw(vol, 'magma', 1.0),
                  mse=utils.mse(vol, vol_est), psnr=utils.psnr(vol, vol_est), wc=wc,
                  wc_img=utils.world_to_image_coords(wc, (8.0, 8.0, 10.0), (16, 16, 20)))
+    mv = rng10.uniform(0.1, 1.0, (5, 4, 3, 3)) * np.array([1.0, 0.3, -0.2, 0.05])[None, :, None, None]
+    extra.update(stokes_movie=mv.copy(), stokes_norm3=emission.normalize_stokes(mv[:, :3].copy(), 2.5, 0.4),
+                 stokes_norm4=emission.normalize_stokes(mv.copy(), 2.5, 0.4, V_flux=-0.1))
     save('g10_alma', **extra, s2=s2, s3=s3, s4=s4, rot2=emission.rotate_evpa(s2, 0.37), rot3=emission.rotate_evpa(s3, -1.2, axis=1),
          rot4=emission.rotate_evpa(s4, 2.9, axis=2), lc_time=tt, lc_I=lc['I'].values, lc_Q=lc['Q'].values, lc_U=lc['U'].values,
          pre_args=np.array([12, 0.25, 0.08, 31.0, -17.5, 9.07, 10.0]), pre_target=target10, pre_t_hr=np.asarray(t10.to('hr').value))

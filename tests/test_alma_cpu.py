@@ -151,3 +151,33 @@ def test_logging_helpers_against_reference_golden(tmp_path):
         rec = [json.loads(l) for l in open(tmp_path / 'log' / 'scalars.jsonl')]
         assert rec == [{'tag': 'datafit/x', 'value': 0.5, 'step': 3}]
         assert np.array_equal(np.load(tmp_path / 'log' / 'emission_estimate_3.npy'), nchw)
+
+
+def test_normalize_stokes_tube_and_flatspace_propagation():
+    """emission.normalize_stokes against the reference's output (fixture g10); generate_tube_xr and
+    propogate_flatspace_emission (emission.py:62-117, 305-341) through their defining properties."""
+    import os
+    gold = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'g10_alma.npz'))
+    mv = gold['stokes_movie']
+    assert np.allclose(emission.normalize_stokes(mv[:, :3].copy(), 2.5, 0.4), gold['stokes_norm3'], rtol=1e-13)
+    out4 = emission.normalize_stokes(mv.copy(), 2.5, 0.4, V_flux=-0.1)
+    assert np.allclose(out4, gold['stokes_norm4'], rtol=1e-13)
+    assert np.isclose(out4[:, 0].sum(axis=(-1, -2)).mean(), 2.5) and np.isclose(out4[:, 3].sum(axis=(-1, -2)).mean(), -0.1)
+    # tube: unit integral, all of it within one std-scale of the orbit circle, only between the two angles
+    tube = emission.generate_tube_xr([49, 49, 49], [0, 0, 1], 0.0, np.pi / 2, 5.0, 0.6, 3.0, (16.0, 'M'))
+    assert np.isclose(tube.integrate(['x', 'y', 'z']), 1.0)
+    X, Y, Z = np.meshgrid(tube.x, tube.y, tube.z, indexing='ij')
+    w = tube.data / tube.data.sum()
+    assert abs((w * np.hypot(X, Y)).sum() - 5.0) < 0.15 and abs((w * Z).sum()) < 1e-12
+    assert (w * ((X < -1.5) | (Y < -1.5))).sum() < 1e-3                                   # first quadrant only
+    with pytest.raises(AttributeError):
+        emission.generate_tube_xr([9, 9, 9], [0, 0, 1], 0.0, 1.0, 2.0, 0.5, 3.0, (16.0, 'M'))
+    # flat-space propagation: rigid rotation (constant Omega > 0) by a quarter turn moves the hotspot from +x to +y ...
+    hs = emission.generate_hotspot_xr([41, 41, 41], [0, 0, 1], 0.0, 5.0, 0.8, 3.0, (16.0, 'M'), normalize=False)
+    quarter = np.pi / 2                                                                  # Omega * t with t in units of M
+    mov = emission.propogate_flatspace_emission(hs, 1.0, np.array([0.0, quarter]))
+    assert mov.shape == (2, 41, 41, 41) and np.allclose(mov[0], hs.data, atol=1e-6)
+    i, j, k = np.unravel_index(np.argmax(mov[1]), mov[1].shape)
+    assert abs(hs.x[i]) < 0.5 and abs(abs(hs.y[j]) - 5.0) < 0.5 and abs(hs.z[k]) < 0.5
+    # ... (the emission seen at x is the initial one at R(-theta) x: the pattern turns counter-clockwise by +theta)
+    assert hs.y[j] > 0
