@@ -64,9 +64,14 @@ struct PolBF16 {
         // round first, then clamp the two bf16 halves as signed 16-bit integers (sign bit set -> 0, -0 -> +0): one
         // v_cvt_pk + one v_pk_max_i16 instead of two v_max per element (hipcc canonicalises before every max).
         // Inline asm only on the VALU result of the convert, never on an MFMA accumulator (hazard, see relu()).
+        typedef short i16x2 __attribute__((ext_vector_type(2)));
         const bf16x2 t = {(__bf16)a, (__bf16)b};
-        unsigned u;
-        asm("v_pk_max_i16 %0, %1, 0" : "=v"(u) : "v"(__builtin_bit_cast(unsigned, t)));
+        unsigned w = __builtin_bit_cast(unsigned, t);
+        asm("" : "+v"(w));                 // keeps the convert one v_cvt_pk_bf16_f32 (else: two converts + v_perm)
+        // v_pk_max_i16 through the vector builtin, not as an inline-asm instruction: its result replaces fragment
+        // registers that an MFMA issued just before may still be reading, and only compiler-visible writes are
+        // covered by the hazard recogniser (tools/check_asm_hazard.py)
+        const unsigned u = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, w), (i16x2){0, 0}));
         put_dword(f, i, u);
         unsigned m;      // (plain VALU reading a VALU result: no hazard the compiler would have to know about; the
                          //  generic elementwise min on u16x2 expands into ~10 compare/select instructions)

@@ -108,5 +108,5 @@ def test_inline_asm_results_do_not_land_in_live_mfma_sources(lib):
     assert all(os.path.exists(o) for o in objs)
     assert chk.violations(objs) == []
     # the scanner itself: a write into SrcB right after the MFMA is reported, one into an unrelated register is not
-    fake = '0000 <k>:\n\tv_mfma_f32_32x32x16_bf16 v[2:17], v[20:23], v[30:33], v[2:17] // 0\n\tv_pk_min_u16 v31, v5, s0 // 1\n\tv_pk_max_i16 v40, v5, 0 // 2\n'
+    fake = '0000 <k>:\n\tv_mfma_f32_32x32x16_bf16 v[2:17], v[20:23], v[30:33], v[2:17] // 0\n\tv_pk_min_u16 v31, v5, s0 // 1\n\tv_pk_min_u16 v40, v5, s0 // 2\n'
     assert [(w, d) for _, w, d, _ in chk.scan(fake)] == [('B', 1)]

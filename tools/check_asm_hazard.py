@@ -4,8 +4,9 @@ inline asm is opaque to hipcc's hazard recogniser.  Measured on gfx950: an asm w
 MFMA corrupted the product; writes into SrcA three or more instructions later are what the shipped kernels do and are
 covered by the parity tests.
 
-The only opcodes this code base emits through inline asm are v_pk_max_i16 and v_pk_min_u16 (fused_common.h), so the built
-objects are disassembled and every such instruction is checked against the most recent MFMA (no other MFMA in between):
+The only opcode this code base emits through inline asm is v_pk_min_u16 (fused_common.h: relu bits; v_pk_max_i16 comes from
+a vector builtin and is visible to the compiler), so the built objects are disassembled and every such instruction is
+checked against the most recent MFMA (no other MFMA in between):
 
     python tools/check_asm_hazard.py [objects ...]        # default: bhnerf_amd/csrc/fused_{fwd,bwd}.o
 """
@@ -17,7 +18,7 @@ import sys
 import tempfile
 
 LLVM = '/opt/rocm/lib/llvm/bin'
-ASM_OPCODES = ('v_pk_max_i16', 'v_pk_min_u16')
+ASM_OPCODES = ('v_pk_min_u16',)
 MIN_DIST_SRCA = 3           # smallest distance (instructions) the verified kernels have
 
 
