@@ -32,7 +32,8 @@ class bhn_model(C.Structure):
 class bhn_geom(C.Structure):
     _fields_ = [('R', C.c_int64), ('G', C.c_int64), ('S', C.c_int32), ('x', C.c_void_p), ('y', C.c_void_p),
                 ('z', C.c_void_p), ('Omega', C.c_void_p), ('t_geo', C.c_void_p), ('w', C.c_void_p),
-                ('dom', C.c_void_p), ('groups', C.c_void_p), ('n_groups', C.c_int64)]
+                ('dom', C.c_void_p), ('groups', C.c_void_p), ('n_groups', C.c_int64), ('ray_idx', C.c_void_p),
+                ('n_points', C.c_int64)]
 
 
 class bhn_frames(C.Structure):

@@ -148,6 +148,7 @@ struct FusedArgs {
     const float *x, *y, *z, *Omega, *t_geo, *w;
     const uint8_t *dom;
     const int *groups;    // active 32-point groups (NULL = all)
+    const int *ray_idx;   // point-level compaction: ray of point p (NULL = p / G)
     long long n_groups;
     long long P, G, R;
     int Sx;               // max(S,1)

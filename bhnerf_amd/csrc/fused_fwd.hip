@@ -203,7 +203,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void fused_fwd_kernel(FusedArgs a) {
         } else {
             // x J g^2 dtau Sigma and sum over the ray (network.py:415-419, kgeo.py:621); a 32-point
             // wave tile may straddle rays when G % 32 != 0 -> segmented sum + one atomic per ray.
-            const long long ray = inb ? p / a.G : -1;
+            const long long ray = inb ? (a.ray_idx ? (long long)a.ray_idx[p] : p / a.G) : -1;
             unsigned long long rem = __ballot(h == 0 && inb);
             while (rem) {
                 const int first = __ffsll((long long)rem) - 1;
@@ -246,6 +246,12 @@ int fused_fill_args(const bhn_model *m, int32_t mode, const void *packed, const 
     a->x = geom->x; a->y = geom->y; a->z = geom->z; a->Omega = geom->Omega; a->t_geo = geom->t_geo;
     a->w = geom->w; a->dom = geom->dom;
     a->R = geom->R; a->G = geom->G; a->P = geom->R * geom->G;
+    if (geom->ray_idx) {                                   // point-level compaction of the domain mask
+        BHN_CHECK_ARG(geom->n_points > 0 && geom->n_points % 32 == 0 && !geom->groups,
+                      "compacted geometry: n_points %lld must be a positive multiple of 32 and groups NULL", (long long)geom->n_points);
+        a->P = geom->n_points;
+        a->ray_idx = reinterpret_cast<const int *>(geom->ray_idx);
+    }
     a->Sx = geom->S > 0 ? geom->S : 1;
     a->tM0 = fr->tM0; a->B = fr->B;
     a->packed = (const char *)packed;

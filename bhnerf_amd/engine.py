@@ -11,6 +11,9 @@ import torch
 from . import _hip
 from .constants import GM_c3_hr
 
+COMPACT_POINTS = True          # point-level compaction of the domain mask for the fused kernels (RayGeometry.compact)
+COMPACT_BELOW = 0.9            # ... when less than this fraction of the samples is inside the domain
+
 
 def _flat(t, n):
     return t.reshape(n).contiguous()
@@ -75,12 +78,43 @@ class RayGeometry:
             if self.groups.numel() == 0:                      # nothing inside the domain: keep one (masked) group
                 self.groups = torch.zeros((1,), dtype=torch.int32, device=dev)
         self.P_eff = self.n_groups * 32                       # points the fused kernels / the tape visit per frame
+        # point-level compaction for the fused MLP kernels: when a sizeable part of the samples lies outside the
+        # domain, a second copy of the planes holds only the in-domain points (ray-major order kept, padded with
+        # masked points to a multiple of 32) plus the ray of every point.  Group-level compaction alone still
+        # evaluates every point of a 32-point group that has one in-domain sample (tutorial domain: 61 % visited
+        # for 28 % in-domain).
+        self.compact = None
+        n_in = int(self.dom.sum().item())
+        if COMPACT_POINTS and 0 < n_in < COMPACT_BELOW * P:
+            idx = torch.nonzero(self.dom).reshape(-1)
+            n_pad = (n_in + 31) // 32 * 32
+
+            def take(v, dtype=torch.float32):
+                out = torch.zeros((n_pad,), dtype=dtype, device=dev)
+                out[:n_in] = v[idx].to(dtype)
+                return out
+            cw = torch.zeros((self.Sx, n_pad), dtype=torch.float32, device=dev)
+            cw[:, :n_in] = self.w[:, idx]
+            self.compact = dict(idx=idx, n=n_in, n_pad=n_pad, x=take(self.coords[0]), y=take(self.coords[1]), z=take(self.coords[2]),
+                                Omega=take(self.Omega), t_geo=take(self.t_geo), w=cw, dom=take(self.dom, torch.uint8),
+                                ray=take(torch.div(torch.arange(P, device=dev), self.G, rounding_mode='floor'), torch.int32))
+            self.P_eff = n_pad
 
     def c_struct(self):
+        """Dense layout (R x G planes): voxel / grid kernels and every caller that indexes points as ray * G + sample."""
         c = self.coords
         return _hip.bhn_geom(self.R, self.G, self.S, c[0].data_ptr(), c[1].data_ptr(), c[2].data_ptr(),
                              self.Omega.data_ptr(), self.t_geo.data_ptr(), self.w.data_ptr(), self.dom.data_ptr(),
-                             self.groups.data_ptr() if self.groups is not None else None, self.n_groups)
+                             self.groups.data_ptr() if self.groups is not None else None, self.n_groups, None, 0)
+
+    def c_struct_fused(self):
+        """What the fused predictor / render kernels get: the point-compacted planes when they exist."""
+        k = self.compact
+        if k is None:
+            return self.c_struct()
+        return _hip.bhn_geom(self.R, self.G, self.S, k['x'].data_ptr(), k['y'].data_ptr(), k['z'].data_ptr(),
+                             k['Omega'].data_ptr(), k['t_geo'].data_ptr(), k['w'].data_ptr(), k['dom'].data_ptr(),
+                             None, k['n_pad'] // 32, k['ray'].data_ptr(), k['n_pad'])
 
     @property
     def active_fraction(self):
@@ -89,7 +123,7 @@ class RayGeometry:
 
     @property
     def visited_fraction(self):
-        """Fraction of ray samples the fused kernels evaluate after 32-point group compaction."""
+        """Fraction of ray samples the fused kernels evaluate after compaction (points, else 32-point groups)."""
         return self.P_eff / float(self.n_groups_total * 32)
 
 
@@ -154,18 +188,23 @@ class FusedPredictor:
     def predict(self, geom, tM0):
         """NeRF_Predictor.__call__ (network.py:191-237) -> emission (B, P) float32."""
         B = int(tM0.numel())
-        out = torch.empty((B, geom.P), dtype=torch.float32, device=self.device)
-        gs, fs = geom.c_struct(), self._frames(tM0)
+        k = geom.compact
+        out = torch.empty((B, geom.P if k is None else k['n_pad']), dtype=torch.float32, device=self.device)
+        gs, fs = geom.c_struct_fused(), self._frames(tM0)
         _hip.check(_hip.lib().bhn_predict_fwd(C.byref(self.model), self.mode, _hip.ptr(self.packed), C.byref(gs),
                                               C.byref(fs), _hip.ptr(out), _hip.stream_ptr(self.device)))
-        return out
+        if k is None:
+            return out
+        full = torch.zeros((B, geom.P), dtype=torch.float32, device=self.device)      # outside the domain: 0 (emission.py:370-373)
+        full[:, k['idx']] = out[:, :k['n']]
+        return full
 
     def render(self, geom, tM0, out=None):
         """image_plane_prediction (network.py:373-420) -> images (B, Sx, R) float32."""
         B = int(tM0.numel())
         if out is None:
             out = torch.empty((B, geom.Sx, geom.R), dtype=torch.float32, device=self.device)
-        gs, fs = geom.c_struct(), self._frames(tM0)
+        gs, fs = geom.c_struct_fused(), self._frames(tM0)
         _hip.check(_hip.lib().bhn_render_fwd(C.byref(self.model), self.mode, _hip.ptr(self.packed), C.byref(gs),
                                              C.byref(fs), _hip.ptr(out), _hip.stream_ptr(self.device)))
         return out
@@ -195,7 +234,7 @@ class FusedPredictor:
         if out is None:
             out = torch.empty((self.nparams,), dtype=torch.float32, device=self.device)
         ws = self.workspace(int(tM0.numel()), geom.P_eff)
-        gs, fs = geom.c_struct(), self._frames(tM0)
+        gs, fs = geom.c_struct_fused(), self._frames(tM0)
         _hip.check(_hip.lib().bhn_render_bwd(C.byref(self.model), self.mode, _hip.ptr(self.packed), C.byref(gs),
                                              C.byref(fs), _hip.ptr(dimages), _hip.ptr(out), _hip.ptr(ws), ws.numel(),
                                              _hip.stream_ptr(self.device)))
@@ -229,7 +268,7 @@ class FusedPredictor:
         if out is None:
             out = torch.empty((B, geom.Sx, geom.R), dtype=torch.float32, device=self.device)
         ws = self.workspace(B, geom.P_eff)
-        gs, fs = geom.c_struct(), self._frames(tM0)
+        gs, fs = geom.c_struct_fused(), self._frames(tM0)
         _hip.check(_hip.lib().bhn_render_fwd_train(C.byref(self.model), self.mode, _hip.ptr(self.packed), C.byref(gs),
                                                    C.byref(fs), _hip.ptr(out), _hip.ptr(ws), ws.numel(),
                                                    _hip.stream_ptr(self.device)))
@@ -241,7 +280,7 @@ class FusedPredictor:
         if out is None:
             out = torch.empty((self.nparams,), dtype=torch.float32, device=self.device)
         ws = self.workspace(int(tM0.numel()), geom.P_eff)
-        gs, fs = geom.c_struct(), self._frames(tM0)
+        gs, fs = geom.c_struct_fused(), self._frames(tM0)
         _hip.check(_hip.lib().bhn_render_bwd_tape(C.byref(self.model), self.mode, _hip.ptr(self.packed), C.byref(gs),
                                                   C.byref(fs), _hip.ptr(dimages), _hip.ptr(out), _hip.ptr(ws), ws.numel(),
                                                   _hip.stream_ptr(self.device)))

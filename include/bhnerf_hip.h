@@ -62,6 +62,13 @@ typedef struct {
      * NULL = all ceil(P/32) groups. */
     const int32_t *groups;
     int64_t n_groups;
+    /* Optional point-level compaction (fused predictor / render kernels only): the arrays above then hold only the
+     * `n_points` in-domain points of the ray set (ray-major order kept, padded with dom = 0 points to a multiple of 32),
+     * w is (Sx, n_points), and ray_idx[i] is the ray (0..R-1) point i belongs to -- the reference's `p / G`
+     * (kgeo.py:621 sums over the last axis).  Out-of-domain samples have emission 0 (emission.py:370-373), so leaving
+     * them out changes no image and no gradient.  NULL / 0 = dense layout, P = R*G. */
+    const int32_t *ray_idx;
+    int64_t n_points;
 } bhn_geom;
 
 /* Frames of one step.  tM0[b] = (t_frames[b]-t_start_obs)/GM_c3 - t_injection, float64, device

@@ -179,3 +179,37 @@ def test_domain_compaction_skips_groups_but_not_results(dev):
     assert ((e == 0) != (e_ref == 0)).mean() < 0.01
     same = (e == 0) == (e_ref == 0)
     assert relerr(e[same], e_ref[same]) < 1e-5 and relerr(img.cpu().numpy(), img_ref) < 2e-5
+
+
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+def test_point_compaction_of_the_domain_mask_changes_nothing(dev, mode):
+    """engine.RayGeometry.compact: the fused kernels evaluate only the in-domain samples (ray index per point instead of
+    p / G).  Images, per-point emission and parameter gradients must equal the dense evaluation (out-of-domain samples
+    have emission 0, emission.py:370-373): same per-point arithmetic, different tiling -> f32 summation-order noise only."""
+    from bhnerf_amd import constants, engine, network, synthetic
+    geo = synthetic.synthetic_geodesics(24, 20, 50, S=3, seed=4)          # ragged: 50 samples per ray
+    rng = np.random.default_rng(2)
+    tree = onp.he_uniform_params(rng, 4, 128, 21, dtype=np.float32)
+    tree['MLP_0']['Dense_4']['bias'] = tree['MLP_0']['Dense_4']['bias'] + 9.0
+    tM0 = engine.frame_offsets(np.linspace(0.0, 0.7, 3), 0.0, geo['t_injection'], constants.GM_c3('hr'), dev)
+    out = {}
+    for compact in (False, True):
+        engine.COMPACT_POINTS = compact
+        try:
+            pred = network.NeRF_Predictor(8.0, 3.0, 7.0, 2.5, net_depth=4, net_width=128, mode=mode, device=dev)
+            eng = pred.engine()
+            geom = pred.geometry(geo['coords'], geo['Omega'], geo['t_geos'], geo['J'], geo['g'], geo['dtau'], geo['Sigma'])
+        finally:
+            engine.COMPACT_POINTS = True
+        assert (geom.compact is not None) == compact
+        eng.pack(eng.flatten(tree))
+        gen = torch.Generator(device=dev).manual_seed(1)
+        d = torch.rand((3, 3, geom.R), device=dev, generator=gen) - 0.4
+        out[compact] = (eng.render(geom, tM0).clone(), eng.predict(geom, tM0).clone(), eng.render_bwd(geom, tM0, d).clone(),
+                        geom.visited_fraction, geom.active_fraction)
+    (img0, e0, g0, vis0, act0), (img1, e1, g1, vis1, act1) = out[False], out[True]
+    assert act0 == act1 and vis1 < vis0 and vis1 <= act1 + 32.0 / geom.P          # only the padding is extra
+    assert float(img0.abs().max()) > 0
+    assert torch.equal(e0, e1)                                                       # per-point values are bit-identical
+    assert float((img0 - img1).abs().max()) <= 2e-6 * float(img0.abs().max())
+    assert float((g0 - g1).abs().max()) <= (1e-5 if mode == 'f32' else 1e-4) * float(g0.abs().max())
