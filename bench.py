@@ -268,6 +268,28 @@ def main():
                'shape': '%d planes x %d rays x %d samples (%.2f GB)' % (Nrt, Rrt, Grt, rt_bytes / 1e9)}
     del e_rt, planes
 
+    # the same workload with the tutorials' recovery domain (rmin 2 M, rmax = fov/2, |z| <= 4 M): the samples outside it
+    # have emission 0 and are compacted away (engine.RayGeometry.compact).  Reported next to the all-active headline,
+    # never as `value`; single GPU only.
+    tutorial_domain = None
+    if world == 1 and not args.masked:
+        pred_m = network.NeRF_Predictor(rmax, 2.0, rmax, 4.0, net_depth=args.depth, net_width=args.width, mode=args.mode, device=dev)
+        opt_m = optimization.Optimizer({'num_iters': 5000, 'lr_init': 1e-4, 'lr_final': 1e-6, 'seed': 1}, pred_m, rt_args)
+        def step_m():
+            opt_m.loss, opt_m.state, _ = train_step(opt_m.state, rt_args, indices=train_step.args[0].sample(batch))
+        for _ in range(max(args.warmup, 2)):
+            step_m()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step_m()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        gm = pred_m.geometry(rt_args['coords'], rt_args['Omega'], rt_args['t_geos'], None, rt_args['g'], rt_args['dtau'], rt_args['Sigma'])
+        tutorial_domain = {'ms_per_step': round(1e3 * dt, 3), 'value': round(samples_step / dt, 1), 'unit': 'ray-samples/s',
+                           'active_fraction': round(gm.active_fraction, 4), 'visited_fraction': round(gm.visited_fraction, 4)}
+        del opt_m, pred_m
+
     out = {
         'metric': 'train ray-samples/sec, 128x128x64-sample image-plane recovery', 'value': value,
         'unit': 'ray-samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -283,6 +305,8 @@ def main():
         'rt_scan': rt_scan,
         'fwd_images_per_s': round(args.frames_per_gpu / (kern_ms['fused_fwd_kernel (inference)'] * 1e-3), 1),
     }
+    if tutorial_domain:
+        out['tutorial_domain'] = tutorial_domain
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(args, geo, GM_c3)
     if rank == 0:
