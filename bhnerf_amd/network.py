@@ -196,8 +196,8 @@ class NeRF_Predictor:
         geom = engine.RayGeometry(coords, Omega, one if g is None else g, one if dtau is None else dtau,
                                   one if Sigma is None else Sigma, t_geos, J, self.rmin, self.rmax, self.z_width, dev)
         self._geoms[key] = (geom, (coords, Omega, t_geos, J, g, dtau, Sigma))   # keep ids alive
-        while len(self._geoms) > 8:
-            self._geoms.popitem(last=False)
+        while len(self._geoms) > 32:            # > the sub-pixel ray sets of a run (scripts use up to 10): a training step
+            self._geoms.popitem(last=False)     # picks one at random, so a smaller cache would rebuild geometry every step
         return geom
 
     # -- reference API -----------------------------------------------------------------------------
