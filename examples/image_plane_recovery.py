@@ -23,6 +23,7 @@ def main():
     ap.add_argument('--frames', type=int, default=16)
     ap.add_argument('--iters', type=int, default=300)
     ap.add_argument('--width', type=int, default=128)
+    ap.add_argument('--mode', default='bf16', choices=['bf16', 'f32'], help='arithmetic of the fused kernels')
     ap.add_argument('--batch', type=int, default=4, help='frames per step')
     args = ap.parse_args()
     fov, rmax = 16.0, 8.0
@@ -41,7 +42,7 @@ def main():
     print('observed movie', movie.shape, 'flux range %.3g .. %.3g' % (movie.sum((-1, -2)).min(), movie.sum((-1, -2)).max()))
 
     rt = network.raytracing_args(geos, Omega, t_injection, t_frames[0], J=1.0)
-    predictor = network.NeRF_Predictor(rmax, 2.0, rmax, 4.0, net_depth=4, net_width=args.width)
+    predictor = network.NeRF_Predictor(rmax, 2.0, rmax, 4.0, net_depth=4, net_width=args.width, mode=args.mode)
     train_step = optimization.TrainStep.image(t_frames, movie, sigma=float(movie.max()) * 0.05, dtype='full')
     opt = optimization.Optimizer({'num_iters': args.iters, 'lr_init': 1e-3, 'lr_final': 1e-4}, predictor, rt)
     import time
