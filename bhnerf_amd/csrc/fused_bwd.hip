@@ -158,13 +158,55 @@ struct TapeEmit {
                 }
         }
     }
+    // bf16: the tile goes to the tape AS THE PRODUCER HOLDS IT (point on the lane: the two B fragments of the 32-feature
+    // block, no transposing MFMAs, no converts) and the dW kernel transposes while it reads the LDS image, with
+    // ds_read_b64_tr_b16 (tr_frag below).  The 16 bytes of lane (pt, h) of fragment s go to slot
+    //     (pt & 3) + 4 (2 s + h) + 16 (pt >> 2)
+    // of the 2 KiB tile, so that the 32 8-byte chunks one half-wave gathers for a transposed read (4 points x
+    // {s, h, 8-byte half}) cover one 256-byte LDS row exactly -- conflict-free -- and one store instruction still
+    // writes eight whole 128-byte lines.
+    static DEVI int native_off(int s) {
+        const int lane = threadIdx.x & 63, pt = lane & 31, h = lane >> 5;
+        return 16 * (pt & 3) + 128 * s + 64 * h + 256 * (pt >> 2);
+    }
+    static DEVI void store_native(char *dst, const typename Pol::frag &f0, const typename Pol::frag &f1, int dbg) {
+        if (!(dbg & 1)) {
+            __builtin_nontemporal_store(f0, reinterpret_cast<typename Pol::frag *>(dst + native_off(0)));
+            __builtin_nontemporal_store(f1, reinterpret_cast<typename Pol::frag *>(dst + native_off(1)));
+        } else {
+            asm volatile("" ::"v"(f0), "v"(f1));
+        }
+    }
     DEVI void emit(char *dst, const typename Pol::frag &f0, const typename Pol::frag &f1, int dbg) const {
         if (dbg & 2) return;
-        typename Pol::frag id[2];
-        load_id(id);
-        store(dst, transpose(f0, f1, id), dbg);
+        if constexpr (Pol::ELEM_BYTES == 2) {
+            store_native(dst, f0, f1, dbg);
+        } else {
+            typename Pol::frag id[2];
+            load_id(id);
+            store(dst, transpose(f0, f1, id), dbg);
+        }
     }
 };
+
+// Transposed read of a bf16 tape tile (TapeEmit::store_native image in LDS): the A / B fragment of k-step s of a dW
+// GEMM (K = points) for lane (n = lane & 31, kh = lane >> 5): feature n, points 16 s + phi16(kh, j), j = 0..7 -- the
+// same point order as the f32 tape tiles.  Two ds_read_b64_tr_b16; per 16-lane group g the instruction gathers 4 points
+// (rows) x 16 features (columns, fragment g & 1 of the tile) and hands lane i of the group column i.  `trl` is the
+// lane's part of the address (tr_lane_off), the rest is an immediate.  EXEC must be all ones.
+DEVI int tr_lane_off() {
+    const int lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+    return 256 * (g >> 1) + 16 * q + 128 * (g & 1) + 64 * (pp & 1) + 8 * (pp >> 1);
+}
+DEVI bf16x8 tr_frag(const char *tile, int s, int trl) {
+    typedef s16x4 __attribute__((address_space(3))) * lds_v4;
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const char *a = tile + 1024 * s + trl;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(a));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(a + 512));
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
 
 // Post object of the training kernels (fused_common.h "Software-pipelined ring steps"): finishes the PENDING
 // output tile in the MFMA shadows of the running step --
@@ -212,7 +254,14 @@ struct TapePost {
                 if (stash) *stash = word;
             }
         }
-        if (!(edbg & 2)) tr = TapeEmit<Pol>::transpose(d0, d1, id);
+        if constexpr (Pol::ELEM_BYTES != 2) {
+            if (!(edbg & 2)) tr = TapeEmit<Pol>::transpose(d0, d1, id);
+        }
+    }
+    DEVI void store_tile() {
+        if (edbg & 2) return;
+        if constexpr (Pol::ELEM_BYTES == 2) TapeEmit<Pol>::store_native(dst, d0, d1, edbg);
+        else TapeEmit<Pol>::store(dst, tr, edbg);
     }
     DEVI void at(int t) {
         if (t == 0) elems<0, 2>();
@@ -223,15 +272,15 @@ struct TapePost {
         if (t == 5) elems<10, 2>();
         if (t == 6) elems<12, 2>();
         if (t == 7) elems<14, 2>();
-        if (t == 6 && !(edbg & 2)) em.load_id(id);
+        if (Pol::ELEM_BYTES != 2 && t == 6 && !(edbg & 2)) em.load_id(id);
         if (t == 8) bits_and_transpose();
-        if (t == 12 && !(edbg & 2)) TapeEmit<Pol>::store(dst, tr, edbg);
+        if (t == 12) store_tile();
     }
     DEVI void all() {
         elems<0, 16>();
-        if (!(edbg & 2)) em.load_id(id);
+        if (Pol::ELEM_BYTES != 2 && !(edbg & 2)) em.load_id(id);
         bits_and_transpose();
-        if (!(edbg & 2)) TapeEmit<Pol>::store(dst, tr, edbg);
+        store_tile();
     }
 };
 
@@ -555,8 +604,10 @@ DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
     constexpr bool out_job = JT == JT_OUT, has_h = JT != JT_FIRST, has_enc = (JT == JT_FIRST || JT == JT_SKIP);
     constexpr bool make_h = JT == JT_HIDDEN1;       // the h tiles of the LDS group image are computed here, not DMA'd
     constexpr int mtA = out_job ? 1 : MT;                              // A tiles (gA rows; dout is 1 row)
-    constexpr int nH = has_h ? MT : 0, nB = nH + (has_enc ? 1 : 0);    // B tiles; tile nB is the ones tile
-    constexpr int NT = nB + 1;
+    constexpr int nH = has_h ? MT : 0, nB = nH + (has_enc ? 1 : 0);    // B tiles; slab tile nB holds the bias column,
+    constexpr int NT = nB;                                             // summed by VALU from the A fragments (Pol::sum8)
+    constexpr bool TR = Pol::ELEM_BYTES == 2;                          // tape tiles are point-on-lane images: transposed LDS reads
+    const int trl = tr_lane_off();
     constexpr int WRR = BG::WRR, WCC = BG::WCC;
     constexpr int MPW = (mtA + WRR - 1) / WRR;                         // A tiles per wave (1 for the output job)
     constexpr int NPWJ = (NT + WCC - 1) / WCC;                         // B tiles owned by one wave
@@ -621,7 +672,7 @@ DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
     constexpr int MO = (MPW + WCC - 1) / WCC;
     float wout_r[MPW];
     f32x16 acc_o[MO], acc_b = {};
-    const bool bias_wave = LAST && wr == WRR - 1 && wc == WCC - 1;
+    const bool bias_wave = LAST && wr == WRR - 1 && wc == (((WCC - 1) * NPWJ < nB) ? WCC - 1 : 0);   // a wave that runs compute_group
     if constexpr (LAST) {
 #pragma unroll
         for (int mi = 0; mi < MPW; ++mi) {
@@ -637,18 +688,19 @@ DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
 
     for (int pass = 0; pass < NPASS; ++pass) {
         const int nbase = wc * NPWJ + pass * NPW;
-        // per-tile LDS offsets and "ones" flags, fixed for the whole stream (no branches in the loop)
+        // per-tile LDS offsets, fixed for the whole stream (no branches in the loop); a wave column whose share of the
+        // B tiles ends early computes on a duplicate of a real tile and drops the result at the flush
         int boff[NPW];
-        bool bones[NPW];
-        unsigned bkeep[NPW], bone[NPW];
 #pragma unroll
         for (int ni = 0; ni < NPW; ++ni) {
             const int n = nbase + ni;
             boff[ni] = (n < nH) ? OFF_H + n * TB : (has_enc ? OFF_E : OFF_H);
-            bones[ni] = n >= nB;
-            bkeep[ni] = bones[ni] ? 0u : 0xFFFFFFFFu;
-            bone[ni] = bones[ni] ? 0x3F803F80u : 0u;           // two bf16 1.0
         }
+        const bool has_tiles = nbase < nB;
+        const bool bias_rows = wc == 0 && pass == 0;          // this wave sums the bias column of its A tiles
+        float bsum[MPW];
+#pragma unroll
+        for (int mi = 0; mi < MPW; ++mi) bsum[mi] = 0.f;
         f32x16 acc[MPW][NPW];
 #pragma unroll
         for (int mi = 0; mi < MPW; ++mi)
@@ -660,18 +712,14 @@ DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
         // B fragments are fetched two MFMA-pairs ahead of their use (counted lgkmcnt instead of a full
         // drain after every read): with the two waves of a SIMD in barrier lockstep nothing else hides
         // the LDS latency.  A fragments of both k-steps are loaded up front.
-        auto load_b = [&](const char *gp, int t) -> frag { return Pol::lds_frag(gp + boff[t % NPW], t / NPW, lane); };
-        auto fix_b = [&](frag bf, int ni) -> frag {   // ones tile: applied when the fragment is consumed
-            if constexpr (Pol::ELEM_BYTES == 2) {      // (bits & 0) | bf16x2(1,1): one op per dword
-                u32x4 bits = __builtin_bit_cast(u32x4, bf);
-#pragma unroll
-                for (int d = 0; d < 4; ++d) bits[d] = (bits[d] & bkeep[ni]) | bone[ni];
-                return __builtin_bit_cast(frag, bits);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) Pol::set(bf, j, bones[ni] ? 1.f : Pol::get(bf, j));
-                return bf;
-            }
+        // (HIDDEN1: the h_1 tiles were written by make_h_write in fragment order, not DMA'd as point-on-lane images)
+        auto load_b = [&](const char *gp, int t) -> frag {
+            if constexpr (TR && !make_h) return tr_frag(gp + boff[t % NPW], t / NPW, trl);
+            else return Pol::lds_frag(gp + boff[t % NPW], t / NPW, lane);
+        };
+        auto load_a = [&](const char *tile, int s2) -> frag {
+            if constexpr (TR) return tr_frag(tile, s2, trl);
+            else return Pol::lds_frag(tile, s2, lane);
         };
         auto compute_group = [&](const char *gp) {
             constexpr int NTOT = 2 * NPW, AHEAD = (Pol::ELEM_BYTES == 2) ? 2 : 1;
@@ -685,11 +733,11 @@ DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
                     const float *d32 = reinterpret_cast<const float *>(gp + OFF_D32) + 16 * s + 4 * (lane >> 5);
                     da = *reinterpret_cast<const f32x4 *>(d32);
                     db = *reinterpret_cast<const f32x4 *>(d32 + 8);
-                    ad = Pol::lds_frag(gp + OFF_D, s, lane);
+                    ad = load_a(gp + OFF_D, s);
                 }
 #pragma unroll
                 for (int mi = 0; mi < MPW; ++mi) {
-                    af[s][mi] = Pol::lds_frag(gp + (wr * MPW + mi) * TB, s, lane);
+                    af[s][mi] = load_a(gp + (wr * MPW + mi) * TB, s);
                     if constexpr (LAST) {
                         if (pass == 0 && (mi % WCC) == wc) acc_o[mi / WCC] = Pol::mma(ad, af[s][mi], acc_o[mi / WCC]);
                         const u32x4 raw = __builtin_bit_cast(u32x4, af[s][mi]);
@@ -713,6 +761,7 @@ DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
                         }
                         af[s][mi] = __builtin_bit_cast(frag, ga);
                     }
+                    if (bias_rows) bsum[mi] = Pol::sum8(af[s][mi], bsum[mi]);
                 }
                 if constexpr (LAST) {
                     if (pass == 0 && bias_wave) acc_b = Pol::mma(ad, ones, acc_b);
@@ -726,7 +775,7 @@ DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
                 if (t + AHEAD < NTOT) bq[(t + AHEAD) % (AHEAD + 1)] = load_b(gp, t + AHEAD);
                 __builtin_amdgcn_sched_barrier(0);          // keep the prefetch ahead of this step's MFMAs
                 const int s = t / NPW, ni = t % NPW;
-                const frag bnow = fix_b(bq[t % (AHEAD + 1)], ni);
+                const frag bnow = bq[t % (AHEAD + 1)];
 #pragma unroll
                 for (int mi = 0; mi < MPW; ++mi) acc[mi][ni] = Pol::mma(af[s][mi], bnow, acc[mi][ni]);
                 __builtin_amdgcn_sched_barrier(0);
@@ -772,7 +821,7 @@ DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
                 q = q < q1 ? q : q1 - 1;
 #pragma unroll
                 for (int i = 0; i < PPW; ++i)
-                    dma_1k<true>(sbase[i] + q * sstride[i], buf + doff[i]);
+                    dma_1k_asm<true>(sbase[i] + q * sstride[i], buf + doff[i]);
             };
             // HIDDEN1: the h tiles of group q+1 are computed while group q is consumed (one group less in flight:
             // this job is MFMA-bound), so the loop-top barrier also publishes them and no latency chain is exposed
@@ -801,7 +850,7 @@ DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
                     // LDS write behind them (the MFMA result is long done by then: no exposed MFMA -> VALU latency)
                     f32x16 hacc = {};
                     if constexpr (make_h) hacc = make_h_mma(make_h_read(gnext));
-                    if (!(A.debug & 1) && wave_works) compute_group(smem + it * GB);
+                    if (!(A.debug & 1) && wave_works && has_tiles) compute_group(smem + it * GB);
                     if constexpr (make_h) {
                         if (q + 1 < q1) make_h_write(gnext, hacc);
                     }
@@ -816,7 +865,7 @@ DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
 #pragma unroll
             for (int ni = 0; ni < NPW; ++ni) {
                 const int m = wr * MPW + mi, n = nbase + ni;
-                if (m >= mtA || n > nB || n >= (wc + 1) * NPWJ) continue;
+                if (m >= mtA || n >= nB || n >= (wc + 1) * NPWJ) continue;
                 float *tp = slab + (long long)(m * BG::NTMAX + n) * 1024;
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
@@ -832,6 +881,20 @@ DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
                     *dst = v;
                 }
             }
+        // bias column (slab tile nB, column 0: what reduce_kernel reads): row i of A tile m is held by lanes i and i + 32
+        if (bias_rows) {
+#pragma unroll
+            for (int mi = 0; mi < MPW; ++mi) {
+                const int m = wr * MPW + mi;
+                float v = bsum[mi] + __shfl_xor(bsum[mi], 32, 64);
+                if (m < mtA && lane < 32) {
+                    const int hh = (lane >> 2) & 1, r = (lane & 3) + 4 * (lane >> 3);
+                    float *dst = slab + (long long)(m * BG::NTMAX + nB) * 1024 + (r >> 2) * 256 + (32 * hh) * 4 + (r & 3);
+                    if (A.accumulate) v += *dst;
+                    *dst = v;
+                }
+            }
+        }
     }
     if constexpr (LAST) {       // the output layer's row: slab row MT, column tiles = h_depth tiles, then the bias tile
         auto flush_tile = [&](int n, const f32x16 &t) {

@@ -89,6 +89,18 @@ struct PolBF16 {
     static DEVI unsigned mask_code(unsigned spread) { return (spread & 0xffu) | ((spread >> 8) & 0xff00u); }
     static DEVI unsigned mask_spread(unsigned code) { return (code & 0xffu) | ((code & 0xff00u) << 8); }
     static DEVI float get(const frag &f, int j) { return (float)f[j]; }
+    // acc + the sum of the fragment's eight values (v_dot2c_f32_bf16 against (1, 1): the bias column of a dW GEMM)
+    // (the pairs are formed from ELEMENTS of the fragment: with the dwords of a u32x4 bit-cast to bf16x2 hipcc 7.2 feeds
+    //  dword 0 to all four dot products -- reproduced in ten lines, found in the ISA)
+    static DEVI float sum8(const frag &f, float acc) {
+        const bf16x2 one = {(__bf16)1.f, (__bf16)1.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bf16x2 p = {f[2 * i], f[2 * i + 1]};
+            acc = __builtin_amdgcn_fdot2_f32_bf16(p, one, acc, false);
+        }
+        return acc;
+    }
     static DEVI float fsin_rev(float rev) { return __builtin_amdgcn_sinf(rev); }   // sin(2*pi*rev)
     static DEVI float fcos_rev(float rev) { return __builtin_amdgcn_cosf(rev); }
     static DEVI float fexp(float x) { return __expf(x); }
@@ -132,6 +144,11 @@ struct PolF32 {
     static DEVI unsigned mask_code(unsigned code) { return code; }
     static DEVI unsigned mask_spread(unsigned code) { return code; }
     static DEVI float get(const frag &f, int j) { return f[j]; }
+    static DEVI float sum8(const frag &f, float acc) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += f[j];
+        return acc;
+    }
     static DEVI float fexp(float x) { return expf(x); }
     static constexpr bool FAST_TRIG = false;
 };
@@ -443,6 +460,25 @@ DEVI void dma_1k(const char *src, char *dst) {
     void *us = reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo);
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(us, 0, 1 << 20, 0x00020000);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)dst, 16, (int)(threadIdx.x & 63) * 16, 0, 0, STREAM ? 2 : 0);
+}
+
+// The same copy as inline asm, for kernels that read the DMA'd LDS image with ds_read_b64_tr_b16 (dW kernel): the
+// transposed-read builtin carries no memory operand, so the compiler's waitcnt pass makes it wait for EVERY LDS-DMA
+// it knows to be in flight -- s_waitcnt vmcnt(0) in front of the first read of each group, i.e. no prefetch at all
+// (measured: dW kernel 5.3 -> 7.5 ms).  Issued from inline asm the DMA is invisible to that pass; its completion is
+// ordered by the kernel's own counted vmcnt waits + barrier, exactly as for the builtin form.  M0 = LDS byte address
+// of the wave's first lane (the compiler never keeps M0 live: it is not an allocatable register).
+template <bool STREAM = false>
+DEVI void dma_1k_asm(const char *src, char *dst) {
+    const unsigned long long u = reinterpret_cast<unsigned long long>(src);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    const u32x4 rs = {lo, hi & 0xffffu, 1u << 20, 0x00020000u};
+    const unsigned m = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char *)dst);
+    const unsigned voff = (threadIdx.x & 63) * 16;
+    if constexpr (STREAM)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen nt lds" ::"s"(m), "v"(voff), "s"(rs) : "memory");
+    else
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(m), "v"(voff), "s"(rs) : "memory");
 }
 
 template <int CHUNK_BYTES, int NWAVES>

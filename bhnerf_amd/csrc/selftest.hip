@@ -3,6 +3,7 @@
 //   [2] accumulator -> next B operand chaining (phi16 order), bf16     [3] same, f32
 //   [4] ds_read_b64_tr_b16 as a [k][n] -> B-operand transposed read
 //   [5]/[6] buffer_load_dwordx4 ... lds (LDS-DMA, dma_1k) lane placement, destinations below / above 64 KiB
+//   [7] bf16 tape tile image (point on the lane) -> K = point fragments by ds_read_b64_tr_b16 (dW kernel)
 #include "fused_common.h"
 
 DEVI int ia(int i, int k) { return ((i * 3 + k * 5) % 7) - 3; }   // asymmetric integer operands
@@ -92,6 +93,32 @@ __global__ void selftest_kernel(int *res, short *dump) {
             }
         }
         atomicAdd(res + 4, bad);
+    }
+    // ---- [7] bf16 tape tile: point-on-lane image (fused_bwd.hip TapeEmit::store_native offsets) read back with the
+    //          transposed reads of the dW kernel (same address math as tr_frag): lane (n, kh), k-step s, element j
+    //          must be X[feature n][point 16 s + phi16(kh, j)]
+    {
+        __syncthreads();
+        char *tile = reinterpret_cast<char *>(img);                        // 2 KiB of the 4 KiB image
+        auto X = [](int f, int p) { return (short)(1 + f * 37 + p); };
+        const int pt = lane & 31;
+        for (int s = 0; s < 2; ++s) {
+            short v[8];
+            for (int j = 0; j < 8; ++j) v[j] = X(16 * s + phi16(h, j), pt);
+            const int off = 16 * (pt & 3) + 128 * s + 64 * h + 256 * (pt >> 2);
+            for (int j = 0; j < 8; ++j) reinterpret_cast<short *>(tile + off)[j] = v[j];
+        }
+        __syncthreads();
+        const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+        const int trl = 256 * (g >> 1) + 16 * q + 128 * (g & 1) + 64 * (pp & 1) + 8 * (pp >> 1);
+        bad = 0;
+        for (int s = 0; s < 2; ++s)
+            for (int rd = 0; rd < 2; ++rd) {
+                const char *addr = tile + 1024 * s + 512 * rd + trl;
+                s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)addr);
+                for (int e = 0; e < 4; ++e) bad += (v[e] != X(r31, 16 * s + phi16(h, 4 * rd + e)));
+            }
+        atomicAdd(res + 7, bad);
     }
 }
 
