@@ -1,24 +1,32 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: train ray-samples/sec of the image-plane recovery step.
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 without a torch.distributed environment: this process only spawns `python -m torch.distributed.run
+--nproc-per-node N bench.py ...` (before it touches a GPU itself) and relays rank 0's JSON line; launched by
+torch.distributed.run (the driver's form) the ranks run directly.  Either way WORLD_SIZE must equal --gpus.
 
 Workload (BASELINE.json configs[1], "Tutorial3 image-plane recovery"): 128x128 rays x 64 samples per
 ray, 64 frames, 4x256 MLP, bf16 MFMA, 8 frames per GPU per step (weak scaling: the frame batch is
 8*N, the reference's own time-frame data parallelism), loss 'full', Adam with linear decay.
-One step = TemporalBatchedArgs.sample -> pack weights -> fused render -> chi^2 -> fused backward
-(chain + dW GEMM + slab reduce) -> RCCL all-reduce of the flat gradient (N>1) -> Adam.
+One step = TemporalBatchedArgs.sample -> pack weights -> training forward (records the tape) -> chi^2 -> delta chain ->
+dW GEMM -> slab reduce -> RCCL all-reduce of the flat gradient (N>1) -> Adam.
 Inputs are synthetic geodesic arrays resident in HBM before the timed region; the
 "all-active" variant (rmin=0, rmax=inf, z_width=inf, nothing pre-injection) is used so that every
 ray-sample goes through the full MLP (evaluated points == total points).
 
-Prints ONE JSON line on rank 0 (see the contract in the task description); `roofline` refers to the
-kernel with the largest share of the step, timed live with HIP events on the launch stream, and
-`cpu_baseline` is the oracle's PyTorch-CPU restatement timed on the host cores on a bounded sample.
+Prints ONE JSON line on rank 0.  `roofline` refers to the kernel with the largest share of the step, every kernel
+timed live with HIP events on the launch stream (`bhn_render_bwd_tape_timed` records the caller's events between the
+kernels of the backward); `roofline.step_mfma_frac` is the whole step on SURVEY 8(d)'s algorithmic-flop basis;
+`parity_mode` is the same step in the f32 (1e-5 parity) arithmetic; `cpu_baseline` is the oracle's PyTorch-CPU
+restatement timed on the host cores on a bounded sample BEFORE the GPU work starts (best of a thread-count sweep).
 """
 import argparse
+import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -29,6 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}      # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+PROFILE_TAG = 'r2'                                  # profiles/<tag>_pmc_traffic.json etc. (tools/collect_profiles.sh)
 
 
 def mlp_flops(depth, width, F=21):
@@ -53,24 +62,52 @@ def parse():
     ap.add_argument('--depth', type=int, default=4)
     ap.add_argument('--masked', action='store_true', help='use the tutorial domain masks instead of all-active')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-rays', type=int, default=4096, help='rays of one frame in the CPU-baseline sample')
+    ap.add_argument('--no-parity-mode', action='store_true', help='skip the f32 parity-mode block')
+    ap.add_argument('--cpu-rays', type=int, default=2048, help='rays of one frame in the CPU-baseline sample')
+    ap.add_argument('--cpu-seconds', type=float, default=25.0, help='time budget of the CPU-baseline thread sweep')
     return ap.parse_args()
 
 
+def spawn_ranks(args):
+    """`bench.py --gpus N` from a plain shell: start N ranks with torch.distributed.run and relay rank 0's line.
+    Runs before this process has initialised a GPU (device_count() does not) and never replaces itself."""
+    import socket
+    n = args.gpus
+    one_dev = os.environ.get('BHNERF_BENCH_ONE_DEVICE') == '1'
+    ndev = torch.cuda.device_count()
+    if ndev < n and not one_dev:
+        raise SystemExit('bench.py --gpus %d: only %d device(s) visible (BHNERF_BENCH_ONE_DEVICE=1 runs all ranks on '
+                         'cuda:0 over gloo, a testing aid)' % (n, ndev))
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr',
+           '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in res.stdout.splitlines() if l.startswith('{"metric"')]
+    if res.returncode != 0 or not lines:
+        sys.stderr.write(res.stdout)
+        return res.returncode or 1
+    print(lines[-1])
+    return 0
+
+
 def cpu_baseline(args, geo, GM_c3):
-    """The oracle's torch-CPU restatement (5 un-fused GEMMs + autograd + Adam, float32, all host
-    threads: the analogue of the reference's XLA-CPU execution) on a bounded sample of the workload."""
+    """The oracle's torch-CPU restatement (5 un-fused GEMMs + autograd + Adam, float32: the analogue of the reference's
+    XLA-CPU execution) on a bounded sample of the workload.  The points are one flat (rays*samples, features) matrix, so
+    every layer is ONE 2-D GEMM.  Thread counts {8,16,32,64,128,all} are tried (more threads than the GEMMs can feed make
+    the step slower: 256 threads measured 7.7x slower than 8 in round 1); the best is reported with its count."""
     from oracle import oracle_np as onp
     from oracle import oracle_torch as ot
     try:
         ncores = len(os.sched_getaffinity(0))      # cores this process may actually use
     except AttributeError:
         ncores = os.cpu_count() or 1
-    torch.set_num_threads(ncores)
     R = args.image * args.image
     nr = min(args.cpu_rays, R)
     t = lambda v: torch.tensor(np.ascontiguousarray(v), dtype=torch.float32)
-    sub = lambda v: t(v.reshape((-1,) + v.shape[-1:])[:nr].reshape(nr, 1, -1))
+    sub = lambda v: t(v.reshape((-1,) + v.shape[-1:])[:nr])                          # (rays, samples)
     geom = dict(coords=torch.stack([sub(geo['coords'][i]) for i in range(3)]), Omega=sub(geo['Omega']),
                 t_geos=sub(geo['t_geos']), g=sub(geo['g']), dtau=sub(geo['dtau']), Sigma=sub(geo['Sigma']), J=None,
                 t_start_obs=0.0, t_injection=float(geo['t_injection']))
@@ -78,28 +115,108 @@ def cpu_baseline(args, geo, GM_c3):
               net_depth=args.depth)
     rng = np.random.default_rng(1)
     tree = onp.he_uniform_params(rng, args.depth, args.width, 21)
-    ks, bs = ot.tree_to_lists(tree, torch.float32)
-    tr = ot.CpuTrainer(ks, bs, geom, hp, num_iters=1000)
     tf = torch.tensor([0.3], dtype=torch.float32)
-    target = torch.zeros((1, nr, 1)); sigma = torch.ones((1, nr, 1))
-    tr.step(tf, target, sigma, target, 1.0, 'full')                      # warm-up
-    times = []
-    for _ in range(3):
-        t0 = time.perf_counter()
-        tr.step(tf, target, sigma, target, 1.0, 'full')
-        times.append(time.perf_counter() - t0)
-    dt = float(np.median(times))
-    return {'value': nr * args.ngeo / dt, 'unit': 'ray-samples/s', 'cores': ncores, 'kind': 'port',
-            'sample': '1 frame x %d rays x %d samples, 4x%d MLP, float32 torch-CPU fwd+bwd+Adam, median of 3 steps (%.2f s/step)'
-                      % (nr, args.ngeo, args.width, dt)}
+    target = torch.zeros((1, nr)); sigma = torch.ones((1, nr))
+    default_threads = torch.get_num_threads()
+    sweep, t_start = {}, time.perf_counter()
+    for nthr in sorted({n for n in (8, 16, 32, 64, 128, ncores) if n <= ncores} or {ncores}):
+        if sweep and time.perf_counter() - t_start > args.cpu_seconds:
+            break
+        torch.set_num_threads(nthr)
+        ks, bs = ot.tree_to_lists(tree, torch.float32)
+        tr = ot.CpuTrainer(ks, bs, geom, hp, num_iters=1000)
+        tr.step(tf, target, sigma, target, 1.0, 'full')                      # warm-up
+        times = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            tr.step(tf, target, sigma, target, 1.0, 'full')
+            times.append(time.perf_counter() - t0)
+        sweep[nthr] = min(times)
+    torch.set_num_threads(default_threads)
+    best = min(sweep, key=sweep.get)
+    dt = sweep[best]
+    return {'value': nr * args.ngeo / dt, 'unit': 'ray-samples/s', 'cores': best, 'host_cores': ncores, 'kind': 'port',
+            'threads_sweep_s_per_step': {str(k): round(v, 4) for k, v in sweep.items()},
+            'sample': '1 frame x %d rays x %d samples as one (%d, features) matrix, 4x%d MLP, float32 torch-CPU fwd+bwd+Adam, '
+                      'best of 2 steps at the best of the thread counts tried (%.3f s/step at %d threads)'
+                      % (nr, args.ngeo, nr * args.ngeo, args.width, dt, best)}
+
+
+class HipEvents:
+    """Raw HIP events (ctypes on the runtime the process already has loaded) for bhn_render_bwd_tape_timed."""
+
+    def __init__(self, n):
+        self.hip = C.CDLL('libamdhip64.so')
+        self.ev = (C.c_void_p * n)()
+        for i in range(n):
+            e = C.c_void_p()
+            assert self.hip.hipEventCreate(C.byref(e)) == 0
+            self.ev[i] = e
+
+    def elapsed(self, i, j):
+        ms = C.c_float()
+        assert self.hip.hipEventElapsedTime(C.byref(ms), C.c_void_p(self.ev[i]), C.c_void_p(self.ev[j])) == 0
+        return float(ms.value)
+
+
+def kernel_times(eng, geom, tM0, dimg, reps=5):
+    """Per-kernel ms of one rank's step share, HIP events on the launch stream: training forward (torch events around
+    the one-kernel call), and the kernels of the tape backward (events recorded by the library between them)."""
+    from bhnerf_amd import _hip
+    lib = _hip.lib()
+    nk = 3
+    names = [lib.bhn_render_bwd_tape_kernel_name(i).decode() for i in range(nk)]
+    B = int(tM0.numel())
+    taped = eng.fits_tape(B, geom.P_eff)
+    group = B if taped else eng.tape_group(B, geom.P_eff)
+    assert group, 'the tape of one frame does not fit the workspace'
+    slices = [slice(b0, min(b0 + group, B)) for b0 in range(0, B, group)]
+    ws = eng.workspace(group, geom.P_eff)
+    out = torch.empty((eng.nparams,), dtype=torch.float32, device=eng.device)
+    acc = {'chain_kernel<MODE_FWD_TRAIN>': 0.0, **{n: 0.0 for n in names}}
+    sets = [HipEvents(nk + 1) for _ in range(reps * len(slices))]
+    fwd_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps * len(slices))]
+    gs = geom.c_struct_fused()
+    for rep in range(-1, reps):                       # rep -1: warm-up
+        for si, sl in enumerate(slices):
+            k = max(rep, 0) * len(slices) + si
+            a, b = fwd_ev[k]
+            a.record(); eng.render_train(geom, tM0[sl]); b.record()
+            fs = eng._frames(tM0[sl])
+            d = dimg[sl].contiguous()
+            _hip.check(lib.bhn_render_bwd_tape_timed(C.byref(eng.model), eng.mode, _hip.ptr(eng.packed), C.byref(gs), C.byref(fs),
+                                                     _hip.ptr(d), _hip.ptr(out), _hip.ptr(ws), ws.numel(),
+                                                     _hip.stream_ptr(eng.device), sets[k].ev, nk + 1))
+        torch.cuda.synchronize()
+    for k in range(reps * len(slices)):
+        a, b = fwd_ev[k]
+        acc['chain_kernel<MODE_FWD_TRAIN>'] += a.elapsed_time(b) / reps
+        for i, n in enumerate(names):
+            acc[n] += sets[k].elapsed(i, i + 1) / reps
+    return acc, group
 
 
 def main():
     args = parse()
     args.fov = 16.0
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit('bench.py --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node equal to --gpus' % (args.gpus, world))
+
+    from bhnerf_amd import constants, synthetic
+    H = W = args.image
+    G, nt = args.ngeo, args.frames
+    geo = synthetic.synthetic_geodesics(H, W, G, fov_M=args.fov, inc_deg=60.0, seed=0)
+    GM_c3 = constants.GM_c3('hr')
+    # ---- CPU leg first: the host cores are idle (nothing has touched the GPU yet), bounded by --cpu-seconds -------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args, geo, GM_c3)
+
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device (no CPU fallback)')
     # BHNERF_BENCH_ONE_DEVICE=1 (testing aid on a 1-GPU box): every rank uses cuda:0 and the gloo backend, so the
@@ -117,45 +234,37 @@ def main():
             dist.init_process_group('gloo', rank=rank, world_size=world)
         else:
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        assert dist.get_world_size() == args.gpus
 
-    from bhnerf_amd import _hip, constants, engine, network, optimization, synthetic, units
-    H = W = args.image
-    G, nt = args.ngeo, args.frames
-    geo = synthetic.synthetic_geodesics(H, W, G, fov_M=args.fov, inc_deg=60.0, seed=0)
-    GM_c3 = constants.GM_c3('hr')
+    from bhnerf_amd import engine, network, optimization, units
     t_frames = np.linspace(0.0, 1.0, nt)
     rmax = args.fov / 2
-    if args.masked:
-        pred = network.NeRF_Predictor(rmax, 6.0 * 0 + 2.0, rmax, 4.0, net_depth=args.depth, net_width=args.width,
-                                      mode=args.mode, device=dev)
-    else:
-        pred = network.NeRF_Predictor(rmax, 0.0, np.inf, np.inf, net_depth=args.depth, net_width=args.width,
-                                      mode=args.mode, device=dev)
+    dom = (rmax, 2.0, rmax, 4.0) if args.masked else (rmax, 0.0, np.inf, np.inf)
+    pred = network.NeRF_Predictor(*dom, net_depth=args.depth, net_width=args.width, mode=args.mode, device=dev)
     rt_args = network.raytracing_args(
         dict(x=geo['coords'][0], y=geo['coords'][1], z=geo['coords'][2], dtau=geo['dtau'], Sigma=geo['Sigma'],
              t=geo['t_geos'], g=geo['g']), geo['Omega'], geo['t_injection'], 0.0 * units.hr, J=1.0)
     target = synthetic.hotspot_movie(geo, t_frames[::max(1, nt // 8)], GM_c3)     # a few distinct frames,
     target = np.ascontiguousarray(np.resize(target, (nt, H, W)))                   # tiled over the movie
     train_step = optimization.TrainStep.image(t_frames * units.hr, target, sigma=1.0, dtype='full')
-    opt = optimization.Optimizer({'num_iters': 5000, 'lr_init': 1e-4, 'lr_final': 1e-6, 'seed': 1}, pred, rt_args)
+    hparams = {'num_iters': 5000, 'lr_init': 1e-4, 'lr_final': 1e-6, 'seed': 1}
+    opt = optimization.Optimizer(hparams, pred, rt_args)
     batch = args.frames_per_gpu * world
     assert batch <= nt, 'frames per step exceed the movie length'
 
-    def one_step():
-        idx = train_step.args[0].sample(batch)
-        opt.loss, opt.state, _ = train_step(opt.state, rt_args, indices=idx)
+    def run_steps(o, n):
+        for _ in range(n):
+            o.loss, o.state, _ = train_step(o.state, rt_args, indices=train_step.args[0].sample(batch))
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        one_step()
+    run_steps(opt, args.warmup)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
+    run_steps(opt, args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -183,35 +292,13 @@ def main():
         torch.cuda.synchronize()
         return float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
-    lib = _hip.lib()
-    taped = eng.fits_tape(args.frames_per_gpu, geom.P_eff)
-    group = args.frames_per_gpu if taped else eng.tape_group(args.frames_per_gpu, geom.P_eff)
-    if group:      # the kernels a training step runs: training forward (records the tape), delta chain, dW GEMM --
-                   # over all frames at once, or frame group by frame group when the tape of all frames does not fit
-        slices = [slice(b0, min(b0 + group, args.frames_per_gpu)) for b0 in range(0, args.frames_per_gpu, group)]
-        def fwd_all():
-            for sl in slices:
-                eng.render_train(geom, tM0[sl])
-        def bwd():
-            for sl in slices:
-                eng.render_bwd_tape(geom, tM0[sl], dimg[sl])
-        kern_ms = {'chain_kernel<MODE_FWD_TRAIN>': timed(fwd_all)}
-        names = (('chain_kernel<MODE_CHAIN>', 1), ('dw_kernel', 2), ('reduce_kernel', 4))
-        fwd_name, chain_name = 'chain_kernel<MODE_FWD_TRAIN>', 'chain_kernel<MODE_CHAIN>'
-    else:
-        kern_ms = {'fused_fwd_kernel': timed(lambda: eng.render(geom, tM0))}
-        bwd = lambda: eng.render_bwd(geom, tM0, dimg)
-        names = (('chain_kernel<FWD_TRAIN+CHAIN> (bhn_render_bwd)', 1), ('dw_kernel', 2), ('reduce_kernel', 4))
-        fwd_name, chain_name = 'fused_fwd_kernel', 'chain_kernel<FWD_TRAIN+CHAIN> (bhn_render_bwd)'
-    for name, mask in names:
-        lib.bhn_debug_set_bwd_stages(mask)
-        kern_ms[name] = timed(bwd)
-    lib.bhn_debug_set_bwd_stages(7)
+    kern_ms, group = kernel_times(eng, geom, tM0, dimg)
+    fwd_name, chain_name = 'chain_kernel<MODE_FWD_TRAIN>', 'chain_kernel<MODE_CHAIN>'
     kern_ms['fused_fwd_kernel (inference)'] = timed(lambda: eng.render(geom, tM0))
     pts = args.frames_per_gpu * geom.P * geom.visited_fraction     # points that go through the MLP
     f_fwd, f_chain, f_dw, f_train = mlp_flops(args.depth, args.width)
-    alg = {fwd_name: f_fwd, chain_name: f_chain + (0 if group else f_fwd), 'dw_kernel': f_dw}
-    dom = max(alg, key=lambda k: kern_ms[k])
+    alg = {fwd_name: f_fwd, chain_name: f_chain, 'dw_kernel': f_dw}
+    dom_k = max(alg, key=lambda k: kern_ms[k])
     # tape bytes per point the dW stream reads once: per 32-point group and layer job the gA tiles (dout for
     # the output layer) + the input tiles (encoded inputs for layer 0, for a skip layer in addition, and -- bf16 -- INSTEAD
     # of h_1 for layer 1, which that job recomputes)
@@ -228,32 +315,61 @@ def main():
         if rides and l == args.depth - 1:
             tiles += 1.5                                                   # dout tile + the 1 KiB piece with the f32 dout
     tape_bpp = tiles * (32 * 32 * elem) / 32.0
+    std = H == 128 and G == 64 and args.frames_per_gpu == 8 and args.width == 256 and args.depth == 4 and args.mode == 'bf16' and not args.masked
     try:      # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (profiles/)
-        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r1_pmc_traffic.json')))['kernels']
-        std = H == 128 and G == 64 and args.frames_per_gpu == 8 and args.width == 256 and args.mode == 'bf16' and not args.masked
-        traffic = pmc.get(dom, {}).get('hbm_bytes') if std else None
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', PROFILE_TAG + '_pmc_traffic.json')))['kernels']
+        traffic = pmc.get(dom_k, {}).get('hbm_bytes') if std else None
     except Exception:
         traffic = None
-    if dom == 'dw_kernel':      # a stream over the tape: HBM-bound (its MFMA work is 0.24 of peak, not the limiter)
-        gbs = tape_bpp * pts / (kern_ms[dom] * 1e-3) / 1e9
-        roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': round(gbs, 1), 'peak': 8000.0, 'unit': 'GB/s',
+    if dom_k == 'dw_kernel':      # a stream over the tape: HBM-bound
+        gbs = tape_bpp * pts / (kern_ms[dom_k] * 1e-3) / 1e9
+        roofline = {'bound': 'hbm', 'kernel': dom_k, 'achieved': round(gbs, 1), 'peak': 8000.0, 'unit': 'GB/s',
                     'frac': round(gbs / 8000.0, 4), 'traffic': traffic}
     else:
-        achieved = alg[dom] * pts / (kern_ms[dom] * 1e-3) / 1e12
-        roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': PEAK_TFLOPS[args.mode],
+        achieved = alg[dom_k] * pts / (kern_ms[dom_k] * 1e-3) / 1e12
+        roofline = {'bound': 'mfma', 'kernel': dom_k, 'achieved': round(achieved, 2), 'peak': PEAK_TFLOPS[args.mode],
                     'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_TFLOPS[args.mode], 4), 'traffic': traffic}
     roofline['kernel_ms'] = {k: round(v, 4) for k, v in kern_ms.items()}
-    try:      # matrix-pipe busy fraction of SIMD cycles from the committed SQ counter passes (profiles/r1_sq_summary.json)
-        sq = json.load(open(os.path.join(ROOT, 'profiles', 'r1_sq_summary.json')))['kernels']
+    roofline['kernel_ms_sum'] = round(sum(v for k, v in kern_ms.items() if 'inference' not in k), 4)
+    try:      # matrix-pipe busy fraction of SIMD cycles from the committed SQ counter passes
+        sq = json.load(open(os.path.join(ROOT, 'profiles', PROFILE_TAG + '_sq_summary.json')))['kernels']
         if std:
-            tag = {', 1>': 'chain_kernel<MODE_FWD_TRAIN>', ', 2>': 'chain_kernel<MODE_CHAIN>', 'dw_kernel': 'dw_kernel',
-                   'fused_fwd_kernel': 'fused_fwd_kernel (inference)'}
+            tag = {', 1>': fwd_name, ', 2>': chain_name, 'dw_kernel': 'dw_kernel', 'fused_fwd_kernel': 'fused_fwd_kernel (inference)'}
             roofline['mfma_busy_frac_pmc'] = {n: v['mfma_busy_frac'] for k, v in sq.items() for t, n in tag.items() if t in k}
     except Exception:
         pass
     roofline['mfma_tflops'] = {k: round(alg[k] * pts / (kern_ms[k] * 1e-3) / 1e12, 1) for k in alg}
     roofline['mfma_tflops']['fused_fwd_kernel (inference)'] = round(f_fwd * pts / (kern_ms['fused_fwd_kernel (inference)'] * 1e-3) / 1e12, 1)
-    roofline['step_algorithmic_tflops'] = round(f_train * value * geom.visited_fraction / 1e12 / world, 2)
+    roofline['mfma_frac'] = {k: round(v / PEAK_TFLOPS[args.mode], 4) for k, v in roofline['mfma_tflops'].items()}
+    step_tflops = f_train * value * geom.visited_fraction / 1e12 / world
+    roofline['step_algorithmic_tflops'] = round(step_tflops, 2)
+    roofline['step_mfma_frac'] = round(step_tflops / PEAK_TFLOPS[args.mode], 4)      # 1,234,944 flop/point at 4x256
+
+    # ---- the same step in the f32 parity arithmetic (the mode that meets north_star's 1e-5), single GPU ----------
+    parity = None
+    if world == 1 and args.mode == 'bf16' and not args.no_parity_mode and not args.masked:
+        pred_p = network.NeRF_Predictor(*dom, net_depth=args.depth, net_width=args.width, mode='f32', device=dev)
+        opt_p = optimization.Optimizer(hparams, pred_p, rt_args)
+        run_steps(opt_p, 1)
+        torch.cuda.synchronize()
+        n_p = max(2, min(args.steps, 3))
+        t0 = time.perf_counter()
+        run_steps(opt_p, n_p)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n_p
+        eng_p = pred_p.engine()
+        geom_p = pred_p.geometry(rt_args['coords'], rt_args['Omega'], rt_args['t_geos'], None, rt_args['g'], rt_args['dtau'], rt_args['Sigma'])
+        eng_p.pack(opt_p.state.flat)
+        kms, grp = kernel_times(eng_p, geom_p, tM0, dimg, reps=2)
+        tf32 = f_train * samples_step / dt / 1e12
+        parity = {'dtype': 'f32', 'ms_per_step': round(1e3 * dt, 3), 'value': round(samples_step / dt, 1), 'unit': 'ray-samples/s',
+                  'steps': n_p, 'step_algorithmic_tflops': round(tf32, 2), 'step_mfma_frac': round(tf32 / PEAK_TFLOPS['f32'], 4),
+                  'peak_tflops': PEAK_TFLOPS['f32'], 'tape_frame_group': grp,
+                  'kernel_ms': {k: round(v, 3) for k, v in kms.items()},
+                  'mfma_frac': {k: round(alg[k] * pts / (kms[k] * 1e-3) / 1e12 / PEAK_TFLOPS['f32'], 4) for k in alg},
+                  'loss': float(torch.as_tensor(opt_p.loss).float().mean())}
+        del opt_p, pred_p, eng_p, geom_p
+        torch.cuda.empty_cache()
 
     # ---- stand-alone radiative-transfer scan (kgeo.radiative_trasfer, HBM-bound): achieved GB/s ---------
     # measured at the size SURVEY 8d quotes (config 3: 256x256 rays x 128 samples, B*S = 8*3 planes, ~1 GB)
@@ -274,15 +390,11 @@ def main():
     tutorial_domain = None
     if world == 1 and not args.masked:
         pred_m = network.NeRF_Predictor(rmax, 2.0, rmax, 4.0, net_depth=args.depth, net_width=args.width, mode=args.mode, device=dev)
-        opt_m = optimization.Optimizer({'num_iters': 5000, 'lr_init': 1e-4, 'lr_final': 1e-6, 'seed': 1}, pred_m, rt_args)
-        def step_m():
-            opt_m.loss, opt_m.state, _ = train_step(opt_m.state, rt_args, indices=train_step.args[0].sample(batch))
-        for _ in range(max(args.warmup, 2)):
-            step_m()
+        opt_m = optimization.Optimizer(hparams, pred_m, rt_args)
+        run_steps(opt_m, max(args.warmup, 2))
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step_m()
+        run_steps(opt_m, args.steps)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / args.steps
         gm = pred_m.geometry(rt_args['coords'], rt_args['Omega'], rt_args['t_geos'], None, rt_args['g'], rt_args['dtau'], rt_args['Sigma'])
@@ -305,10 +417,12 @@ def main():
         'rt_scan': rt_scan,
         'fwd_images_per_s': round(args.frames_per_gpu / (kern_ms['fused_fwd_kernel (inference)'] * 1e-3), 1),
     }
+    if parity:
+        out['parity_mode'] = parity
     if tutorial_domain:
         out['tutorial_domain'] = tutorial_domain
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline(args, geo, GM_c3)
+    if cpu:
+        out['cpu_baseline'] = cpu
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

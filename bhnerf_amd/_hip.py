@@ -13,7 +13,13 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
-LIB_PATH = os.path.join(CSRC, 'libbhnerf_hip.so')
+# BHNERF_HIP_LIB: an alternative build of the library, e.g. the debug build (make debug) for the tools/ scripts
+LIB_PATH = os.environ.get('BHNERF_HIP_LIB') or os.path.join(CSRC, 'libbhnerf_hip.so')
+DEBUG_SIGNATURES = {        # include/bhnerf_hip_debug.h: only libbhnerf_hip_dbg.so exports these
+    'bhn_debug_set_bwd_stages': (C.c_int, [C.c_int32]),
+    'bhn_debug_set_fwd_variant': (C.c_int, [C.c_int32]),
+    'bhn_debug_read': (C.c_int, [C.c_void_p, C.c_size_t]),
+}
 
 BHN_F32, BHN_BF16 = 0, 1
 MODES = {'f32': BHN_F32, 'fp32': BHN_F32, 'float32': BHN_F32, 'bf16': BHN_BF16, 'bfloat16': BHN_BF16}
@@ -61,6 +67,7 @@ SIGNATURES = {
     'bhn_render_fwd_train': (C.c_int, [_MP, _I32, _P, _GP, _FP, _P, _P, _SZ, _P]),
     'bhn_render_bwd_tape': (C.c_int, [_MP, _I32, _P, _GP, _FP, _P, _P, _P, _SZ, _P]),
     'bhn_chi2_image': (C.c_int, [_P, _P, _P, _P, _F, _I32, _I32, _I32, _I64, _P, _P, _P]),
+    'bhn_chi2_eht_ws_floats': (_SZ, [_I32, _I32, _I32, _I64]),
     'bhn_chi2_eht': (C.c_int, [_P, _P, _P, _P, _F, _I32, _I32, _I32, _I32, _I64, _P, _P, _P, _P]),
     'bhn_voxel_render_fwd': (C.c_int, [_GP, _FP, _P, _I32, _I32, _I32, _I64, C.POINTER(C.c_float), _P, _P]),
     'bhn_trilinear': (C.c_int, [_P, _I64, _P, _I32, _I32, _I32, C.POINTER(C.c_float), _P, _P]),
@@ -68,10 +75,9 @@ SIGNATURES = {
     'bhn_grid_render_fwd': (C.c_int, [_GP, _FP, _P, _I32, _F, _P, _P]),
     'bhn_grid_render_bwd': (C.c_int, [_GP, _FP, _P, _I32, _F, _P, _P, _P]),
     'bhn_adam_step': (C.c_int, [_P, _P, _P, _P, _I64, _I64, _F, _F, _F, _F, _F, _P]),
-    'bhn_debug_set_bwd_stages': (C.c_int, [_I32]),
-    'bhn_debug_set_fwd_variant': (C.c_int, [_I32]),
-    'bhn_debug_read': (C.c_int, [_P, C.c_size_t]),
-    'bhn_selftest': (C.c_int, [C.POINTER(_I32)]),
+    'bhn_render_bwd_tape_timed': (C.c_int, [_MP, _I32, _P, _GP, _FP, _P, _P, _P, _SZ, _P, C.POINTER(C.c_void_p), _I32]),
+    'bhn_render_bwd_tape_kernel_name': (C.c_char_p, [_I32]),
+    'bhn_selftest': (C.c_int, [C.POINTER(_I32), _P, _SZ]),
 }
 
 _lib = None
@@ -102,6 +108,10 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)
             fn.restype, fn.argtypes = res, args
+        for name, (res, args) in DEBUG_SIGNATURES.items():
+            if hasattr(handle, name):
+                fn = getattr(handle, name)
+                fn.restype, fn.argtypes = res, args
         _lib = handle
     return _lib
 
@@ -143,5 +153,6 @@ def make_model(net_depth, net_width, posenc_deg, do_skip, scale, rmin, rmax, z_w
 
 def selftest():
     res = (C.c_int32 * 8)()
-    check(lib().bhn_selftest(res))
+    scratch = torch.zeros((16384,), dtype=torch.uint8, device='cuda')
+    check(lib().bhn_selftest(res, ptr(scratch), scratch.numel()))
     return list(res), lib().bhn_last_error().decode()

@@ -2,10 +2,15 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 #include <stdio.h>
 #include <string.h>
 
 #include "../../include/bhnerf_hip.h"
+#ifdef BHN_DEBUG
+#include <stdlib.h>
+#include "../../include/bhnerf_hip_debug.h"
+#endif
 
 #define BHN_MAX_LAYERS 9   // net_depth <= 8 hidden layers + the output layer
 #define BHN_ENC_PAD 32     // encoded input (3 + 6*deg <= 27) padded to one 32-feature block
@@ -58,3 +63,18 @@ int bhn_mlp_shape(const bhn_model *m, MlpShape *s);   // validates, returns BHN_
 
 // Number of compute units of a device (cached).
 int bhn_num_cus(int device);
+
+// Per-device one-time setup of a kernel (hipFuncSetAttribute applies to the device that is current when it is
+// called; a process may drive several devices, from several threads): run `f` once per device, remember its result.
+#define BHN_MAX_DEVICES 64
+struct DeviceOnce {
+    std::once_flag flag[BHN_MAX_DEVICES];
+    hipError_t rc[BHN_MAX_DEVICES];
+    int value[BHN_MAX_DEVICES];
+    template <class F>
+    hipError_t run(int dev, F &&f) {
+        if (dev < 0 || dev >= BHN_MAX_DEVICES) return hipErrorInvalidDevice;
+        std::call_once(flag[dev], [&] { rc[dev] = f(value[dev]); });
+        return rc[dev];
+    }
+};

@@ -23,6 +23,12 @@
 #ifndef BHN_JOBL_W
 #define BHN_JOBL_W 6           // extra weight (in tiles at width 256, scaled with the width) of the layer depth-1 dW job when it rebuilds gA_{depth-1} and carries the output row
 #endif
+// Run-time measurement switches exist only in the debug build (make debug); the release kernels see the constant 0
+#ifdef BHN_DEBUG
+#define BHN_DBG(x) (x)
+#else
+#define BHN_DBG(x) 0
+#endif
 #ifndef BHN_TAPED_DIST
 #define BHN_TAPED_DIST 6         // weight chunks in flight in the training-forward / delta-chain kernels (bf16; 4 measured 2 % slower)
 #endif
@@ -284,7 +290,9 @@ struct TapePost {
     }
 };
 
+#ifdef BHN_DEBUG
 void *bhn_debug_buffer();
+#endif
 // ---------------------------------------------------------------------------------------------
 // chain kernel
 // ---------------------------------------------------------------------------------------------
@@ -307,7 +315,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
     constexpr int MW = (MT + 1) / 2;                                   // mask words per layer per lane
     constexpr int TB = BG::TILE_BYTES;
     const FusedArgs &a = A.f;
-    const int edbg = (A.debug >> 6) & 3;           // measurement aid for the tape emission
+    const int edbg = BHN_DBG((A.debug >> 6) & 3);  // measurement aid for the tape emission
     constexpr int sdbg = 0;                        // (a run-time MFMA-skip flag put every MFMA in its own basic block)
     using RG = DmaRing<CB, Pol::NWAVES>;
     constexpr int DIST = BG::RING_DIST_TAPED;
@@ -837,20 +845,20 @@ DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
                 }
                 int it = 0;
                 for (long long q = q0; q < q1; ++q) {
-                    if (!(A.debug & 2)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT * PPW) : "memory");
+                    if (!BHN_DBG(A.debug & 2)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT * PPW) : "memory");
                     if constexpr (make_h) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's h-tile writes
                     __builtin_amdgcn_s_barrier();
                     asm volatile("" ::: "memory");      // the raw barrier is not a compiler fence: keep the
                                                          // DMA issue and the ds_reads below it
                     const int nx = (it == 0) ? NBUF - 1 : it - 1;
-                    if (!(A.debug & 2)) issue(q + NBUF - 1, smem + nx * GB);
+                    if (!BHN_DBG(A.debug & 2)) issue(q + NBUF - 1, smem + nx * GB);
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     char *gnext = smem + ((it == NBUF - 1) ? 0 : it + 1) * GB;
                     // the next group's h tile: LDS reads and the two MFMAs ahead of this group's dW MFMAs, relu / pack /
                     // LDS write behind them (the MFMA result is long done by then: no exposed MFMA -> VALU latency)
                     f32x16 hacc = {};
                     if constexpr (make_h) hacc = make_h_mma(make_h_read(gnext));
-                    if (!(A.debug & 1) && wave_works && has_tiles) compute_group(smem + it * GB);
+                    if (!BHN_DBG(A.debug & 1) && wave_works && has_tiles) compute_group(smem + it * GB);
                     if constexpr (make_h) {
                         if (q + 1 < q1) make_h_write(gnext, hacc);
                     }
@@ -926,7 +934,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void dw_kernel(BwdArgs A) {
     const int depth = A.f.depth;
     int job = 0;
     while (job < depth && (int)blockIdx.x >= A.wg_begin[job + 1]) ++job;
-    if ((A.debug >> 2) && (A.debug >> 2) - 1 != job) return;
+    if (BHN_DBG(A.debug >> 2) && (A.debug >> 2) - 1 != job) return;
     if (job == depth) dw_body<W, Pol, JT_OUT>(A, job, smem);
     else if (job == 0) dw_body<W, Pol, JT_FIRST>(A, job, smem);
     else if (job == depth - 1 && A.t.drop_ga) {
@@ -988,15 +996,20 @@ int fused_fill_args(const bhn_model *m, int32_t mode, const void *packed, const 
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// measurement aid: bit 0 chain kernel, bit 1 dW kernel, bit 2 reduce kernel (default all)
+#ifndef BHN_DEBUG
+static constexpr int g_bwd_stages = 7, g_bwd_debug = 0;
+#else
+// measurement build only: bit 0 chain kernel, bit 1 dW kernel, bit 2 reduce kernel (default all)
 static thread_local int g_bwd_stages = 7;
 static thread_local int g_bwd_debug = 0;
+static int dbg_env_int(const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; }
 extern "C" int bhn_debug_set_bwd_stages(int32_t mask) {
     g_bwd_stages = mask & 7;
     g_bwd_debug = (mask >> 3) & 0xFFF;    // bit 12: ring-step time stamps of one tile (tools/dbg_chain_steps.py); bit 3: dW kernel without MFMA work, bit 4: without tape loads,
                                          // bits 5-8: run only dW job (value-1); bit 9: emit without global stores; bit 10: no emit
     return BHN_OK;
 }
+#endif
 
 template <int W, class Pol>
 static void tape_layout(int depth, bool layer1_takes_enc, long long NQ, TapeLayout *t) {
@@ -1036,11 +1049,16 @@ template <int W, class Pol>
 static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packed, const bhn_geom *geom,
                    const bhn_frames *fr, const float *dimages, float *images, float *dparams, void *workspace,
                    size_t workspace_bytes, hipStream_t st, size_t *query_bytes, int query_B, long long query_P,
-                   int device) {
+                   int device, void *const *events = nullptr, int n_events = 0) {
     using BG = BwdGeom<W, Pol>;
     using PK = Pack<W, Pol>;
     const int ncu = bhn_num_cus(device);
-    static const int grid_override = getenv("BHN_DEBUG_DW_GRID") ? atoi(getenv("BHN_DEBUG_DW_GRID")) : 0;
+#ifdef BHN_DEBUG
+    static const int grid_override = dbg_env_int("BHN_DEBUG_DW_GRID", 0);
+    static const int job1_w = dbg_env_int("BHN_DEBUG_JOB1_W", BHN_JOB1_W), jobl_w = dbg_env_int("BHN_DEBUG_JOBL_W", BHN_JOBL_W);
+#else
+    constexpr int grid_override = 0, job1_w = BHN_JOB1_W, jobl_w = BHN_JOBL_W;
+#endif
     const int grid_dw = grid_override > 0 ? grid_override : ncu;        // one dW workgroup per CU
     const size_t slab_bytes = align_up((size_t)grid_dw * BG::SLAB_FLOATS * 4, 256);
     if (what == RUN_QUERY) {
@@ -1101,10 +1119,10 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
         for (int l = 0; l <= depth; ++l) {
             const int mtA = (l == depth) ? 0 : BG::MT;
             int nB = (l >= 1 ? BG::MT : 0) + ((l == 0 || s.skip_in[l]) ? 1 : 0);
-            if (l == 1 && t1.drop_h1) nB = (getenv("BHN_DEBUG_JOB1_W") ? atoi(getenv("BHN_DEBUG_JOB1_W")) : BHN_JOB1_W) * BG::MT / 8;   // reads only the encoded inputs instead of h_1 but has the
+            if (l == 1 && t1.drop_h1) nB = job1_w * BG::MT / 8;   // reads only the encoded inputs instead of h_1 but has the
                                                                   // same MFMA work + the recompute: not byte-bound any more
             work[l] = (double)(mtA + nB) + 0.5;
-            if (l == depth - 1 && t1.drop_ga) work[l] += (getenv("BHN_DEBUG_JOBL_W") ? atof(getenv("BHN_DEBUG_JOBL_W")) : BHN_JOBL_W) * BG::MT / 8.0;    // + dout pieces, the rebuild of gA and the output row
+            if (l == depth - 1 && t1.drop_ga) work[l] += jobl_w * BG::MT / 8.0;    // + dout pieces, the rebuild of gA and the output row
             if (l > last_job) work[l] = 0;
             tot += work[l];
         }
@@ -1132,13 +1150,14 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
     auto k_fwd = chain_kernel<W, Pol, 3, MODE_FWD_TRAIN>;
     auto k_chn = chain_kernel<W, Pol, 3, MODE_CHAIN>;
     auto kdw = dw_kernel<W, Pol>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        BHN_HIP(hipFuncSetAttribute((const void *)k_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        BHN_HIP(hipFuncSetAttribute((const void *)k_chn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        BHN_HIP(hipFuncSetAttribute((const void *)kdw, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
-    }
+    static DeviceOnce once;                 // per template instantiation and device
+    BHN_HIP(once.run(device, [&](int &) {
+        for (const void *k : {(const void *)k_fwd, (const void *)k_chn, (const void *)kdw}) {
+            const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }));
     BHN_CHECK_ARG(lds_taped <= 160 * 1024 && lds_dw <= 160 * 1024, "LDS budget exceeded (chain %zu, dw %zu)", lds_taped, lds_dw);
     const int B_total = A.f.B;
     const double *tM0 = A.f.tM0;
@@ -1153,7 +1172,9 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
         tape_layout<W, Pol>(depth, l1enc, A.f.total_tiles * Pol::NWAVES, &A.t);
         A.accumulate = pass > 0;
         A.debug = g_bwd_debug;
+#ifdef BHN_DEBUG
         A.ts_buf = (g_bwd_debug & 512) ? reinterpret_cast<long long *>(bhn_debug_buffer()) : nullptr;
+#endif
         long long grid = ncu;
         if (grid > A.f.total_tiles) grid = A.f.total_tiles;
         if (what == RUN_FWD_TRAIN) {
@@ -1161,6 +1182,11 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
             BHN_HIP(hipGetLastError());
             continue;
         }
+        // bhn_render_bwd_tape_timed: event i is recorded behind kernel i - 1 (single-pass calls only)
+        auto mark = [&](int i) -> hipError_t {
+            return (events && i < n_events && events[i] && pass == 0) ? hipEventRecord((hipEvent_t)events[i], st) : hipSuccess;
+        };
+        BHN_HIP(mark(0));
         if (g_bwd_stages & 1) {
             if (what == RUN_RECOMPUTE) {     // forward again (tape only: A.f.images is null), then the chain
                 hipLaunchKernelGGL(k_fwd, dim3((unsigned)grid), dim3(Pol::NTHREADS), lds_taped, st, A);
@@ -1169,23 +1195,26 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
             hipLaunchKernelGGL(k_chn, dim3((unsigned)grid), dim3(Pol::NTHREADS), lds_taped, st, A);
         }
         BHN_HIP(hipGetLastError());
+        BHN_HIP(mark(1));
         if (g_bwd_stages & 2) hipLaunchKernelGGL(kdw, dim3((unsigned)A.wg_begin[depth + 1]), dim3(Pol::NTHREADS), lds_dw, st, A);
         BHN_HIP(hipGetLastError());
+        BHN_HIP(mark(2));
     }
     if (what != RUN_FWD_TRAIN && (g_bwd_stages & 4)) hipLaunchKernelGGL((reduce_kernel<W, Pol>), dim3(256), dim3(256), 0, st, A);
     BHN_HIP(hipGetLastError());
+    if (events && n_events > 3 && events[3]) BHN_HIP(hipEventRecord((hipEvent_t)events[3], st));
     return BHN_OK;
 }
 
 template <class Pol>
 static int bwd_dispatch(int what, int width, const bhn_model *m, int32_t mode, const void *packed, const bhn_geom *geom,
                         const bhn_frames *fr, const float *dimages, float *images, float *dparams, void *ws, size_t wsb,
-                        hipStream_t st, size_t *qb, int qB, long long qP, int device) {
+                        hipStream_t st, size_t *qb, int qB, long long qP, int device, void *const *ev = nullptr, int nev = 0) {
     switch (width) {
-        case 32: return bwd_run<32, Pol>(what, m, mode, packed, geom, fr, dimages, images, dparams, ws, wsb, st, qb, qB, qP, device);
-        case 64: return bwd_run<64, Pol>(what, m, mode, packed, geom, fr, dimages, images, dparams, ws, wsb, st, qb, qB, qP, device);
-        case 128: return bwd_run<128, Pol>(what, m, mode, packed, geom, fr, dimages, images, dparams, ws, wsb, st, qb, qB, qP, device);
-        case 256: return bwd_run<256, Pol>(what, m, mode, packed, geom, fr, dimages, images, dparams, ws, wsb, st, qb, qB, qP, device);
+        case 32: return bwd_run<32, Pol>(what, m, mode, packed, geom, fr, dimages, images, dparams, ws, wsb, st, qb, qB, qP, device, ev, nev);
+        case 64: return bwd_run<64, Pol>(what, m, mode, packed, geom, fr, dimages, images, dparams, ws, wsb, st, qb, qB, qP, device, ev, nev);
+        case 128: return bwd_run<128, Pol>(what, m, mode, packed, geom, fr, dimages, images, dparams, ws, wsb, st, qb, qB, qP, device, ev, nev);
+        case 256: return bwd_run<256, Pol>(what, m, mode, packed, geom, fr, dimages, images, dparams, ws, wsb, st, qb, qB, qP, device, ev, nev);
         default:
             bhn_set_error("net_width %d: fused kernels are built for 32, 64, 128, 256", width);
             return BHN_EUNSUPPORTED;
@@ -1194,16 +1223,16 @@ static int bwd_dispatch(int what, int width, const bhn_model *m, int32_t mode, c
 
 static int bwd_entry(int what, const bhn_model *m, int32_t mode, const void *packed, const bhn_geom *geom,
                      const bhn_frames *fr, const float *dimages, float *images, float *dparams, void *workspace,
-                     size_t workspace_bytes, void *stream) {
+                     size_t workspace_bytes, void *stream, void *const *ev = nullptr, int nev = 0) {
     BHN_CHECK_ARG(m, "null model");
     BHN_CHECK_ARG(mode == BHN_F32 || mode == BHN_BF16, "bad mode %d", mode);
     int dev = 0;
     BHN_HIP(hipGetDevice(&dev));
     return (mode == BHN_BF16)
                ? bwd_dispatch<PolBF16>(what, m->net_width, m, mode, packed, geom, fr, dimages, images, dparams, workspace,
-                                       workspace_bytes, (hipStream_t)stream, nullptr, 0, 0, dev)
+                                       workspace_bytes, (hipStream_t)stream, nullptr, 0, 0, dev, ev, nev)
                : bwd_dispatch<PolF32>(what, m->net_width, m, mode, packed, geom, fr, dimages, images, dparams, workspace,
-                                      workspace_bytes, (hipStream_t)stream, nullptr, 0, 0, dev);
+                                      workspace_bytes, (hipStream_t)stream, nullptr, 0, 0, dev, ev, nev);
 }
 
 extern "C" size_t bhn_render_bwd_workspace_bytes(const bhn_model *m, int32_t mode, int32_t B, int64_t P, int32_t device) {
@@ -1232,4 +1261,17 @@ extern "C" int bhn_render_bwd_tape(const bhn_model *m, int32_t mode, const void 
                                    const bhn_frames *fr, const float *dimages, float *dparams, void *workspace,
                                    size_t workspace_bytes, void *stream) {
     return bwd_entry(RUN_BWD_TAPE, m, mode, packed, geom, fr, dimages, nullptr, dparams, workspace, workspace_bytes, stream);
+}
+
+extern "C" int bhn_render_bwd_tape_timed(const bhn_model *m, int32_t mode, const void *packed, const bhn_geom *geom,
+                                         const bhn_frames *fr, const float *dimages, float *dparams, void *workspace,
+                                         size_t workspace_bytes, void *stream, void *const *events, int32_t n_events) {
+    BHN_CHECK_ARG(events && n_events >= 1 && n_events <= BHN_BWD_TAPE_KERNELS + 1, "events: 1..%d HIP events", BHN_BWD_TAPE_KERNELS + 1);
+    return bwd_entry(RUN_BWD_TAPE, m, mode, packed, geom, fr, dimages, nullptr, dparams, workspace, workspace_bytes, stream,
+                     events, n_events);
+}
+
+extern "C" const char *bhn_render_bwd_tape_kernel_name(int32_t i) {
+    static const char *const names[BHN_BWD_TAPE_KERNELS] = {"chain_kernel<MODE_CHAIN>", "dw_kernel", "reduce_kernel"};
+    return (i >= 0 && i < BHN_BWD_TAPE_KERNELS) ? names[i] : nullptr;
 }

@@ -270,17 +270,18 @@ static int launch_fwd_w(FusedArgs &a, hipStream_t st) {
     using PK = Pack<W, Pol>;
     const size_t lds = (size_t)((Pol::ELEM_BYTES == 2 ? BHN_FWD_DIST : 3) + (Pol::PHASE_LAG ? 2 : 1)) * PK::CHUNK_BYTES + (size_t)(a.depth + 1) * W * 4;
     auto kern = fused_fwd_kernel<W, Pol, 3, RENDER, DBG>;
-    static bool attr_done = false;
-    static int occ = 1;
-    if (!attr_done) {
-        BHN_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        int o = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, kern, Pol::NTHREADS, lds) == hipSuccess && o > 0) occ = o;
-        attr_done = true;
-    }
     int dev = 0;
     BHN_HIP(hipGetDevice(&dev));
-    long long grid = (long long)bhn_num_cus(dev) * occ;
+    static DeviceOnce once;                 // per template instantiation and device: LDS attribute + occupancy
+    BHN_HIP(once.run(dev, [&](int &occ) {
+        occ = 1;
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        int o = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, kern, Pol::NTHREADS, lds) == hipSuccess && o > 0) occ = o;
+        return hipSuccess;
+    }));
+    long long grid = (long long)bhn_num_cus(dev) * once.value[dev];
     if (grid > a.total_tiles) grid = a.total_tiles;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(Pol::NTHREADS), lds, st, a);
     BHN_HIP(hipGetLastError());
@@ -300,8 +301,9 @@ static int launch_fwd(FusedArgs &a, int width, hipStream_t st) {
     }
 }
 
-// measurement aid: low 4 bits 1 = production kernel (default), 3 = ablation build of the 4x256 render kernel with the
-// flags of fused_fwd_kernel<DBG> in bits 4.. .  (Variant 2, a 4 waves x 64 points tile, was 17 % slower and is gone.)
+#ifdef BHN_DEBUG
+// Measurement build only (make debug -> libbhnerf_hip_dbg.so, include/bhnerf_hip_debug.h): low 4 bits 1 = production
+// kernel (default), 3 = ablation build of the 4x256 render kernel with the flags of fused_fwd_kernel<DBG> in bits 4.. .
 static thread_local int g_fwd_variant = 1;
 extern "C" int bhn_debug_set_fwd_variant(int32_t v) {
     g_fwd_variant = v;
@@ -321,6 +323,7 @@ extern "C" int bhn_debug_read(void *dst_host, size_t bytes) {
     BHN_HIP(hipMemcpy(dst_host, g_dbg_buf, bytes, hipMemcpyDeviceToHost));
     return BHN_OK;
 }
+#endif
 
 extern "C" int bhn_predict_fwd(const bhn_model *m, int32_t mode, const void *packed, const bhn_geom *geom,
                                const bhn_frames *fr, float *emission, void *stream) {
@@ -347,6 +350,7 @@ extern "C" int bhn_render_fwd(const bhn_model *m, int32_t mode, const void *pack
     if (rc != BHN_OK) return rc;
     a.images = images;
     BHN_HIP(hipMemsetAsync(images, 0, sizeof(float) * (size_t)a.B * a.Sx * a.R, (hipStream_t)stream));
+#ifdef BHN_DEBUG
     a.debug = (g_fwd_variant >> 4) & 64;                                       // bit 64: no phase lag (A/B measurements)
     if (mode == BHN_BF16 && s.width == 256 && (g_fwd_variant & 15) == 3) {     // ablation build, see fused_fwd_kernel
         a.debug = g_fwd_variant >> 4;                                          // includes bit 64
@@ -354,6 +358,7 @@ extern "C" int bhn_render_fwd(const bhn_model *m, int32_t mode, const void *pack
         BHN_CHECK_ARG(a.emission, "no debug buffer");
         return launch_fwd_w<256, PolBF16, true, true>(a, (hipStream_t)stream);
     }
+#endif
     return mode == BHN_BF16 ? launch_fwd<PolBF16, true>(a, s.width, (hipStream_t)stream)
                             : launch_fwd<PolF32, true>(a, s.width, (hipStream_t)stream);
 }

@@ -145,18 +145,17 @@ __global__ void selftest_dma_kernel(const unsigned *src, int *res) {
     atomicAdd(res + 6, bad_hi);
 }
 
-extern "C" int bhn_selftest(int32_t *results_host) {
+extern "C" int bhn_selftest(int32_t *results_host, void *scratch_dev, size_t scratch_bytes) {
     BHN_CHECK_ARG(results_host, "null results");
-    int *d_res = nullptr;
-    short *d_dump = nullptr;
-    BHN_HIP(hipMalloc(&d_res, 8 * sizeof(int)));
-    BHN_HIP(hipMalloc(&d_dump, 512 * sizeof(short)));
+    BHN_CHECK_ARG(scratch_dev && scratch_bytes >= BHN_SELFTEST_SCRATCH_BYTES, "selftest needs %d bytes of device scratch", BHN_SELFTEST_SCRATCH_BYTES);
+    // caller-owned scratch: [8 int results][512 short dump][8 KiB DMA source]
+    int *d_res = reinterpret_cast<int *>(scratch_dev);
+    short *d_dump = reinterpret_cast<short *>(reinterpret_cast<char *>(scratch_dev) + 64);
+    unsigned *d_src = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(scratch_dev) + 2048);
     BHN_HIP(hipMemset(d_res, 0, 8 * sizeof(int)));
     hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, 0, d_res, d_dump);
     BHN_HIP(hipGetLastError());
     {
-        unsigned *d_src = nullptr;
-        BHN_HIP(hipMalloc(&d_src, 8 * 1024));
         unsigned hsrc[2048];
         for (int i = 0; i < 2048; ++i) hsrc[i] = 0x9E3779B9u * (unsigned)(i + 1);
         BHN_HIP(hipMemcpy(d_src, hsrc, sizeof(hsrc), hipMemcpyHostToDevice));
@@ -164,7 +163,6 @@ extern "C" int bhn_selftest(int32_t *results_host) {
         hipLaunchKernelGGL(selftest_dma_kernel, dim3(1), dim3(512), 104 * 1024, 0, d_src, d_res);
         BHN_HIP(hipGetLastError());
         BHN_HIP(hipDeviceSynchronize());
-        (void)hipFree(d_src);
     }
     BHN_HIP(hipMemcpy(results_host, d_res, 8 * sizeof(int), hipMemcpyDeviceToHost));
     short dump[512];
@@ -175,7 +173,5 @@ extern "C" int bhn_selftest(int32_t *results_host) {
         for (int l = 0; l < 20 && n < 360; ++l) n += snprintf(buf + n, sizeof(buf) - n, "%d:%d,%d,%d,%d ", l, dump[l * 8], dump[l * 8 + 1], dump[l * 8 + 2], dump[l * 8 + 3]);
         bhn_set_error("tr16 read map mismatch; lane:first-read values = %s", buf);
     }
-    (void)hipFree(d_res);
-    (void)hipFree(d_dump);
     return BHN_OK;
 }

@@ -21,15 +21,14 @@ extern "C" int bhn_version(void) { return BHN_ABI_VERSION; }
 extern "C" const char *bhn_last_error(void) { return g_err; }
 
 int bhn_num_cus(int device) {
-    static int cache[64];
-    if (device < 0 || device >= 64) return 256;
-    if (cache[device] == 0) {
-        int n = 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || n <= 0)
-            n = 256;
-        cache[device] = n;
-    }
-    return cache[device];
+    static DeviceOnce once;
+    if (device < 0 || device >= BHN_MAX_DEVICES) return 256;
+    (void)once.run(device, [&](int &n) {
+        n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || n <= 0) n = 256;
+        return hipSuccess;
+    });
+    return once.value[device];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -286,19 +285,28 @@ __global__ __launch_bounds__(256) void chi2_image_kernel(const float *__restrict
             if (dimages) dimages[plane * R + r] = 2.f * scale * d / s;
         }
         const float tot = block_sum_256(acc, red);
-        if (threadIdx.x == 0) atomicAdd(loss, scale * tot);
+        if (threadIdx.x == 0) loss[1 + plane] = scale * tot;
     } else {            // 'lc': light curve = image summed over pixels (network.py:479-480)
         float acc = 0.f;
         for (int64_t r = threadIdx.x; r < R; r += 256) acc += img[r];
         const float lc = block_sum_256(acc, red);
         const float s = sigma[plane];
         const float d = (lc - target[plane] - offset[plane]) / s;
-        if (threadIdx.x == 0) atomicAdd(loss, scale * d * d);
+        if (threadIdx.x == 0) loss[1 + plane] = scale * d * d;
         if (dimages) {
             const float gr = 2.f * scale * d / s;
             for (int64_t r = threadIdx.x; r < R; r += 256) dimages[plane * R + r] = gr;
         }
     }
+}
+
+// loss[0] = sum of the n partial terms loss[1..n] in a fixed order (one block): the logged loss is bitwise reproducible
+__global__ __launch_bounds__(256) void loss_sum_kernel(float *__restrict__ loss, const float *__restrict__ part, int64_t n) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 256) acc += part[i];
+    const float tot = block_sum_256(acc, red);
+    if (threadIdx.x == 0) loss[0] = tot;
 }
 
 extern "C" int bhn_chi2_image(const float *images, const float *target, const float *sigma, const float *offset,
@@ -307,9 +315,10 @@ extern "C" int bhn_chi2_image(const float *images, const float *target, const fl
     BHN_CHECK_ARG(images && target && sigma && offset && loss, "null pointer");
     BHN_CHECK_ARG(dtype == 0 || dtype == 1, "image dtype (%d) not supported", dtype);
     BHN_CHECK_ARG(B > 0 && Sx > 0 && R > 0, "bad sizes");
-    BHN_HIP(hipMemsetAsync(loss, 0, sizeof(float), (hipStream_t)stream));
     hipLaunchKernelGGL(chi2_image_kernel, dim3(B * Sx), dim3(256), 0, (hipStream_t)stream, images, target, sigma,
                        offset, scale, dtype, R, loss, dimages);
+    BHN_HIP(hipGetLastError());
+    hipLaunchKernelGGL(loss_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, loss, loss + 1, (int64_t)B * Sx);
     BHN_HIP(hipGetLastError());
     return BHN_OK;
 }
@@ -348,33 +357,57 @@ extern "C" int bhn_adam_step(float *params, const float *grads, float *m, float 
 // phases (the product over the C axis is the bispectrum, network.py:558).  HBM-bound: A is read once
 // in the forward GEMV and once in the backward; algorithmic bytes 2 * 8*N*C*nvis*R.
 // ------------------------------------------------------------------------------------------
+// Stage 1 of the visibility GEMV: block (row, split) sums its slice of the R axis; `part` is [row][RS].  With few rows
+// (EHT2017: 8 frames x ~28 baselines) one block per row would leave most of the 256 CUs idle on 512 KB dot products, so
+// the R axis is split until the grid has >= ~2048 blocks; stage 2 (eht_loss_kernel) adds the RS partial sums of a row in
+// a fixed order -- no atomics, bitwise reproducible.  16-byte loads (two complex64 per lane).
 __global__ __launch_bounds__(256) void eht_vis_kernel(const float *__restrict__ images, const float2 *__restrict__ A,
-                                                      int C, int nvis, int64_t R, float2 *__restrict__ vis) {
+                                                      int C, int nvis, int64_t R, int RS, float2 *__restrict__ part) {
     __shared__ float red[4];
     const int64_t row = blockIdx.x;                         // (n, c, k)
     const int64_t n = row / ((int64_t)C * nvis);
+    const int64_t span = ((R + RS - 1) / RS + 1) & ~(int64_t)1;          // even: slices start on 16-byte boundaries when R is even
+    const int64_t r0 = blockIdx.y * span, r1 = r0 + span < R ? r0 + span : R;
     const float2 *a = A + row * R;
     const float *img = images + n * R;
     float re = 0.f, im = 0.f;
-    for (int64_t r = threadIdx.x; r < R; r += 256) {
-        const float2 v = a[r];
-        const float x = img[r];
-        re += v.x * x;
-        im += v.y * x;
+    if ((R & 1) == 0) {
+        for (int64_t r = r0 + 2 * threadIdx.x; r < r1; r += 512) {      // r0, r1, R even: (r, r + 1) is a whole pair
+            const float4 v = *reinterpret_cast<const float4 *>(a + r);       // (re0, im0, re1, im1)
+            const float2 x = *reinterpret_cast<const float2 *>(img + r);
+            re += v.x * x.x + v.z * x.y;
+            im += v.y * x.x + v.w * x.y;
+        }
+    } else {
+        for (int64_t r = r0 + threadIdx.x; r < r1; r += 256) {
+            const float2 v = a[r];
+            const float x = img[r];
+            re += v.x * x;
+            im += v.y * x;
+        }
     }
     const float sre = block_sum_256(re, red);
     const float sim = block_sum_256(im, red);
-    if (threadIdx.x == 0) vis[row] = make_float2(sre, sim);
+    if (threadIdx.x == 0) part[row * RS + blockIdx.y] = make_float2(sre, sim);
 }
 
 // per (n,k): chi^2 term and gv = dL/dRe(vis) + i dL/dIm(vis), written over vis
-__global__ void eht_loss_kernel(float2 *__restrict__ vis, const float *__restrict__ target, const float *__restrict__ sigma,
-                                float scale, int dtype, int64_t N, int C, int nvis, float *__restrict__ loss, int want_grad) {
+__global__ __launch_bounds__(256) void eht_loss_kernel(float2 *__restrict__ vis, const float2 *__restrict__ part, int RS,
+                                                       const float *__restrict__ target, const float *__restrict__ sigma,
+                                                       float scale, int dtype, int64_t N, int C, int nvis,
+                                                       float *__restrict__ loss_part, int want_grad) {
+    __shared__ float red[4];
     const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     float term = 0.f;
     if (t < N * nvis) {
         const int64_t n = t / nvis, k = t % nvis;
         const float s = sigma[t];
+        for (int c = 0; c < C; ++c) {                 // stage 2 of the GEMV: the row's RS partial sums, fixed order
+            const int64_t row = (n * C + c) * nvis + k;
+            float sr = 0.f, si = 0.f;
+            for (int j = 0; j < RS; ++j) { const float2 p = part[row * RS + j]; sr += p.x; si += p.y; }
+            vis[row] = make_float2(sr, si);
+        }
         if (dtype == 0) {            // 'vis': sum (|vis - target| / sigma)^2, target complex (network.py:548)
             const float2 v = vis[(n * C) * nvis + k];
             const float dr = v.x - target[2 * t], di = v.y - target[2 * t + 1];
@@ -407,9 +440,8 @@ __global__ void eht_loss_kernel(float2 *__restrict__ vis, const float *__restric
             }
         }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) term += __shfl_xor(term, o, 64);
-    if ((threadIdx.x & 63) == 0 && term != 0.f) atomicAdd(loss, scale * term);
+    const float tot = block_sum_256(term, red);
+    if (threadIdx.x == 0) loss_part[blockIdx.x] = scale * tot;
 }
 
 // dimg[n,r] = sum_{c,k} Re(gv) A_re + Im(gv) A_im
@@ -428,6 +460,22 @@ __global__ __launch_bounds__(256) void eht_bwd_kernel(const float2 *__restrict__
     dimages[n * R + r] = acc;
 }
 
+// R-axis splits of the visibility GEMV: enough blocks to fill the chip, slices of >= 2048 elements
+static int eht_splits(int64_t rows, int64_t R) {
+    int64_t rs = (2048 + rows - 1) / rows;
+    const int64_t most = R / 2048 > 1 ? R / 2048 : 1;
+    if (rs > most) rs = most;
+    if (rs > 64) rs = 64;
+    return (int)(rs < 1 ? 1 : rs);
+}
+
+// workspace layout (floats): [vis: 2 rows][partial sums: 2 rows RS][loss terms per block: ceil(N nvis / 256)]
+extern "C" size_t bhn_chi2_eht_ws_floats(int32_t N, int32_t C, int32_t nvis, int64_t R) {
+    if (N <= 0 || C <= 0 || nvis <= 0 || R <= 0) return 0;
+    const int64_t rows = (int64_t)N * C * nvis;
+    return (size_t)(2 * rows * (1 + eht_splits(rows, R)) + ((int64_t)N * nvis + 255) / 256);
+}
+
 extern "C" int bhn_chi2_eht(const float *images, const float *A, const float *target, const float *sigma, float scale,
                             int32_t dtype, int32_t N, int32_t C, int32_t nvis, int64_t R, float *vis_ws, float *loss,
                             float *dimages, void *stream) {
@@ -436,17 +484,22 @@ extern "C" int bhn_chi2_eht(const float *images, const float *A, const float *ta
     BHN_CHECK_ARG(N > 0 && nvis > 0 && R > 0, "bad sizes");
     BHN_CHECK_ARG((dtype == 2) ? (C >= 1 && C <= 8) : (C == 1), "A must have %s visibilities per closure", dtype == 2 ? "1..8" : "1");
     hipStream_t st = (hipStream_t)stream;
-    BHN_HIP(hipMemsetAsync(loss, 0, sizeof(float), st));
-    hipLaunchKernelGGL(eht_vis_kernel, dim3((unsigned)(N * C * nvis)), dim3(256), 0, st, images,
-                       reinterpret_cast<const float2 *>(A), C, nvis, R, reinterpret_cast<float2 *>(vis_ws));
+    const int64_t rows = (int64_t)N * C * nvis, tot = (int64_t)N * nvis;
+    const int RS = eht_splits(rows, R);
+    float2 *vis = reinterpret_cast<float2 *>(vis_ws), *part = vis + rows;
+    float *loss_part = vis_ws + 2 * rows * (1 + RS);
+    const unsigned nblk = (unsigned)((tot + 255) / 256);
+    hipLaunchKernelGGL(eht_vis_kernel, dim3((unsigned)rows, (unsigned)RS), dim3(256), 0, st, images,
+                       reinterpret_cast<const float2 *>(A), C, nvis, R, RS, part);
     BHN_HIP(hipGetLastError());
-    const int64_t tot = (int64_t)N * nvis;
-    hipLaunchKernelGGL(eht_loss_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, reinterpret_cast<float2 *>(vis_ws),
-                       target, sigma, scale, dtype, (int64_t)N, C, nvis, loss, dimages ? 1 : 0);
+    hipLaunchKernelGGL(eht_loss_kernel, dim3(nblk), dim3(256), 0, st, vis, part, RS, target, sigma, scale, dtype, (int64_t)N,
+                       C, nvis, loss_part, dimages ? 1 : 0);
+    BHN_HIP(hipGetLastError());
+    hipLaunchKernelGGL(loss_sum_kernel, dim3(1), dim3(256), 0, st, loss, loss_part, (int64_t)nblk);
     BHN_HIP(hipGetLastError());
     if (dimages) {
         hipLaunchKernelGGL(eht_bwd_kernel, dim3((unsigned)((R + 255) / 256), (unsigned)N), dim3(256), 0, st,
-                           reinterpret_cast<const float2 *>(vis_ws), reinterpret_cast<const float2 *>(A), C, nvis, R, dimages);
+                           reinterpret_cast<const float2 *>(vis), reinterpret_cast<const float2 *>(A), C, nvis, R, dimages);
         BHN_HIP(hipGetLastError());
     }
     return BHN_OK;

@@ -4,6 +4,7 @@ This is the layer the reference-shaped API (network.py / optimization.py of this
 built on.  Everything here runs on the HIP library; nothing falls back to the CPU.
 """
 import ctypes as C
+import functools
 
 import numpy as np
 import torch
@@ -19,6 +20,17 @@ def _flat(t, n):
     return t.reshape(n).contiguous()
 
 
+def _on_device(fn):
+    """Run a method with its object's device current: the C ABI launches on the CURRENT device of the calling thread
+    (kernel attributes and occupancy are cached per device), while streams and pointers come from ``self.device`` --
+    a predictor built for cuda:1 must work when the process's current device is cuda:0."""
+    @functools.wraps(fn)
+    def wrapper(self, *args, **kw):
+        with torch.cuda.device(self.device):
+            return fn(self, *args, **kw)
+    return wrapper
+
+
 class RayGeometry:
     """Static per-(ray, sample) inputs resident in HBM, laid out as flat [ray][sample] planes.
 
@@ -30,7 +42,10 @@ class RayGeometry:
 
     def __init__(self, coords, Omega, g, dtau, Sigma, t_geos, J=None, rmin=0.0, rmax=np.inf, z_width=np.inf,
                  device='cuda'):
-        dev = torch.device(device)
+        with torch.cuda.device(torch.device(device)):
+            self._build(coords, Omega, g, dtau, Sigma, t_geos, J, rmin, rmax, z_width, torch.device(device))
+
+    def _build(self, coords, Omega, g, dtau, Sigma, t_geos, J, rmin, rmax, z_width, dev):
         coords = _hip.as_f32(coords, dev)
         self.spatial = tuple(coords.shape[1:-1])
         self.G = int(coords.shape[-1])
@@ -174,6 +189,7 @@ class FusedPredictor:
             tree['Dense_%d' % i] = {'kernel': flat[ko:ko + fi * fo].view(fi, fo), 'bias': flat[bo:bo + fo]}
         return {'MLP_0': tree}
 
+    @_on_device
     def pack(self, flat):
         _hip.require_device(flat)
         assert flat.dtype == torch.float32 and flat.numel() == self.nparams and flat.is_contiguous()
@@ -185,6 +201,7 @@ class FusedPredictor:
         assert tM0.dtype == torch.float64 and tM0.is_cuda and tM0.is_contiguous()
         return _hip.bhn_frames(int(tM0.numel()), tM0.data_ptr())
 
+    @_on_device
     def predict(self, geom, tM0):
         """NeRF_Predictor.__call__ (network.py:191-237) -> emission (B, P) float32."""
         B = int(tM0.numel())
@@ -199,6 +216,7 @@ class FusedPredictor:
         full[:, k['idx']] = out[:, :k['n']]
         return full
 
+    @_on_device
     def render(self, geom, tM0, out=None):
         """image_plane_prediction (network.py:373-420) -> images (B, Sx, R) float32."""
         B = int(tM0.numel())
@@ -209,6 +227,7 @@ class FusedPredictor:
                                              C.byref(fs), _hip.ptr(out), _hip.stream_ptr(self.device)))
         return out
 
+    @_on_device
     def workspace(self, B, P):
         """Backward workspace (slabs + tape).  Sized for all B frames when that fits under
         ``max_workspace_bytes`` (default 1/4 of the device memory), else for as many frames as fit;
@@ -228,6 +247,7 @@ class FusedPredictor:
             self._ws = torch.empty((want,), dtype=torch.uint8, device=self.device)
         return self._ws
 
+    @_on_device
     def render_bwd(self, geom, tM0, dimages, out=None):
         """d loss / d params given d loss / d images (B,Sx,R): the reverse of ``render``."""
         assert dimages.dtype == torch.float32 and dimages.is_contiguous() and dimages.is_cuda
@@ -262,6 +282,7 @@ class FusedPredictor:
                 return nb
         return 0
 
+    @_on_device
     def render_train(self, geom, tM0, out=None):
         """Training forward: images (B,Sx,R) + tape recorded in the workspace (see render_bwd_tape)."""
         B = int(tM0.numel())
@@ -274,6 +295,7 @@ class FusedPredictor:
                                                    _hip.stream_ptr(self.device)))
         return out
 
+    @_on_device
     def render_bwd_tape(self, geom, tM0, dimages, out=None):
         """Gradient from the tape recorded by ``render_train`` (same geom / frames / packed weights)."""
         assert dimages.dtype == torch.float32 and dimages.is_contiguous() and dimages.is_cuda
@@ -321,6 +343,7 @@ class GridEngine:
     def unflatten(self, flat):
         return {'grid': flat.view(self.res, self.res, self.res)}
 
+    @_on_device
     def pack(self, flat):
         _hip.require_device(flat)
         assert flat.dtype == torch.float32 and flat.numel() == self.nparams and flat.is_contiguous()
@@ -330,6 +353,7 @@ class GridEngine:
         assert tM0.dtype == torch.float64 and tM0.is_cuda and tM0.is_contiguous()
         return _hip.bhn_frames(int(tM0.numel()), tM0.data_ptr())
 
+    @_on_device
     def predict(self, geom, tM0):
         out = torch.empty((int(tM0.numel()), geom.P), dtype=torch.float32, device=self.device)
         gs, fs = geom.c_struct(), self._frames(tM0)
@@ -337,6 +361,7 @@ class GridEngine:
                                                    _hip.ptr(out), _hip.stream_ptr(self.device)))
         return out
 
+    @_on_device
     def render(self, geom, tM0, out=None):
         B = int(tM0.numel())
         if out is None:
@@ -346,6 +371,7 @@ class GridEngine:
                                                   _hip.ptr(out), _hip.stream_ptr(self.device)))
         return out
 
+    @_on_device
     def render_bwd(self, geom, tM0, dimages, out=None):
         assert dimages.dtype == torch.float32 and dimages.is_contiguous() and dimages.is_cuda
         if out is None:
@@ -372,12 +398,13 @@ def chi2_image(images, target, sigma, offset, scale, dtype, want_grad=True):
     if code is None:
         raise AttributeError('image dtype ({}) not supported'.format(dtype))
     B, Sx, R = images.shape
-    loss = torch.empty((1,), dtype=torch.float32, device=images.device)
+    loss = torch.empty((1 + B * Sx,), dtype=torch.float32, device=images.device)     # [total | per-plane terms]
     dimg = torch.empty_like(images) if want_grad else None
-    _hip.check(_hip.lib().bhn_chi2_image(_hip.ptr(images), _hip.ptr(target), _hip.ptr(sigma), _hip.ptr(offset),
-                                         float(scale), code, B, Sx, R, _hip.ptr(loss), _hip.ptr(dimg),
-                                         _hip.stream_ptr(images.device)))
-    return loss, dimg
+    with torch.cuda.device(images.device):
+        _hip.check(_hip.lib().bhn_chi2_image(_hip.ptr(images), _hip.ptr(target), _hip.ptr(sigma), _hip.ptr(offset),
+                                             float(scale), code, B, Sx, R, _hip.ptr(loss), _hip.ptr(dimg),
+                                             _hip.stream_ptr(images.device)))
+    return loss[:1], dimg
 
 
 EHT_DTYPES = {'vis': 0, 'amp': 1, 'cphase': 2}
@@ -412,11 +439,12 @@ def chi2_eht(images, A, target, sigma, scale, dtype, want_grad=True):
     """loss_fn_eht tail (network.py:541-564) on device -> (loss[1], dimages shaped like images or None)."""
     code, img, Ar, tgt, sig, N, C_, nvis, R = _eht_operands(images, A, target, sigma, dtype)
     dev = img.device
-    ws = torch.empty((N * C_ * nvis * 2,), dtype=torch.float32, device=dev)
+    ws = torch.empty((int(_hip.lib().bhn_chi2_eht_ws_floats(N, C_, nvis, R)),), dtype=torch.float32, device=dev)
     loss = torch.empty((1,), dtype=torch.float32, device=dev)
     dimg = torch.empty_like(img) if want_grad else None
-    _hip.check(_hip.lib().bhn_chi2_eht(_hip.ptr(img), _hip.ptr(Ar), _hip.ptr(tgt), _hip.ptr(sig), float(scale), code, N, C_,
-                                       nvis, R, _hip.ptr(ws), _hip.ptr(loss), _hip.ptr(dimg), _hip.stream_ptr(dev)))
+    with torch.cuda.device(dev):
+        _hip.check(_hip.lib().bhn_chi2_eht(_hip.ptr(img), _hip.ptr(Ar), _hip.ptr(tgt), _hip.ptr(sig), float(scale), code, N, C_,
+                                           nvis, R, _hip.ptr(ws), _hip.ptr(loss), _hip.ptr(dimg), _hip.stream_ptr(dev)))
     return loss, (dimg.reshape(images.shape) if want_grad else None)
 
 
@@ -436,6 +464,7 @@ class EhtChi2Function(torch.autograd.Function):
 
 
 def adam_step(params, grads, m, v, t, lr, b1=0.9, b2=0.999, eps=1e-8, grad_scale=1.0):
-    _hip.check(_hip.lib().bhn_adam_step(_hip.ptr(params), _hip.ptr(grads), _hip.ptr(m), _hip.ptr(v), params.numel(),
-                                        int(t), float(lr), b1, b2, eps, float(grad_scale),
-                                        _hip.stream_ptr(params.device)))
+    with torch.cuda.device(params.device):
+        _hip.check(_hip.lib().bhn_adam_step(_hip.ptr(params), _hip.ptr(grads), _hip.ptr(m), _hip.ptr(v), params.numel(),
+                                            int(t), float(lr), b1, b2, eps, float(grad_scale),
+                                            _hip.stream_ptr(params.device)))

@@ -96,6 +96,14 @@ class TrainState:
         self.num_iters, self.lr_init, self.lr_final = int(num_iters), float(lr_init), float(lr_final)
         self.grad = torch.zeros(flat.numel() + _world()[1], dtype=torch.float32, device=flat.device)
 
+    def grad_buffer(self):
+        """Flat gradient + one loss slot per rank (the single all-reduce message); re-sized when the process group was
+        initialised after this state was built."""
+        want = self.flat.numel() + _world()[1]
+        if self.grad.numel() != want:
+            self.grad = torch.zeros(want, dtype=torch.float32, device=self.flat.device)
+        return self.grad
+
     @property
     def params(self):
         tree = ParamTree(self.predictor.engine().unflatten(self.flat))
@@ -186,10 +194,13 @@ class NeRF_Predictor:
         return self._engine
 
     def geometry(self, coords, Omega, t_geos, J=None, g=None, dtau=None, Sigma=None):
-        """Prepared RayGeometry for these arrays, cached on the identity of the inputs."""
+        """Prepared RayGeometry for these arrays, cached on the IDENTITY of the inputs (the reference's ray-tracing
+        arguments are immutable jax arrays): an in-place edit of an array is not seen -- pass a new array, or call
+        ``clear_geometry_cache()``."""
         key = tuple(id(v) for v in (coords, Omega, t_geos, J, g, dtau, Sigma)) + (self.rmin, self.rmax, self.z_width)
         hit = self._geoms.get(key)
         if hit is not None:
+            self._geoms.move_to_end(key)            # LRU: logging geometries must not evict the training ray sets
             return hit[0]
         dev = self.engine().device
         one = 1.0
@@ -199,6 +210,9 @@ class NeRF_Predictor:
         while len(self._geoms) > 32:            # > the sub-pixel ray sets of a run (scripts use up to 10): a training step
             self._geoms.popitem(last=False)     # picks one at random, so a smaller cache would rebuild geometry every step
         return geom
+
+    def clear_geometry_cache(self):
+        self._geoms.clear()
 
     # -- reference API -----------------------------------------------------------------------------
     def init_params(self, raytracing_args=None, seed=1):
@@ -429,7 +443,7 @@ def _step_image(state, t_units, dtype, target, sigma, offset, t_frames, coords, 
         tgt, sig, off = (_hip.as_f32(v, dev).reshape(tshape) for v in (target, sigma, offset))
         images = torch.empty((B, geom.Sx, geom.R), dtype=torch.float32, device=dev)
         n = eng.nparams
-        buf = state.grad
+        buf = state.grad_buffer()
         part = torch.empty((n,), dtype=torch.float32, device=dev)
         loss = torch.zeros((1,), dtype=torch.float32, device=dev)
         for b0 in range(0, B, group):
@@ -458,7 +472,7 @@ def _step_image(state, t_units, dtype, target, sigma, offset, t_frames, coords, 
     rank, world = _world()
     if train:
         n = eng.nparams
-        buf = state.grad
+        buf = state.grad_buffer()
         (eng.render_bwd_tape if taped else eng.render_bwd)(geom, tM0, dimg, out=buf[:n])
         loss_vec = dp_allreduce(buf, n, loss, rank, world)      # jax.lax.pmean(grads) (network.py:620)
         state.apply_gradients(buf[:n], grad_scale=1.0 / world)

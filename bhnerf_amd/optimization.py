@@ -148,6 +148,12 @@ class Optimizer(object):
         return self.state.params
 
 
+def _shared_rng(stream):
+    """Generator that is identical on every rank (BHNERF_BATCH_SEED, default 0; `stream` separates its users): all
+    ranks must draw the same frame batches and the same ray set, as the reference's one process does."""
+    return np.random.default_rng([int(os.environ.get('BHNERF_BATCH_SEED', '0')), int(stream)])
+
+
 class TrainStep(object):
     """Container of per-loss step functions (optimization.py:145-272)."""
 
@@ -162,13 +168,16 @@ class TrainStep(object):
         assert self.dtype.size == self.args.size == self.test_pmap.size == \
             self.grad_pmap.size == self.scale.size, 'input list sizes are not equal'
         self.num_losses = self.dtype.size
+        # the sub-pixel ray set of a training step is ONE choice for all devices (optimization.py:169 runs once in the
+        # reference's single process): every rank draws it from a generator seeded like TemporalBatchedArgs._rng
+        self._rng = _shared_rng(1)
 
     def __call__(self, state, raytracing_args, indices, update_state=True):
         """One pass over the losses.  Training picks ONE ray set at random (stochastic sub-pixel sampling,
         optimization.py:169) and lets every loss take its own Adam step; testing averages over all ray sets."""
         ray_sets = list(np.atleast_1d(raytracing_args))
         if update_state:
-            ray_sets = [ray_sets[np.random.choice(len(ray_sets))]]
+            ray_sets = [ray_sets[int(self._rng.integers(len(ray_sets)))]]
         fns = self.grad_pmap if update_state else self.test_pmap
         loss_acc = images_acc = 0.0
         for rt in ray_sets:
@@ -245,7 +254,7 @@ class TemporalBatchedArgs(object):
         self.args = self.host_args + [self.t_values]
         self.default_t_units = units.hr
         self._dev = None
-        self._rng = np.random.default_rng(int(os.environ.get('BHNERF_BATCH_SEED', '0')))
+        self._rng = _shared_rng(0)
 
     def sample(self, batchsize, replace=False):
         """Random frame batch; identical on every rank (same seed, same call sequence)."""
@@ -362,8 +371,8 @@ class SummaryWriter(object):
         matplotlib.use('Agg', force=False)
         import matplotlib.pyplot as plt
         rt = opt.raytracing_args
-        if isinstance(rt, (list, tuple)):
-            rt = rt[np.random.choice(len(rt))]
+        if isinstance(rt, (list, tuple)):                       # same choice on every rank (all ranks render the movie)
+            rt = rt[int(_shared_rng(2 + int(opt.step)).integers(len(rt)))]
         loss, movie = total_movie_loss(batchsize, opt.state, train_step, rt, return_frames=True)
         lc_est = np.asarray(movie).sum(axis=(-1, -2))
         target = np.asarray(target)

@@ -13,7 +13,9 @@
  *     thread-local message.  Nothing aborts, nothing prints.
  *   - the CALLER owns and allocates every buffer (device memory unless marked host); workspace
  *     sizes are queried with bhn_*_bytes().  No hidden allocation, no hidden synchronisation,
- *     no global mutable state except the error string and a per-device property cache.
+ *     no global mutable state except the thread-local error string and per-device one-time caches
+ *     (CU count, kernel attributes; std::call_once): re-entrant across threads, streams and devices.
+ *     The CURRENT device of the calling thread must be the device that owns `stream` and the buffers.
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it and the call returns
  *     immediately (graph-capturable: no malloc/free/sync inside).
  *   - arrays are C-contiguous float32 unless stated.  P = R*G points per frame, flat index
@@ -32,7 +34,7 @@
 extern "C" {
 #endif
 
-#define BHN_ABI_VERSION 1
+#define BHN_ABI_VERSION 2
 
 enum { BHN_OK = 0, BHN_EINVAL = 1, BHN_EUNSUPPORTED = 2, BHN_EHIP = 3, BHN_EWORKSPACE = 4 };
 enum { BHN_F32 = 0, BHN_BF16 = 1 };
@@ -144,8 +146,9 @@ int bhn_render_bwd_tape(const bhn_model *m, int32_t mode, const void *packed, co
                         size_t workspace_bytes, void *stream);
 
 /* loss_fn_image (network.py:476-484): dtype 0 = 'full', 1 = 'lc'.  target/sigma/offset are
- * (B,Sx,R) for 'full', (B,Sx) for 'lc'.  Writes loss[0] = scale*chi^2 and dimages = dloss/dimages
- * (pass NULL to skip the gradient). */
+ * (B,Sx,R) for 'full', (B,Sx) for 'lc'.  `loss` holds 1 + B*Sx floats: loss[1 + plane] = scale*chi^2 of that
+ * (frame, Stokes) plane, loss[0] = their sum, added in a fixed order (bitwise reproducible; no atomics).
+ * dimages = dloss/dimages (pass NULL to skip the gradient). */
 int bhn_chi2_image(const float *images, const float *target, const float *sigma, const float *offset,
                    float scale, int32_t dtype, int32_t B, int32_t Sx, int64_t R, float *loss,
                    float *dimages, void *stream);
@@ -153,8 +156,11 @@ int bhn_chi2_image(const float *images, const float *target, const float *sigma,
 /* loss_fn_eht (network.py:486-564): visibilities = A . image, then chi^2 of dtype 0 = 'vis' (complex
  * target), 1 = 'amp', 2 = 'cphase' (closure phase of the product over the C axis).  images (N,R) with
  * N = B*Sx planes; A complex64 interleaved (N,C,nvis,R), C = 1 for vis/amp; target (N,nvis) (complex
- * interleaved for 'vis'); sigma (N,nvis); vis_ws: caller scratch of 2*N*C*nvis floats.  Writes
- * loss[0] = scale*chi^2 and, unless NULL, dimages (N,R). */
+ * interleaved for 'vis'); sigma (N,nvis); vis_ws: caller scratch of bhn_chi2_eht_ws_floats(N,C,nvis,R) floats.
+ * Writes loss[0] = scale*chi^2 and, unless NULL, dimages (N,R).  The visibility GEMV is split over the R axis into
+ * enough blocks to fill the chip and reduced in two fixed-order stages (no atomics: loss and gradient are bitwise
+ * reproducible). */
+size_t bhn_chi2_eht_ws_floats(int32_t N, int32_t C, int32_t nvis, int64_t R);
 int bhn_chi2_eht(const float *images, const float *A, const float *target, const float *sigma, float scale,
                  int32_t dtype, int32_t N, int32_t C, int32_t nvis, int64_t R, float *vis_ws, float *loss,
                  float *dimages, void *stream);
@@ -187,18 +193,23 @@ int bhn_grid_render_bwd(const bhn_geom *geom, const bhn_frames *fr, const float 
 int bhn_adam_step(float *params, const float *grads, float *m, float *v, int64_t n, int64_t t, float lr,
                   float b1, float b2, float eps, float grad_scale, void *stream);
 
-/* Measurement aid (bench.py): run only some kernels of bhn_render_bwd on this thread.
- * bit 0 = chain kernel, bit 1 = dW GEMM kernel, bit 2 = slab reduction; default 7. */
-int bhn_debug_set_bwd_stages(int32_t mask);
-/* Measurement aid: bf16 forward kernel variant.  Low 4 bits: 1 = production kernel (default), 3 = ablation build
- * of the 4x256 render kernel; bits 4.. = its ablation flags (fused_fwd.hip). */
-int bhn_debug_set_fwd_variant(int32_t variant);
-/* Measurement aid: copy the first `bytes` (<= 4096) of the ablation build's stamp buffer to the host. */
-int bhn_debug_read(void *dst_host, size_t bytes);
+/* bhn_render_bwd_tape with the caller's HIP events recorded on `stream` at its kernel boundaries, so that each kernel
+ * of the backward can be timed live (bench.py's roofline): events[0] before the first kernel, events[i] behind kernel
+ * i - 1 (i = 1..BHN_BWD_TAPE_KERNELS); n_events <= BHN_BWD_TAPE_KERNELS + 1, NULL entries are skipped.  The events are
+ * hipEvent_t handles created by the caller; nothing is synchronised or allocated here.
+ * bhn_render_bwd_tape_kernel_name(i): the name of kernel i as it appears in a rocprofv3 kernel trace (prefix). */
+#define BHN_BWD_TAPE_KERNELS 3
+int bhn_render_bwd_tape_timed(const bhn_model *m, int32_t mode, const void *packed, const bhn_geom *geom,
+                              const bhn_frames *fr, const float *dimages, float *dparams, void *workspace,
+                              size_t workspace_bytes, void *stream, void *const *events, int32_t n_events);
+const char *bhn_render_bwd_tape_kernel_name(int32_t i);
 
-/* Device self-checks of the MFMA / LDS-transpose lane maps the kernels rely on (exact integer
- * data).  results: 8 int32 mismatch counts on the host, all 0 when the maps hold. */
-int bhn_selftest(int32_t *results_host);
+/* Device self-checks of the MFMA / LDS-transpose / LDS-DMA lane maps the kernels rely on (exact integer
+ * data).  results: 8 int32 mismatch counts on the host, all 0 when the maps hold.  scratch_dev: caller-owned device
+ * memory of >= BHN_SELFTEST_SCRATCH_BYTES.  The one synchronous call of the library (runs on the null stream and
+ * waits for the device). */
+#define BHN_SELFTEST_SCRATCH_BYTES 16384
+int bhn_selftest(int32_t *results_host, void *scratch_dev, size_t scratch_bytes);
 
 #ifdef __cplusplus
 }

@@ -34,7 +34,27 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     for name in syms:
         assert hasattr(lib, name), name
     assert sorted(_hip.SIGNATURES) == syms        # the ctypes table binds exactly the declared ABI
-    assert lib.bhn_version() == 1
+    assert lib.bhn_version() == 2
+
+
+def test_release_library_has_no_hidden_allocation_or_environment_reads(lib):
+    """include/bhnerf_hip.h conventions: the caller owns every buffer and the library keeps no hidden state.  The
+    release build must not even REFERENCE an allocator or getenv (the measurement switches live in the debug build,
+    include/bhnerf_hip_debug.h), and must not export a debug entry point."""
+    import shutil
+    import subprocess
+    from bhnerf_amd import _hip
+    nm = shutil.which('nm')
+    if nm is None:
+        pytest.skip('nm not available')
+    so = os.path.join(_hip.CSRC, 'libbhnerf_hip.so')
+    undefined = subprocess.run([nm, '-D', '--undefined-only', so], capture_output=True, text=True, check=True).stdout
+    for banned in ('hipMalloc', 'hipFree', 'hipHostMalloc', 'getenv', 'hipStreamSynchronize'):
+        assert banned not in undefined, banned
+    defined = subprocess.run([nm, '-D', '--defined-only', so], capture_output=True, text=True, check=True).stdout
+    assert 'bhn_debug' not in defined
+    hdr = open(os.path.join(ROOT, 'include', 'bhnerf_hip.h')).read()
+    assert 'bhn_debug' not in hdr
 
 
 @pytest.mark.parametrize('depth,width,n', [(4, 128, 55169), (4, 256, 208641), (8, 256, 471809), (6, 64, None)])

@@ -1,5 +1,6 @@
 import sys, numpy as np, torch
 sys.path.insert(0, '/root/repo')
+import os; os.environ.setdefault('BHNERF_HIP_LIB', '/root/repo/bhnerf_amd/csrc/libbhnerf_hip_dbg.so')   # debug build: make -C bhnerf_amd/csrc debug
 from bhnerf_amd import _hip, engine, network, synthetic, constants
 dev = torch.device('cuda:0')
 H = W = 128; G = 64; B = 8

@@ -3,6 +3,7 @@ at config 2: ticks spent computing and ticks waiting (DMA wait + barrier) per st
 Needs the library built with the stamps compiled in:  make -C bhnerf_amd/csrc CXXFLAGS="... -DBHN_CHAIN_STAMPS=1"."""
 import sys, ctypes as C, numpy as np, torch
 sys.path.insert(0, '/root/repo')
+import os; os.environ.setdefault('BHNERF_HIP_LIB', '/root/repo/bhnerf_amd/csrc/libbhnerf_hip_dbg.so')   # debug build: make -C bhnerf_amd/csrc debug
 from bhnerf_amd import _hip, engine, network, synthetic, constants
 dev = torch.device('cuda:0')
 lib = _hip.lib()

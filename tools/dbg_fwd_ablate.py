@@ -1,6 +1,7 @@
 """Inference forward (4x256 bf16, config 2) with one cost knocked out at a time (fused_fwd_kernel DBG build)."""
 import sys, numpy as np, torch
 sys.path.insert(0, '/root/repo')
+import os; os.environ.setdefault('BHNERF_HIP_LIB', '/root/repo/bhnerf_amd/csrc/libbhnerf_hip_dbg.so')   # debug build: make -C bhnerf_amd/csrc debug
 from bhnerf_amd import _hip, engine, network, synthetic, constants
 dev = torch.device('cuda:0')
 def timed(fn, reps=6):

@@ -2,6 +2,7 @@
 for waves 0 and 4 of workgroup 0: cycles spent computing, waiting for the weight DMA, waiting at the barrier."""
 import sys, ctypes as C, numpy as np, torch
 sys.path.insert(0, '/root/repo')
+import os; os.environ.setdefault('BHNERF_HIP_LIB', '/root/repo/bhnerf_amd/csrc/libbhnerf_hip_dbg.so')   # debug build: make -C bhnerf_amd/csrc debug
 from bhnerf_amd import _hip, engine, network, synthetic, constants
 dev = torch.device('cuda:0')
 lib = _hip.lib()
