@@ -313,7 +313,7 @@ def main():
         recomputed = l == 1 and args.mode == 'bf16' and l != skip_layer
         tiles += mt + (1 if recomputed else mt) + (1 if l == skip_layer else 0)
         if rides and l == args.depth - 1:
-            tiles += 1.5                                                   # dout tile + the 1 KiB piece with the f32 dout
+            tiles += 0.5                                                   # the 1 KiB piece that starts with the group's 32 f32 dout
     tape_bpp = tiles * (32 * 32 * elem) / 32.0
     std = H == 128 and G == 64 and args.frames_per_gpu == 8 and args.width == 256 and args.depth == 4 and args.mode == 'bf16' and not args.masked
     try:      # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (profiles/)

@@ -18,10 +18,10 @@
 #define BHN_CHAIN_STAMPS 0      // 1: ring-step time stamps in the chain kernels (tools/dbg_chain_steps.py needs this build)
 #endif
 #ifndef BHN_JOB1_W
-#define BHN_JOB1_W 12          // weight of the layer-1 dW job in B tiles at width 256 (measured optimum; scaled with the width)
+#define BHN_JOB1_W 13          // weight of the layer-1 dW job in B tiles at width 256 (measured optimum; scaled with the width)
 #endif
 #ifndef BHN_JOBL_W
-#define BHN_JOBL_W 6           // extra weight (in tiles at width 256, scaled with the width) of the layer depth-1 dW job when it rebuilds gA_{depth-1} and carries the output row
+#define BHN_JOBL_W 12           // extra weight (in tiles at width 256, scaled with the width) of the layer depth-1 dW job when it rebuilds gA_{depth-1} and carries the output row
 #endif
 // Run-time measurement switches exist only in the debug build (make debug); the release kernels see the constant 0
 #ifdef BHN_DEBUG
@@ -30,7 +30,7 @@
 #define BHN_DBG(x) 0
 #endif
 #ifndef BHN_TAPED_DIST
-#define BHN_TAPED_DIST 6         // weight chunks in flight in the training-forward / delta-chain kernels (bf16; 4 measured 2 % slower)
+#define BHN_TAPED_DIST 7         // weight chunks in flight in the training-forward / delta-chain kernels (bf16; 4 measured 2 % slower)
 #endif
 
 struct TapeLayout {
@@ -59,6 +59,8 @@ struct BwdArgs {
     int accumulate;                            // 1: add to what the slabs already hold
     int debug;                                 // measurement aid: 1 skip MFMA work, 2 skip tape loads
     long long *ts_buf;                         // measurement aid: ring-step time stamps (debug bit 9)
+    long long wrap;                            // measurement aid (debug build): tape tile addresses wrap after this many groups
+    int policy;                                // measurement aid (debug build): 0 nt, 1 plain, 2 sc1 tape stores / loads
     float *dparams;
     long long kernel_off[BHN_MAX_LAYERS + 1], bias_off[BHN_MAX_LAYERS + 1];
     int in_dim[BHN_MAX_LAYERS + 1];
@@ -83,6 +85,7 @@ struct BwdGeom {
     static constexpr int NPW = (NPW_ALL + NPASS - 1) / NPASS;
     static constexpr int GROUP_BYTES = (2 * MT + 1) * TILE_BYTES;   // A tiles + h tiles + enc tile
     static constexpr int GROUP_BYTES_LAST = GROUP_BYTES + TILE_BYTES + 1024;   // + dout tile + f32 dout piece (dw_body LAST)
+    static constexpr int GROUP_BYTES_LAST2 = GROUP_BYTES + 1024;               // + the KiB that starts with the f32 dout (dw_body2 LAST)
     // chain kernels: prefetch distance of the LDS-DMA weight ring (RING_DIST_TAPED+1 buffers of one chunk)
     static constexpr int RING_DIST_TAPED = (Pol::ELEM_BYTES == 2) ? BHN_TAPED_DIST : 3;
     // dW kernel: LDS-DMA ring of NBUF groups (counted vmcnt, raw s_barrier); f32: 2 buffers
@@ -176,7 +179,15 @@ struct TapeEmit {
         return 16 * (pt & 3) + 128 * s + 64 * h + 256 * (pt >> 2);
     }
     static DEVI void store_native(char *dst, const typename Pol::frag &f0, const typename Pol::frag &f1, int dbg) {
-        if (!(dbg & 1)) {
+        if (BHN_DBG(dbg & 12)) {          // measurement: cache policy of the tape stores (4: plain, 8: sc1)
+            typename Pol::frag *p0 = reinterpret_cast<typename Pol::frag *>(dst + native_off(0));
+            typename Pol::frag *p1 = reinterpret_cast<typename Pol::frag *>(dst + native_off(1));
+            if (dbg & 4) { *p0 = f0; *p1 = f1; }
+            else {
+                asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p0), "v"(f0) : "memory");
+                asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p1), "v"(f1) : "memory");
+            }
+        } else if (!(dbg & 1)) {
             __builtin_nontemporal_store(f0, reinterpret_cast<typename Pol::frag *>(dst + native_off(0)));
             __builtin_nontemporal_store(f1, reinterpret_cast<typename Pol::frag *>(dst + native_off(1)));
         } else {
@@ -315,7 +326,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
     constexpr int MW = (MT + 1) / 2;                                   // mask words per layer per lane
     constexpr int TB = BG::TILE_BYTES;
     const FusedArgs &a = A.f;
-    const int edbg = BHN_DBG((A.debug >> 6) & 3);  // measurement aid for the tape emission
+    const int edbg = BHN_DBG(((A.debug >> 6) & 3) | (A.policy << 2));  // measurement aid for the tape emission (bits 2,3: store policy)
     constexpr int sdbg = 0;                        // (a run-time MFMA-skip flag put every MFMA in its own basic block)
     using RG = DmaRing<CB, Pol::NWAVES>;
     constexpr int DIST = BG::RING_DIST_TAPED;
@@ -403,6 +414,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
         const long long p = (MODE != MODE_CHAIN) ? in.p : cin.p;
         const bool inb = (MODE != MODE_CHAIN) ? in.inb : cin.inb;
         const long long q = tile * Pol::NWAVES + wv;                     // 32-point group on the tape
+        const long long qs = BHN_DBG(A.wrap) ? q % A.wrap : q;           // (debug: h / gA tiles wrap into a cache-resident window)
         unsigned *mask_g = reinterpret_cast<unsigned *>(A.tape + A.t.mask_off) + q * (long long)(a.depth * MW * 64);
         float *e_g = reinterpret_cast<float *>(A.tape + A.t.e_off) + q * 32;
         frag enc[2], act[KS], next[KS];
@@ -436,7 +448,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
                     }
                     if (dst) em.emit(dst + (long long)m * TB, d0, d1, edbg);
                 }
-            } l0{em, drop_h1 ? nullptr : A.tape + A.t.h_off[1] + q * MT * TB, mask_g + lane,
+            } l0{em, drop_h1 ? nullptr : A.tape + A.t.h_off[1] + qs * MT * TB, mask_g + lane,
                  nullptr, 0u, edbg};
             f32x16 pend;
             layer0_step<W, Pol, RG, YS0>(rs, ap, enc, act, bias_lds, h, pend, l0);
@@ -458,7 +470,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
                     frag &d1 = m == 0 ? act[KS - 1] : next[2 * (m > 0 ? m - 1 : 0) + 1];
                     const int widx = (pl_layer * MW + (pm >> 1)) * 64 + lane;
                     const bool no_h = drop_h1 && pl_layer == 0;     // layer 0's last tile: relu bits only
-                    TapePost<Pol, true> post(pend, d0, d1, 0u, em, A.tape + A.t.h_off[pl_layer + 1] + (q * MT + pm) * TB,
+                    TapePost<Pol, true> post(pend, d0, d1, 0u, em, A.tape + A.t.h_off[pl_layer + 1] + (qs * MT + pm) * TB,
                                                  mask_g + widx, nullptr,
                                                  macc, pm & 1, pm == MT - 1, no_h ? (edbg | 2) : edbg);
                     // bias rows of the next tile: (l, m+1), or the first tile of the next sequence part
@@ -508,12 +520,16 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
                 d = cin.dE * e * (1.f - e);                        // sigmoid'(out-10) = e(1-e)
             }
             dout = __shfl(d, pl, 64);                               // both lane halves need it
-            // dout as a 32x32 (feature x point) tile whose feature 0 is dout: the A operand of dW_out
-            frag d0 = Pol::zero(), d1 = Pol::zero();
-            Pol::set(d0, 0, h == 0 ? d : 0.f);
             char *dgrp = A.tape + A.t.dout_off + q * A.t.dout_stride;
-            em.emit(dgrp, d0, d1, edbg);
-            if (A.t.drop_ga && h == 0 && !(edbg & 2)) __builtin_nontemporal_store(d, reinterpret_cast<float *>(dgrp + TB) + pl);
+            if (A.t.drop_ga) {
+                // 32 f32 per group: the job of layer depth-1 rebuilds gA_{depth-1} and makes the output layer's row from them
+                if (h == 0 && !(edbg & 2)) __builtin_nontemporal_store(d, reinterpret_cast<float *>(dgrp) + pl);
+            } else {
+                // dout as a 32x32 (feature x point) tile whose feature 0 is dout: the A operand of dW_out
+                frag d0 = Pol::zero(), d1 = Pol::zero();
+                Pol::set(d0, 0, h == 0 ? d : 0.f);
+                em.emit(dgrp, d0, d1, edbg);
+            }
         }
         if constexpr (MODE == MODE_CHAIN) {
             // ---- gA_{depth-1} = wout * dout * relu'(a_{depth-1}); its last tile stays pending ---------------
@@ -521,7 +537,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
             f32x16 pend = {};
             {
                 const bool keep_ga = !A.t.drop_ga;                    // else the dW kernel rebuilds gA_{depth-1}
-                char *gdst = A.tape + A.t.ga_off[a.depth - 1] + q * MT * TB;
+                char *gdst = A.tape + A.t.ga_off[a.depth - 1] + qs * MT * TB;
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
                     const unsigned mw = cin.mtop[m >> 1] >> ((m & 1) * 16);
@@ -559,7 +575,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
                     frag &d0 = m == 0 ? dl[KS - 2] : next[2 * (m > 0 ? m - 1 : 0)];
                     frag &d1 = m == 0 ? dl[KS - 1] : next[2 * (m > 0 ? m - 1 : 0) + 1];
                     const bool no_ga = A.t.drop_ga && pnd_layer == a.depth - 1;     // gA_{depth-1}'s last tile: not recorded
-                    TapePost<Pol, false> post(pend, d0, d1, pnd_mask, em, A.tape + A.t.ga_off[pnd_layer] + (q * MT + pm) * TB,
+                    TapePost<Pol, false> post(pend, d0, d1, pnd_mask, em, A.tape + A.t.ga_off[pnd_layer] + (qs * MT + pm) * TB,
                                                   nullptr, nullptr, no_acc, false, false, no_ga ? (edbg | 2) : edbg);
                     if (!(m & 1)) {                                  // word (l-1, m/2): use the oldest, fetch two ahead
                         mcur = mq0;
@@ -582,7 +598,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
             }
             if (a.depth > 1) {           // flush the last tile of gA_0 (no further step to hide it behind)
                 TapePost<Pol, false> post(pend, dl[KS - 2], dl[KS - 1], pnd_mask, em,
-                                              A.tape + A.t.ga_off[0] + (q * MT + MT - 1) * TB, nullptr, nullptr, no_acc, false, false, edbg);
+                                              A.tape + A.t.ga_off[0] + (qs * MT + MT - 1) * TB, nullptr, nullptr, no_acc, false, false, edbg);
                 post.all();
             }
         }   // MODE_CHAIN
@@ -827,9 +843,13 @@ DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
             }
             auto issue = [&](long long q, char *buf) {
                 q = q < q1 ? q : q1 - 1;
+                if (BHN_DBG(A.wrap)) q %= A.wrap;
 #pragma unroll
-                for (int i = 0; i < PPW; ++i)
-                    dma_1k_asm<true>(sbase[i] + q * sstride[i], buf + doff[i]);
+                for (int i = 0; i < PPW; ++i) {
+                    if (BHN_DBG(A.policy == 1)) dma_1k_asm<0>(sbase[i] + q * sstride[i], buf + doff[i]);
+                    else if (BHN_DBG(A.policy == 2)) dma_1k_asm<2>(sbase[i] + q * sstride[i], buf + doff[i]);
+                    else dma_1k_asm<1>(sbase[i] + q * sstride[i], buf + doff[i]);
+                }
             };
             // HIDDEN1: the h tiles of group q+1 are computed while group q is consumed (one group less in flight:
             // this job is MFMA-bound), so the loop-top barrier also publishes them and no latency chain is exposed
@@ -928,6 +948,352 @@ DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// dW job body, bf16, software-pipelined over the 32-point groups (round 2).
+//
+// The first version (dw_body above, still used by the f32 policy) ran per group: vmcnt wait -> barrier -> DMA issue ->
+// A-fragment LDS reads -> wait -> MFMAs; with the two waves of a SIMD in barrier lockstep everything in front of the
+// MFMAs was dead time for the matrix pipe (about 2600 cycles per group for 1024-1280 cycles of MFMA work; the
+// kernel took the same time whether its tape came from HBM or from an L2-resident window, tools/dbg_wrap.py).  Here
+// group q+1 is published one barrier EARLY (the wait at the top of iteration q is for group q+1), so that while the
+// MFMAs of group q run, the A fragments of group q+1 are read from LDS and prepared (layer depth-1: gA rebuilt from
+// h_depth, the output layer's row; all: bias sums) and its first two B fragments are fetched.  Ring of 4 group buffers:
+// q consumed, q+1 landed, q+2 and q+3 in flight.  State is double-buffered in registers by unrolling the loop twice.
+//
+// Other changes against dw_body: the skip layer's encoded-input tile is one EXTRA accumulator tile per wave (wave
+// (wr, wc) pairs it with its A tile mi == wc) instead of a ninth column tile that left half of a 2x5 tile grid idle;
+// layer depth-1 (LAST) makes the output layer's row and bias with v_dot2c / adds from the h_depth fragments and the f32
+// dout it already holds (no dout tile on the tape, no 1-row MFMAs, 32 accumulator registers fewer).
+// ---------------------------------------------------------------------------------------------
+template <int W, class Pol, int JT, bool LAST = false>
+DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
+    using BG = BwdGeom<W, Pol>;
+    using frag = typename Pol::frag;
+    static_assert(Pol::ELEM_BYTES == 2 && JT != JT_OUT, "bf16 jobs of layers 0 .. depth-1");
+    static_assert(!LAST || JT == JT_HIDDEN || JT == JT_SKIP, "LAST: hidden / skip job");
+    static_assert(BG::NBUF == 4, "ring of four group buffers");
+    constexpr int MT = BG::MT, TB = BG::TILE_BYTES;
+    constexpr int OFF_H = MT * TB, OFF_E = 2 * MT * TB, OFF_D32 = BG::GROUP_BYTES;       // LDS group image [A][h][enc][f32 dout piece]
+    constexpr int GB = LAST ? BG::GROUP_BYTES_LAST2 : BG::GROUP_BYTES;
+    constexpr bool has_h = JT != JT_FIRST, make_h = JT == JT_HIDDEN1, enc_extra = JT == JT_SKIP;
+    constexpr int nH = has_h ? MT : 0, nB = nH + ((JT == JT_FIRST || JT == JT_SKIP) ? 1 : 0);   // slab tile nB: the bias column
+    constexpr int nBr = has_h ? MT : 1;                                // B tiles of the regular tile grid
+    constexpr int WRR = BG::WRR, WCC = BG::WCC;
+    constexpr int MPW = (MT + WRR - 1) / WRR, NPW = (nBr + WCC - 1) / WCC;
+    static_assert(NPW <= 5, "one sweep");
+    constexpr int ME = (MPW + WCC - 1) / WCC;                          // A tiles a wave pairs with the enc tile / the output row
+    constexpr int NTOT = 2 * NPW;                                      // MFMA steps per group (k-step major)
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int trl = tr_lane_off();
+    const int nwg = A.wg_begin[job + 1] - A.wg_begin[job];
+    const int kb = blockIdx.x - A.wg_begin[job];
+    const long long q0 = A.t.NQ * kb / nwg, q1 = A.t.NQ * (kb + 1) / nwg;
+    const char *srcA = LAST ? A.tape + A.t.h_off[job + 1] : A.tape + A.t.ga_off[job];
+    const char *srcD = A.tape + A.t.dout_off;
+    const char *srcH = has_h ? A.tape + A.t.h_off[job] : nullptr;
+    const char *srcE = A.tape + (make_h ? A.t.encp_off : A.t.enc_off);
+    const int wr = wv % WRR, wc = wv / WRR;
+    const int nbase = wc * NPW;
+    const bool works = wr * MPW < MT && nbase < nBr;                   // this wave owns accumulator tiles
+    // HIDDEN1: W_0 and b_0 behind the ring (see dw_body)
+    char *w0_lds = smem + BG::NBUF * GB;
+    float *b0_lds = reinterpret_cast<float *>(w0_lds + 2 * MT * Pol::FRAG_BYTES);
+    if constexpr (make_h) {
+        const char *w0 = A.f.packed + A.f.fwd_off;
+        for (int i = tid; i < 2 * MT * Pol::FRAG_BYTES / 16; i += Pol::NTHREADS)
+            reinterpret_cast<u32x4 *>(w0_lds)[i] = reinterpret_cast<const u32x4 *>(w0)[i];
+        for (int i = tid; i < W; i += Pol::NTHREADS) b0_lds[i] = reinterpret_cast<const float *>(A.f.packed + A.f.bias_off)[i];
+    }
+    struct HIn { frag e0, e1, w0, w1; float b; };
+    auto make_h_read = [&](const char *gp) {
+        HIn in;
+        in.e0 = Pol::lds_frag(gp + OFF_E, 0, lane); in.e1 = Pol::lds_frag(gp + OFF_E, 1, lane);
+        const int t = wv < MT ? wv : 0;
+        in.w0 = Pol::lds_frag(w0_lds, 2 * t, lane); in.w1 = Pol::lds_frag(w0_lds, 2 * t + 1, lane);
+        in.b = b0_lds[32 * t + (lane & 31)];
+        return in;
+    };
+    auto make_h_mma = [&](const HIn &in) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = in.b;
+        acc = Pol::mma(in.e0, in.w0, acc);
+        acc = Pol::mma(in.e1, in.w1, acc);
+        return acc;
+    };
+    auto make_h_write = [&](char *gp, const f32x16 &acc) {
+        if (wv < MT) {
+            frag o[2];
+            unsigned unused = 0;
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) Pol::relu_pair(o[r >> 3], (r & 7) >> 1, r >> 1, acc[r], acc[r + 1], unused);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) *reinterpret_cast<frag *>(gp + OFF_H + wv * TB + s2 * Pol::FRAG_BYTES + lane * 16) = o[s2];
+        }
+    };
+    // LAST: W_out of this lane's feature in each of the wave's A tiles
+    float wout_r[MPW];
+    if constexpr (LAST) {
+#pragma unroll
+        for (int mi = 0; mi < MPW; ++mi) {
+            const int f = 32 * (wr * MPW + mi) + (lane & 31);
+            wout_r[mi] = f < W ? reinterpret_cast<const float *>(A.f.packed + A.f.wout_off)[f] : 0.f;
+        }
+    }
+    float *slab = A.f.slabs + (long long)blockIdx.x * BG::SLAB_FLOATS;
+
+    int boff[NPW];
+#pragma unroll
+    for (int ni = 0; ni < NPW; ++ni) {
+        const int n = nbase + ni;
+        boff[ni] = has_h ? OFF_H + (n < nH ? n : 0) * TB : OFF_E;        // a column share that ends early repeats tile 0 (dropped at the flush)
+    }
+    const bool bias_rows = wc == 0;                                    // this wave sums the bias column of its A tiles
+    const bool out_bias_wave = LAST && wr == 0 && wc == 0;             // ... and this one the output layer's bias
+    f32x16 acc[MPW][NPW], acc_e[ME];
+    float bsum[MPW], orow[ME], bout = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < MPW; ++mi) {
+        bsum[mi] = 0.f;
+#pragma unroll
+        for (int ni = 0; ni < NPW; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < ME; ++e) {
+        orow[e] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_e[e][r] = 0.f;
+    }
+
+    // ---- per-group A state: fragments of the wave's A tiles for both k-steps (+ LAST: the f32 dout of the lane's points)
+    struct AState { frag af[2][MPW]; f32x4 da[2], db[2]; };
+    auto load_b = [&](const char *gp, int t) -> frag {
+        if constexpr (make_h) return Pol::lds_frag(gp + boff[t % NPW], t / NPW, lane);     // written by make_h_write in fragment order
+        else return tr_frag(gp + boff[t % NPW], t / NPW, trl);
+    };
+    auto a_load = [&](const char *gp, AState &st) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+            for (int mi = 0; mi < MPW; ++mi) st.af[s2][mi] = tr_frag(gp + (wr * MPW + mi) * TB, s2, trl);
+            if constexpr (LAST) {
+                // dout of this lane's eight points of k-step s2: tape point order p = (j&3) + 8(j>>2) + 16 s2 + 4 (lane>>5)
+                const float *d32 = reinterpret_cast<const float *>(gp + OFF_D32) + 16 * s2 + 4 * (lane >> 5);
+                st.da[s2] = *reinterpret_cast<const f32x4 *>(d32);
+                st.db[s2] = *reinterpret_cast<const f32x4 *>(d32 + 8);
+            }
+        }
+    };
+    // piece k = (k-step, A tile) of the preparation of a group's A fragments; `live`: the group exists (the state of
+    // the group behind the last one is loaded but must not be accumulated)
+    auto a_prep = [&](AState &st, int k, bool live) {
+        const int s2 = k / MPW, mi = k % MPW;
+        if constexpr (LAST) {
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            typedef short i16x2 __attribute__((ext_vector_type(2)));
+            const f32x4 da = st.da[s2], db = st.db[s2];
+            const frag rawf = st.af[s2][mi];
+            const u32x4 raw = __builtin_bit_cast(u32x4, rawf);
+            u32x4 ga;
+            float o = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x2 dd = {i < 2 ? da[2 * i] : db[2 * i - 4], i < 2 ? da[2 * i + 1] : db[2 * i - 3]};
+                // the output layer's row: dW_out[f] += dout_p h_depth[p][f], bf16 operands, f32 accumulation (v_dot2c)
+                const typename Pol::bf16x2 dpk = {(__bf16)dd[0], (__bf16)dd[1]};
+                const typename Pol::bf16x2 hp = {rawf[2 * i], rawf[2 * i + 1]};
+                o = __builtin_amdgcn_fdot2_f32_bf16(hp, dpk, o, false);
+                // gA_{depth-1} = (h_depth != 0) * bf16(W_out * dout): same product and rounding as the delta chain (dw_body)
+                const f32x2 pr = dd * wout_r[mi];
+                const typename Pol::bf16x2 t = {(__bf16)pr[0], (__bf16)pr[1]};
+                const unsigned sgn = raw[i] + 0x7fff7fffu;
+                const i16x2 on = __builtin_bit_cast(i16x2, sgn) >> (i16x2){15, 15};
+                ga[i] = __builtin_bit_cast(unsigned, t) & __builtin_bit_cast(unsigned, on);
+            }
+            st.af[s2][mi] = __builtin_bit_cast(frag, ga);
+            if (live && (mi % WCC) == wc) orow[mi / WCC] += o;
+            if (live && out_bias_wave && mi == 0) bout += (da[0] + da[1]) + (da[2] + da[3]) + (db[0] + db[1]) + (db[2] + db[3]);
+        }
+        if (live && bias_rows) bsum[mi] = Pol::sum8(st.af[s2][mi], bsum[mi]);
+    };
+    constexpr int NPREP = 2 * MPW;
+    constexpr int T_PREP = NTOT > 3 ? 3 : NTOT - 1;
+    // MFMA phase of the group in `gp` (A fragments `cur`, first B fragments `bc`), with the loads / preparation of the
+    // next group's A state `nx` and first B fragments `bn` from `gnext` folded into its steps
+    auto mma_phase = [&](const char *gp, const AState &cur, const frag (&bc)[2], const char *gnext, AState &nx, frag (&bn)[2],
+                         bool live_next) {
+        frag bq[3], benc;
+        if constexpr (make_h) {
+            bq[0] = load_b(gp, 0);
+            if (NTOT > 1) bq[1] = load_b(gp, 1);
+        } else {
+            bq[0] = bc[0]; bq[1] = bc[1];
+        }
+#pragma unroll
+        for (int t = 0; t < NTOT; ++t) {
+            if (t + 2 < NTOT) bq[(t + 2) % 3] = load_b(gp, t + 2);
+            if (enc_extra && (t % NPW) == (NPW >= 2 ? NPW - 2 : 0)) benc = tr_frag(gp + OFF_E, t / NPW, trl);     // used at ni == NPW-1
+            if (t == 0) a_load(gnext, nx);
+            __builtin_amdgcn_sched_barrier(0);
+            const int s2 = t / NPW, ni = t % NPW;
+#pragma unroll
+            for (int mi = 0; mi < MPW; ++mi) acc[mi][ni] = Pol::mma(cur.af[s2][mi], bq[t % 3], acc[mi][ni]);
+            if constexpr (enc_extra) {
+                if (ni == NPW - 1) {
+#pragma unroll
+                    for (int mi = 0; mi < MPW; ++mi)
+                        if ((mi % WCC) == wc) acc_e[mi / WCC] = Pol::mma(cur.af[s2][mi], benc, acc_e[mi / WCC]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NPREP; ++k)
+                if (t == (T_PREP + k < NTOT ? T_PREP + k : NTOT - 1)) a_prep(nx, k, live_next);
+            if constexpr (!make_h) {
+                if (t == (NTOT >= 2 ? NTOT - 2 : 0)) bn[0] = load_b(gnext, 0);
+                if (t == NTOT - 1) bn[1] = load_b(gnext, NTOT > 1 ? 1 : 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // ---- the stream: pieces (1 KiB = one wave-wide DMA) this job needs: [A tiles][h tiles][enc tile][f32 dout piece]
+    constexpr int PA = MT * TB / 1024, PH = (has_h && !make_h) ? MT * TB / 1024 : 0,
+                  PE = (JT == JT_FIRST || JT == JT_SKIP || make_h) ? TB / 1024 : 0, PD = LAST ? 1 : 0;
+    constexpr int NPJ = PA + PH + PE + PD, PPW = (NPJ + Pol::NWAVES - 1) / Pol::NWAVES;
+    const int wvu = __builtin_amdgcn_readfirstlane(wv);
+    const char *sbase[PPW];
+    long long sstride[PPW];
+    int doff[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        int piece = wvu + Pol::NWAVES * i;
+        piece = piece < NPJ ? piece : NPJ - 1;                  // tail waves re-issue the last piece
+        if (piece < PA) {
+            doff[i] = piece * 1024; sbase[i] = srcA + piece * 1024; sstride[i] = (long long)MT * TB;
+        } else if (piece < PA + PH) {
+            doff[i] = OFF_H + (piece - PA) * 1024; sbase[i] = srcH + (piece - PA) * 1024; sstride[i] = (long long)MT * TB;
+        } else if (piece < PA + PH + PE) {
+            doff[i] = OFF_E + (piece - PA - PH) * 1024; sbase[i] = srcE + (piece - PA - PH) * 1024; sstride[i] = TB;
+        } else {                                                // LAST: the KiB that starts with this group's 32 f32 dout
+            doff[i] = OFF_D32; sbase[i] = srcD; sstride[i] = A.t.dout_stride;
+        }
+    }
+    auto issue = [&](long long q, char *buf) {
+        q = q < q1 ? q : q1 - 1;
+        if (BHN_DBG(A.wrap)) q %= A.wrap;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            if (BHN_DBG(A.policy == 1)) dma_1k_asm<0>(sbase[i] + q * sstride[i], buf + doff[i]);
+            else if (BHN_DBG(A.policy == 2)) dma_1k_asm<2>(sbase[i] + q * sstride[i], buf + doff[i]);
+            else dma_1k_asm<1>(sbase[i] + q * sstride[i], buf + doff[i]);
+        }
+    };
+    __syncthreads();                                            // W_0 / b_0 visible (HIDDEN1)
+    if (q0 < q1) {
+        AState sa, sb;
+        frag ba[2], bb[2];
+        issue(q0, smem);
+        issue(q0 + 1, smem + GB);
+        issue(q0 + 2, smem + 2 * GB);
+        if (!BHN_DBG(A.debug & 2)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if constexpr (make_h) make_h_write(smem, make_h_mma(make_h_read(smem)));     // published by the first loop barrier
+        if (works) {
+            a_load(smem, sa);
+#pragma unroll
+            for (int k = 0; k < NPREP; ++k) a_prep(sa, k, true);
+            if constexpr (!make_h) { ba[0] = load_b(smem, 0); ba[1] = load_b(smem, NTOT > 1 ? 1 : 0); }
+        }
+        auto body = [&](AState &cur, AState &nx, frag (&bc)[2], frag (&bn)[2], long long q, int it) {
+            // group q+1 has landed for this wave (q+2 may still be in flight), then it is published to the workgroup
+            if (!BHN_DBG(A.debug & 2)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+            if constexpr (make_h) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's h-tile writes
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");      // the raw barrier is not a compiler fence
+            // every wave has finished group q-1: its buffer takes group q+3
+            if (!BHN_DBG(A.debug & 2)) issue(q + 3, smem + ((it + 3) & 3) * GB);
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const char *gp = smem + it * GB;
+            char *gnext = smem + ((it + 1) & 3) * GB;
+            const bool live_next = q + 1 < q1;
+            f32x16 hacc = {};
+            if constexpr (make_h) hacc = make_h_mma(make_h_read(gnext));
+            if (!BHN_DBG(A.debug & 1) && works) mma_phase(gp, cur, bc, gnext, nx, bn, live_next);
+            if constexpr (make_h) {
+                if (live_next) make_h_write(gnext, hacc);
+            }
+        };
+        int it = 0;
+        for (long long q = q0; q < q1;) {
+            body(sa, sb, ba, bb, q, it);
+            ++q; it = (it + 1) & 3;
+            if (q >= q1) break;
+            body(sb, sa, bb, ba, q, it);
+            ++q; it = (it + 1) & 3;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    // ---- flush: slab[(m*NTMAX+n)][r/4][lane][r%4] ---------------------------------------------
+    auto flush_tile = [&](int m, int n, const f32x16 &t) {
+        float *tp = slab + (long long)(m * BG::NTMAX + n) * 1024;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = t[4 * g4 + e];
+            f32x4 *dst = reinterpret_cast<f32x4 *>(tp + g4 * 256 + lane * 4);
+            if (A.accumulate) {
+                const f32x4 old = *dst;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += old[e];
+            }
+            *dst = v;
+        }
+    };
+    // one float of row i (= lane & 31, halves added) of slab tile (m, n), column 0
+    auto flush_column0 = [&](int m, int n, float v, bool on) {
+        v += __shfl_xor(v, 32, 64);
+        if (on && lane < 32) {
+            const int hh = (lane >> 2) & 1, r = (lane & 3) + 4 * (lane >> 3);
+            float *dst = slab + (long long)(m * BG::NTMAX + n) * 1024 + (r >> 2) * 256 + (32 * hh) * 4 + (r & 3);
+            if (A.accumulate) v += *dst;
+            *dst = v;
+        }
+    };
+#pragma unroll
+    for (int mi = 0; mi < MPW; ++mi) {
+        const int m = wr * MPW + mi;
+#pragma unroll
+        for (int ni = 0; ni < NPW; ++ni) {
+            const int n = nbase + ni;
+            if (m < MT && n < nBr) flush_tile(m, n, acc[mi][ni]);
+        }
+        if (enc_extra && (mi % WCC) == wc && m < MT) flush_tile(m, nH, acc_e[mi / WCC]);
+        flush_column0(m, nB, bsum[mi], bias_rows && m < MT);
+        if constexpr (LAST) {
+            // the output layer's row: slab row MT, tile m, row 0, column f = lane & 31 (where reduce_kernel reads dW_out[32 m + f])
+            float v = orow[mi / WCC] + __shfl_xor(orow[mi / WCC], 32, 64);
+            if ((mi % WCC) == wc && m < MT && lane < 32) {
+                float *dst = slab + (long long)(MT * BG::NTMAX + m) * 1024 + lane * 4;
+                if (A.accumulate) v += *dst;
+                *dst = v;
+            }
+        }
+    }
+    if constexpr (LAST) {
+        float v = bout + __shfl_xor(bout, 32, 64);
+        if (out_bias_wave && lane == 0) {
+            float *dst = slab + (long long)(MT * BG::NTMAX + MT) * 1024;
+            if (A.accumulate) v += *dst;
+            *dst = v;
+        }
+    }
+}
+
 template <int W, class Pol>
 __global__ __launch_bounds__(Pol::NTHREADS) void dw_kernel(BwdArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];       // NBUF x GROUP_BYTES
@@ -935,17 +1301,21 @@ __global__ __launch_bounds__(Pol::NTHREADS) void dw_kernel(BwdArgs A) {
     int job = 0;
     while (job < depth && (int)blockIdx.x >= A.wg_begin[job + 1]) ++job;
     if (BHN_DBG(A.debug >> 2) && (A.debug >> 2) - 1 != job) return;
-    if (job == depth) dw_body<W, Pol, JT_OUT>(A, job, smem);
-    else if (job == 0) dw_body<W, Pol, JT_FIRST>(A, job, smem);
-    else if (job == depth - 1 && A.t.drop_ga) {
-        if constexpr (Pol::ELEM_BYTES == 2) {
-            if ((A.f.skip_mask >> job) & 1) dw_body<W, Pol, JT_SKIP, true>(A, job, smem);
-            else dw_body<W, Pol, JT_HIDDEN, true>(A, job, smem);
-        }
-    } else if ((A.f.skip_mask >> job) & 1) dw_body<W, Pol, JT_SKIP>(A, job, smem);
-    else if (job == 1 && A.t.drop_h1) {
-        if constexpr (Pol::ELEM_BYTES == 2) dw_body<W, Pol, JT_HIDDEN1>(A, job, smem);
-    } else dw_body<W, Pol, JT_HIDDEN>(A, job, smem);
+    if constexpr (Pol::ELEM_BYTES == 2) {           // bf16: software-pipelined bodies; the output layer rides on job depth-1
+        if (job == depth) dw_body<W, Pol, JT_OUT>(A, job, smem);         // (depth < 3 only)
+        else if (job == 0) dw_body2<W, Pol, JT_FIRST>(A, job, smem);
+        else if (job == depth - 1 && A.t.drop_ga) {
+            if ((A.f.skip_mask >> job) & 1) dw_body2<W, Pol, JT_SKIP, true>(A, job, smem);
+            else dw_body2<W, Pol, JT_HIDDEN, true>(A, job, smem);
+        } else if ((A.f.skip_mask >> job) & 1) dw_body2<W, Pol, JT_SKIP>(A, job, smem);
+        else if (job == 1 && A.t.drop_h1) dw_body2<W, Pol, JT_HIDDEN1>(A, job, smem);
+        else dw_body2<W, Pol, JT_HIDDEN>(A, job, smem);
+    } else {
+        if (job == depth) dw_body<W, Pol, JT_OUT>(A, job, smem);
+        else if (job == 0) dw_body<W, Pol, JT_FIRST>(A, job, smem);
+        else if ((A.f.skip_mask >> job) & 1) dw_body<W, Pol, JT_SKIP>(A, job, smem);
+        else dw_body<W, Pol, JT_HIDDEN>(A, job, smem);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1030,7 +1400,7 @@ static void tape_layout(int depth, bool layer1_takes_enc, long long NQ, TapeLayo
         t->ga_off[l] = off; off += per_tensor;
     }
     t->enc_off = off; off += NQ * (long long)BG::TILE_BYTES;
-    t->dout_stride = BG::TILE_BYTES + (t->drop_ga ? 128 : 0);   // dout as an A tile: row 0 = dout, rows 1..31 zero (+ f32 dout)
+    t->dout_stride = t->drop_ga ? 128 : BG::TILE_BYTES;         // 32 f32 dout per group, or dout as an A tile (row 0 = dout)
     t->dout_off = off; off += NQ * t->dout_stride;
     t->mask_off = off; off += NQ * (long long)depth * ((BG::MT + 1) / 2) * 256;
     t->e_off = off; off += NQ * 128;
@@ -1146,7 +1516,7 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
     const size_t lds_fixed = (size_t)(depth + 1) * W * 4 + 128 + W * 4 + 2 * Pol::FRAG_BYTES;
     const size_t lds_taped = (size_t)(BG::RING_DIST_TAPED + 1) * PK::CHUNK_BYTES + lds_fixed;
     size_t lds_dw = (size_t)BG::NBUF * BG::GROUP_BYTES + (t1.drop_h1 ? (size_t)2 * BG::MT * Pol::FRAG_BYTES + W * 4 : 0);
-    if (t1.drop_ga && (size_t)BG::NBUF * BG::GROUP_BYTES_LAST > lds_dw) lds_dw = (size_t)BG::NBUF * BG::GROUP_BYTES_LAST;
+    if (t1.drop_ga && (size_t)BG::NBUF * BG::GROUP_BYTES_LAST2 > lds_dw) lds_dw = (size_t)BG::NBUF * BG::GROUP_BYTES_LAST2;
     auto k_fwd = chain_kernel<W, Pol, 3, MODE_FWD_TRAIN>;
     auto k_chn = chain_kernel<W, Pol, 3, MODE_CHAIN>;
     auto kdw = dw_kernel<W, Pol>;
@@ -1174,6 +1544,8 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
         A.debug = g_bwd_debug;
 #ifdef BHN_DEBUG
         A.ts_buf = (g_bwd_debug & 512) ? reinterpret_cast<long long *>(bhn_debug_buffer()) : nullptr;
+        A.wrap = dbg_env_int("BHN_DEBUG_WRAP", 0);
+        A.policy = dbg_env_int("BHN_DEBUG_POLICY", 0);
 #endif
         long long grid = ncu;
         if (grid > A.f.total_tiles) grid = A.f.total_tiles;

@@ -468,15 +468,19 @@ DEVI void dma_1k(const char *src, char *dst) {
 // (measured: dW kernel 5.3 -> 7.5 ms).  Issued from inline asm the DMA is invisible to that pass; its completion is
 // ordered by the kernel's own counted vmcnt waits + barrier, exactly as for the builtin form.  M0 = LDS byte address
 // of the wave's first lane (the compiler never keeps M0 live: it is not an allocatable register).
-template <bool STREAM = false>
+template <int POLICY = 0>      // 0 default, 1 nt (bytes one CU reads once from HBM), 2 sc1 (bytes another CU has just written)
 DEVI void dma_1k_asm(const char *src, char *dst) {
     const unsigned long long u = reinterpret_cast<unsigned long long>(src);
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
     const u32x4 rs = {lo, hi & 0xffffu, 1u << 20, 0x00020000u};
-    const unsigned m = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char *)dst);
+    // LDS byte address = low 32 bits of the flat address (the shared aperture base sits in the high half); no
+    // addrspacecast: its null check (v_cmp against src_shared_base) fails hipcc 7.2's machine verifier in some contexts
+    const unsigned m = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<unsigned long long>(dst));
     const unsigned voff = (threadIdx.x & 63) * 16;
-    if constexpr (STREAM)
+    if constexpr (POLICY == 1)
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen nt lds" ::"s"(m), "v"(voff), "s"(rs) : "memory");
+    else if constexpr (POLICY == 2)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen sc1 lds" ::"s"(m), "v"(voff), "s"(rs) : "memory");
     else
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(m), "v"(voff), "s"(rs) : "memory");
 }

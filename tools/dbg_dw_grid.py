@@ -1,4 +1,5 @@
 """dW kernel time as a function of the number of workgroups (BHN_DEBUG_DW_GRID): is the tape stream bound per CU or by HBM?"""
+import os; os.environ.setdefault('BHNERF_HIP_LIB', '/root/repo/bhnerf_amd/csrc/libbhnerf_hip_dbg.so')
 import os, subprocess, sys
 if len(sys.argv) > 1:
     import numpy as np, torch

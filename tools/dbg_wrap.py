@@ -1,0 +1,35 @@
+"""What would the tape producers / the dW stream cost if the tape never left the chip?  Debug build: BHN_DEBUG_WRAP=<groups>
+wraps the h / gA tile addresses of the producers and every tape read of the dW kernel into a window of that many
+32-point groups (results are garbage, timing is what is measured).  Run once per window size:
+    BHN_DEBUG_WRAP=8192 python tools/dbg_wrap.py"""
+import sys, numpy as np, torch
+sys.path.insert(0, '/root/repo')
+import os; os.environ.setdefault('BHNERF_HIP_LIB', '/root/repo/bhnerf_amd/csrc/libbhnerf_hip_dbg.so')   # debug build: make -C bhnerf_amd/csrc debug
+from bhnerf_amd import _hip, engine, network, synthetic, constants
+dev = torch.device('cuda:0')
+H = W = 128; G = 64; B = 8
+geo = synthetic.synthetic_geodesics(H, W, G)
+pred = network.NeRF_Predictor(8.0, 0.0, np.inf, np.inf, net_depth=4, net_width=256, mode='bf16', device=dev)
+eng = pred.engine()
+geom = pred.geometry(geo['coords'], geo['Omega'], geo['t_geos'], None, geo['g'], geo['dtau'], geo['Sigma'])
+flat = eng.flatten(network.MLP(4, 256).init(1, 21)); eng.pack(flat)
+tM0 = engine.frame_offsets(np.linspace(0, 1, B), 0.0, geo['t_injection'], constants.GM_c3('hr'), dev)
+dimg = torch.rand((B, 1, geom.R), device=dev) * 1e-3
+def timed(fn, reps=4):
+    fn(); torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in ev:
+        a.record(); fn(); b.record()
+    torch.cuda.synchronize()
+    return float(np.mean([a.elapsed_time(b) for a, b in ev]))
+lib = _hip.lib()
+eng.render_train(geom, tM0); eng.render_bwd_tape(geom, tM0, dimg)
+wrap = int(os.environ.get('BHN_DEBUG_WRAP', '0'))
+t1 = timed(lambda: eng.render_train(geom, tM0))
+lib.bhn_debug_set_bwd_stages(1)
+t2 = timed(lambda: eng.render_bwd_tape(geom, tM0, dimg))
+lib.bhn_debug_set_bwd_stages(2)
+t3 = timed(lambda: eng.render_bwd_tape(geom, tM0, dimg))
+lib.bhn_debug_set_bwd_stages(7)
+pol = int(os.environ.get('BHN_DEBUG_POLICY', '0'))
+print('policy %d wrap %8d groups (window %7.1f MB per 16 KB tensor-group)  fwd_train %.3f ms   chain %.3f ms   dW %.3f ms' % (pol, wrap, wrap * 16384 / 1e6, t1, t2, t3))
