@@ -384,6 +384,19 @@ def main():
                'shape': '%d planes x %d rays x %d samples (%.2f GB)' % (Nrt, Rrt, Grt, rt_bytes / 1e9)}
     del e_rt, planes
 
+    # ---- EHT visibility loss at BASELINE config 4's size (EHT2017: 28 baselines, 256x256 image, 8 frames): HBM-bound ----
+    Ne, nvis, Re = 8, 28, 256 * 256
+    img_e = torch.rand((Ne, Re), device=dev)
+    A_e = torch.view_as_complex(torch.randn((Ne, nvis, Re, 2), device=dev))
+    tgt_e = torch.view_as_complex(torch.randn((Ne, nvis, 2), device=dev))
+    sig_e = torch.ones((Ne, nvis), device=dev)
+    eht_ms = timed(lambda: engine.chi2_eht(img_e, A_e, tgt_e, sig_e, 1.0, 'vis'), reps=10)
+    eht_bytes = 2 * 8 * Ne * nvis * Re                                          # A read by the GEMV and by its adjoint
+    eht_loss = {'kernel': 'eht_vis_kernel + eht_loss_kernel + eht_bwd_kernel', 'bound': 'hbm', 'achieved': round(eht_bytes / (eht_ms * 1e-3) / 1e9, 1),
+                'peak': 8000.0, 'unit': 'GB/s', 'frac': round(eht_bytes / (eht_ms * 1e-3) / 8e12, 4), 'ms': round(eht_ms, 4),
+                'shape': "loss 'vis' + gradient, %d frames x %d visibilities x %d pixels (%.1f MB)" % (Ne, nvis, Re, eht_bytes / 1e6)}
+    del img_e, A_e, tgt_e, sig_e
+
     # the same workload with the tutorials' recovery domain (rmin 2 M, rmax = fov/2, |z| <= 4 M): the samples outside it
     # have emission 0 and are compacted away (engine.RayGeometry.compact).  Reported next to the all-active headline,
     # never as `value`; single GPU only.
@@ -415,6 +428,7 @@ def main():
                    'loss': loss_now},
         'roofline': roofline,
         'rt_scan': rt_scan,
+        'eht_loss': eht_loss,
         'fwd_images_per_s': round(args.frames_per_gpu / (kern_ms['fused_fwd_kernel (inference)'] * 1e-3), 1),
     }
     if parity:
