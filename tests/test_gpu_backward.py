@@ -3,24 +3,28 @@ loss_fn_image against (i) torch.autograd on the float64 oracle and (ii) the fini
 the REFERENCE's own loss_fn_image stored in the golden fixtures; Adam training steps against the
 oracle trainer; workspace frame-chunking.
 
-Tolerances (error / largest gradient entry, and relative L2): f32 mode L2 5e-4, max 1e-3; bf16 mode
-L2 5e-2, max 1.5e-1 (bf16 activations / deltas on the tape, f32 accumulate; the tiny fixtures have
-only ~100 points to average over).  The max-norm bound is looser than the typical 1e-7..1e-6 f32
-error because a ReLU-net gradient is discontinuous: when one pre-activation lies within f32 rounding
-of zero, f32 and f64 disagree on relu' for that (point, unit) and every layer below it changes by that
-one point's contribution (~1e-4 of the maximum) while the image is unaffected (observed: W=128, S=3)."""
+Tolerances (error / largest gradient entry, and relative L2), set from what the kernels deliver on these fixtures
+(tools/diag_tol.py, round 2): f32 mode 2e-5 for both (observed <= 1.6e-6), loss 1e-5 (observed <= 1.6e-6); bf16 mode L2
+6e-2, max 1.2e-1, loss 3e-2 (observed <= 3.7e-2 / 7.5e-2 / 1.7e-2: bf16 activations and deltas on the tape, f32
+accumulation, and only 100-500 points per fixture to average the rounding over -- the full-size test holds 2e-2).
+A ReLU-net gradient is discontinuous: where a pre-activation lies within f32 rounding of zero, f32 and f64 may
+disagree on relu' for that (point, unit) and every layer below changes by that one point's contribution.  Such cases
+are DETECTED (conftest.relu_tie_count on the float64 reference forward) and only then the f32 bound falls back to 1e-3;
+none of the committed fixtures has one."""
 import numpy as np
 import pytest
 import torch
 
-from conftest import golden_tree
+from conftest import golden_tree, relu_tie_count
 from oracle import oracle_np as onp
 from oracle import oracle_torch as ot
 
 pytestmark = pytest.mark.gpu
 PRED = ['a', 'b', 'c', 'd', 'e', 'f']
-GTOL = {'f32': 1e-3, 'bf16': 1.5e-1}       # max-norm
-L2TOL = {'f32': 5e-4, 'bf16': 5e-2}        # relative L2
+GTOL = {'f32': 2e-5, 'bf16': 1.2e-1}       # max-norm
+L2TOL = {'f32': 2e-5, 'bf16': 6e-2}        # relative L2
+LOSSTOL = {'f32': 1e-5, 'bf16': 3e-2}
+TIE_FALLBACK = 1e-3                        # f32 bound when the fixture has a ReLU tie (detected, see the module docstring)
 
 
 def l2err(a, b):
@@ -94,17 +98,19 @@ def test_gradient_vs_oracle_and_reference_fd(dev, golden, tag, dt, mode):
                                            rt['t_start_obs'], rt['t_geos'], rt['t_injection'], scale, units.hr, dt)
     loss.backward()
     gdev = params.grad.cpu().numpy().astype(np.float64)
-    assert abs(loss.item() - loss_ref.item()) <= 10 * GTOL[mode] * abs(loss_ref.item())
+    assert abs(loss.item() - loss_ref.item()) <= LOSSTOL[mode] * abs(loss_ref.item())
     gmax = np.abs(gref).max()
     assert gmax > 0
+    ties = relu_tie_count(g) if mode == 'f32' else 0
+    gtol, l2tol = (TIE_FALLBACK, TIE_FALLBACK) if ties else (GTOL[mode], L2TOL[mode])
     err = np.abs(gdev - gref).max() / gmax
-    assert err < GTOL[mode], err
-    assert l2err(gdev, gref) < L2TOL[mode], l2err(gdev, gref)
+    assert err < gtol, (err, ties)
+    assert l2err(gdev, gref) < l2tol, (l2err(gdev, gref), ties)
     if dt == 'full':      # finite differences of the reference's own loss_fn_image (float64)
         eng = pred.engine()
         for (li, i, j), fd in zip(g['fd_idx'], g['fd_val']):
             idx = eng.kernel_off[li] + i * eng.out_dim[li] + j if i >= 0 else eng.bias_off[li] + j
-            assert abs(gdev[idx] - fd) <= GTOL[mode] * np.abs(g['fd_val']).max() + 2e-5 * abs(fd)
+            assert abs(gdev[idx] - fd) <= gtol * np.abs(g['fd_val']).max() + 2e-5 * abs(fd)
 
 
 @pytest.mark.parametrize('tag', ['a', 'b', 'f'])
@@ -225,6 +231,7 @@ def test_random_problem_f32_and_bf16(dev, width, depth, S, deg):
     loss_ref, img_ref, grads_ref = tr.loss_and_grad(t(t_frames), t(target), t(sigma), t(offset), 1.0, 'full')
     n = len(tr.k)
     gref = np.concatenate([np.concatenate([grads_ref[i].numpy().ravel(), grads_ref[n + i].numpy().ravel()]) for i in range(n)])
+    ties = relu_tie_count(g)
     for mode in ('f32', 'bf16'):
         pred, rt = device_setup(g, mode, dev)
         params = pred.engine().flatten(golden_tree(g)).requires_grad_(True)
@@ -233,12 +240,13 @@ def test_random_problem_f32_and_bf16(dev, width, depth, S, deg):
                                                rt['J'], rt['g'], rt['dtau'], rt['Sigma'], 0.0, rt['t_geos'], t_inj, 1.0,
                                                units.hr, 'full')
         loss.backward()
-        tol_img = {'f32': 1e-5, 'bf16': 3e-2}[mode]
+        tol_img = {'f32': 1e-5, 'bf16': 1e-2}[mode]
         ierr = np.abs(images.detach().cpu().numpy().reshape(img_ref.shape) - img_ref.numpy()).max() / img_ref.abs().max().item()
         assert ierr < tol_img, (mode, ierr)
+        gtol, l2tol = (TIE_FALLBACK, TIE_FALLBACK) if (ties and mode == 'f32') else (GTOL[mode], L2TOL[mode])
         gerr = np.abs(params.grad.cpu().numpy() - gref).max() / np.abs(gref).max()
-        assert gerr < GTOL[mode], (mode, gerr)
-        assert l2err(params.grad.cpu().numpy(), gref) < L2TOL[mode]
+        assert gerr < gtol, (mode, gerr, ties)
+        assert l2err(params.grad.cpu().numpy(), gref) < l2tol, (mode, l2err(params.grad.cpu().numpy(), gref), ties)
 
 
 @pytest.mark.parametrize('mode', ['f32', 'bf16'])

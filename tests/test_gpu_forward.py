@@ -13,7 +13,8 @@ from oracle import oracle_np as onp
 
 pytestmark = pytest.mark.gpu
 PRED = ['a', 'b', 'c', 'd', 'e', 'f']
-TOL = {'f32': 1e-5, 'bf16': 3e-2}
+TOL = {'f32': 1e-5, 'bf16': 2e-2}          # emission (observed <= 9.4e-7 / 1.0e-2, tools/diag_tol.py)
+IMG_TOL = {'f32': 1e-5, 'bf16': 1e-2}      # images (observed <= 6.8e-7 / 5.7e-3)
 
 
 @pytest.fixture(scope='module')
@@ -72,7 +73,13 @@ def test_geom_prepare(dev, golden):
     c = g['coords'].astype(np.float32)
     r2 = (c ** 2).sum(0)
     dom = ~((r2 < np.float32(hp[1]) ** 2) | (r2 > np.float32(hp[2]) ** 2) | (np.abs(c[2]) > hp[3]))
-    assert (geo.dom.cpu().numpy().reshape(dom.shape) != dom).mean() < 0.02     # only f32 boundary ties may differ
+    # the mask equals the float64 reference's except where the decision lies within f32 rounding (none in this fixture)
+    from conftest import mask_tie_points
+    ties = mask_tie_points(g)[0]
+    dom64 = ~((g['coords'] ** 2).sum(0) < hp[1] ** 2) & ~((g['coords'] ** 2).sum(0) > hp[2] ** 2) & ~(np.abs(g['coords'][2]) > hp[3])
+    bad = (geo.dom.cpu().numpy().reshape(dom.shape) != dom64) & ~ties
+    assert not bad.any(), int(bad.sum())
+    assert (geo.dom.cpu().numpy().reshape(dom.shape) != dom).sum() <= ties.sum()
     assert 0.0 < geo.active_fraction < 1.0
 
 
@@ -95,9 +102,12 @@ def test_predictor_apply_golden(dev, golden, tag, mode):
                    float(g['t_start_obs']), g['t_geos'].astype(np.float32), float(g['t_injection']))
     assert tuple(e.shape) == g['emission'].shape
     e = e.cpu().numpy()
-    # masks must agree exactly away from f32 ties of the domain boundary
-    assert ((e == 0) != (g['emission'] == 0)).mean() < 0.02
-    same = (e == 0) == (g['emission'] == 0)
+    # the masks (domain, injection) agree exactly except where the reference's decision lies within f32 rounding
+    from conftest import mask_tie_points
+    ties = mask_tie_points(g).reshape(e.shape)
+    mismatch = (e == 0) != (g['emission'] == 0)
+    assert not (mismatch & ~ties).any(), int((mismatch & ~ties).sum())
+    same = ~mismatch
     assert relerr(e[same], g['emission'][same]) < TOL[mode], relerr(e[same], g['emission'][same])
 
 
@@ -114,8 +124,14 @@ def test_image_plane_prediction_golden(dev, golden, tag, mode):
                                                 f('dtau'), f('Sigma'), float(g['t_start_obs']), f('t_geos'),
                                                 float(g['t_injection']), units.hr)
     assert tuple(images.shape) == g['images'].shape          # incl. the b=1 squeeze quirk (tag d)
-    # a boundary tie may flip one sample of a ray: compare with a tolerance scaled to the image maximum
-    assert relerr(images.cpu().numpy(), g['images']) < max(TOL[mode], 1e-5)
+    # a boundary tie may flip one sample of a ray: pixels whose ray holds no tie point are held to the tolerance
+    from conftest import mask_tie_points
+    tie_ray = mask_tie_points(g).any(axis=-1)                                  # (b, H, W)
+    got, ref = images.cpu().numpy(), g['images']
+    S = g['J'].shape[0] if g['J'].ndim else 0
+    clean = ~np.broadcast_to(tie_ray[:, None] if S else tie_ray, (len(g['t_frames']),) + ((S,) if S else ()) + tie_ray.shape[1:]).reshape(ref.shape)
+    assert clean.any()
+    assert np.abs(got - ref)[clean].max() / np.abs(ref).max() < IMG_TOL[mode]
 
 
 def test_chi2_and_adam(dev):

@@ -62,7 +62,7 @@ def oracle_images(problem, rays):
     return onp.image_plane_prediction(e, 1.0, sub(geo['g']), sub(geo['dtau']), sub(geo['Sigma'])).reshape(B, 96)      # (B, nrays)
 
 
-@pytest.mark.parametrize('mode,tol', [('f32', 1e-5), ('bf16', 2e-2)])
+@pytest.mark.parametrize('mode,tol', [('f32', 1e-5), ('bf16', 1e-2)])
 def test_forward_full_size_against_oracle_on_a_ray_subset_and_both_routes(dev, problem, mode, tol):
     from bhnerf_amd import kgeo
     pred, eng, geom = setup(problem, mode, dev)
@@ -131,7 +131,7 @@ def test_gradient_full_width_against_oracle_on_a_ray_subset(dev, problem):
     loss_ref, _, grads_ref = tr.loss_and_grad(t64(problem['t_frames']), t64(target), t64(sigma), t64(offset), 1.0, 'full')
     n = len(tr.k)
     gref = np.concatenate([np.concatenate([grads_ref[i].numpy().ravel(), grads_ref[n + i].numpy().ravel()]) for i in range(n)])
-    for mode, l2tol in (('f32', 5e-4), ('bf16', 5e-2)):
+    for mode, l2tol in (('f32', 2e-5), ('bf16', 2e-2)):
         pred = network.NeRF_Predictor(8.0, 2.0, 8.0, 4.0, net_depth=4, net_width=256, mode=mode, device=dev)
         params = pred.engine().flatten(problem['tree']).requires_grad_(True)
         tree = network.ParamTree()
@@ -140,7 +140,7 @@ def test_gradient_full_width_against_oracle_on_a_ray_subset(dev, problem):
                                         g['g'], g['dtau'], g['Sigma'], 0.0, g['t_geos'], float(geo['t_injection']), 1.0, units.hr, 'full')
         loss.backward()
         gdev = params.grad.cpu().numpy().astype(np.float64)
-        assert abs(loss.item() - loss_ref.item()) <= (1e-4 if mode == 'f32' else 5e-2) * abs(loss_ref.item())
+        assert abs(loss.item() - loss_ref.item()) <= (1e-5 if mode == 'f32' else 2e-2) * abs(loss_ref.item())
         err = float(np.linalg.norm(gdev - gref) / np.linalg.norm(gref))
         assert err < l2tol, (mode, err)
 
