@@ -63,6 +63,8 @@ def parse():
     ap.add_argument('--masked', action='store_true', help='use the tutorial domain masks instead of all-active')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity-mode', action='store_true', help='skip the f32 parity-mode block')
+    ap.add_argument('--no-tutorial-domain', action='store_true',
+                    help='skip the masked-domain variant (profiling runs: keeps every launch of a kernel the same shape)')
     ap.add_argument('--cpu-rays', type=int, default=2048, help='rays of one frame in the CPU-baseline sample')
     ap.add_argument('--cpu-seconds', type=float, default=25.0, help='time budget of the CPU-baseline thread sweep')
     return ap.parse_args()
@@ -401,7 +403,7 @@ def main():
     # have emission 0 and are compacted away (engine.RayGeometry.compact).  Reported next to the all-active headline,
     # never as `value`; single GPU only.
     tutorial_domain = None
-    if world == 1 and not args.masked:
+    if world == 1 and not args.masked and not args.no_tutorial_domain:
         pred_m = network.NeRF_Predictor(rmax, 2.0, rmax, 4.0, net_depth=args.depth, net_width=args.width, mode=args.mode, device=dev)
         opt_m = optimization.Optimizer(hparams, pred_m, rt_args)
         run_steps(opt_m, max(args.warmup, 2))

@@ -123,7 +123,7 @@ def _read(path):
         f.seek(0)
         if head[:2] == b'PK' or head[:1] == b'\x80':               # torch.save (zip / legacy pickle): round-1 files
             import torch
-            sd = torch.load(f, map_location='cpu')
+            sd = torch.load(f, map_location='cpu', weights_only=True)      # tensors only: never unpickle code
             return {'_legacy': True, **sd}
         return msgpack_restore(f.read())
 

@@ -21,7 +21,7 @@
 #define BHN_JOB1_W 13          // weight of the layer-1 dW job in B tiles at width 256 (measured optimum; scaled with the width)
 #endif
 #ifndef BHN_JOBL_W
-#define BHN_JOBL_W 12           // extra weight (in tiles at width 256, scaled with the width) of the layer depth-1 dW job when it rebuilds gA_{depth-1} and carries the output row
+#define BHN_JOBL_W 10           // extra weight (in tiles at width 256, scaled with the width) of the layer depth-1 dW job when it rebuilds gA_{depth-1} and carries the output row
 #endif
 // Run-time measurement switches exist only in the debug build (make debug); the release kernels see the constant 0
 #ifdef BHN_DEBUG
@@ -38,6 +38,11 @@ struct TapeLayout {
     long long h_off[BHN_MAX_LAYERS + 1];       // h_l, l = 1..depth  (inputs of layer l)
     long long ga_off[BHN_MAX_LAYERS];          // gA_l, l = 0..depth-1
     long long enc_off, dout_off, mask_off, e_off, total;   // mask: relu bits [group][layer][word][lane]; e: [group][32] f32
+    // the recorded h_l / gA_l tensors are equally spaced: h_off[l] = h_lin + l * lin_stride, ga_off[l] = ga_lin + l * lin_stride.
+    // The producers address them this way: indexing the offset ARRAYS with the run-time layer made the compiler fetch
+    // the entry from the kernel-argument segment in every ring step (s_load + s_waitcnt lgkmcnt(0), which also drains
+    // the LDS prefetch queue).
+    long long h_lin, ga_lin, lin_stride;
     // bf16: h_1 = relu(W_0^T enc + b_0) is NOT on the tape; the dW job of layer 1 recomputes it from the encoded
     // inputs kept a second time in their forward (point-on-lane) fragment form -- 64 B instead of 512 B per point
     long long encp_off;
@@ -206,6 +211,14 @@ struct TapeEmit {
     }
 };
 
+// A wave-uniform 64-bit value moved into SGPRs.  The compiler keeps the result of a 64-bit division (no scalar divide) in
+// VGPRs and then does every address computation that depends on it on the vector ALU, followed by v_readfirstlane for
+// the scalar operands of the DMA: ~60 VALU instructions per group in the dW stream (round-2 ISA census).
+DEVI long long uniform64(long long v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+
 // Transposed read of a bf16 tape tile (TapeEmit::store_native image in LDS): the A / B fragment of k-step s of a dW
 // GEMM (K = points) for lane (n = lane & 31, kh = lane >> 5): feature n, points 16 s + phi16(kh, j), j = 0..7 -- the
 // same point order as the f32 tape tiles.  Two ds_read_b64_tr_b16; per 16-lane group g the instruction gathers 4 points
@@ -337,8 +350,11 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
     // cancel out of the balance, so only this store count has to be a lower bound (relu-bit words, epilogue stores and
     // prefetch loads only add slack); the exceptions are the steps right after a layer-0 step without h_1 emission.
     constexpr int ES = (Pol::ELEM_BYTES == 2) ? 2 : 4;                 // global stores of one tile emission
-    constexpr int YS = ES * (DIST - 2) + ((KS >= 16 && Pol::ELEM_BYTES == 2) ? ES : 0);   // (f32: kept conservative)
-    constexpr int YS0 = ES * (DIST - 2);                               // steps whose own stores precede their DMA issue
+#ifndef BHN_YS_EXTRA
+#define BHN_YS_EXTRA 0          // EXPERIMENT ONLY (-DBHN_YS_EXTRA=n): lets n more stores stay in flight than the ring proof allows
+#endif                          // (racy: wrong results possible) -- measures what the in-order vmcnt coupling of stores and weight DMA costs
+    constexpr int YS = ES * (DIST - 2) + ((KS >= 16 && Pol::ELEM_BYTES == 2) ? ES : 0) + BHN_YS_EXTRA;   // (f32: kept conservative)
+    constexpr int YS0 = ES * (DIST - 2) + BHN_YS_EXTRA;                // steps whose own stores precede their DMA issue
     constexpr int YS_L1r = (KS >= 16) ? YS - ES : 0;                   // first steps of layer 1 when h_1 is not emitted
     constexpr int YS_L1 = YS_L1r > 0 ? YS_L1r : 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -349,6 +365,10 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
     char *id_lds = reinterpret_cast<char *>(wout_lds + W);
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 31, h = lane >> 5;
+    const int wvu = __builtin_amdgcn_readfirstlane(wv);           // the wave index as a scalar: tape addresses stay in SGPRs
+    // scalars of the tape layout, pinned in registers (the compiler otherwise re-fetches kernel arguments inside the steps)
+    long long h_lin = A.t.h_lin, ga_lin = A.t.ga_lin, lin_stride = A.t.lin_stride;
+    asm volatile("" : "+s"(h_lin), "+s"(ga_lin), "+s"(lin_stride));
     TapeEmit<Pol> em;
     em.init(id_lds);
     for (int i = tid; i < (a.depth + 1) * W; i += Pol::NTHREADS)
@@ -387,13 +407,13 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
         for (int i = 0; i < MW; ++i) c.mtop[i] = 0u;
         if (tile < a.total_tiles) {
             const unsigned *mg = reinterpret_cast<const unsigned *>(A.tape + A.t.mask_off) +
-                                 (tile * Pol::NWAVES + wv) * (long long)(a.depth * MW * 64);
+                                 (tile * Pol::NWAVES + wvu) * (long long)(a.depth * MW * 64);
 #pragma unroll
             for (int i = 0; i < MW; ++i) c.mtop[i] = __builtin_nontemporal_load(mg + ((a.depth - 1) * MW + i) * 64 + lane);
             c.q0 = chain_word(mg, 0);
             c.q1 = chain_word(mg, 1);
             tile_point<Pol::NWAVES>(a, tile, wv, pl, c.b, c.p, c.inb);
-            if (h == 0) c.e = (reinterpret_cast<const float *>(A.tape + A.t.e_off) + (tile * Pol::NWAVES + wv) * 32)[pl];
+            if (h == 0) c.e = (reinterpret_cast<const float *>(A.tape + A.t.e_off) + (tile * Pol::NWAVES + wvu) * 32)[pl];
             if (h == 0 && c.inb) {
                 const long long ray = a.ray_idx ? (long long)a.ray_idx[c.p] : c.p / a.G;
                 for (int s = 0; s < a.Sx; ++s)
@@ -413,7 +433,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
         const int b = (MODE != MODE_CHAIN) ? in.b : cin.b;
         const long long p = (MODE != MODE_CHAIN) ? in.p : cin.p;
         const bool inb = (MODE != MODE_CHAIN) ? in.inb : cin.inb;
-        const long long q = tile * Pol::NWAVES + wv;                     // 32-point group on the tape
+        const long long q = tile * Pol::NWAVES + wvu;                    // 32-point group on the tape
         const long long qs = BHN_DBG(A.wrap) ? q % A.wrap : q;           // (debug: h / gA tiles wrap into a cache-resident window)
         unsigned *mask_g = reinterpret_cast<unsigned *>(A.tape + A.t.mask_off) + q * (long long)(a.depth * MW * 64);
         float *e_g = reinterpret_cast<float *>(A.tape + A.t.e_off) + q * 32;
@@ -448,7 +468,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
                     }
                     if (dst) em.emit(dst + (long long)m * TB, d0, d1, edbg);
                 }
-            } l0{em, drop_h1 ? nullptr : A.tape + A.t.h_off[1] + qs * MT * TB, mask_g + lane,
+            } l0{em, drop_h1 ? nullptr : A.tape + h_lin + lin_stride + qs * MT * TB, mask_g + lane,
                  nullptr, 0u, edbg};
             f32x16 pend;
             layer0_step<W, Pol, RG, YS0>(rs, ap, enc, act, bias_lds, h, pend, l0);
@@ -470,7 +490,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
                     frag &d1 = m == 0 ? act[KS - 1] : next[2 * (m > 0 ? m - 1 : 0) + 1];
                     const int widx = (pl_layer * MW + (pm >> 1)) * 64 + lane;
                     const bool no_h = drop_h1 && pl_layer == 0;     // layer 0's last tile: relu bits only
-                    TapePost<Pol, true> post(pend, d0, d1, 0u, em, A.tape + A.t.h_off[pl_layer + 1] + (qs * MT + pm) * TB,
+                    TapePost<Pol, true> post(pend, d0, d1, 0u, em, A.tape + h_lin + (pl_layer + 1) * lin_stride + (qs * MT + pm) * TB,
                                                  mask_g + widx, nullptr,
                                                  macc, pm & 1, pm == MT - 1, no_h ? (edbg | 2) : edbg);
                     // bias rows of the next tile: (l, m+1), or the first tile of the next sequence part
@@ -537,7 +557,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
             f32x16 pend = {};
             {
                 const bool keep_ga = !A.t.drop_ga;                    // else the dW kernel rebuilds gA_{depth-1}
-                char *gdst = A.tape + A.t.ga_off[a.depth - 1] + qs * MT * TB;
+                char *gdst = A.tape + ga_lin + (a.depth - 1) * lin_stride + qs * MT * TB;
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
                     const unsigned mw = cin.mtop[m >> 1] >> ((m & 1) * 16);
@@ -575,7 +595,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
                     frag &d0 = m == 0 ? dl[KS - 2] : next[2 * (m > 0 ? m - 1 : 0)];
                     frag &d1 = m == 0 ? dl[KS - 1] : next[2 * (m > 0 ? m - 1 : 0) + 1];
                     const bool no_ga = A.t.drop_ga && pnd_layer == a.depth - 1;     // gA_{depth-1}'s last tile: not recorded
-                    TapePost<Pol, false> post(pend, d0, d1, pnd_mask, em, A.tape + A.t.ga_off[pnd_layer] + (qs * MT + pm) * TB,
+                    TapePost<Pol, false> post(pend, d0, d1, pnd_mask, em, A.tape + ga_lin + pnd_layer * lin_stride + (qs * MT + pm) * TB,
                                                   nullptr, nullptr, no_acc, false, false, no_ga ? (edbg | 2) : edbg);
                     if (!(m & 1)) {                                  // word (l-1, m/2): use the oldest, fetch two ahead
                         mcur = mq0;
@@ -598,7 +618,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
             }
             if (a.depth > 1) {           // flush the last tile of gA_0 (no further step to hide it behind)
                 TapePost<Pol, false> post(pend, dl[KS - 2], dl[KS - 1], pnd_mask, em,
-                                              A.tape + A.t.ga_off[0] + (qs * MT + MT - 1) * TB, nullptr, nullptr, no_acc, false, false, edbg);
+                                              A.tape + ga_lin + (qs * MT + MT - 1) * TB, nullptr, nullptr, no_acc, false, false, edbg);
                 post.all();
             }
         }   // MODE_CHAIN
@@ -636,10 +656,10 @@ DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
     constexpr int MPW = (mtA + WRR - 1) / WRR;                         // A tiles per wave (1 for the output job)
     constexpr int NPWJ = (NT + WCC - 1) / WCC;                         // B tiles owned by one wave
     constexpr int NPASS = (NPWJ + 4) / 5, NPW = (NPWJ + NPASS - 1) / NPASS;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: wave-uniform branches
     const int nwg = A.wg_begin[job + 1] - A.wg_begin[job];
     const int kb = blockIdx.x - A.wg_begin[job];
-    const long long q0 = A.t.NQ * kb / nwg, q1 = A.t.NQ * (kb + 1) / nwg;
+    const long long q0 = uniform64(A.t.NQ * kb / nwg), q1 = uniform64(A.t.NQ * (kb + 1) / nwg);
     const char *srcA = out_job ? A.tape + A.t.dout_off : (LAST ? A.tape + A.t.h_off[job + 1] : A.tape + A.t.ga_off[out_job ? 0 : job]);
     const long long strideA = out_job ? A.t.dout_stride : (long long)MT * TB;       // dout is one tile per group
     const char *srcD = A.tape + A.t.dout_off;
@@ -984,11 +1004,11 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
     static_assert(NPW <= 5, "one sweep");
     constexpr int ME = (MPW + WCC - 1) / WCC;                          // A tiles a wave pairs with the enc tile / the output row
     constexpr int NTOT = 2 * NPW;                                      // MFMA steps per group (k-step major)
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: wave-uniform branches
     const int trl = tr_lane_off();
     const int nwg = A.wg_begin[job + 1] - A.wg_begin[job];
     const int kb = blockIdx.x - A.wg_begin[job];
-    const long long q0 = A.t.NQ * kb / nwg, q1 = A.t.NQ * (kb + 1) / nwg;
+    const long long q0 = uniform64(A.t.NQ * kb / nwg), q1 = uniform64(A.t.NQ * (kb + 1) / nwg);
     const char *srcA = LAST ? A.tape + A.t.h_off[job + 1] : A.tape + A.t.ga_off[job];
     const char *srcD = A.tape + A.t.dout_off;
     const char *srcH = has_h ? A.tape + A.t.h_off[job] : nullptr;
@@ -1099,22 +1119,24 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
             const u32x4 raw = __builtin_bit_cast(u32x4, rawf);
             u32x4 ga;
             float o = 0.f;
+            const bool my_row = (mi % WCC) == wc;        // (scalar) this wave makes the output layer's row for this A tile
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const f32x2 dd = {i < 2 ? da[2 * i] : db[2 * i - 4], i < 2 ? da[2 * i + 1] : db[2 * i - 3]};
                 // the output layer's row: dW_out[f] += dout_p h_depth[p][f], bf16 operands, f32 accumulation (v_dot2c)
                 const typename Pol::bf16x2 dpk = {(__bf16)dd[0], (__bf16)dd[1]};
                 const typename Pol::bf16x2 hp = {rawf[2 * i], rawf[2 * i + 1]};
-                o = __builtin_amdgcn_fdot2_f32_bf16(hp, dpk, o, false);
-                // gA_{depth-1} = (h_depth != 0) * bf16(W_out * dout): same product and rounding as the delta chain (dw_body)
-                const f32x2 pr = dd * wout_r[mi];
-                const typename Pol::bf16x2 t = {(__bf16)pr[0], (__bf16)pr[1]};
-                const unsigned sgn = raw[i] + 0x7fff7fffu;
+                if (my_row) o = __builtin_amdgcn_fdot2_f32_bf16(hp, dpk, o, false);
+                // gA_{depth-1}[p][f] = (h_depth[p][f] != 0) W_out[f] dout_p.  W_out[f] is constant along the sum over points,
+                // so the A operand is only (h != 0) bf16(dout_p) -- three VALU per two points instead of seven (this job was
+                // VALU-bound: 237 VALU against 20 MFMAs per group) -- and the rows of dW_{depth-1} (and its bias) are scaled
+                // by W_out[f] in f32 at the flush, which is also closer to the exact product than rounding it per point.
+                const unsigned sgn = raw[i] + 0x7fff7fffu;          // bf16 h >= 0: sets the half's sign bit iff h != 0, no carry
                 const i16x2 on = __builtin_bit_cast(i16x2, sgn) >> (i16x2){15, 15};
-                ga[i] = __builtin_bit_cast(unsigned, t) & __builtin_bit_cast(unsigned, on);
+                ga[i] = __builtin_bit_cast(unsigned, dpk) & __builtin_bit_cast(unsigned, on);
             }
             st.af[s2][mi] = __builtin_bit_cast(frag, ga);
-            if (live && (mi % WCC) == wc) orow[mi / WCC] += o;
+            if (live && my_row) orow[mi / WCC] += o;
             if (live && out_bias_wave && mi == 0) bout += (da[0] + da[1]) + (da[2] + da[3]) + (db[0] + db[1]) + (db[2] + db[3]);
         }
         if (live && bias_rows) bsum[mi] = Pol::sum8(st.af[s2][mi], bsum[mi]);
@@ -1238,6 +1260,9 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     // ---- flush: slab[(m*NTMAX+n)][r/4][lane][r%4] ---------------------------------------------
+    // LAST: row i of A tile m carries the factor W_out[32 m + i] (a_prep); accumulator register r of a lane holds row
+    // (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    const float *wout_g = reinterpret_cast<const float *>(A.f.packed + A.f.wout_off);
     auto flush_tile = [&](int m, int n, const f32x16 &t) {
         float *tp = slab + (long long)(m * BG::NTMAX + n) * 1024;
 #pragma unroll
@@ -1245,6 +1270,11 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
             f32x4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = t[4 * g4 + e];
+            if constexpr (LAST) {
+                const f32x4 w4 = *reinterpret_cast<const f32x4 *>(wout_g + 32 * m + 8 * g4 + 4 * (lane >> 5));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= w4[e];
+            }
             f32x4 *dst = reinterpret_cast<f32x4 *>(tp + g4 * 256 + lane * 4);
             if (A.accumulate) {
                 const f32x4 old = *dst;
@@ -1273,7 +1303,7 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
             if (m < MT && n < nBr) flush_tile(m, n, acc[mi][ni]);
         }
         if (enc_extra && (mi % WCC) == wc && m < MT) flush_tile(m, nH, acc_e[mi / WCC]);
-        flush_column0(m, nB, bsum[mi], bias_rows && m < MT);
+        flush_column0(m, nB, LAST ? bsum[mi] * wout_r[mi] : bsum[mi], bias_rows && m < MT);
         if constexpr (LAST) {
             // the output layer's row: slab row MT, tile m, row 0, column f = lane & 31 (where reduce_kernel reads dW_out[32 m + f])
             float v = orow[mi / WCC] + __shfl_xor(orow[mi / WCC], 32, 64);
@@ -1399,6 +1429,12 @@ static void tape_layout(int depth, bool layer1_takes_enc, long long NQ, TapeLayo
         if (l == depth - 1 && t->drop_ga) { t->ga_off[l] = -1; continue; }
         t->ga_off[l] = off; off += per_tensor;
     }
+    t->lin_stride = per_tensor;
+    {
+        const int lmin = t->drop_h1 ? 2 : 1;
+        t->h_lin = (lmin <= depth ? t->h_off[lmin] : 0) - lmin * per_tensor;
+        t->ga_lin = t->ga_off[0];
+    }
     t->enc_off = off; off += NQ * (long long)BG::TILE_BYTES;
     t->dout_stride = t->drop_ga ? 128 : BG::TILE_BYTES;         // 32 f32 dout per group, or dout as an A tile (row 0 = dout)
     t->dout_off = off; off += NQ * t->dout_stride;
@@ -1481,8 +1517,11 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
     A.F = s.F;
     for (int l = 0; l <= depth; ++l) { A.kernel_off[l] = s.kernel_off[l]; A.bias_off[l] = s.bias_off[l]; A.in_dim[l] = s.in_dim[l]; }
     A.kernel_off[depth + 1] = s.nparams;
-    // dW jobs: the kernel is a stream over the tape (HBM-bound), so every layer gets workgroups in
-    // proportion to the bytes it reads per 32-point group (A tiles + B tiles), not to its MFMA count
+    // dW jobs: every layer gets workgroups in proportion to the tiles it streams per 32-point group (A + B), with
+    // measured corrections for the two jobs that compute more than they stream (layer 1: recompute of h_1; layer depth-1:
+    // rebuild of gA, output row).  Balancing the jobs so that each takes the same time when it runs ALONE
+    // (tools/dbg_dw.py) measured slower (5.0 vs 4.75 ms): run together they share the HBM stream, and the light
+    // layer-0 job finishing early leaves its bandwidth to the others.
     {
         double work[BHN_MAX_LAYERS + 1], tot = 0;
         const int last_job = t1.drop_ga ? depth - 1 : depth;       // drop_ga: the output row rides on layer depth-1's job
@@ -1492,7 +1531,7 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
             if (l == 1 && t1.drop_h1) nB = job1_w * BG::MT / 8;   // reads only the encoded inputs instead of h_1 but has the
                                                                   // same MFMA work + the recompute: not byte-bound any more
             work[l] = (double)(mtA + nB) + 0.5;
-            if (l == depth - 1 && t1.drop_ga) work[l] += jobl_w * BG::MT / 8.0;    // + dout pieces, the rebuild of gA and the output row
+            if (l == depth - 1 && t1.drop_ga) work[l] += jobl_w * BG::MT / 8.0;    // + the rebuild of gA and the output row
             if (l > last_job) work[l] = 0;
             tot += work[l];
         }

@@ -377,9 +377,15 @@ DEVI typename Pol::frag stream_frag(const char *ch, const char *chn, int idx, in
     return idx < NF ? Pol::lds_frag(ch, idx, lane) : Pol::lds_frag(chn, idx - NF, lane);
 }
 
-struct DmaJob {                                 // chunk to start copying in the middle of a step (src == nullptr: none)
-    const char *src;
+// Chunk to start copying in the middle of a step.  The source is an OFFSET from the base of one buffer resource that the
+// ring builds once per kernel (RingState::start): issuing a piece then costs an s_add for the scalar offset and the M0
+// set-up instead of rebuilding a 128-bit resource from a 64-bit pointer per piece (~40 SALU instructions per ring step,
+// a quarter of its instruction count: round-2 ISA census).
+struct DmaJob {
+    bool on;
+    unsigned soff;                              // byte offset of the chunk from the ring's source base
     char *dst;
+    __amdgpu_buffer_rsrc_t rs;
 };
 
 // Work folded into the MFMA shadows of a ring step ("Post" objects): at(t) is called right after MFMA t of the
@@ -427,7 +433,7 @@ DEVI f32x16 ring_step(const char *ch, const char *chn, APipe<Pol> &ap, const typ
         a[(t + PF - 1) % PF] = stream_frag<Pol, NF>(ch, chn, t + PF - 1, lane);
         if (do_mma) acc = Pol::mma(a[t % PF], src[t], acc);
         if (do_post && KS >= 16) post.at(t);
-        if (t == (KS >= 16 ? 9 : 0) && dma.src) RG::issue(dma.src, dma.dst);
+        if (t == (KS >= 16 ? 9 : 0) && dma.on) RG::issue(dma);
         if (t == (KS >= 16 ? 13 : 0)) ap.bias = bias_acc(bias_next, 0, lane >> 5);   // next tile's bias, before the barrier
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -490,13 +496,22 @@ struct DmaRing {
     static constexpr int NPIECE = CHUNK_BYTES / 1024;
     static constexpr int PPW = (NPIECE + NWAVES - 1) / NWAVES;
     static_assert(CHUNK_BYTES % 1024 == 0, "chunks are whole KiB");
-    static DEVI void issue(const char *src, char *dst) {
+    // buffer resource over the whole packed-weight buffer from `base` on (raw buffer, no range limit that matters)
+    static DEVI __amdgpu_buffer_rsrc_t resource(const char *base) {
+        const unsigned long long u = reinterpret_cast<unsigned long long>(base);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+        void *us = reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo);
+        return __builtin_amdgcn_make_buffer_rsrc(us, 0, 0x7fffffff, 0x00020000);
+    }
+    static DEVI void issue(const DmaJob &j) {
         const int wvu = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        const int voff = (int)(threadIdx.x & 63) * 16;
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
             int piece = wvu + NWAVES * i;
-            piece = piece < NPIECE ? piece : NPIECE - 1;
-            dma_1k(src + piece * 1024, dst + piece * 1024);
+            piece = piece < NPIECE ? piece : NPIECE - 1;        // tail waves re-issue the last piece (equal vmcnt for all waves)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(j.rs, (__attribute__((address_space(3))) void *)(j.dst + piece * 1024), 16, voff,
+                                                     (int)(j.soff + piece * 1024), 0, 0);
         }
     }
     // vmcnt retires in issue order and counts loads, stores and LDS-DMA alike: a chunk has landed once at
@@ -532,25 +547,32 @@ struct RingState {
     char *ring;
     // chunk sequence of one tile, consumed cyclically: NCA forward chunks (img_a, in order), then the transposed
     // chunks of the delta chain (img_b): hidden layers nlb .. 1, MT chunks each, stored layer-major ascending
-    const char *img_a, *img_b;
+    const char *img_a;
+    unsigned off_b;         // byte offset of the transposed image from img_a (both live in the packed-weight buffer)
+    __amdgpu_buffer_rsrc_t rs;
     int NC, NCA, nlb, cur, issue_c, dbg, lag;
     long long *ts;          // STAMPS (measurement builds): per-step time stamps (compute done, barrier passed)
     static DEVI int wrap(int i) { return i < 0 ? i + NB : (i >= NB ? i - NB : i); }
-    DEVI const char *ch() const { return ring + wrap(cur - lag) * CB; }
-    DEVI const char *chn() const { return ring + wrap(cur - lag + 1) * CB; }
-    DEVI const char *next_src() {
-        const char *src;
-        if (issue_c < NCA) src = img_a + (size_t)issue_c * CB;
+    // The buffer offset is made opaque to the compiler: when the number of ring buffers divides the steps of a layer it
+    // proves the ring position of every unrolled step, folds it into the LDS address of each fragment read and, LDS being
+    // larger than the 16-bit offset field of ds_read, pays one v_add per read (16 per step, round-2 ISA census).  From
+    // an SGPR base it is one v_add per step and immediate offsets.
+    static DEVI int opaque(int v) { asm volatile("" : "+s"(v)); return v; }
+    DEVI const char *ch() const { return ring + opaque(wrap(cur - lag) * CB); }
+    DEVI const char *chn() const { return ring + opaque(wrap(cur - lag + 1) * CB); }
+    DEVI unsigned next_src() {
+        unsigned src;
+        if (issue_c < NCA) src = (unsigned)issue_c * CB;
         else {
             const int i = issue_c - NCA;
-            src = img_b + (size_t)((nlb - 1 - i / MT) * MT + i % MT) * CB;
+            src = off_b + (unsigned)((nlb - 1 - i / MT) * MT + i % MT) * CB;
         }
         issue_c = (issue_c + 1 == NC) ? 0 : issue_c + 1;
         return src;
     }
     DEVI DmaJob job() {
-        if (dbg & 4) return DmaJob{nullptr, nullptr};
-        return DmaJob{next_src(), ring + wrap(cur - (LAG ? 2 : 1)) * CB};
+        if (dbg & 4) return DmaJob{false, 0u, nullptr, rs};
+        return DmaJob{true, next_src(), ring + wrap(cur - (LAG ? 2 : 1)) * CB, rs};
     }
     // STORES: global stores this wave is GUARANTEED to have issued after the DMA pieces of chunk c+2 (issued in the
     // middle of step c-2) other than the two younger chunks: vmcnt retires in order and counts stores, so they may
@@ -570,14 +592,16 @@ struct RingState {
     }
     DEVI void idle_step() {      // a step in which this wave consumes nothing (lagging waves: first; the others: last)
         const DmaJob j = job();
-        if (j.src) RG::issue(j.src, j.dst);
+        if (j.on) RG::issue(j);
         step_end();
     }
     DEVI void start(char *ring_, const char *a_, int nca, const char *b_, int nlb_, int dbg_, int lag_) {
-        ring = ring_; img_a = a_; img_b = b_; NCA = nca; nlb = nlb_; NC = nca + nlb_ * MT;
+        ring = ring_; img_a = a_; NCA = nca; nlb = nlb_; NC = nca + nlb_ * MT;
+        off_b = b_ ? (unsigned)(b_ - a_) : 0u;                  // (the transposed image follows the forward image)
+        rs = RG::resource(a_);
         dbg = dbg_; cur = 0; issue_c = 0; lag = LAG ? lag_ : 0; ts = nullptr;
 #pragma unroll
-        for (int j = 0; j < DIST; ++j) RG::issue(next_src(), ring + j * CB);
+        for (int j = 0; j < DIST; ++j) RG::issue(DmaJob{true, next_src(), ring + j * CB, rs});
         RG::template wait_younger<RG::PPW * (DIST - 2)>();
         lds_barrier();
     }
@@ -616,7 +640,7 @@ DEVI void layer0_step(RS &rs, APipe<Pol> &ap, const typename Pol::frag (&enc)[2]
             acc = Pol::mma(a[t % PF], enc[ks], acc);
         }
         if (m > 0) l0.tile(m - 1, prev, act[2 * (m > 0 ? m - 1 : 0)], act[2 * (m > 0 ? m - 1 : 0) + 1]);
-        if (m == (MT > 1 ? 1 : 0) && dj.src) RG::issue(dj.src, dj.dst);
+        if (m == (MT > 1 ? 1 : 0) && dj.on) RG::issue(dj);
         __builtin_amdgcn_sched_barrier(0);
         prev = acc;
         acc = nb;

@@ -1,25 +1,34 @@
 #!/bin/bash
-# Everything under profiles/ comes from this script (run on the GPU box: gpurun -- bash tools/collect_profiles.sh):
-#   bench line, rocprofv3 --kernel-trace --stats of the same command, HBM traffic (FETCH_SIZE / WRITE_SIZE, separate
-#   passes) and SQ counter passes (MFMA busy, wave waits, LDS conflicts) of tools/pmc_run.py.
+# Everything under profiles/ comes from this script (run on the GPU box: gpurun -- bash tools/collect_profiles.sh [tag]):
+#   <tag>_bench_line.json         the bench line of `python3 bench.py`
+#   <tag>_bench_kernel_stats.csv  rocprofv3 --kernel-trace --stats of the same command (per-kernel averages)
+#   <tag>_f32_kernel_stats.csv    the same for `bench.py --mode f32` (the parity mode)
+#   <tag>_pmc_traffic.json        HBM traffic per launch (FETCH_SIZE / WRITE_SIZE, separate --pmc passes, gfx950 x2 on FETCH_SIZE)
+#   <tag>_sq_counters.txt / <tag>_sq_summary.json   SQ counter passes of tools/pmc_run.py (MFMA busy, waits, LDS conflicts)
+# The files land in gpurun_out/profiles/ (merged back by gpurun); copy them to profiles/ and commit.
+set -euo pipefail
+TAG=${1:-r2}
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/profiles
 mkdir -p $O
-python3 $R/bench.py > $O/bench_line.json 2> $O/bench.err
-rm -rf /tmp/kt; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o kt -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > /tmp/kt.log 2>&1
-cp $(find /tmp/kt -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv
+need() { [ -s "$1" ] || { echo "collect_profiles: missing or empty $1" >&2; exit 1; }; }
+python3 $R/bench.py > $O/${TAG}_bench_line.json 2> $O/bench.err
+need $O/${TAG}_bench_line.json
+rm -rf /tmp/kt; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o kt -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity-mode --no-tutorial-domain > /tmp/kt.log 2>&1
+f=$(find /tmp/kt -name "*kernel_stats.csv" | head -1); need "$f"; cp "$f" $O/${TAG}_bench_kernel_stats.csv
+rm -rf /tmp/ktf; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ktf -o kt -- python3 $R/bench.py --mode f32 --steps 3 --warmup 1 --no-cpu-baseline --no-tutorial-domain > /tmp/ktf.log 2>&1
+f=$(find /tmp/ktf -name "*kernel_stats.csv" | head -1); need "$f"; cp "$f" $O/${TAG}_f32_kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/pm_$c; rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pm_$c -o p -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /tmp/pm_$c.log 2>&1
-  cp $(find /tmp/pm_$c -name "*counter_collection.csv" | head -1) /tmp/pm_$c.csv
+  rm -rf /tmp/pm_$c; rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pm_$c -o p -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity-mode --no-tutorial-domain > /tmp/pm_$c.log 2>&1
+  f=$(find /tmp/pm_$c -name "*counter_collection.csv" | head -1); need "$f"; cp "$f" /tmp/pm_$c.csv
 done
-python3 - > $O/pmc_traffic.json <<'PY'
+python3 - > $O/${TAG}_pmc_traffic.json <<'PY'
 import csv, json, collections
 out = collections.OrderedDict()
-names = {'Li1EEv7BwdArgs': 'chain_kernel<MODE_FWD_TRAIN>', 'Li2EEv7BwdArgs': 'chain_kernel<MODE_CHAIN>'}
 def short(k):
-    if 'chain_kernel' in k: return 'chain_kernel<MODE_FWD_TRAIN>' if ', 1>' in k else 'chain_kernel<MODE_CHAIN>' if ', 2>' in k else 'chain_kernel<MODE_RECOMPUTE>'
-    for n in ('dw_kernel', 'reduce_kernel', 'rt_kernel', 'adam_kernel', 'chi2_image_kernel', 'pack_weights_kernel'):
+    if 'chain_kernel' in k: return 'chain_kernel<MODE_FWD_TRAIN>' if ', 1>' in k else 'chain_kernel<MODE_CHAIN>' if ', 2>' in k else None
+    for n in ('dw_kernel', 'reduce_kernel', 'rt_kernel', 'adam_kernel', 'chi2_image_kernel', 'pack_weights_kernel', 'eht_vis_kernel', 'eht_bwd_kernel'):
         if n in k: return n
     if 'fused_fwd_kernel' in k: return 'fused_fwd_kernel (inference)'
     return None
@@ -32,11 +41,13 @@ for c in ('FETCH_SIZE', 'WRITE_SIZE'):
         out.setdefault(n, {})[c + '_KiB'] = round(sum(v) / len(v), 1)
 for n, d in out.items():
     d['hbm_bytes'] = int((2 * d.get('FETCH_SIZE_KiB', 0) + d.get('WRITE_SIZE_KiB', 0)) * 1024)
-print(json.dumps({'note': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace) of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline`; averages per launch in KiB as reported; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 with the gfx950 correction (FETCH_SIZE reports half of wide coalesced reads, MI355X_MICROARCH.md HBM section)', 'kernels': out}, indent=1))
+print(json.dumps({'note': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace) of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity-mode --no-tutorial-domain`; averages per launch in KiB as reported; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 with the gfx950 correction (FETCH_SIZE reports half of wide coalesced reads, MI355X_MICROARCH.md HBM section)', 'kernels': out}, indent=1))
 PY
+need $O/${TAG}_pmc_traffic.json
 bash $R/tools/pmc_collect.sh > /tmp/sq.log 2>&1
-cat $R/gpurun_out/pmc/pass*.txt > $O/sq_counters.txt
-python3 - $O/sq_counters.txt > $O/sq_summary.json <<'PY'
+ls $R/gpurun_out/pmc/pass*.txt > /dev/null
+cat $R/gpurun_out/pmc/pass*.txt > $O/${TAG}_sq_counters.txt
+python3 - $O/${TAG}_sq_counters.txt > $O/${TAG}_sq_summary.json <<'PY'
 import sys, json, re, collections
 k = None; d = collections.OrderedDict()
 for l in open(sys.argv[1]):
@@ -59,4 +70,5 @@ for k, c in d.items():
         pass
 print(json.dumps({'note': 'from sq_counters.txt (rocprofv3 --pmc SQ_* passes of tools/pmc_run.py, one launch each): mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES) = fraction of SIMD cycles with the matrix pipe busy', 'kernels': out}, indent=1))
 PY
+need $O/${TAG}_sq_summary.json
 ls -la $O

@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 SQ counter passes over tools/pmc_run.py; summaries -> gpurun_out/pmc/pass*.csv
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $R/gpurun_out/pmc
 i=0
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY" \

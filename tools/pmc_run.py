@@ -1,6 +1,6 @@
 """One training-forward, delta-chain, dW and inference-forward launch at config 2 (for rocprofv3 --pmc passes)."""
-import sys, numpy as np, torch
-sys.path.insert(0, '/root/repo')
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bhnerf_amd import _hip, engine, network, synthetic, constants
 dev = torch.device('cuda:0')
 H = W = 128; G = 64; B = 8
