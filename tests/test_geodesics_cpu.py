@@ -176,3 +176,57 @@ def test_raytracing_args_takes_the_traced_geodesics(geos):
     rt = network.raytracing_args(geo, Omega, 0.0, 0.0 * units.hr, J=np.nan_to_num(J))
     assert list(rt)[:3] == ['coords', 'Omega', 'J'] or 'coords' in rt
     assert np.shape(rt['coords']) == (3, 6, 6, 40) and np.shape(rt['J']) == (3, 6, 6, 40)
+
+
+def _gl_radial_integral(r, roots):
+    """Antiderivative I_r(r) = int_{r4}^{r} dr / sqrt(R(r)) for four real roots r1 < r2 < r3 < r4 <= r of the radial
+    potential (Gralla & Lupsasca 2020, "Null geodesics of the Kerr exterior", eq. B35 / B40: case 2):
+        I_r = 2 / sqrt(r31 r42) F(arcsin sqrt((r - r4) r31 / ((r - r3) r41)) | k),   k = r32 r41 / (r31 r42)."""
+    import mpmath as mp
+    r1, r2, r3, r4 = roots
+    r31, r32, r41, r42 = r3 - r1, r3 - r2, r4 - r1, r4 - r2
+    k = r32 * r41 / (r31 * r42)
+    x2 = (r - r4) * r31 / ((r - r3) * r41)
+    return 2 / mp.sqrt(r31 * r42) * mp.ellipf(mp.asin(mp.sqrt(x2)), k)
+
+
+@pytest.mark.parametrize('spin,inc_deg', [(0.0, 60.0), (0.94, 60.0), (0.94, 17.0)])
+def test_radial_motion_matches_the_published_analytic_solution(spin, inc_deg):
+    """Pin for SURVEY 8 f3: the external `kgeo` package the reference calls (kgeo.py:61-62, `raytrace_ana`) implements the
+    analytic Kerr solution of Gralla & Lupsasca; it is absent, so the own tracer is held to that published closed form
+    instead (mpmath elliptic integrals, 30 digits): along every scattering ray the Mino time elapsed since the observer is
+    I_r(r_o) -+ I_r(r) before / after the radial turning point.  RK4 at the default step agrees to 1e-4 of the ray's total
+    Mino time and converges towards the closed form when the step is refined."""
+    import mpmath as mp
+    mp.mp.dps = 30
+
+    def worst(h):
+        g = G.image_plane_geos(spin, np.deg2rad(inc_deg), (-9.0, 9.0), (-9.0, 9.0), ngeo=40, num_alpha=3, num_beta=4, h=h)
+        err, rays = 0.0, 0
+        for i in range(3):
+            for j in range(4):
+                lam, eta, a = float(g.lam[i, j]), float(g.eta[i, j]), spin
+                # R(r) = r^4 + (a^2 - eta - lam^2) r^2 + 2 M (eta + (lam - a)^2) r - a^2 eta
+                roots = mp.polyroots([1, 0, a * a - eta - lam * lam, 2 * (eta + (lam - a) ** 2), -a * a * eta], maxsteps=200, extraprec=200)
+                if any(abs(mp.im(z)) > 1e-12 for z in roots):
+                    continue                                   # plunging ray: two complex roots, another case of the paper
+                roots = sorted(mp.re(z) for z in roots)
+                r, tau = g.r[i, j], -g.mino[i, j]
+                if not np.isfinite(r).all() or r.min() < float(roots[3]) * (1 - 1e-3):
+                    continue
+                k0 = int(np.argmin(r))
+                assert abs(r[k0] - float(roots[3])) < 0.5      # the ray turns at the largest root
+                I_o = _gl_radial_integral(mp.mpf(float(g.r_o)), roots)
+                for k in range(len(r)):
+                    if k == k0:
+                        continue                               # the sample next to the turning point: branch ambiguous
+                    I_k = _gl_radial_integral(mp.mpf(float(r[k])), roots)
+                    want = I_o - I_k if k < k0 else I_o + I_k
+                    err = max(err, abs(float(want) - tau[k]) / float(2 * I_o))
+                rays += 1
+        assert rays >= 6
+        return err
+
+    coarse, fine = worst(0.02), worst(0.005)
+    assert coarse < 1e-4, coarse
+    assert fine < 1e-5 and fine < 0.5 * coarse, (coarse, fine)
