@@ -415,7 +415,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
             tile_point<Pol::NWAVES>(a, tile, wv, pl, c.b, c.p, c.inb);
             if (h == 0) c.e = (reinterpret_cast<const float *>(A.tape + A.t.e_off) + (tile * Pol::NWAVES + wvu) * 32)[pl];
             if (h == 0 && c.inb) {
-                const long long ray = a.ray_idx ? (long long)a.ray_idx[c.p] : c.p / a.G;
+                const long long ray = a.ray_idx ? (long long)a.ray_idx[c.p] : (long long)a.fd_G.div((unsigned)c.p);
                 for (int s = 0; s < a.Sx; ++s)
                     c.dE += a.dimages[((long long)c.b * a.Sx + s) * a.R + ray] * a.w[(long long)s * a.P + c.p];
             }
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
         if constexpr (MODE == MODE_FWD_TRAIN) {
             // record what the delta chain needs, then the render epilogue of fused_fwd_kernel
             if (h == 0) e_g[pl] = e;
-            const long long ray = inb ? (a.ray_idx ? (long long)a.ray_idx[p] : p / a.G) : -1;
+            const long long ray = inb ? (a.ray_idx ? (long long)a.ray_idx[p] : (long long)a.fd_G.div((unsigned)p)) : -1;
             unsigned long long rem = a.images ? __ballot(h == 0 && inb) : 0ull;      // bhn_render_bwd: tape only
             while (rem) {
                 const int first = __ffsll((long long)rem) - 1;

@@ -154,6 +154,30 @@ struct PolF32 {
 };
 
 // ---------------------------------------------------------------------------------------------
+// Division of a 32-bit unsigned by a run-time constant (Granlund & Montgomery): the divisor's multiplier and shifts
+// come from the host.  hipcc expands `long long / long long` into ~100 instructions (there is no integer divide);
+// the tile -> (frame, group) map and the point -> ray map did that twice per tile and once per point: a fifth of the
+// instructions between the output layer of one tile and layer 0 of the next (round-2 ISA census).
+// ---------------------------------------------------------------------------------------------
+struct FastDiv {
+    unsigned d, m, sh1, sh2;
+    __host__ __device__ static FastDiv make(unsigned d) {
+        FastDiv f;
+        f.d = d;
+        unsigned l = 0;
+        while (l < 32 && (1ull << l) < d) ++l;                         // ceil(log2 d)
+        f.m = (unsigned)((((1ull << l) - d) << 32) / d + 1);
+        f.sh1 = l < 1 ? l : 1;
+        f.sh2 = l > 1 ? l - 1 : 0;
+        return f;
+    }
+    __device__ __forceinline__ unsigned div(unsigned n) const {
+        const unsigned t = __umulhi(m, n);
+        return (t + ((n - t) >> sh1)) >> sh2;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
 // Kernel arguments (passed by value)
 // ---------------------------------------------------------------------------------------------
 struct FusedArgs {
@@ -183,7 +207,8 @@ struct FusedArgs {
     long long slab_floats;
     // tiling
     int tiles_per_frame;
-    long long total_tiles;
+    long long total_tiles;          // < 2^32 (checked on the host), as is P: the maps below use 32-bit FastDiv
+    FastDiv fd_tpf, fd_G;
     int debug;            // measurement builds only
     int deg;              // posenc degree 0..BHN_DEG_MAX (run time: only the prologue and the weight packing depend on it)
 };
@@ -216,8 +241,9 @@ struct PointState {
 // number (tile % tiles_per_frame) * NWAVES + wv of the (compacted) group list
 template <int NWAVES>
 DEVI void tile_point(const FusedArgs &a, long long tile, int wv, int pl, int &b, long long &p, bool &inb) {
-    b = (int)(tile / a.tiles_per_frame);
-    const long long gi = (tile % a.tiles_per_frame) * NWAVES + wv;
+    const unsigned tq = a.fd_tpf.div((unsigned)tile);
+    b = (int)tq;
+    const long long gi = (long long)((unsigned)tile - tq * (unsigned)a.tiles_per_frame) * NWAVES + wv;
     const bool gok = gi < a.n_groups;
     const long long grp = gok ? (a.groups ? (long long)a.groups[gi] : gi) : 0;
     p = grp * 32 + pl;

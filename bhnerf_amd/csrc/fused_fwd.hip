@@ -203,7 +203,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void fused_fwd_kernel(FusedArgs a) {
         } else {
             // x J g^2 dtau Sigma and sum over the ray (network.py:415-419, kgeo.py:621); a 32-point
             // wave tile may straddle rays when G % 32 != 0 -> segmented sum + one atomic per ray.
-            const long long ray = inb ? (a.ray_idx ? (long long)a.ray_idx[p] : p / a.G) : -1;
+            const long long ray = inb ? (a.ray_idx ? (long long)a.ray_idx[p] : (long long)a.fd_G.div((unsigned)p)) : -1;
             unsigned long long rem = __ballot(h == 0 && inb);
             while (rem) {
                 const int first = __ffsll((long long)rem) - 1;
@@ -262,6 +262,10 @@ int fused_fill_args(const bhn_model *m, int32_t mode, const void *packed, const 
     BHN_CHECK_ARG(a->n_groups > 0 && a->n_groups <= (a->P + 31) / 32, "bad n_groups %lld", (long long)a->n_groups);
     a->tiles_per_frame = (int)((a->n_groups + nwaves - 1) / nwaves);
     a->total_tiles = (long long)a->tiles_per_frame * a->B;
+    BHN_CHECK_ARG(a->total_tiles < (1ll << 31) && a->P < (1ll << 31) && a->G < (1ll << 31),
+                  "problem too large for one call: %lld tiles, %lld points per frame (limit 2^31)", a->total_tiles, (long long)a->P);
+    a->fd_tpf = FastDiv::make((unsigned)a->tiles_per_frame);
+    a->fd_G = FastDiv::make((unsigned)a->G);
     return BHN_OK;
 }
 
