@@ -30,7 +30,7 @@
 #define BHN_DBG(x) 0
 #endif
 #ifndef BHN_TAPED_DIST
-#define BHN_TAPED_DIST 7         // weight chunks in flight in the training-forward / delta-chain kernels (bf16; 4 measured 2 % slower)
+#define BHN_TAPED_DIST 6         // weight chunks in flight in the training-forward / delta-chain kernels (bf16; 4 measured 2 % slower)
 #endif
 
 struct TapeLayout {
@@ -363,6 +363,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
     float *zero_lds = bias_lds + (a.depth + 1) * W;
     float *wout_lds = zero_lds + 32;
     char *id_lds = reinterpret_cast<char *>(wout_lds + W);
+    char *seg_lds = id_lds + 2 * Pol::FRAG_BYTES;                  // RaySum scratch of the render epilogue
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 31, h = lane >> 5;
     const int wvu = __builtin_amdgcn_readfirstlane(wv);           // the wave index as a scalar: tape addresses stay in SGPRs
@@ -521,19 +522,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
         if constexpr (MODE == MODE_FWD_TRAIN) {
             // record what the delta chain needs, then the render epilogue of fused_fwd_kernel
             if (h == 0) e_g[pl] = e;
-            const long long ray = inb ? (a.ray_idx ? (long long)a.ray_idx[p] : (long long)a.fd_G.div((unsigned)p)) : -1;
-            unsigned long long rem = a.images ? __ballot(h == 0 && inb) : 0ull;      // bhn_render_bwd: tape only
-            while (rem) {
-                const int first = __ffsll((long long)rem) - 1;
-                const long long r0 = __shfl(ray, first, 64);
-                const bool mine = (h == 0) && inb && (ray == r0);
-                for (int s = 0; s < a.Sx; ++s) {
-                    float v = (mine && e != 0.f) ? a.w[(long long)s * a.P + p] * e : 0.f;
-                    v = half_wave_sum(v);
-                    if (lane == first) atomicAdd(a.images + ((long long)b * a.Sx + s) * a.R + r0, v);
-                }
-                rem &= ~__ballot(mine);
-            }
+            if (a.images) RaySum<Pol::NWAVES>::run(a, seg_lds, b, p, inb, e, 0.f, false);      // (bhn_render_bwd: tape only)
         } else {
             float d = 0.f;
             if (h == 0 && inb && e != 0.f) {
@@ -1552,7 +1541,7 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
         }
     }
     // ring + bias rows + zero row + output weights + identity fragments
-    const size_t lds_fixed = (size_t)(depth + 1) * W * 4 + 128 + W * 4 + 2 * Pol::FRAG_BYTES;
+    const size_t lds_fixed = (size_t)(depth + 1) * W * 4 + 128 + W * 4 + 2 * Pol::FRAG_BYTES + RaySum<Pol::NWAVES>::BYTES;
     const size_t lds_taped = (size_t)(BG::RING_DIST_TAPED + 1) * PK::CHUNK_BYTES + lds_fixed;
     size_t lds_dw = (size_t)BG::NBUF * BG::GROUP_BYTES + (t1.drop_h1 ? (size_t)2 * BG::MT * Pol::FRAG_BYTES + W * 4 : 0);
     if (t1.drop_ga && (size_t)BG::NBUF * BG::GROUP_BYTES_LAST2 > lds_dw) lds_dw = (size_t)BG::NBUF * BG::GROUP_BYTES_LAST2;

@@ -704,3 +704,66 @@ DEVI float half_wave_sum(float v) {
     for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Render epilogue: x J g^2 dtau Sigma and the sum over the ray (network.py:415-419, kgeo.py:621).
+// A 32-point wave tile may hold pieces ("segments") of several rays, and a ray may run over several wave tiles.  Round 1
+// added every segment to its pixel with a float atomic: more than two adds per pixel (rays of > 64 samples, masked
+// domains) made images -- and with them gradients -- depend on the arrival order.  Now every wave leaves its segment
+// sums in LDS, and after ONE workgroup barrier the lane that owns the first segment of a ray within the workgroup tile
+// (32 NW consecutive points) adds the ray's following segments in wave order and issues a single atomic.  A pixel then
+// receives one add per workgroup tile its ray touches, ceil((G - 1) / (32 NW)) + 1: two for G <= 32 NW + 1 (257 samples
+// in bf16 mode, 129 in f32 mode) -- two commutative adds onto zero, bitwise reproducible.
+// LDS: SEG_BYTES<NW> at `lds`; rewritten a whole tile (>= 3 barriers) later, so one barrier suffices.
+// ---------------------------------------------------------------------------------------------
+template <int NW>
+struct RaySum {
+    static constexpr int SMAX = 4;                                   // Stokes planes (bhn_geom.S <= 4)
+    static constexpr int BYTES = NW * 32 * 4 + NW * SMAX * 32 * 4 + NW * 4;
+    static DEVI void run(const FusedArgs &a, char *lds, int b, long long p, bool inb, float e, float w0, bool have_w0) {
+        const int lane = threadIdx.x & 63, h = lane >> 5, pl = lane & 31;
+        const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        int *seg_ray = reinterpret_cast<int *>(lds);                                  // [NW][32]
+        float *seg_val = reinterpret_cast<float *>(lds + NW * 32 * 4);                // [NW][SMAX][32]
+        int *seg_n = reinterpret_cast<int *>(lds + NW * 32 * 4 + NW * SMAX * 32 * 4); // [NW]
+        const long long ray = inb ? (a.ray_idx ? (long long)a.ray_idx[p] : (long long)a.fd_G.div((unsigned)p)) : -1;
+        unsigned long long rem = __ballot(h == 0 && inb);
+        int k = 0;
+        while (rem) {
+            const int first = __ffsll((long long)rem) - 1;
+            const long long r0 = __shfl(ray, first, 64);
+            const bool mine = (h == 0) && inb && (ray == r0);
+            for (int s = 0; s < a.Sx; ++s) {
+                float v = (mine && e != 0.f) ? ((s == 0 && have_w0) ? w0 : a.w[(long long)s * a.P + p]) * e : 0.f;
+                v = half_wave_sum(v);
+                if (lane == first) seg_val[(wv * SMAX + s) * 32 + k] = v;
+            }
+            if (lane == first) seg_ray[wv * 32 + k] = (int)r0;
+            ++k;
+            rem &= ~__ballot(mine);
+        }
+        if (lane == 0) seg_n[wv] = k;
+        lds_barrier();
+        if (h == 0 && pl < seg_n[wv]) {
+            const int r = seg_ray[wv * 32 + pl];
+            bool owner = true;                      // the ray starts in this workgroup tile with this segment
+            if (pl == 0 && wv > 0) {
+                const int np = seg_n[wv - 1];
+                owner = !(np > 0 && seg_ray[(wv - 1) * 32 + np - 1] == r);
+            }
+            if (owner) {
+                for (int s = 0; s < a.Sx; ++s) {
+                    float sum = seg_val[(wv * SMAX + s) * 32 + pl];
+                    if (pl == seg_n[wv] - 1) {      // the wave's last segment may continue in the following waves
+                        for (int w2 = wv + 1; w2 < NW; ++w2) {
+                            if (seg_n[w2] == 0 || seg_ray[w2 * 32] != r) break;
+                            sum += seg_val[(w2 * SMAX + s) * 32];
+                            if (seg_n[w2] != 1) break;
+                        }
+                    }
+                    atomicAdd(a.images + ((long long)b * a.Sx + s) * a.R + r, sum);
+                }
+            }
+        }
+    }
+};

@@ -139,6 +139,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void fused_fwd_kernel(FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *ring = smem;                                              // NB x CB
     float *bias_lds = reinterpret_cast<float *>(smem + NB * CB);     // (depth+1) x W
+    char *seg_lds = reinterpret_cast<char *>(bias_lds + (a.depth + 1) * W);      // RaySum scratch
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 31, h = lane >> 5;
     for (int i = tid; i < (a.depth + 1) * W; i += Pol::NTHREADS)
@@ -201,21 +202,8 @@ __global__ __launch_bounds__(Pol::NTHREADS) void fused_fwd_kernel(FusedArgs a) {
         } else if (!RENDER) {
             if (h == 0 && inb) a.emission[(long long)b * a.P + p] = e;
         } else {
-            // x J g^2 dtau Sigma and sum over the ray (network.py:415-419, kgeo.py:621); a 32-point
-            // wave tile may straddle rays when G % 32 != 0 -> segmented sum + one atomic per ray.
-            const long long ray = inb ? (a.ray_idx ? (long long)a.ray_idx[p] : (long long)a.fd_G.div((unsigned)p)) : -1;
-            unsigned long long rem = __ballot(h == 0 && inb);
-            while (rem) {
-                const int first = __ffsll((long long)rem) - 1;
-                const long long r0 = __shfl(ray, first, 64);
-                const bool mine = (h == 0) && inb && (ray == r0);
-                for (int s = 0; s < a.Sx; ++s) {
-                    float v = (mine && e != 0.f) ? (s == 0 ? w0 : a.w[(long long)s * a.P + p]) * e : 0.f;
-                    v = half_wave_sum(v);
-                    if (lane == first) atomicAdd(a.images + ((long long)b * a.Sx + s) * a.R + r0, v);
-                }
-                rem &= ~__ballot(mine);
-            }
+            // x J g^2 dtau Sigma and the sum over the ray: segment sums per wave, combined per workgroup tile (RaySum)
+            RaySum<Pol::NWAVES>::run(a, seg_lds, b, p, inb, e, w0, true);
         }
     }
     if (!rs.lag) rs.idle_step();                        // every wave runs the same number of ring steps (barriers)
@@ -272,7 +260,8 @@ int fused_fill_args(const bhn_model *m, int32_t mode, const void *packed, const 
 template <int W, class Pol, bool RENDER, bool DBG = false>
 static int launch_fwd_w(FusedArgs &a, hipStream_t st) {
     using PK = Pack<W, Pol>;
-    const size_t lds = (size_t)((Pol::ELEM_BYTES == 2 ? BHN_FWD_DIST : 3) + (Pol::PHASE_LAG ? 2 : 1)) * PK::CHUNK_BYTES + (size_t)(a.depth + 1) * W * 4;
+    const size_t lds = (size_t)((Pol::ELEM_BYTES == 2 ? BHN_FWD_DIST : 3) + (Pol::PHASE_LAG ? 2 : 1)) * PK::CHUNK_BYTES + (size_t)(a.depth + 1) * W * 4
+                       + RaySum<Pol::NWAVES>::BYTES;
     auto kern = fused_fwd_kernel<W, Pol, 3, RENDER, DBG>;
     int dev = 0;
     BHN_HIP(hipGetDevice(&dev));
