@@ -169,6 +169,8 @@ class FusedPredictor:
         self.packed = torch.empty((int(lib.bhn_packed_bytes(C.byref(self.model), self.mode)),), dtype=torch.uint8,
                                   device=self.device)
         self._ws = None
+        # queried once, here: torch's device-property query is not safe to call from two host threads at the same time
+        self._total_memory = int(torch.cuda.get_device_properties(self.device).total_memory)
 
     # -- parameters --------------------------------------------------------------------------
     def flatten(self, tree):
@@ -240,7 +242,7 @@ class FusedPredictor:
             raise _hip.HipError(lib.bhn_last_error().decode() or 'render_bwd workspace query failed')
         cap = getattr(self, 'max_workspace_bytes', None)
         if cap is None:
-            cap = torch.cuda.get_device_properties(self.device).total_memory // 4
+            cap = self._total_memory // 4
         want = min(full, max(one, cap))
         if self._ws is None or self._ws.numel() < want:
             self._ws = None
@@ -275,7 +277,7 @@ class FusedPredictor:
         dev = self.device.index or 0
         cap = getattr(self, 'max_workspace_bytes', None)
         if cap is None:
-            cap = torch.cuda.get_device_properties(self.device).total_memory // 4
+            cap = self._total_memory // 4
         for nb in range(int(B), 0, -1):
             need = int(lib.bhn_render_bwd_workspace_bytes(C.byref(self.model), self.mode, nb, P, dev))
             if 0 < need <= cap:

@@ -256,3 +256,56 @@ def test_render_is_bitwise_reproducible_for_long_and_masked_rays(dev, mode, G):
         for _ in range(3):
             assert torch.equal(eng.render(geom, tM0), ref)
         assert torch.equal(eng.render_train(geom, tM0), ref)                  # the training forward sums the same way
+
+
+def test_two_threads_two_streams_are_independent(dev):
+    """ABI conventions (include/bhnerf_hip.h): no global mutable state except the thread-local error string and
+    per-device one-time caches, so two host threads may drive the library on two streams of one device at the same time.
+    Each thread owns a predictor (packed weights, outputs) and a stream and renders repeatedly; every result must equal
+    the single-threaded one bit for bit."""
+    import threading
+    from bhnerf_amd import constants, engine, network, synthetic
+    H = W = 32; G = 64
+    geo = synthetic.synthetic_geodesics(H, W, G, fov_M=16.0, inc_deg=60.0, seed=7)
+    tM0 = engine.frame_offsets(np.linspace(0, 1, 4), 0.0, geo['t_injection'], constants.GM_c3('hr'), dev)
+
+    def make(seed, width, mode):
+        pred = network.NeRF_Predictor(8.0, 2.0, 8.0, 4.0, net_depth=4, net_width=width, mode=mode, device=dev)
+        eng = pred.engine()
+        flat = eng.flatten(network.MLP(4, width).init(seed, 21))
+        with torch.no_grad():
+            eng.unflatten(flat)['MLP_0']['Dense_4']['bias'] += 8.0
+        geom = pred.geometry(geo['coords'], geo['Omega'], geo['t_geos'], None, geo['g'], geo['dtau'], geo['Sigma'])
+        return eng, flat, geom
+
+    jobs = [make(1, 128, 'bf16'), make(2, 256, 'bf16')]              # two different kernels (template instantiations)
+    refs = []
+    for eng, flat, geom in jobs:
+        eng.pack(flat)
+        refs.append(eng.render(geom, tM0).clone())
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(k):
+        try:
+            eng, flat, geom = jobs[k]
+            stream = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(stream):
+                for _ in range(20):
+                    eng.pack(flat)
+                    out = eng.render(geom, tM0)
+                    dimg = torch.ones_like(out)
+                    g1 = eng.render_bwd(geom, tM0, dimg)
+                    stream.synchronize()
+                    if not torch.equal(out, refs[k]) or not torch.isfinite(g1).all():
+                        errors.append((k, 'mismatch'))
+        except Exception:                                              # noqa: BLE001
+            import traceback
+            errors.append((k, traceback.format_exc()))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
