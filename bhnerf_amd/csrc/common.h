@@ -50,7 +50,8 @@ void bhn_set_error(const char *fmt, ...);
 // Shape of the MLP of network.py:49-62 as the kernels see it.
 struct MlpShape {
     int depth;                  // hidden layers
-    int width;                  // hidden width (multiple of 32)
+    int width;                  // KERNEL width: the model's width padded to 32, 64, 128 or 256 (zero weights for the padding units)
+    int width_true;             // the model's hidden width (network.py:154): what the flat parameter layout uses
     int F;                      // encoded input features 3 + 6*deg (network.py:118-122)
     int deg;                    // posenc degree (0..BHN_DEG_MAX)
     int skip_in[BHN_MAX_LAYERS];   // 1 if layer l takes concat[h, enc] as input (network.py:59-61)

@@ -70,6 +70,7 @@ struct BwdArgs {
     long long kernel_off[BHN_MAX_LAYERS + 1], bias_off[BHN_MAX_LAYERS + 1];
     int in_dim[BHN_MAX_LAYERS + 1];
     int F;
+    int width_true;                            // the model's hidden width (flat parameter layout); W is the kernel width
     long long nparams;
 };
 
@@ -1349,10 +1350,11 @@ __global__ void reduce_kernel(BwdArgs A) {
         int l = 0;
         while (l < depth && t >= A.kernel_off[l + 1]) ++l;
         const bool is_bias = t >= A.bias_off[l];
+        const int WT = A.width_true;
         int o, kin = 0;
         if (is_bias) o = (int)(t - A.bias_off[l]);
         else {
-            const int outw = (l == depth) ? 1 : W;
+            const int outw = (l == depth) ? 1 : WT;
             o = (int)((t - A.kernel_off[l]) % outw);
             kin = (int)((t - A.kernel_off[l]) / outw);
         }
@@ -1365,8 +1367,8 @@ __global__ void reduce_kernel(BwdArgs A) {
         int n, col;
         if (is_bias) { n = nB; col = 0; }
         else if (l == 0) { n = 0; col = bhn_enc_feature_slot(kin, A.f.deg); }
-        else if (kin < W) { n = kin >> 5; col = kin & 31; }
-        else { n = nH; col = bhn_enc_feature_slot(kin - W, A.f.deg); }
+        else if (kin < WT) { n = kin >> 5; col = kin & 31; }
+        else { n = nH; col = bhn_enc_feature_slot(kin - WT, A.f.deg); }
         // the output layer's row rides on the job of layer depth-1 (slab row MT) when gA_{depth-1} is not on the tape
         const bool rides = l == depth && A.t.drop_ga;
         const int jl = rides ? depth - 1 : l;
@@ -1504,6 +1506,7 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
     A.dparams = dparams;
     A.nparams = s.nparams;
     A.F = s.F;
+    A.width_true = s.width_true;
     for (int l = 0; l <= depth; ++l) { A.kernel_off[l] = s.kernel_off[l]; A.bias_off[l] = s.bias_off[l]; A.in_dim[l] = s.in_dim[l]; }
     A.kernel_off[depth + 1] = s.nparams;
     // dW jobs: every layer gets workgroups in proportion to the tiles it streams per 32-point group (A + B), with
@@ -1628,10 +1631,14 @@ static int bwd_entry(int what, const bhn_model *m, int32_t mode, const void *pac
     BHN_CHECK_ARG(mode == BHN_F32 || mode == BHN_BF16, "bad mode %d", mode);
     int dev = 0;
     BHN_HIP(hipGetDevice(&dev));
+    MlpShape shape;
+    const int rcs = bhn_mlp_shape(m, &shape);
+    if (rcs != BHN_OK) return rcs;
+    const int kernel_width = shape.width;
     return (mode == BHN_BF16)
-               ? bwd_dispatch<PolBF16>(what, m->net_width, m, mode, packed, geom, fr, dimages, images, dparams, workspace,
+               ? bwd_dispatch<PolBF16>(what, kernel_width, m, mode, packed, geom, fr, dimages, images, dparams, workspace,
                                        workspace_bytes, (hipStream_t)stream, nullptr, 0, 0, dev, ev, nev)
-               : bwd_dispatch<PolF32>(what, m->net_width, m, mode, packed, geom, fr, dimages, images, dparams, workspace,
+               : bwd_dispatch<PolF32>(what, kernel_width, m, mode, packed, geom, fr, dimages, images, dparams, workspace,
                                       workspace_bytes, (hipStream_t)stream, nullptr, 0, 0, dev, ev, nev);
 }
 

@@ -42,7 +42,9 @@ struct PackArgs {
 
 __global__ void pack_weights_kernel(PackArgs a) {
     const MlpShape &s = a.s;
-    const int W = s.width, MT = W / 32, KS = W / 16, CH = a.L.CH, D = s.depth;
+    // W: kernel width (fragment geometry); WT: the model's width (strides of the flat parameters).  Hidden units >= WT
+    // are padding: zero weights in and out, zero bias.
+    const int W = s.width, WT = s.width_true, MT = W / 32, KS = W / 16, CH = a.L.CH, D = s.depth;
     const long long n_frag_elems = (long long)(a.L.n_fwd + a.L.n_bwd) * CH * 512;
     const long long n_bias = (long long)(D + 1) * W;
     const long long total = n_frag_elems + n_bias + W;
@@ -52,12 +54,12 @@ __global__ void pack_weights_kernel(PackArgs a) {
             if (u < n_bias) {
                 const int l = (int)(u / W), o = (int)(u % W);
                 float v = 0.f;
-                if (l < D) v = a.params[s.bias_off[l] + o];
+                if (l < D) { if (o < WT) v = a.params[s.bias_off[l] + o]; }
                 else if (o == 0) v = a.params[s.bias_off[D]];
                 reinterpret_cast<float *>(a.packed + a.L.bias_off)[u] = v;
             } else {
                 const int k = (int)(u - n_bias);
-                reinterpret_cast<float *>(a.packed + a.L.wout_off)[k] = a.params[s.kernel_off[D] + k];
+                reinterpret_cast<float *>(a.packed + a.L.wout_off)[k] = k < WT ? a.params[s.kernel_off[D] + k] : 0.f;
             }
             continue;
         }
@@ -74,24 +76,27 @@ __global__ void pack_weights_kernel(PackArgs a) {
                 if (f < 2 * MT) {
                     const int m = f >> 1, q = 16 * (f & 1) + ph;
                     const int fe = bhn_enc_slot_feature(q, s.deg);
-                    if (fe >= 0) v = a.params[s.kernel_off[0] + (long long)fe * W + 32 * m + i];
+                    if (fe >= 0 && 32 * m + i < WT) v = a.params[s.kernel_off[0] + (long long)fe * WT + 32 * m + i];
                 }
             } else if (c == a.L.n_fwd - 1) {                // output layer, only row 0 is real
-                if (f < KS && i == 0) v = a.params[s.kernel_off[D] + 16 * f + ph];
+                if (f < KS && i == 0 && 16 * f + ph < WT) v = a.params[s.kernel_off[D] + 16 * f + ph];
             } else {
                 const int l = 1 + (c - 1) / MT, m = (c - 1) % MT;
+                const int o = 32 * m + i;
                 if (f < KS) {
-                    v = a.params[s.kernel_off[l] + (long long)(16 * f + ph) * W + 32 * m + i];
+                    const int k = 16 * f + ph;
+                    if (k < WT && o < WT) v = a.params[s.kernel_off[l] + (long long)k * WT + o];
                 } else if (s.skip_in[l]) {
                     const int q = 16 * (f - KS) + ph;
                     const int fe = bhn_enc_slot_feature(q, s.deg);
-                    if (fe >= 0) v = a.params[s.kernel_off[l] + (long long)(W + fe) * W + 32 * m + i];
+                    if (fe >= 0 && o < WT) v = a.params[s.kernel_off[l] + (long long)(WT + fe) * WT + o];
                 }
             }
         } else {
             const int cb = c - a.L.n_fwd;
             const int l = 1 + cb / MT, m = cb % MT;
-            if (f < KS) v = a.params[s.kernel_off[l] + (long long)(32 * m + i) * W + 16 * f + ph];
+            const int k = 32 * m + i, o = 16 * f + ph;     // transposed image: row = input unit k, column = output unit o
+            if (f < KS && k < WT && o < WT) v = a.params[s.kernel_off[l] + (long long)k * WT + o];
         }
         char *img = a.packed + (fwd ? a.L.fwd_off + (size_t)c * a.L.chunk_bytes
                                     : a.L.bwd_off + (size_t)(c - a.L.n_fwd) * a.L.chunk_bytes);

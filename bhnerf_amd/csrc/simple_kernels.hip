@@ -37,12 +37,14 @@ int bhn_num_cus(int device) {
 int bhn_mlp_shape(const bhn_model *m, MlpShape *s) {
     BHN_CHECK_ARG(m && s, "null model");
     BHN_CHECK_ARG(m->net_depth >= 2 && m->net_depth <= 8, "net_depth %d outside 2..8", m->net_depth);
-    BHN_CHECK_ARG(m->net_width >= 32 && m->net_width <= 256 && m->net_width % 32 == 0,
-                  "net_width %d must be a multiple of 32 in 32..256", m->net_width);
+    BHN_CHECK_ARG(m->net_width >= 1 && m->net_width <= 256, "net_width %d outside 1..256", m->net_width);
     BHN_CHECK_ARG(m->posenc_deg >= 0 && m->posenc_deg <= 4, "posenc_deg %d outside 0..4", m->posenc_deg);
     memset(s, 0, sizeof(*s));
     s->depth = m->net_depth;
-    s->width = m->net_width;
+    // the fused kernels exist for widths 32, 64, 128, 256: any other width runs on the next one with zero weights, biases
+    // and gradients for the padding units (relu(0) = 0: they change nothing), the flat parameter layout keeps the true width
+    s->width_true = m->net_width;
+    s->width = m->net_width <= 32 ? 32 : m->net_width <= 64 ? 64 : m->net_width <= 128 ? 128 : 256;
     s->F = 3 + 6 * m->posenc_deg;
     s->deg = m->posenc_deg;
     const int skip_layer = m->net_depth / 2;
@@ -50,14 +52,14 @@ int bhn_mlp_shape(const bhn_model *m, MlpShape *s) {
     int64_t off = 0;
     for (int i = 0; i <= s->depth; ++i) {
         s->in_dim[i] = cur;
-        s->skip_in[i] = (cur == s->width + s->F) ? 1 : 0;
-        const int out = (i == s->depth) ? 1 : s->width;
+        s->skip_in[i] = (cur == s->width_true + s->F) ? 1 : 0;
+        const int out = (i == s->depth) ? 1 : s->width_true;
         s->kernel_off[i] = off;
         off += (int64_t)cur * out;
         s->bias_off[i] = off;
         off += out;
-        cur = s->width;
-        if (m->do_skip && i < s->depth && i % skip_layer == 0 && i > 0) cur = s->width + s->F;
+        cur = s->width_true;
+        if (m->do_skip && i < s->depth && i % skip_layer == 0 && i > 0) cur = s->width_true + s->F;
     }
     s->nparams = off;
     if (s->skip_in[s->depth]) {

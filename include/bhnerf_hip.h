@@ -43,7 +43,7 @@ enum { BHN_F32 = 0, BHN_BF16 = 1 };
  * net_depth,net_width,do_skip; activation=relu and out_channel=1 are fixed as in every driver). */
 typedef struct {
     int32_t net_depth;    /* hidden Dense+ReLU layers, 2..8 (network.py:153) */
-    int32_t net_width;    /* 32..256, multiple of 32 (network.py:154)        */
+    int32_t net_width;    /* 1..256 (network.py:154); widths other than 32/64/128/256 run zero-padded on the next one */
     int32_t posenc_deg;   /* 0..4, 3+6*deg <= 32 features (network.py:151)   */
     int32_t do_skip;      /* skip-concat after layer depth/2 (network.py:59-61) */
     float scale, rmin, rmax, z_width;

@@ -57,7 +57,7 @@ def test_release_library_has_no_hidden_allocation_or_environment_reads(lib):
     assert 'bhn_debug' not in hdr
 
 
-@pytest.mark.parametrize('depth,width,n', [(4, 128, 55169), (4, 256, 208641), (8, 256, 471809), (6, 64, None)])
+@pytest.mark.parametrize('depth,width,n', [(4, 128, 55169), (4, 256, 208641), (8, 256, 471809), (6, 64, None), (4, 100, None), (4, 7, None)])
 def test_param_layout_matches_flax_tree_order(lib, depth, width, n):
     from bhnerf_amd import _hip
     m = _hip.make_model(depth, width, 3, True, 8.0, 0.0, 8.0, 4.0)
@@ -80,7 +80,7 @@ def test_param_layout_matches_flax_tree_order(lib, depth, width, n):
 
 def test_argument_validation_reports_errors(lib):
     from bhnerf_amd import _hip
-    bad_width = _hip.make_model(4, 100, 3, True, 1.0, 0.0, 1.0, 1.0)
+    bad_width = _hip.make_model(4, 300, 3, True, 1.0, 0.0, 1.0, 1.0)
     assert lib.bhn_param_count(C.byref(bad_width)) == -1
     assert b'net_width' in lib.bhn_last_error()
     skip_into_output = _hip.make_model(5, 64, 3, True, 1.0, 0.0, 1.0, 1.0)       # depth 5: concat feeds the output layer
