@@ -30,7 +30,7 @@
 #define BHN_DBG(x) 0
 #endif
 #ifndef BHN_TAPED_DIST
-#define BHN_TAPED_DIST 6         // weight chunks in flight in the training-forward / delta-chain kernels (bf16; 4 measured 2 % slower)
+#define BHN_TAPED_DIST 7         // weight chunks in flight in the training-forward / delta-chain kernels (bf16; 4 measured 2 % slower)
 #endif
 
 struct TapeLayout {
@@ -116,7 +116,7 @@ struct TapeEmit {
     const char *table;
     DEVI void init(char *lds) {         // call from every thread of the workgroup before the first barrier
         table = lds;
-        if (threadIdx.x < 64) {
+        if (Pol::ELEM_BYTES != 2 && threadIdx.x < 64) {      // (bf16 tiles are not transposed by the matrix core any more)
             const int lane = threadIdx.x, n = lane & 31, h = lane >> 5;
             typename Pol::frag id[2];
 #pragma unroll
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
     float *zero_lds = bias_lds + (a.depth + 1) * W;
     float *wout_lds = zero_lds + 32;
     char *id_lds = reinterpret_cast<char *>(wout_lds + W);
-    char *seg_lds = id_lds + 2 * Pol::FRAG_BYTES;                  // RaySum scratch of the render epilogue
+    char *seg_lds = id_lds + (Pol::ELEM_BYTES == 2 ? 0 : 2 * Pol::FRAG_BYTES);   // RaySum scratch (bf16 has no identity table)
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 31, h = lane >> 5;
     const int wvu = __builtin_amdgcn_readfirstlane(wv);           // the wave index as a scalar: tape addresses stay in SGPRs
@@ -1544,7 +1544,7 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
         }
     }
     // ring + bias rows + zero row + output weights + identity fragments
-    const size_t lds_fixed = (size_t)(depth + 1) * W * 4 + 128 + W * 4 + 2 * Pol::FRAG_BYTES + RaySum<Pol::NWAVES>::BYTES;
+    const size_t lds_fixed = (size_t)(depth + 1) * W * 4 + 128 + W * 4 + (Pol::ELEM_BYTES == 2 ? 0 : 2 * Pol::FRAG_BYTES) + RaySum<Pol::NWAVES>::BYTES;
     const size_t lds_taped = (size_t)(BG::RING_DIST_TAPED + 1) * PK::CHUNK_BYTES + lds_fixed;
     size_t lds_dw = (size_t)BG::NBUF * BG::GROUP_BYTES + (t1.drop_h1 ? (size_t)2 * BG::MT * Pol::FRAG_BYTES + W * 4 : 0);
     if (t1.drop_ga && (size_t)BG::NBUF * BG::GROUP_BYTES_LAST2 > lds_dw) lds_dw = (size_t)BG::NBUF * BG::GROUP_BYTES_LAST2;

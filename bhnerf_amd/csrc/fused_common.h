@@ -209,6 +209,8 @@ struct FusedArgs {
     int tiles_per_frame;
     long long total_tiles;          // < 2^32 (checked on the host), as is P: the maps below use 32-bit FastDiv
     FastDiv fd_tpf, fd_G;
+    int ray_direct;                 // every ray touches at most two 32-point wave tiles: one atomic per (tile, ray) is already
+                                    // order-independent (RaySum::direct), no combine through LDS needed
     int debug;            // measurement builds only
     int deg;              // posenc degree 0..BHN_DEG_MAX (run time: only the prologue and the weight packing depend on it)
 };
@@ -720,7 +722,27 @@ template <int NW>
 struct RaySum {
     static constexpr int SMAX = 4;                                   // Stokes planes (bhn_geom.S <= 4)
     static constexpr int BYTES = NW * 32 * 4 + NW * SMAX * 32 * 4 + NW * 4;
+    // Dense layouts whose rays start on a 32-point boundary and are at most 64 samples long (G = 32, 64), or at most 33
+    // samples anywhere: a pixel gets at most two adds from per-tile atomics as well -- round 1's epilogue, kept for these
+    // (BASELINE config 2 is G = 64): the LDS combine and its barrier cost 3 % of the inference forward.
+    static DEVI void direct(const FusedArgs &a, int b, long long p, bool inb, float e, float w0, bool have_w0) {
+        const int lane = threadIdx.x & 63, h = lane >> 5;
+        const long long ray = inb ? (long long)a.fd_G.div((unsigned)p) : -1;
+        unsigned long long rem = __ballot(h == 0 && inb);
+        while (rem) {
+            const int first = __ffsll((long long)rem) - 1;
+            const long long r0 = __shfl(ray, first, 64);
+            const bool mine = (h == 0) && inb && (ray == r0);
+            for (int s = 0; s < a.Sx; ++s) {
+                float v = (mine && e != 0.f) ? ((s == 0 && have_w0) ? w0 : a.w[(long long)s * a.P + p]) * e : 0.f;
+                v = half_wave_sum(v);
+                if (lane == first) atomicAdd(a.images + ((long long)b * a.Sx + s) * a.R + r0, v);
+            }
+            rem &= ~__ballot(mine);
+        }
+    }
     static DEVI void run(const FusedArgs &a, char *lds, int b, long long p, bool inb, float e, float w0, bool have_w0) {
+        if (a.ray_direct) return direct(a, b, p, inb, e, w0, have_w0);
         const int lane = threadIdx.x & 63, h = lane >> 5, pl = lane & 31;
         const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
         int *seg_ray = reinterpret_cast<int *>(lds);                                  // [NW][32]
