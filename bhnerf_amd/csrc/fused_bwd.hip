@@ -480,7 +480,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
 #pragma nounroll
             for (int l = 1; l <= a.depth; ++l) {
                 const bool out = l == a.depth;
-                const bool sk = !out && ((a.skip_mask >> l) & 1);
+                const bool sk = (a.skip_mask >> l) & 1;              // (odd depths: also the output layer)
                 const float *bl = bias_lds + l * W;
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
@@ -620,7 +620,8 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
 // dW kernel
 // ---------------------------------------------------------------------------------------------
 // Job types of the dW kernel (compile-time so that the streaming loop is straight-line code)
-enum { JT_FIRST = 0, JT_HIDDEN = 1, JT_SKIP = 2, JT_OUT = 3, JT_HIDDEN1 = 4 };   // HIDDEN1: layer 1 with h_1 recomputed from the encoded inputs
+enum { JT_FIRST = 0, JT_HIDDEN = 1, JT_SKIP = 2, JT_OUT = 3, JT_HIDDEN1 = 4, JT_OUTSKIP = 5 };   // HIDDEN1: layer 1 with h_1 recomputed from the
+                                                     // encoded inputs; OUTSKIP: output layer fed by concat[h, enc] (odd depths with do_skip)
 
 // LAST (layer depth-1 when TapeLayout::drop_ga): the A region of the group image holds the h_depth tiles, from which
 // the A fragments gA_{depth-1} = (h_depth != 0) * W_out * dout are rebuilt (same f32 product and rounding as the
@@ -635,7 +636,7 @@ DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
     constexpr int OFF_H = MT * TB, OFF_E = 2 * MT * TB;               // LDS group image [A][h][enc]
     constexpr int OFF_D = BG::GROUP_BYTES, OFF_D32 = OFF_D + TB;      // LAST: [dout tile][1 KiB piece starting with 32 f32 dout]
     constexpr int GB = LAST ? BG::GROUP_BYTES_LAST : BG::GROUP_BYTES;
-    constexpr bool out_job = JT == JT_OUT, has_h = JT != JT_FIRST, has_enc = (JT == JT_FIRST || JT == JT_SKIP);
+    constexpr bool out_job = JT == JT_OUT || JT == JT_OUTSKIP, has_h = JT != JT_FIRST, has_enc = (JT == JT_FIRST || JT == JT_SKIP || JT == JT_OUTSKIP);
     constexpr bool make_h = JT == JT_HIDDEN1;       // the h tiles of the LDS group image are computed here, not DMA'd
     constexpr int mtA = out_job ? 1 : MT;                              // A tiles (gA rows; dout is 1 row)
     constexpr int nH = has_h ? MT : 0, nB = nH + (has_enc ? 1 : 0);    // B tiles; slab tile nB holds the bias column,
@@ -976,12 +977,13 @@ DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
 // layer depth-1 (LAST) makes the output layer's row and bias with v_dot2c / adds from the h_depth fragments and the f32
 // dout it already holds (no dout tile on the tape, no 1-row MFMAs, 32 accumulator registers fewer).
 // ---------------------------------------------------------------------------------------------
-template <int W, class Pol, int JT, bool LAST = false>
+template <int W, class Pol, int JT, bool LAST = false, bool OUTENC = false>     // OUTENC: the output layer riding on LAST takes concat[h, enc]
 DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
     using BG = BwdGeom<W, Pol>;
     using frag = typename Pol::frag;
-    static_assert(Pol::ELEM_BYTES == 2 && JT != JT_OUT, "bf16 jobs of layers 0 .. depth-1");
+    static_assert(Pol::ELEM_BYTES == 2 && JT != JT_OUT && JT != JT_OUTSKIP, "bf16 jobs of layers 0 .. depth-1");
     static_assert(!LAST || JT == JT_HIDDEN || JT == JT_SKIP, "LAST: hidden / skip job");
+    static_assert(!OUTENC || LAST, "OUTENC: a LAST job");
     static_assert(BG::NBUF == 4, "ring of four group buffers");
     constexpr int MT = BG::MT, TB = BG::TILE_BYTES;
     constexpr int OFF_H = MT * TB, OFF_E = 2 * MT * TB, OFF_D32 = BG::GROUP_BYTES;       // LDS group image [A][h][enc][f32 dout piece]
@@ -1062,7 +1064,7 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
     const bool bias_rows = wc == 0;                                    // this wave sums the bias column of its A tiles
     const bool out_bias_wave = LAST && wr == 0 && wc == 0;             // ... and this one the output layer's bias
     f32x16 acc[MPW][NPW], acc_e[ME];
-    float bsum[MPW], orow[ME], bout = 0.f;
+    float bsum[MPW], orow[ME], bout = 0.f, oenc = 0.f;
 #pragma unroll
     for (int mi = 0; mi < MPW; ++mi) {
         bsum[mi] = 0.f;
@@ -1079,7 +1081,7 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
     }
 
     // ---- per-group A state: fragments of the wave's A tiles for both k-steps (+ LAST: the f32 dout of the lane's points)
-    struct AState { frag af[2][MPW]; f32x4 da[2], db[2]; };
+    struct AState { frag af[2][MPW]; f32x4 da[2], db[2]; frag ef[2]; };      // ef: encoded-input fragments (OUTENC, one wave)
     auto load_b = [&](const char *gp, int t) -> frag {
         if constexpr (make_h) return Pol::lds_frag(gp + boff[t % NPW], t / NPW, lane);     // written by make_h_write in fragment order
         else return tr_frag(gp + boff[t % NPW], t / NPW, trl);
@@ -1094,6 +1096,7 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
                 const float *d32 = reinterpret_cast<const float *>(gp + OFF_D32) + 16 * s2 + 4 * (lane >> 5);
                 st.da[s2] = *reinterpret_cast<const f32x4 *>(d32);
                 st.db[s2] = *reinterpret_cast<const f32x4 *>(d32 + 8);
+                if constexpr (OUTENC) st.ef[s2] = tr_frag(gp + OFF_E, s2, trl);       // lane = encoded-input slot, 8 points
             }
         }
     };
@@ -1117,6 +1120,12 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
                 const typename Pol::bf16x2 dpk = {(__bf16)dd[0], (__bf16)dd[1]};
                 const typename Pol::bf16x2 hp = {rawf[2 * i], rawf[2 * i + 1]};
                 if (my_row) o = __builtin_amdgcn_fdot2_f32_bf16(hp, dpk, o, false);
+                if constexpr (OUTENC) {      // ... and its encoded-input part dW_out[W + slot] += dout_p enc[p][slot] (one wave, once per k-step)
+                    if (live && out_bias_wave && mi == 0) {
+                        const typename Pol::bf16x2 ep = {st.ef[s2][2 * i], st.ef[s2][2 * i + 1]};
+                        oenc = __builtin_amdgcn_fdot2_f32_bf16(ep, dpk, oenc, false);
+                    }
+                }
                 // gA_{depth-1}[p][f] = (h_depth[p][f] != 0) W_out[f] dout_p.  W_out[f] is constant along the sum over points,
                 // so the A operand is only (h != 0) bf16(dout_p) -- three VALU per two points instead of seven (this job was
                 // VALU-bound: 237 VALU against 20 MFMAs per group) -- and the rows of dW_{depth-1} (and its bias) are scaled
@@ -1173,7 +1182,7 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
 
     // ---- the stream: pieces (1 KiB = one wave-wide DMA) this job needs: [A tiles][h tiles][enc tile][f32 dout piece]
     constexpr int PA = MT * TB / 1024, PH = (has_h && !make_h) ? MT * TB / 1024 : 0,
-                  PE = (JT == JT_FIRST || JT == JT_SKIP || make_h) ? TB / 1024 : 0, PD = LAST ? 1 : 0;
+                  PE = (JT == JT_FIRST || JT == JT_SKIP || make_h || OUTENC) ? TB / 1024 : 0, PD = LAST ? 1 : 0;
     constexpr int NPJ = PA + PH + PE + PD, PPW = (NPJ + Pol::NWAVES - 1) / Pol::NWAVES;
     const int wvu = __builtin_amdgcn_readfirstlane(wv);
     const char *sbase[PPW];
@@ -1304,12 +1313,20 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
             }
         }
     }
-    if constexpr (LAST) {
+    if constexpr (LAST) {          // output layer: [tiles 0..MT-1: h part][tile MT: encoded-input part (OUTENC)][bias]
         float v = bout + __shfl_xor(bout, 32, 64);
         if (out_bias_wave && lane == 0) {
-            float *dst = slab + (long long)(MT * BG::NTMAX + MT) * 1024;
+            float *dst = slab + (long long)(MT * BG::NTMAX + MT + (OUTENC ? 1 : 0)) * 1024;
             if (A.accumulate) v += *dst;
             *dst = v;
+        }
+        if constexpr (OUTENC) {
+            float ve = oenc + __shfl_xor(oenc, 32, 64);
+            if (out_bias_wave && lane < 32) {
+                float *dst = slab + (long long)(MT * BG::NTMAX + MT) * 1024 + lane * 4;      // row 0, column = slot
+                if (A.accumulate) ve += *dst;
+                *dst = ve;
+            }
         }
     }
 }
@@ -1322,17 +1339,27 @@ __global__ __launch_bounds__(Pol::NTHREADS) void dw_kernel(BwdArgs A) {
     while (job < depth && (int)blockIdx.x >= A.wg_begin[job + 1]) ++job;
     if (BHN_DBG(A.debug >> 2) && (A.debug >> 2) - 1 != job) return;
     if constexpr (Pol::ELEM_BYTES == 2) {           // bf16: software-pipelined bodies; the output layer rides on job depth-1
-        if (job == depth) dw_body<W, Pol, JT_OUT>(A, job, smem);         // (depth < 3 only)
-        else if (job == 0) dw_body2<W, Pol, JT_FIRST>(A, job, smem);
+        const bool out_skip = (A.f.skip_mask >> depth) & 1;             // odd depths with do_skip
+        if (job == depth) {                                               // (depth < 3 only)
+            if (out_skip) dw_body<W, Pol, JT_OUTSKIP>(A, job, smem);
+            else dw_body<W, Pol, JT_OUT>(A, job, smem);
+        } else if (job == 0) dw_body2<W, Pol, JT_FIRST>(A, job, smem);
         else if (job == depth - 1 && A.t.drop_ga) {
-            if ((A.f.skip_mask >> job) & 1) dw_body2<W, Pol, JT_SKIP, true>(A, job, smem);
-            else dw_body2<W, Pol, JT_HIDDEN, true>(A, job, smem);
+            if ((A.f.skip_mask >> job) & 1) {
+                if (out_skip) dw_body2<W, Pol, JT_SKIP, true, true>(A, job, smem);
+                else dw_body2<W, Pol, JT_SKIP, true>(A, job, smem);
+            } else {
+                if (out_skip) dw_body2<W, Pol, JT_HIDDEN, true, true>(A, job, smem);
+                else dw_body2<W, Pol, JT_HIDDEN, true>(A, job, smem);
+            }
         } else if ((A.f.skip_mask >> job) & 1) dw_body2<W, Pol, JT_SKIP>(A, job, smem);
         else if (job == 1 && A.t.drop_h1) dw_body2<W, Pol, JT_HIDDEN1>(A, job, smem);
         else dw_body2<W, Pol, JT_HIDDEN>(A, job, smem);
     } else {
-        if (job == depth) dw_body<W, Pol, JT_OUT>(A, job, smem);
-        else if (job == 0) dw_body<W, Pol, JT_FIRST>(A, job, smem);
+        if (job == depth) {
+            if ((A.f.skip_mask >> depth) & 1) dw_body<W, Pol, JT_OUTSKIP>(A, job, smem);
+            else dw_body<W, Pol, JT_OUT>(A, job, smem);
+        } else if (job == 0) dw_body<W, Pol, JT_FIRST>(A, job, smem);
         else if ((A.f.skip_mask >> job) & 1) dw_body<W, Pol, JT_SKIP>(A, job, smem);
         else dw_body<W, Pol, JT_HIDDEN>(A, job, smem);
     }

@@ -79,7 +79,12 @@ __global__ void pack_weights_kernel(PackArgs a) {
                     if (fe >= 0 && 32 * m + i < WT) v = a.params[s.kernel_off[0] + (long long)fe * WT + 32 * m + i];
                 }
             } else if (c == a.L.n_fwd - 1) {                // output layer, only row 0 is real
-                if (f < KS && i == 0 && 16 * f + ph < WT) v = a.params[s.kernel_off[D] + 16 * f + ph];
+                if (f < KS) {
+                    if (i == 0 && 16 * f + ph < WT) v = a.params[s.kernel_off[D] + 16 * f + ph];
+                } else if (s.skip_in[D] && i == 0) {        // odd depths: the output layer takes concat[h, enc]
+                    const int fe = bhn_enc_slot_feature(16 * (f - KS) + ph, s.deg);
+                    if (fe >= 0) v = a.params[s.kernel_off[D] + WT + fe];
+                }
             } else {
                 const int l = 1 + (c - 1) / MT, m = (c - 1) % MT;
                 const int o = 32 * m + i;
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void fused_fwd_kernel(FusedArgs a) {
             const char *ch = rs.ch(), *chn = rs.chn();
             const DmaJob dj = rs.job();
             PackPost<Pol> post(pend, act[KS - 2], act[KS - 1]);
-            const f32x16 acc = ring_step<W, Pol, RG>(ch, chn, ap, act, enc, false, bias_lds /* next tile, layer 0 */, post, dj, dbg);
+            const f32x16 acc = ring_step<W, Pol, RG>(ch, chn, ap, act, enc, (a.skip_mask >> a.depth) & 1, bias_lds /* next tile, layer 0 */, post, dj, dbg);
             outv = acc[0];
             rs.step_end();
         }

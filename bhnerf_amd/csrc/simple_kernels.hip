@@ -61,12 +61,7 @@ int bhn_mlp_shape(const bhn_model *m, MlpShape *s) {
         cur = s->width_true;
         if (m->do_skip && i < s->depth && i % skip_layer == 0 && i > 0) cur = s->width_true + s->F;
     }
-    s->nparams = off;
-    if (s->skip_in[s->depth]) {
-        bhn_set_error("net_depth %d with do_skip feeds the skip-concat into the output layer; "
-                      "the fused kernels support depths 4, 6, 8 (or do_skip=0)", m->net_depth);
-        return BHN_EUNSUPPORTED;
-    }
+    s->nparams = off;      // (odd depths with do_skip feed the skip-concat into the OUTPUT layer, network.py:59-62: skip_in[depth])
     return BHN_OK;
 }
 

@@ -84,8 +84,10 @@ def test_argument_validation_reports_errors(lib):
     assert lib.bhn_param_count(C.byref(bad_width)) == -1
     assert b'net_width' in lib.bhn_last_error()
     skip_into_output = _hip.make_model(5, 64, 3, True, 1.0, 0.0, 1.0, 1.0)       # depth 5: concat feeds the output layer
-    assert lib.bhn_param_count(C.byref(skip_into_output)) == -1
-    assert b'depths 4, 6, 8' in lib.bhn_last_error()
+    assert lib.bhn_param_count(C.byref(skip_into_output)) == sum(a * b + b for a, b in onp.mlp_layer_dims(5, 64, 21))
+    assert onp.mlp_layer_dims(5, 64, 21)[-1] == (64 + 21, 1)
+    too_deep = _hip.make_model(9, 64, 3, True, 1.0, 0.0, 1.0, 1.0)
+    assert lib.bhn_param_count(C.byref(too_deep)) == -1 and b'net_depth' in lib.bhn_last_error()
     no_skip = _hip.make_model(5, 64, 3, False, 1.0, 0.0, 1.0, 1.0)
     assert lib.bhn_param_count(C.byref(no_skip)) == sum(a * b + b for a, b in onp.mlp_layer_dims(5, 64, 21, do_skip=False))
     assert lib.bhn_radiative_transfer_fwd(None, None, None, None, None, 1, 1, 1, None) == 1     # BHN_EINVAL, no launch
