@@ -741,10 +741,9 @@ struct RaySum {
             rem &= ~__ballot(mine);
         }
     }
-    static DEVI void run(const FusedArgs &a, char *lds, int b, long long p, bool inb, float e, float w0, bool have_w0) {
-        if (a.ray_direct) return direct(a, b, p, inb, e, w0, have_w0);
-        const int lane = threadIdx.x & 63, h = lane >> 5, pl = lane & 31;
-        const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // Segment sums of the 32-point tile of (virtual) wave vw -> LDS; with ray_direct: straight to the pixels.
+    static DEVI void put(const FusedArgs &a, char *lds, int vw, long long p, bool inb, float e, float w0, bool have_w0, int b = -1) {
+        const int lane = threadIdx.x & 63, h = lane >> 5;
         int *seg_ray = reinterpret_cast<int *>(lds);                                  // [NW][32]
         float *seg_val = reinterpret_cast<float *>(lds + NW * 32 * 4);                // [NW][SMAX][32]
         int *seg_n = reinterpret_cast<int *>(lds + NW * 32 * 4 + NW * SMAX * 32 * 4); // [NW]
@@ -758,26 +757,36 @@ struct RaySum {
             for (int s = 0; s < a.Sx; ++s) {
                 float v = (mine && e != 0.f) ? ((s == 0 && have_w0) ? w0 : a.w[(long long)s * a.P + p]) * e : 0.f;
                 v = half_wave_sum(v);
-                if (lane == first) seg_val[(wv * SMAX + s) * 32 + k] = v;
+                if (lane == first) {
+                    if (a.ray_direct) atomicAdd(a.images + ((long long)b * a.Sx + s) * a.R + r0, v);
+                    else seg_val[(vw * SMAX + s) * 32 + k] = v;
+                }
             }
-            if (lane == first) seg_ray[wv * 32 + k] = (int)r0;
+            if (lane == first && !a.ray_direct) seg_ray[vw * 32 + k] = (int)r0;
             ++k;
             rem &= ~__ballot(mine);
         }
-        if (lane == 0) seg_n[wv] = k;
-        lds_barrier();
-        if (h == 0 && pl < seg_n[wv]) {
-            const int r = seg_ray[wv * 32 + pl];
+        if (lane == 0 && !a.ray_direct) seg_n[vw] = k;
+    }
+    // after a workgroup barrier: the lane that owns the first segment of a ray within the workgroup tile adds the ray's
+    // following segments in (virtual) wave order and issues one atomic
+    static DEVI void combine(const FusedArgs &a, char *lds, int vw, int b) {
+        const int lane = threadIdx.x & 63, h = lane >> 5, pl = lane & 31;
+        const int *seg_ray = reinterpret_cast<const int *>(lds);
+        const float *seg_val = reinterpret_cast<const float *>(lds + NW * 32 * 4);
+        const int *seg_n = reinterpret_cast<const int *>(lds + NW * 32 * 4 + NW * SMAX * 32 * 4);
+        if (h == 0 && pl < seg_n[vw]) {
+            const int r = seg_ray[vw * 32 + pl];
             bool owner = true;                      // the ray starts in this workgroup tile with this segment
-            if (pl == 0 && wv > 0) {
-                const int np = seg_n[wv - 1];
-                owner = !(np > 0 && seg_ray[(wv - 1) * 32 + np - 1] == r);
+            if (pl == 0 && vw > 0) {
+                const int np = seg_n[vw - 1];
+                owner = !(np > 0 && seg_ray[(vw - 1) * 32 + np - 1] == r);
             }
             if (owner) {
                 for (int s = 0; s < a.Sx; ++s) {
-                    float sum = seg_val[(wv * SMAX + s) * 32 + pl];
-                    if (pl == seg_n[wv] - 1) {      // the wave's last segment may continue in the following waves
-                        for (int w2 = wv + 1; w2 < NW; ++w2) {
+                    float sum = seg_val[(vw * SMAX + s) * 32 + pl];
+                    if (pl == seg_n[vw] - 1) {      // the wave's last segment may continue in the following waves
+                        for (int w2 = vw + 1; w2 < NW; ++w2) {
                             if (seg_n[w2] == 0 || seg_ray[w2 * 32] != r) break;
                             sum += seg_val[(w2 * SMAX + s) * 32];
                             if (seg_n[w2] != 1) break;
@@ -787,5 +796,12 @@ struct RaySum {
                 }
             }
         }
+    }
+    static DEVI void run(const FusedArgs &a, char *lds, int b, long long p, bool inb, float e, float w0, bool have_w0) {
+        if (a.ray_direct) return direct(a, b, p, inb, e, w0, have_w0);
+        const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        put(a, lds, wv, p, inb, e, w0, have_w0);
+        lds_barrier();
+        combine(a, lds, wv, b);
     }
 };

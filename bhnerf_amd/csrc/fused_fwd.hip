@@ -221,6 +221,174 @@ __global__ __launch_bounds__(Pol::NTHREADS) void fused_fwd_kernel(FusedArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Wide forward (EXPERIMENT, only with -DBHN_WIDE_FWD; not part of the product build): 4 waves x 64 points.  Every A
+// fragment read from LDS feeds TWO MFMAs (two independent accumulator chains per wave, one wave per SIMD, up to 512
+// registers): half the LDS fragment reads, waits, ring bookkeeping and barriers per MFMA of the 8 x 32 kernel, whose time
+// is 64 % LDS fragment stream.  bf16 only; same tile -> group map (a workgroup tile = 8 consecutive groups).
+// MEASURED (round 2, same box): 3.55 ms against 3.00 ms -- 18 % SLOWER, as a first version in round 1 was.  The ISA
+// shows why: 481 registers, so half of the activations live in AGPRs, which the VALU cannot read or write: 51
+// v_accvgpr_read/write per step and ~250 at every layer boundary; a step is 256 instructions for 36 MFMAs, and a
+// single wave per SIMD issues one instruction per 4 cycles: 1024 cycles of issue against 1152 of MFMA with nothing to
+// overlap them.  Kept as a record of the experiment (results equal: tests/test_gpu_forward.py pass with it).
+// ---------------------------------------------------------------------------------------------
+template <int W, class Pol, class RG>
+DEVI void wide_step(const char *ch, const char *chn, APipe<Pol> &ap, const typename Pol::frag (&s0)[W / 16], const typename Pol::frag (&s1)[W / 16],
+                    const typename Pol::frag (&e0)[2], const typename Pol::frag (&e1)[2], bool with_enc, f32x16 &acc0, f32x16 &acc1,
+                    const float *bias_next, PackPost<Pol> &p0, PackPost<Pol> &p1, DmaJob dma) {
+    const int lane = threadIdx.x & 63;
+    constexpr int KS = W / 16, NF = KS + 2, PF = Pol::LDS_PREFETCH;
+    typename Pol::frag a[PF];
+#pragma unroll
+    for (int i = 0; i < PF - 1; ++i) a[i] = ap.f[i];
+    acc0 = ap.bias; acc1 = ap.bias;
+    if (KS < 16) { p0.all(); p1.all(); }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < KS; ++t) {
+        a[(t + PF - 1) % PF] = stream_frag<Pol, NF>(ch, chn, t + PF - 1, lane);
+        acc0 = Pol::mma(a[t % PF], s0[t], acc0);
+        acc1 = Pol::mma(a[t % PF], s1[t], acc1);
+        if (KS >= 16) { p0.at(t); p1.at(t); }
+        if (t == (KS >= 16 ? 9 : 0) && dma.on) RG::issue(dma);
+        if (t == (KS >= 16 ? 13 : 0)) ap.bias = bias_acc(bias_next, 0, lane >> 5);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int t = KS; t < NF; ++t) {
+        a[(t + PF - 1) % PF] = stream_frag<Pol, NF>(ch, chn, t + PF - 1, lane);
+        if (with_enc) {
+            acc0 = Pol::mma(a[t % PF], e0[t - KS], acc0);
+            acc1 = Pol::mma(a[t % PF], e1[t - KS], acc1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int i = 0; i < PF - 1; ++i) ap.f[i] = a[(NF + i) % PF];
+}
+
+template <int W, class Pol, int DEG, bool RENDER>
+__global__ __launch_bounds__(256) void fused_fwd_wide_kernel(FusedArgs a) {
+    using PK = Pack<W, Pol>;
+    using frag = typename Pol::frag;
+    static_assert(Pol::ELEM_BYTES == 2, "bf16");
+    constexpr int CB = PK::CHUNK_BYTES, MT = PK::MT, KS = PK::KS, NW = 4, NF = KS + 2, PF = Pol::LDS_PREFETCH;
+    using RG = DmaRing<CB, NW>;
+    constexpr int DIST = BHN_FWD_DIST;
+    using RS = RingState<RG, CB, DIST, false, MT, false>;
+    constexpr int NB = RS::NB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *ring = smem;
+    float *bias_lds = reinterpret_cast<float *>(smem + NB * CB);
+    char *seg_lds = reinterpret_cast<char *>(bias_lds + (a.depth + 1) * W);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 31, h = lane >> 5;
+    for (int i = tid; i < (a.depth + 1) * W; i += 256) bias_lds[i] = reinterpret_cast<const float *>(a.packed + a.bias_off)[i];
+    RS rs;
+    rs.start(ring, a.packed + a.fwd_off, PK::fwd_chunks(a.depth), nullptr, 0, 0, 0);
+    APipe<Pol> ap;
+    ap.prime(rs.ch(), bias_lds);
+    // wave wv owns the 32-point groups 2 wv and 2 wv + 1 of the workgroup tile (virtual waves of an 8-wave tile)
+    PointIn nx0 = load_point<8>(a, blockIdx.x, 2 * wv, pl), nx1 = load_point<8>(a, blockIdx.x, 2 * wv + 1, pl);
+    for (long long tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
+        const PointIn in0 = nx0, in1 = nx1;
+        frag enc0[2], enc1[2];
+        bool live0, live1;
+        point_prologue<Pol, DEG>(a, in0, enc0, live0);
+        point_prologue<Pol, DEG>(a, in1, enc1, live1);
+        nx0 = load_point<8>(a, tile + gridDim.x, 2 * wv, pl);
+        nx1 = load_point<8>(a, tile + gridDim.x, 2 * wv + 1, pl);
+        float w00 = 0.f, w01 = 0.f;
+        if (RENDER && h == 0 && in0.inb) w00 = a.w[in0.p];
+        if (RENDER && h == 0 && in1.inb) w01 = a.w[in1.p];
+        frag act0[KS], act1[KS], nxt0[KS], nxt1[KS];
+        f32x16 pend0, pend1;
+        // ---- layer 0: fragment 2m+ks of chunk 0, B = enc[ks]; tile m-1 is packed behind the MFMAs of tile m
+        {
+            const char *ch = rs.ch(), *chn = rs.chn();
+            const DmaJob dj = rs.job();
+            frag af[PF];
+#pragma unroll
+            for (int i = 0; i < PF - 1; ++i) af[i] = ap.f[i];
+            f32x16 prev0 = {}, prev1 = {};
+            f32x16 c0 = ap.bias, c1 = ap.bias;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const f32x16 nb = bias_acc(bias_lds + 32 * (m + 1), 0, h);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int t = 2 * m + ks;
+                    af[(t + PF - 1) % PF] = stream_frag<Pol, NF>(ch, chn, t + PF - 1, lane);
+                    c0 = Pol::mma(af[t % PF], enc0[ks], c0);
+                    c1 = Pol::mma(af[t % PF], enc1[ks], c1);
+                }
+                if (m > 0) {
+                    unsigned mk = 0;
+                    pack_elems<Pol, 0, 16>(prev0, act0[2 * (m > 0 ? m - 1 : 0)], act0[2 * (m > 0 ? m - 1 : 0) + 1], mk);
+                    pack_elems<Pol, 0, 16>(prev1, act1[2 * (m > 0 ? m - 1 : 0)], act1[2 * (m > 0 ? m - 1 : 0) + 1], mk);
+                }
+                if (m == (MT > 1 ? 1 : 0) && dj.on) RG::issue(dj);
+                __builtin_amdgcn_sched_barrier(0);
+                prev0 = c0; prev1 = c1;
+                c0 = nb; c1 = nb;
+            }
+#pragma unroll
+            for (int t = KS; t < NF; ++t) af[(t + PF - 1) % PF] = stream_frag<Pol, NF>(ch, chn, t + PF - 1, lane);
+#pragma unroll
+            for (int i = 0; i < PF - 1; ++i) ap.f[i] = af[(NF + i) % PF];
+            ap.bias = c0;
+            pend0 = prev0; pend1 = prev1;
+            rs.step_end();
+        }
+        // ---- hidden layers: ping-pong act <-> nxt
+#pragma nounroll
+        for (int l = 1; l < a.depth; ++l) {
+            const bool sk = (a.skip_mask >> l) & 1;
+            const float *bl = bias_lds + l * W;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const char *ch = rs.ch(), *chn = rs.chn();
+                const DmaJob dj = rs.job();
+                PackPost<Pol> p0(pend0, m == 0 ? act0[KS - 2] : nxt0[2 * (m > 0 ? m - 1 : 0)], m == 0 ? act0[KS - 1] : nxt0[2 * (m > 0 ? m - 1 : 0) + 1]);
+                PackPost<Pol> p1(pend1, m == 0 ? act1[KS - 2] : nxt1[2 * (m > 0 ? m - 1 : 0)], m == 0 ? act1[KS - 1] : nxt1[2 * (m > 0 ? m - 1 : 0) + 1]);
+                f32x16 c0, c1;
+                wide_step<W, Pol, RG>(ch, chn, ap, act0, act1, enc0, enc1, sk, c0, c1, bl + 32 * (m + 1), p0, p1, dj);
+                rs.step_end();
+                pend0 = c0; pend1 = c1;
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS - 2; ++ks) { act0[ks] = nxt0[ks]; act1[ks] = nxt1[ks]; }
+        }
+        float out0, out1;
+        {
+            const char *ch = rs.ch(), *chn = rs.chn();
+            const DmaJob dj = rs.job();
+            PackPost<Pol> p0(pend0, act0[KS - 2], act0[KS - 1]);
+            PackPost<Pol> p1(pend1, act1[KS - 2], act1[KS - 1]);
+            f32x16 c0, c1;
+            wide_step<W, Pol, RG>(ch, chn, ap, act0, act1, enc0, enc1, (a.skip_mask >> a.depth) & 1, c0, c1, bias_lds, p0, p1, dj);
+            out0 = c0[0]; out1 = c1[0];
+            rs.step_end();
+        }
+        float e0 = 0.f, e1 = 0.f;
+        if (h == 0 && live0) e0 = 1.f / (1.f + Pol::fexp(10.f - out0));
+        if (h == 0 && live1) e1 = 1.f / (1.f + Pol::fexp(10.f - out1));
+        if (!RENDER) {
+            if (h == 0 && in0.inb) a.emission[(long long)in0.b * a.P + in0.p] = e0;
+            if (h == 0 && in1.inb) a.emission[(long long)in1.b * a.P + in1.p] = e1;
+        } else {
+            RaySum<8>::put(a, seg_lds, 2 * wv, in0.p, in0.inb, e0, w00, true, in0.b);
+            RaySum<8>::put(a, seg_lds, 2 * wv + 1, in1.p, in1.inb, e1, w01, true, in1.b);
+            if (!a.ray_direct) {
+                lds_barrier();
+                RaySum<8>::combine(a, seg_lds, 2 * wv, in0.b);
+                RaySum<8>::combine(a, seg_lds, 2 * wv + 1, in1.b);
+            }
+        }
+    }
+    rs.idle_step();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 int fused_fill_args(const bhn_model *m, int32_t mode, const void *packed, const bhn_geom *geom,
@@ -268,8 +436,32 @@ int fused_fill_args(const bhn_model *m, int32_t mode, const void *packed, const 
     return BHN_OK;
 }
 
+#ifdef BHN_WIDE_FWD
+template <int W, class Pol, bool RENDER>
+static int launch_fwd_wide(FusedArgs &a, hipStream_t st) {
+    using PK = Pack<W, Pol>;
+    const size_t lds = (size_t)(BHN_FWD_DIST + 1) * PK::CHUNK_BYTES + (size_t)(a.depth + 1) * W * 4 + RaySum<8>::BYTES;
+    auto kern = fused_fwd_wide_kernel<W, Pol, 3, RENDER>;
+    int dev = 0;
+    BHN_HIP(hipGetDevice(&dev));
+    static DeviceOnce once;
+    BHN_HIP(once.run(dev, [&](int &occ) {
+        occ = 1;
+        return hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }));
+    long long grid = (long long)bhn_num_cus(dev);
+    if (grid > a.total_tiles) grid = a.total_tiles;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, a);
+    BHN_HIP(hipGetLastError());
+    return BHN_OK;
+}
+#endif
+
 template <int W, class Pol, bool RENDER, bool DBG = false>
 static int launch_fwd_w(FusedArgs &a, hipStream_t st) {
+#ifdef BHN_WIDE_FWD
+    if constexpr (Pol::ELEM_BYTES == 2 && W == 256 && !DBG) return launch_fwd_wide<W, Pol, RENDER>(a, st);
+#endif
     using PK = Pack<W, Pol>;
     const size_t lds = (size_t)((Pol::ELEM_BYTES == 2 ? BHN_FWD_DIST : 3) + (Pol::PHASE_LAG ? 2 : 1)) * PK::CHUNK_BYTES + (size_t)(a.depth + 1) * W * 4
                        + RaySum<Pol::NWAVES>::BYTES;
