@@ -12,6 +12,7 @@
 //                 share of the tape through LDS; bias gradients come from a constant ones B-fragment.
 //                 One slab flush per workgroup at the end: no float atomics, deterministic.
 //   reduce_kernel sums the slabs of each layer's workgroups into the flat dparams (flax tree order).
+#include <utility>
 #include "fused_common.h"
 
 #ifndef BHN_CHAIN_STAMPS
@@ -87,10 +88,12 @@ struct BwdGeom {
     static constexpr int WCC = Pol::NWAVES / WRR;
     static constexpr int MPW = (MT + WRR - 1) / WRR;
     static constexpr int NPW_ALL = (NTMAX + WCC - 1) / WCC;          // B tiles owned per wave
-    static constexpr int NPASS = (NPW_ALL + 4) / 5;                    // <= 5 B tiles accumulated per sweep
+    // B tiles accumulated per sweep of the tape: 5 with 8 waves (2 per SIMD, 256 registers each); all of them with the
+    // f32 policy's 4 waves (1 per SIMD, 512 registers: 16 accumulator tiles in the AGPRs) -- ONE sweep instead of two
+    static constexpr int SWEEP = (Pol::NWAVES <= 4) ? NTMAX : 5;
+    static constexpr int NPASS = (NPW_ALL + SWEEP - 1) / SWEEP;
     static constexpr int NPW = (NPW_ALL + NPASS - 1) / NPASS;
     static constexpr int GROUP_BYTES = (2 * MT + 1) * TILE_BYTES;   // A tiles + h tiles + enc tile
-    static constexpr int GROUP_BYTES_LAST = GROUP_BYTES + TILE_BYTES + 1024;   // + dout tile + f32 dout piece (dw_body LAST)
     static constexpr int GROUP_BYTES_LAST2 = GROUP_BYTES + 1024;               // + the KiB that starts with the f32 dout (dw_body2 LAST)
     // chain kernels: prefetch distance of the LDS-DMA weight ring (RING_DIST_TAPED+1 buffers of one chunk)
     static constexpr int RING_DIST_TAPED = (Pol::ELEM_BYTES == 2) ? BHN_TAPED_DIST : 3;
@@ -623,103 +626,132 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
 enum { JT_FIRST = 0, JT_HIDDEN = 1, JT_SKIP = 2, JT_OUT = 3, JT_HIDDEN1 = 4, JT_OUTSKIP = 5 };   // HIDDEN1: layer 1 with h_1 recomputed from the
                                                      // encoded inputs; OUTSKIP: output layer fed by concat[h, enc] (odd depths with do_skip)
 
-// LAST (layer depth-1 when TapeLayout::drop_ga): the A region of the group image holds the h_depth tiles, from which
-// the A fragments gA_{depth-1} = (h_depth != 0) * W_out * dout are rebuilt (same f32 product and rounding as the
-// delta-chain kernel), and which are also the B operand of the output layer's row dW_out = sum dout . h_depth
-// (A = the dout tile) -- slab row MT, no separate output job.  Group image [h_depth][h_{depth-1}][enc][dout tile][f32 dout].
-template <int W, class Pol, int JT, bool LAST = false>
+// The tape stream of one dW job: every group is NPJ pieces of 1 KiB (one wave-wide 16-byte LDS-DMA) out of up to four
+// regions -- [A tiles][h tiles][enc tile][dout piece] -- and wave w issues pieces NW*i + w.  A ROW of NW consecutive
+// pieces that lies inside one region needs no per-piece address arithmetic: one buffer resource per region and group
+// (base = the wave's first piece), the row as a compile-time scalar offset.  Round 2 ISA census of the f32 kernel: with
+// 17 pieces per wave, a run-time region select and a 64-bit multiply-add per piece, the issue was ~330 SALU instructions
+// in front of every group's MFMAs (one wave per SIMD: nothing hides them).  Rows that straddle regions (bf16: the 2-piece
+// enc tile + dout piece) keep the generic per-piece form.
+template <int NW, int PA, int PH, int PE, int PD, int OFF_H, int OFF_E, int OFF_D>
+struct TapeStream {
+    static constexpr int NPJ = PA + PH + PE + PD, PPW = (NPJ + NW - 1) / NW;
+    static constexpr int region_of(int piece) { return piece < PA ? 0 : piece < PA + PH ? 1 : piece < PA + PH + PE ? 2 : 3; }
+    static constexpr int region_start(int r) { return r == 0 ? 0 : r == 1 ? PA : r == 2 ? PA + PH : PA + PH + PE; }
+    static constexpr int region_lds(int r) { return r == 0 ? 0 : r == 1 ? OFF_H : r == 2 ? OFF_E : OFF_D; }
+    static constexpr bool uniform_row(int i) {
+        return i >= 0 && NW * i + NW <= NPJ && region_of(NW * i) == region_of(NW * i + NW - 1);
+    }
+    static constexpr int mixed_before(int i) { int n = 0; for (int k = 0; k < i; ++k) n += uniform_row(k) ? 0 : 1; return n; }
+    static constexpr int NMIX = mixed_before(PPW) > 0 ? mixed_before(PPW) : 1;
+    // Every member is indexed by compile-time constants only (a run-time index would put the object into scratch memory):
+    // the region of this wave's piece of a mixed row is resolved once, here, on the constructor's arguments.
+    const char *src[4];          // region bases
+    long long stride[4];         // bytes per group
+    const char *msrc[NMIX];      // mixed rows: base of this wave's piece, its bytes per group, its LDS offset
+    long long mstride[NMIX];
+    int mlds[NMIX];
+    int wvu;
+    DEVI TapeStream(const char *a, long long sa, const char *h, long long sh, const char *e, long long se, const char *d, long long sd, int wave) {
+        wvu = wave;
+        src[0] = a; src[1] = h; src[2] = e; src[3] = d;
+        stride[0] = sa; stride[1] = sh; stride[2] = se; stride[3] = sd;
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            if (uniform_row(i)) continue;
+            int piece = wave + NW * i;
+            piece = piece < NPJ ? piece : NPJ - 1;                    // tail waves re-issue the last piece (equal vmcnt for all waves)
+            const int r = piece < PA ? 0 : piece < PA + PH ? 1 : piece < PA + PH + PE ? 2 : 3;
+            const int st = r == 0 ? 0 : r == 1 ? PA : r == 2 ? PA + PH : PA + PH + PE;
+            const int ld = r == 0 ? 0 : r == 1 ? OFF_H : r == 2 ? OFF_E : OFF_D;
+            const unsigned long long base = reinterpret_cast<unsigned long long>(r == 0 ? a : r == 1 ? h : r == 2 ? e : d);
+            msrc[k] = reinterpret_cast<const char *>(base + (unsigned long long)((piece - st) * 1024));
+            mstride[k] = r == 0 ? sa : r == 1 ? sh : r == 2 ? se : sd;
+            mlds[k] = ld + (piece - st) * 1024;
+            ++k;
+        }
+    }
+    static DEVI u32x4 rsrc(const char *p) {
+        const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+        return u32x4{lo, hi & 0xffffu, 0x7fffffffu, 0x00020000u};
+    }
+    template <int POLICY>
+    static DEVI void dma(const u32x4 &rs, unsigned soff, unsigned m) {
+        const unsigned voff = (threadIdx.x & 63) * 16;
+        if constexpr (POLICY == 1)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen nt lds" ::"s"(m), "v"(voff), "s"(rs), "s"(soff) : "memory");
+        else if constexpr (POLICY == 2)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen sc1 lds" ::"s"(m), "v"(voff), "s"(rs), "s"(soff) : "memory");
+        else
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(m), "v"(voff), "s"(rs), "s"(soff) : "memory");
+    }
+    template <int POLICY, int I>
+    DEVI void row(long long q, unsigned lb, u32x4 (&rs)[4]) const {
+        constexpr int p0 = NW * I;
+        if constexpr (uniform_row(I)) {                               // a whole row inside one region
+            constexpr int r = region_of(p0), rel = (p0 - region_start(r)) * 1024;
+            if constexpr (!(uniform_row(I - 1) && region_of(NW * (I - 1)) == r))      // first such row: the region's resource
+                rs[r] = rsrc(src[r] + wvu * 1024 + q * stride[r]);
+            dma<POLICY>(rs[r], (unsigned)rel, lb + (unsigned)(wvu * 1024 + region_lds(r) + rel));
+        } else {                                                      // a row across regions / the ragged tail
+            constexpr int k = mixed_before(I);
+            dma<POLICY>(rsrc(msrc[k] + q * mstride[k]), 0u, lb + (unsigned)mlds[k]);
+        }
+    }
+    template <int POLICY, int... I>
+    DEVI void rows(long long q, unsigned lb, u32x4 (&rs)[4], std::integer_sequence<int, I...>) const {
+        (row<POLICY, I>(q, lb, rs), ...);
+    }
+    // group q -> LDS image at `buf`
+    template <int POLICY>
+    DEVI void issue(long long q, char *buf) const {
+        const unsigned lb = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<unsigned long long>(buf));
+        u32x4 rs[4];                                                  // (indexed by compile-time constants only)
+        rows<POLICY>(q, lb, rs, std::make_integer_sequence<int, PPW>{});
+    }
+};
+
+// dW job body of the f32 policy (all jobs) and of the bf16 output-layer job at depths < 3 (deeper bf16 networks: dw_body2).
+template <int W, class Pol, int JT>
 DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
     using BG = BwdGeom<W, Pol>;
     using frag = typename Pol::frag;
-    static_assert(!LAST || (Pol::ELEM_BYTES == 2 && (JT == JT_HIDDEN || JT == JT_SKIP)), "LAST: bf16 hidden / skip job");
+    static_assert(JT != JT_HIDDEN1, "h_1 recompute: dw_body2");
     constexpr int MT = BG::MT, TB = BG::TILE_BYTES;
     constexpr int OFF_H = MT * TB, OFF_E = 2 * MT * TB;               // LDS group image [A][h][enc]
-    constexpr int OFF_D = BG::GROUP_BYTES, OFF_D32 = OFF_D + TB;      // LAST: [dout tile][1 KiB piece starting with 32 f32 dout]
-    constexpr int GB = LAST ? BG::GROUP_BYTES_LAST : BG::GROUP_BYTES;
+    constexpr int GB = BG::GROUP_BYTES;
     constexpr bool out_job = JT == JT_OUT || JT == JT_OUTSKIP, has_h = JT != JT_FIRST, has_enc = (JT == JT_FIRST || JT == JT_SKIP || JT == JT_OUTSKIP);
-    constexpr bool make_h = JT == JT_HIDDEN1;       // the h tiles of the LDS group image are computed here, not DMA'd
     constexpr int mtA = out_job ? 1 : MT;                              // A tiles (gA rows; dout is 1 row)
     constexpr int nH = has_h ? MT : 0, nB = nH + (has_enc ? 1 : 0);    // B tiles; slab tile nB holds the bias column,
     constexpr int NT = nB;                                             // summed by VALU from the A fragments (Pol::sum8)
     constexpr bool TR = Pol::ELEM_BYTES == 2;                          // tape tiles are point-on-lane images: transposed LDS reads
+    constexpr bool AGPR = Pol::NWAVES == 4;                            // one wave per SIMD (f32): accumulators in AGPRs, one sweep
     const int trl = tr_lane_off();
-    constexpr int WRR = BG::WRR, WCC = BG::WCC;
+    // wave grid: rows = A tiles, columns = B tiles; the output job has ONE A tile (dout), so all waves go to the columns
+    // (with the hidden jobs' grid only a quarter of its waves had work: 4x the MFMA time per group of an f32 job)
+    constexpr int WRR = out_job ? 1 : BG::WRR, WCC = Pol::NWAVES / WRR;
     constexpr int MPW = (mtA + WRR - 1) / WRR;                         // A tiles per wave (1 for the output job)
     constexpr int NPWJ = (NT + WCC - 1) / WCC;                         // B tiles owned by one wave
-    constexpr int NPASS = (NPWJ + 4) / 5, NPW = (NPWJ + NPASS - 1) / NPASS;
+    constexpr int NPASS = (NPWJ + BG::SWEEP - 1) / BG::SWEEP, NPW = (NPWJ + NPASS - 1) / NPASS;
+    constexpr int NPIN = 256 / (16 * MPW);                             // accumulator tiles per A tile that fit the 256 AGPRs
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: wave-uniform branches
     const int nwg = A.wg_begin[job + 1] - A.wg_begin[job];
     const int kb = blockIdx.x - A.wg_begin[job];
     const long long q0 = uniform64(A.t.NQ * kb / nwg), q1 = uniform64(A.t.NQ * (kb + 1) / nwg);
-    const char *srcA = out_job ? A.tape + A.t.dout_off : (LAST ? A.tape + A.t.h_off[job + 1] : A.tape + A.t.ga_off[out_job ? 0 : job]);
+    const char *srcA = out_job ? A.tape + A.t.dout_off : A.tape + A.t.ga_off[out_job ? 0 : job];
     const long long strideA = out_job ? A.t.dout_stride : (long long)MT * TB;       // dout is one tile per group
-    const char *srcD = A.tape + A.t.dout_off;
     const char *srcH = has_h ? A.tape + A.t.h_off[job] : nullptr;
-    const char *srcE = A.tape + (make_h ? A.t.encp_off : A.t.enc_off);
+    const char *srcE = A.tape + A.t.enc_off;
     const int wr = wv % WRR, wc = wv / WRR;
-    // HIDDEN1: W_0 (the forward's layer-0 chunk: A-operand fragment 2m+ks of W_0^T = B-operand fragment of W_0) and
-    // b_0 behind the ring
-    char *w0_lds = smem + BG::NBUF * GB;
-    float *b0_lds = reinterpret_cast<float *>(w0_lds + 2 * MT * Pol::FRAG_BYTES);
-    if constexpr (make_h) {
-        const char *w0 = A.f.packed + A.f.fwd_off;
-        for (int i = tid; i < 2 * MT * Pol::FRAG_BYTES / 16; i += Pol::NTHREADS)
-            reinterpret_cast<u32x4 *>(w0_lds)[i] = reinterpret_cast<const u32x4 *>(w0)[i];
-        for (int i = tid; i < W; i += Pol::NTHREADS) b0_lds[i] = reinterpret_cast<const float *>(A.f.packed + A.f.bias_off)[i];
-    }
-    // h_1 tile `wv` of a group image from its encoded-input fragments: D[point][feature] = enc^T . W_0 + b_0, in three
-    // phases (LDS reads, two MFMAs, relu + pack + LDS write) placed around the dW MFMAs of the group being consumed.
-    struct HIn { frag e0, e1, w0, w1; float b; };
-    auto make_h_read = [&](const char *gp) {
-        HIn in;
-        in.e0 = Pol::lds_frag(gp + OFF_E, 0, lane); in.e1 = Pol::lds_frag(gp + OFF_E, 1, lane);
-        const int t = wv < MT ? wv : 0;
-        in.w0 = Pol::lds_frag(w0_lds, 2 * t, lane); in.w1 = Pol::lds_frag(w0_lds, 2 * t + 1, lane);
-        in.b = b0_lds[32 * t + (lane & 31)];
-        return in;
-    };
-    auto make_h_mma = [&](const HIn &in) {
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = in.b;
-        acc = Pol::mma(in.e0, in.w0, acc);
-        acc = Pol::mma(in.e1, in.w1, acc);
-        return acc;
-    };
-    auto make_h_write = [&](char *gp, const f32x16 &acc) {
-        if (wv < MT) {
-            frag o[2];
-            unsigned unused = 0;
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) Pol::relu_pair(o[r >> 3], (r & 7) >> 1, r >> 1, acc[r], acc[r + 1], unused);
-            if constexpr (Pol::ELEM_BYTES == 2) {
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) *reinterpret_cast<frag *>(gp + OFF_H + wv * TB + s2 * Pol::FRAG_BYTES + lane * 16) = o[s2];
-            }
-        }
-    };
     const bool wave_works = wr * MPW < mtA;                            // output job: only the wr == 0 waves
-    frag ones;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) Pol::set(ones, j, 1.f);
-    // LAST: W_out of this lane's feature in each of the wave's A tiles; the output row's tiles are shared out over the
-    // waves that hold the same A tiles (A tile mi -> the wave with wc == mi % WCC), its bias column goes to one wave
-    constexpr int MO = (MPW + WCC - 1) / WCC;
-    float wout_r[MPW];
-    f32x16 acc_o[MO], acc_b = {};
-    const bool bias_wave = LAST && wr == WRR - 1 && wc == (((WCC - 1) * NPWJ < nB) ? WCC - 1 : 0);   // a wave that runs compute_group
-    if constexpr (LAST) {
-#pragma unroll
-        for (int mi = 0; mi < MPW; ++mi) {
-            const int f = 32 * (wr * MPW + mi) + (lane & 31);
-            wout_r[mi] = f < W ? reinterpret_cast<const float *>(A.f.packed + A.f.wout_off)[f] : 0.f;
-        }
-#pragma unroll
-        for (int o = 0; o < MO; ++o)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc_o[o][r] = 0.f;
-    }
     float *slab = A.f.slabs + (long long)blockIdx.x * BG::SLAB_FLOATS;
+    // pieces (1 KiB = one wave-wide DMA) this job really needs: [A tiles | dout][h tiles][enc tile]
+    constexpr int PA = out_job ? TB / 1024 : MT * TB / 1024, PH = has_h ? MT * TB / 1024 : 0, PE = has_enc ? TB / 1024 : 0;
+    using Stream = TapeStream<Pol::NWAVES, PA, PH, PE, 0, OFF_H, OFF_E, 0>;
+    constexpr int PPW = Stream::PPW;
+    const Stream stream(srcA, strideA, srcH, (long long)MT * TB, srcE, TB, nullptr, 0, wv);
 
     for (int pass = 0; pass < NPASS; ++pass) {
         const int nbase = wc * NPWJ + pass * NPW;
@@ -740,16 +772,23 @@ DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
 #pragma unroll
         for (int mi = 0; mi < MPW; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < NPW; ++ni)
+            for (int ni = 0; ni < NPW; ++ni) {
+                if constexpr (AGPR) {
+                    // zeroed by an MFMA with a literal-zero SrcC, straight into the AGPRs: 256 zeros initialised through
+                    // VGPRs made hipcc spill the stream's state, and every reload inside the loop is an
+                    // `s_waitcnt vmcnt(0)` that also waits for the group just issued
+                    const f32x16 z = {};
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(0.f, 0.f, z, 0, 0, 0);
+                } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+                }
+            }
         __syncthreads();
-        // B fragments are fetched two MFMA-pairs ahead of their use (counted lgkmcnt instead of a full
-        // drain after every read): with the two waves of a SIMD in barrier lockstep nothing else hides
-        // the LDS latency.  A fragments of both k-steps are loaded up front.
-        // (HIDDEN1: the h_1 tiles were written by make_h_write in fragment order, not DMA'd as point-on-lane images)
+        // B fragments are fetched AHEAD MFMA groups ahead of their use (counted lgkmcnt instead of a full drain after
+        // every read).  A fragments of both k-steps are loaded up front.
         auto load_b = [&](const char *gp, int t) -> frag {
-            if constexpr (TR && !make_h) return tr_frag(gp + boff[t % NPW], t / NPW, trl);
+            if constexpr (TR) return tr_frag(gp + boff[t % NPW], t / NPW, trl);
             else return Pol::lds_frag(gp + boff[t % NPW], t / NPW, lane);
         };
         auto load_a = [&](const char *tile, int s2) -> frag {
@@ -758,50 +797,24 @@ DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
         };
         auto compute_group = [&](const char *gp) {
             constexpr int NTOT = 2 * NPW, AHEAD = (Pol::ELEM_BYTES == 2) ? 2 : 1;
+            if constexpr (AGPR) {
+                // the accumulators stay in AGPRs, in place (the MFMA takes SrcC / vDst from either file).  Left to itself
+                // hipcc keeps the loop-carried tiles in VGPRs and copies them to AGPRs and back around every group
+                // (v_accvgpr_write / _read: 256 VALU per group behind the MFMA results) -- the f32 dW kernel ran at 64 %
+                // matrix-pipe occupancy.  The empty asm ties the tiles to the AGPR class across the back edge.
+#pragma unroll
+                for (int mi = 0; mi < MPW; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NPW && ni < NPIN; ++ni) asm volatile("" : "+a"(acc[mi][ni]));
+            }
             frag af[2][MPW];
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                f32x4 da = {}, db = {};
-                frag ad = {};
-                if constexpr (LAST) {
-                    // dout of this lane's eight points of k-step s: tape point order p = (j&3) + 8(j>>2) + 16s + 4(lane>>5)
-                    const float *d32 = reinterpret_cast<const float *>(gp + OFF_D32) + 16 * s + 4 * (lane >> 5);
-                    da = *reinterpret_cast<const f32x4 *>(d32);
-                    db = *reinterpret_cast<const f32x4 *>(d32 + 8);
-                    ad = load_a(gp + OFF_D, s);
-                }
+            for (int s = 0; s < 2; ++s)
 #pragma unroll
                 for (int mi = 0; mi < MPW; ++mi) {
                     af[s][mi] = load_a(gp + (wr * MPW + mi) * TB, s);
-                    if constexpr (LAST) {
-                        if (pass == 0 && (mi % WCC) == wc) acc_o[mi / WCC] = Pol::mma(ad, af[s][mi], acc_o[mi / WCC]);
-                        const u32x4 raw = __builtin_bit_cast(u32x4, af[s][mi]);
-                        u32x4 ga;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            // (W_out * dout) of two points: v_pk_mul_f32 + v_cvt_pk_bf16_f32; relu'(a) from h >= 0 (bf16 halves
-                            // <= 0x7f80): + 0x7fff sets the half's sign bit iff h != 0 without a carry, >> 15 (packed,
-                            // arithmetic) spreads it.  Two compiler traps on the way here: inline asm (v_pk_min_u16) wrote
-                            // into registers the output-row MFMA issued just before was still reading as SrcB (opaque to
-                            // the hazard recogniser: wrong dW_out), and "(0 - h) >> 15" on the four dwords as i16x2 vectors
-                            // was combined by hipcc 7.2 into ONE mask for all four dwords (wrong dW_{depth-1}).
-                            typedef float f32x2 __attribute__((ext_vector_type(2)));
-                            typedef short i16x2 __attribute__((ext_vector_type(2)));
-                            const f32x2 dd = {i < 2 ? da[2 * i] : db[2 * i - 4], i < 2 ? da[2 * i + 1] : db[2 * i - 3]};
-                            const f32x2 pr = dd * wout_r[mi];
-                            const typename Pol::bf16x2 t = {(__bf16)pr[0], (__bf16)pr[1]};
-                            const unsigned sgn = raw[i] + 0x7fff7fffu;
-                            const i16x2 on = __builtin_bit_cast(i16x2, sgn) >> (i16x2){15, 15};
-                            ga[i] = __builtin_bit_cast(unsigned, t) & __builtin_bit_cast(unsigned, on);
-                        }
-                        af[s][mi] = __builtin_bit_cast(frag, ga);
-                    }
                     if (bias_rows) bsum[mi] = Pol::sum8(af[s][mi], bsum[mi]);
                 }
-                if constexpr (LAST) {
-                    if (pass == 0 && bias_wave) acc_b = Pol::mma(ad, ones, acc_b);
-                }
-            }
             frag bq[AHEAD + 1];
 #pragma unroll
             for (int t = 0; t < AHEAD && t < NTOT; ++t) bq[t] = load_b(gp, t);
@@ -817,82 +830,31 @@ DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
             }
         };
         {
-            // (f32: 2 buffers -- the DMA of group q+1 runs under the MFMAs of group q, which at 8 MFMAs per fragment
-            //  pair are several times longer than an HBM round trip)
-            // LDS-DMA ring: group q+NBUF-1 is issued right after the barrier that proves buffer
-            // (q-1)%NBUF has been consumed; the counted wait leaves NBUF-2 younger groups in flight.
-            // pieces (1 KiB = one wave-wide DMA) this job really needs: [A tiles | dout][h tiles][enc tile]
+            // LDS-DMA ring: group q+NBUF-1 is issued right after the barrier that proves buffer (q-1)%NBUF has been
+            // consumed; the counted wait leaves NBUF-2 younger groups in flight.  (f32: 2 buffers of 68 KB -- the DMA of
+            // group q+1 runs under the MFMAs of group q, which are several times longer than an HBM round trip)
             constexpr int NBUF = BG::NBUF;
-            constexpr int PA = out_job ? TB / 1024 : MT * TB / 1024, PH = (has_h && !make_h) ? MT * TB / 1024 : 0,
-                          PE = (has_enc || make_h) ? TB / 1024 : 0, PD = LAST ? TB / 1024 + 1 : 0;
-            constexpr int NPJ = PA + PH + PE + PD, PPW = (NPJ + Pol::NWAVES - 1) / Pol::NWAVES;
-            const int wvu = __builtin_amdgcn_readfirstlane(wv);
-            const char *sbase[PPW];
-            long long sstride[PPW];
-            int doff[PPW];
-#pragma unroll
-            for (int i = 0; i < PPW; ++i) {
-                int piece = wvu + Pol::NWAVES * i;
-                piece = piece < NPJ ? piece : NPJ - 1;                  // tail waves re-issue the last piece
-                if (piece < PA) {
-                    doff[i] = piece * 1024;
-                    sbase[i] = srcA + piece * 1024;
-                    sstride[i] = strideA;
-                } else if (piece < PA + PH) {
-                    doff[i] = OFF_H + (piece - PA) * 1024;
-                    sbase[i] = srcH + (piece - PA) * 1024;
-                    sstride[i] = (long long)MT * TB;
-                } else if (piece < PA + PH + PE) {
-                    doff[i] = OFF_E + (piece - PA - PH) * 1024;
-                    sbase[i] = srcE + (piece - PA - PH) * 1024;
-                    sstride[i] = TB;
-                } else {                                                // LAST: dout tile, then the piece that starts with f32 dout
-                    doff[i] = OFF_D + (piece - PA - PH - PE) * 1024;
-                    sbase[i] = srcD + (piece - PA - PH - PE) * 1024;
-                    sstride[i] = A.t.dout_stride;
-                }
-            }
             auto issue = [&](long long q, char *buf) {
                 q = q < q1 ? q : q1 - 1;
                 if (BHN_DBG(A.wrap)) q %= A.wrap;
-#pragma unroll
-                for (int i = 0; i < PPW; ++i) {
-                    if (BHN_DBG(A.policy == 1)) dma_1k_asm<0>(sbase[i] + q * sstride[i], buf + doff[i]);
-                    else if (BHN_DBG(A.policy == 2)) dma_1k_asm<2>(sbase[i] + q * sstride[i], buf + doff[i]);
-                    else dma_1k_asm<1>(sbase[i] + q * sstride[i], buf + doff[i]);
-                }
+                if (BHN_DBG(A.policy == 1)) stream.template issue<0>(q, buf);
+                else if (BHN_DBG(A.policy == 2)) stream.template issue<2>(q, buf);
+                else stream.template issue<1>(q, buf);
             };
-            // HIDDEN1: the h tiles of group q+1 are computed while group q is consumed (one group less in flight:
-            // this job is MFMA-bound), so the loop-top barrier also publishes them and no latency chain is exposed
-            constexpr int INFLIGHT = make_h ? (NBUF >= 3 ? NBUF - 3 : 0) : NBUF - 2;
+            constexpr int INFLIGHT = NBUF - 2;
             if (q0 < q1) {
 #pragma unroll
                 for (int j = 0; j < NBUF - 1; ++j) issue(q0 + j, smem + j * GB);
-                if constexpr (make_h) {
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * PPW) : "memory");
-                    __builtin_amdgcn_s_barrier();
-                    asm volatile("" ::: "memory");
-                    make_h_write(smem, make_h_mma(make_h_read(smem)));
-                }
                 int it = 0;
                 for (long long q = q0; q < q1; ++q) {
                     if (!BHN_DBG(A.debug & 2)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT * PPW) : "memory");
-                    if constexpr (make_h) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's h-tile writes
                     __builtin_amdgcn_s_barrier();
                     asm volatile("" ::: "memory");      // the raw barrier is not a compiler fence: keep the
                                                          // DMA issue and the ds_reads below it
                     const int nx = (it == 0) ? NBUF - 1 : it - 1;
                     if (!BHN_DBG(A.debug & 2)) issue(q + NBUF - 1, smem + nx * GB);
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    char *gnext = smem + ((it == NBUF - 1) ? 0 : it + 1) * GB;
-                    // the next group's h tile: LDS reads and the two MFMAs ahead of this group's dW MFMAs, relu / pack /
-                    // LDS write behind them (the MFMA result is long done by then: no exposed MFMA -> VALU latency)
-                    f32x16 hacc = {};
-                    if constexpr (make_h) hacc = make_h_mma(make_h_read(gnext));
                     if (!BHN_DBG(A.debug & 1) && wave_works && has_tiles) compute_group(smem + it * GB);
-                    if constexpr (make_h) {
-                        if (q + 1 < q1) make_h_write(gnext, hacc);
-                    }
                     it = (it == NBUF - 1) ? 0 : it + 1;
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -905,6 +867,9 @@ DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
             for (int ni = 0; ni < NPW; ++ni) {
                 const int m = wr * MPW + mi, n = nbase + ni;
                 if (m >= mtA || n >= nB || n >= (wc + 1) * NPWJ) continue;
+                // (AGPR: the tile stays in its AGPRs until here -- hipcc otherwise copies all tiles to VGPRs at the loop exit,
+                //  256 live VGPRs whose pressure spills the loop's state)
+                if constexpr (AGPR) { if (ni < NPIN) asm volatile("" : "+a"(acc[mi][ni])); }
                 float *tp = slab + (long long)(m * BG::NTMAX + n) * 1024;
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
@@ -919,6 +884,7 @@ DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
                     }
                     *dst = v;
                 }
+                __builtin_amdgcn_sched_barrier(0);      // one tile at a time
             }
         // bias column (slab tile nB, column 0: what reduce_kernel reads): row i of A tile m is held by lanes i and i + 32
         if (bias_rows) {
@@ -934,28 +900,6 @@ DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
                 }
             }
         }
-    }
-    if constexpr (LAST) {       // the output layer's row: slab row MT, column tiles = h_depth tiles, then the bias tile
-        auto flush_tile = [&](int n, const f32x16 &t) {
-            float *tp = slab + (long long)(MT * BG::NTMAX + n) * 1024;
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = t[4 * g4 + e];
-                f32x4 *dst = reinterpret_cast<f32x4 *>(tp + g4 * 256 + lane * 4);
-                if (A.accumulate) {
-                    const f32x4 old = *dst;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += old[e];
-                }
-                *dst = v;
-            }
-        };
-#pragma unroll
-        for (int mi = 0; mi < MPW; ++mi)
-            if ((mi % WCC) == wc && wr * MPW + mi < MT) flush_tile(wr * MPW + mi, acc_o[mi / WCC]);
-        if (bias_wave) flush_tile(MT, acc_b);
     }
 }
 
@@ -1183,34 +1127,15 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
     // ---- the stream: pieces (1 KiB = one wave-wide DMA) this job needs: [A tiles][h tiles][enc tile][f32 dout piece]
     constexpr int PA = MT * TB / 1024, PH = (has_h && !make_h) ? MT * TB / 1024 : 0,
                   PE = (JT == JT_FIRST || JT == JT_SKIP || make_h || OUTENC) ? TB / 1024 : 0, PD = LAST ? 1 : 0;
-    constexpr int NPJ = PA + PH + PE + PD, PPW = (NPJ + Pol::NWAVES - 1) / Pol::NWAVES;
-    const int wvu = __builtin_amdgcn_readfirstlane(wv);
-    const char *sbase[PPW];
-    long long sstride[PPW];
-    int doff[PPW];
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-        int piece = wvu + Pol::NWAVES * i;
-        piece = piece < NPJ ? piece : NPJ - 1;                  // tail waves re-issue the last piece
-        if (piece < PA) {
-            doff[i] = piece * 1024; sbase[i] = srcA + piece * 1024; sstride[i] = (long long)MT * TB;
-        } else if (piece < PA + PH) {
-            doff[i] = OFF_H + (piece - PA) * 1024; sbase[i] = srcH + (piece - PA) * 1024; sstride[i] = (long long)MT * TB;
-        } else if (piece < PA + PH + PE) {
-            doff[i] = OFF_E + (piece - PA - PH) * 1024; sbase[i] = srcE + (piece - PA - PH) * 1024; sstride[i] = TB;
-        } else {                                                // LAST: the KiB that starts with this group's 32 f32 dout
-            doff[i] = OFF_D32; sbase[i] = srcD; sstride[i] = A.t.dout_stride;
-        }
-    }
+    using Stream = TapeStream<Pol::NWAVES, PA, PH, PE, PD, OFF_H, OFF_E, OFF_D32>;
+    constexpr int PPW = Stream::PPW;
+    const Stream stream(srcA, (long long)MT * TB, srcH, (long long)MT * TB, srcE, TB, srcD, A.t.dout_stride, wv);
     auto issue = [&](long long q, char *buf) {
         q = q < q1 ? q : q1 - 1;
         if (BHN_DBG(A.wrap)) q %= A.wrap;
-#pragma unroll
-        for (int i = 0; i < PPW; ++i) {
-            if (BHN_DBG(A.policy == 1)) dma_1k_asm<0>(sbase[i] + q * sstride[i], buf + doff[i]);
-            else if (BHN_DBG(A.policy == 2)) dma_1k_asm<2>(sbase[i] + q * sstride[i], buf + doff[i]);
-            else dma_1k_asm<1>(sbase[i] + q * sstride[i], buf + doff[i]);
-        }
+        if (BHN_DBG(A.policy == 1)) stream.template issue<0>(q, buf);
+        else if (BHN_DBG(A.policy == 2)) stream.template issue<2>(q, buf);
+        else stream.template issue<1>(q, buf);
     };
     __syncthreads();                                            // W_0 / b_0 visible (HIDDEN1)
     if (q0 < q1) {
@@ -1332,7 +1257,7 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
 }
 
 template <int W, class Pol>
-__global__ __launch_bounds__(Pol::NTHREADS) void dw_kernel(BwdArgs A) {
+__global__ __launch_bounds__(Pol::NTHREADS) __attribute__((amdgpu_waves_per_eu(Pol::NWAVES == 4 ? 1 : (W <= 128 ? 4 : 2)))) void dw_kernel(BwdArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];       // NBUF x GROUP_BYTES
     const int depth = A.f.depth;
     int job = 0;
@@ -1551,6 +1476,16 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
                                                                   // same MFMA work + the recompute: not byte-bound any more
             work[l] = (double)(mtA + nB) + 0.5;
             if (l == depth - 1 && t1.drop_ga) work[l] += jobl_w * BG::MT / 8.0;    // + the rebuild of gA and the output row
+            if constexpr (Pol::ELEM_BYTES == 4) {
+                // f32: the jobs are MFMA-bound (a 32x32x2 MFMA is 64 cycles; one 32x32 tile product over a 32-point
+                // group = 16 of them = 0.55 us at the observed 1.87 GHz) unless they stream more than ~34 GB/s per
+                // workgroup (one 68 KB group in flight per ~2 us round trip = 0.075 tile products per KiB: measured 26 GB/s for the layer-0 job alone)
+                const int a_tiles = (l == depth) ? 1 : BG::MT;           // the output job's A operand is the dout tile
+                const int wrr = (l == depth) ? 1 : BG::WRR, wcc = Pol::NWAVES / wrr;
+                const double tp = (double)((a_tiles + wrr - 1) / wrr) * ((nB + wcc - 1) / wcc);
+                const double kib = (double)(a_tiles + nB) * BG::TILE_BYTES / 1024.0;
+                work[l] = (tp > 0.075 * kib ? tp : 0.075 * kib) + 0.1;
+            }
             if (l > last_job) work[l] = 0;
             tot += work[l];
         }
@@ -1571,7 +1506,7 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
         }
     }
     // ring + bias rows + zero row + output weights + identity fragments
-    const size_t lds_fixed = (size_t)(depth + 1) * W * 4 + 128 + W * 4 + (Pol::ELEM_BYTES == 2 ? 0 : 2 * Pol::FRAG_BYTES) + RaySum<Pol::NWAVES>::BYTES;
+    const size_t lds_fixed = (size_t)(depth + 1) * W * 4 + 128 + W * 4 + (Pol::ELEM_BYTES == 2 ? 0 : 2 * Pol::FRAG_BYTES) + RaySum<Pol::NWAVES>::bytes(A.f.Sx);
     const size_t lds_taped = (size_t)(BG::RING_DIST_TAPED + 1) * PK::CHUNK_BYTES + lds_fixed;
     size_t lds_dw = (size_t)BG::NBUF * BG::GROUP_BYTES + (t1.drop_h1 ? (size_t)2 * BG::MT * Pol::FRAG_BYTES + W * 4 : 0);
     if (t1.drop_ga && (size_t)BG::NBUF * BG::GROUP_BYTES_LAST2 > lds_dw) lds_dw = (size_t)BG::NBUF * BG::GROUP_BYTES_LAST2;

@@ -721,7 +721,9 @@ DEVI float half_wave_sum(float v) {
 template <int NW>
 struct RaySum {
     static constexpr int SMAX = 4;                                   // Stokes planes (bhn_geom.S <= 4)
-    static constexpr int BYTES = NW * 32 * 4 + NW * SMAX * 32 * 4 + NW * 4;
+    static constexpr int BYTES = NW * 32 * 4 + NW * SMAX * 32 * 4 + NW * 4;                      // at Sx = 4
+    // the scratch is sized for the Stokes planes actually rendered (the f32 8x256 training forward has 1.9 KB left)
+    __host__ __device__ static constexpr int bytes(int sx) { return NW * 32 * 4 + NW * sx * 32 * 4 + NW * 4; }
     // Dense layouts whose rays start on a 32-point boundary and are at most 64 samples long (G = 32, 64), or at most 33
     // samples anywhere: a pixel gets at most two adds from per-tile atomics as well -- round 1's epilogue, kept for these
     // (BASELINE config 2 is G = 64): the LDS combine and its barrier cost 3 % of the inference forward.
@@ -745,8 +747,8 @@ struct RaySum {
     static DEVI void put(const FusedArgs &a, char *lds, int vw, long long p, bool inb, float e, float w0, bool have_w0, int b = -1) {
         const int lane = threadIdx.x & 63, h = lane >> 5;
         int *seg_ray = reinterpret_cast<int *>(lds);                                  // [NW][32]
-        float *seg_val = reinterpret_cast<float *>(lds + NW * 32 * 4);                // [NW][SMAX][32]
-        int *seg_n = reinterpret_cast<int *>(lds + NW * 32 * 4 + NW * SMAX * 32 * 4); // [NW]
+        float *seg_val = reinterpret_cast<float *>(lds + NW * 32 * 4);                // [NW][Sx][32]
+        int *seg_n = reinterpret_cast<int *>(lds + NW * 32 * 4 + NW * a.Sx * 32 * 4); // [NW]
         const long long ray = inb ? (a.ray_idx ? (long long)a.ray_idx[p] : (long long)a.fd_G.div((unsigned)p)) : -1;
         unsigned long long rem = __ballot(h == 0 && inb);
         int k = 0;
@@ -759,7 +761,7 @@ struct RaySum {
                 v = half_wave_sum(v);
                 if (lane == first) {
                     if (a.ray_direct) atomicAdd(a.images + ((long long)b * a.Sx + s) * a.R + r0, v);
-                    else seg_val[(vw * SMAX + s) * 32 + k] = v;
+                    else seg_val[(vw * a.Sx + s) * 32 + k] = v;
                 }
             }
             if (lane == first && !a.ray_direct) seg_ray[vw * 32 + k] = (int)r0;
@@ -774,7 +776,7 @@ struct RaySum {
         const int lane = threadIdx.x & 63, h = lane >> 5, pl = lane & 31;
         const int *seg_ray = reinterpret_cast<const int *>(lds);
         const float *seg_val = reinterpret_cast<const float *>(lds + NW * 32 * 4);
-        const int *seg_n = reinterpret_cast<const int *>(lds + NW * 32 * 4 + NW * SMAX * 32 * 4);
+        const int *seg_n = reinterpret_cast<const int *>(lds + NW * 32 * 4 + NW * a.Sx * 32 * 4);
         if (h == 0 && pl < seg_n[vw]) {
             const int r = seg_ray[vw * 32 + pl];
             bool owner = true;                      // the ray starts in this workgroup tile with this segment
@@ -784,11 +786,11 @@ struct RaySum {
             }
             if (owner) {
                 for (int s = 0; s < a.Sx; ++s) {
-                    float sum = seg_val[(vw * SMAX + s) * 32 + pl];
+                    float sum = seg_val[(vw * a.Sx + s) * 32 + pl];
                     if (pl == seg_n[vw] - 1) {      // the wave's last segment may continue in the following waves
                         for (int w2 = vw + 1; w2 < NW; ++w2) {
                             if (seg_n[w2] == 0 || seg_ray[w2 * 32] != r) break;
-                            sum += seg_val[(w2 * SMAX + s) * 32];
+                            sum += seg_val[(w2 * a.Sx + s) * 32];
                             if (seg_n[w2] != 1) break;
                         }
                     }

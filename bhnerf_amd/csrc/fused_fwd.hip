@@ -440,7 +440,7 @@ int fused_fill_args(const bhn_model *m, int32_t mode, const void *packed, const 
 template <int W, class Pol, bool RENDER>
 static int launch_fwd_wide(FusedArgs &a, hipStream_t st) {
     using PK = Pack<W, Pol>;
-    const size_t lds = (size_t)(BHN_FWD_DIST + 1) * PK::CHUNK_BYTES + (size_t)(a.depth + 1) * W * 4 + RaySum<8>::BYTES;
+    const size_t lds = (size_t)(BHN_FWD_DIST + 1) * PK::CHUNK_BYTES + (size_t)(a.depth + 1) * W * 4 + RaySum<8>::bytes(a.Sx);
     auto kern = fused_fwd_wide_kernel<W, Pol, 3, RENDER>;
     int dev = 0;
     BHN_HIP(hipGetDevice(&dev));
@@ -464,7 +464,7 @@ static int launch_fwd_w(FusedArgs &a, hipStream_t st) {
 #endif
     using PK = Pack<W, Pol>;
     const size_t lds = (size_t)((Pol::ELEM_BYTES == 2 ? BHN_FWD_DIST : 3) + (Pol::PHASE_LAG ? 2 : 1)) * PK::CHUNK_BYTES + (size_t)(a.depth + 1) * W * 4
-                       + RaySum<Pol::NWAVES>::BYTES;
+                       + RaySum<Pol::NWAVES>::bytes(a.Sx);
     auto kern = fused_fwd_kernel<W, Pol, 3, RENDER, DBG>;
     int dev = 0;
     BHN_HIP(hipGetDevice(&dev));

@@ -3,9 +3,10 @@ sys.path.insert(0, '/root/repo')
 import os; os.environ.setdefault('BHNERF_HIP_LIB', '/root/repo/bhnerf_amd/csrc/libbhnerf_hip_dbg.so')   # debug build: make -C bhnerf_amd/csrc debug
 from bhnerf_amd import _hip, engine, network, synthetic, constants
 dev = torch.device('cuda:0')
+MODE = sys.argv[1] if len(sys.argv) > 1 else 'bf16'       # python tools/dbg_dw.py [bf16|f32]
 H = W = 128; G = 64; B = 8
 geo = synthetic.synthetic_geodesics(H, W, G)
-pred = network.NeRF_Predictor(8.0, 0.0, np.inf, np.inf, net_depth=4, net_width=256, mode='bf16', device=dev)
+pred = network.NeRF_Predictor(8.0, 0.0, np.inf, np.inf, net_depth=4, net_width=256, mode=MODE, device=dev)
 eng = pred.engine()
 geom = pred.geometry(geo['coords'], geo['Omega'], geo['t_geos'], None, geo['g'], geo['dtau'], geo['Sigma'])
 flat = eng.flatten(network.MLP(4, 256).init(1, 21)); eng.pack(flat)
