@@ -61,6 +61,8 @@ def parse():
     ap.add_argument('--width', type=int, default=256)
     ap.add_argument('--depth', type=int, default=4)
     ap.add_argument('--masked', action='store_true', help='use the tutorial domain masks instead of all-active')
+    ap.add_argument('--overlap-allreduce', action='store_true',
+                    help='N > 1: run the all-reduce of step k under step k+1 (one-step-stale gradients; NOT the reference semantics, off by default)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity-mode', action='store_true', help='skip the f32 parity-mode block')
     ap.add_argument('--no-tutorial-domain', action='store_true',
@@ -249,7 +251,7 @@ def main():
     target = synthetic.hotspot_movie(geo, t_frames[::max(1, nt // 8)], GM_c3)     # a few distinct frames,
     target = np.ascontiguousarray(np.resize(target, (nt, H, W)))                   # tiled over the movie
     train_step = optimization.TrainStep.image(t_frames * units.hr, target, sigma=1.0, dtype='full')
-    hparams = {'num_iters': 5000, 'lr_init': 1e-4, 'lr_final': 1e-6, 'seed': 1}
+    hparams = {'num_iters': 5000, 'lr_init': 1e-4, 'lr_final': 1e-6, 'seed': 1, 'overlap_allreduce': args.overlap_allreduce}
     opt = optimization.Optimizer(hparams, pred, rt_args)
     batch = args.frames_per_gpu * world
     assert batch <= nt, 'frames per step exceed the movie length'
@@ -424,7 +426,7 @@ def main():
         'dtype': args.mode, 'data': 'synthetic',
         'config': {'workload': 'Tutorial3 image-plane recovery: %dx%d rays x %d samples, %d frames, %dx%d MLP, loss full'
                                % (H, W, G, nt, args.depth, args.width),
-                   'frames_per_step': batch, 'frames_per_gpu': args.frames_per_gpu, 'parallelism': 'dp%d (time-frames)' % world,
+                   'frames_per_step': batch, 'frames_per_gpu': args.frames_per_gpu, 'parallelism': 'dp%d (time-frames)' % world + (', stale-gradient all-reduce overlap' if (args.overlap_allreduce and world > 1) else ''),
                    'active_fraction': round(geom.active_fraction, 4), 'visited_fraction': round(geom.visited_fraction, 4),
                    'tape_frame_group': group,
                    'loss': loss_now},

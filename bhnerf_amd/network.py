@@ -95,14 +95,52 @@ class TrainState:
         self.step = 0
         self.num_iters, self.lr_init, self.lr_final = int(num_iters), float(lr_init), float(lr_final)
         self.grad = torch.zeros(flat.numel() + _world()[1], dtype=torch.float32, device=flat.device)
+        # Opt-in (north_star: "all-reduce ... overlapped with the next forward"): the all-reduce of step k runs
+        # under the forward and backward of step k+1 and its gradient is applied after them -- one-step-stale gradients,
+        # NOT the reference's synchronous pmean (network.py:620), hence off by default.
+        self.overlap_allreduce = False
+        self._grad2 = None
+        self._pending = None                    # (work handle, buffer) of the all-reduce in flight
 
     def grad_buffer(self):
         """Flat gradient + one loss slot per rank (the single all-reduce message); re-sized when the process group was
-        initialised after this state was built."""
+        initialised after this state was built.  With an all-reduce in flight: the other buffer of the pair."""
         want = self.flat.numel() + _world()[1]
         if self.grad.numel() != want:
+            self.finish_allreduce()
             self.grad = torch.zeros(want, dtype=torch.float32, device=self.flat.device)
+            self._grad2 = None
+        if self._pending is not None and self._pending[1] is self.grad:
+            if self._grad2 is None:
+                self._grad2 = torch.zeros_like(self.grad)
+            return self._grad2
         return self.grad
+
+    def exchange_overlapped(self, buf, n, loss, rank, world):
+        """Stale-gradient data parallelism (overlap_allreduce): start this step's all-reduce asynchronously, then complete
+        the PREVIOUS step's (it ran under this step's forward and backward) and apply its gradient.  Returns the loss
+        vector of the completed step (first step: this rank's own loss, NaN elsewhere; no update yet)."""
+        import torch.distributed as dist
+        prev = self._pending
+        buf[n:].zero_()
+        buf[n + rank] = loss.reshape(-1)[0]
+        self._pending = (dist.all_reduce(buf, async_op=True), buf)
+        if prev is None:
+            out = torch.full((world,), float('nan'), dtype=torch.float32, device=buf.device)
+            out[rank] = loss.reshape(-1)[0]
+            return out
+        prev[0].wait()                          # the compute stream waits for the collective; the host does not block
+        self.apply_gradients(prev[1][:n], grad_scale=1.0 / world)
+        return prev[1][n:].clone()
+
+    def finish_allreduce(self):
+        """Complete and apply the all-reduce still in flight (end of a run, before a checkpoint is written)."""
+        if self._pending is not None:
+            work, buf = self._pending
+            self._pending = None
+            work.wait()
+            self.apply_gradients(buf[:self.flat.numel()], grad_scale=1.0 / _world()[1])
+        return self
 
     @property
     def params(self):
@@ -418,6 +456,15 @@ def dp_allreduce(buf, n, loss, rank, world):
     return buf[n:].clone()
 
 
+def _exchange_and_apply(state, buf, n, loss, rank, world):
+    """jax.lax.pmean(grads) + apply_gradients (network.py:620-621): one all-reduce, Adam with grad / world."""
+    if world > 1 and getattr(state, 'overlap_allreduce', False):
+        return state.exchange_overlapped(buf, n, loss, rank, world)
+    loss_vec = dp_allreduce(buf, n, loss, rank, world)
+    state.apply_gradients(buf[:n], grad_scale=1.0 / world)
+    return loss_vec
+
+
 def _step_image(state, t_units, dtype, target, sigma, offset, t_frames, coords, Omega, J, g, dtau, Sigma,
                 t_start_obs, t_geos, t_injection, scale, train, eht=False):
     """Per-process body of gradient_step_image/_eht and test_image/_eht with no torch.autograd in the
@@ -457,8 +504,7 @@ def _step_image(state, t_units, dtype, target, sigma, offset, t_frames, coords, 
                 eng.render_bwd_tape(geom, tM0[sl], dimg, out=part)
                 buf[:n] += part
         rank, world = _world()
-        loss_vec = dp_allreduce(buf, n, loss, rank, world)
-        state.apply_gradients(buf[:n], grad_scale=1.0 / world)
+        loss_vec = _exchange_and_apply(state, buf, n, loss, rank, world)
         out = images.reshape((1, B) + ((geom.S,) if geom.S else ()) + geom.spatial)
         return loss_vec, state, out
     images = eng.render_train(geom, tM0) if taped else eng.render(geom, tM0)
@@ -474,8 +520,7 @@ def _step_image(state, t_units, dtype, target, sigma, offset, t_frames, coords, 
         n = eng.nparams
         buf = state.grad_buffer()
         (eng.render_bwd_tape if taped else eng.render_bwd)(geom, tM0, dimg, out=buf[:n])
-        loss_vec = dp_allreduce(buf, n, loss, rank, world)      # jax.lax.pmean(grads) (network.py:620)
-        state.apply_gradients(buf[:n], grad_scale=1.0 / world)
+        loss_vec = _exchange_and_apply(state, buf, n, loss, rank, world)
     else:
         if world > 1:
             import torch.distributed as dist

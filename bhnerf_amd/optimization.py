@@ -112,6 +112,8 @@ class Optimizer(object):
             params=predictor.init_params(raytracing_args, seed=self.seed), num_iters=self.num_iters,
             lr_init=hparams.get('lr_init', 1e-4), lr_final=hparams.get('lr_final', 1e-6),
             lr_inject=hparams.get('lr_inject', None), checkpoint_dir=checkpoint_dir)
+        # opt-in: all-reduce of step k under the forward / backward of step k+1 (one-step-stale gradients; network.TrainState)
+        self.state.overlap_allreduce = bool(hparams.get('overlap_allreduce', False))
         if checkpoint_dir and network._world()[0] == 0:
             predictor.save_params(checkpoint_dir)
 
@@ -121,6 +123,8 @@ class Optimizer(object):
 
     def save_checkpoint(self):
         due = self.step % self.save_period == 0 or self.step == self.final_step
+        if self.checkpoint_dir and due:
+            self.state.finish_allreduce()       # (overlap_allreduce: every rank applies the gradient in flight, then rank 0 writes)
         if not (self.checkpoint_dir and due and network._world()[0] == 0):
             return
         # the flax file format of the reference (optimization.py:118-121), see checkpoints.py
@@ -140,6 +144,7 @@ class Optimizer(object):
                 self.loss = loss.as_subclass(HostReadable) if isinstance(loss, torch.Tensor) else loss
                 self.log()
                 self.save_checkpoint()
+            self.state.finish_allreduce()
         except KeyboardInterrupt:
             return
 

@@ -119,6 +119,11 @@ class CpuTrainer:
 
     def step(self, t_frames, target, sigma, offset, scale=1.0, dtype='full', grad_div=1.0):
         loss, images, grads = self.loss_and_grad(t_frames, target, sigma, offset, scale, dtype)
+        self.apply(grads, grad_div)
+        return loss, images
+
+    def apply(self, grads, grad_div=1.0):
+        """One Adam update with the linearly decayed learning rate (split out of step() for the stale-gradient test)."""
         lr = onp.linear_lr(self.count, self.lr_init, self.lr_final, self.num_iters)
         self.count += 1
         t = self.count
@@ -130,7 +135,6 @@ class CpuTrainer:
                 mhat = m / (1.0 - 0.9 ** t)
                 vhat = v / (1.0 - 0.999 ** t)
                 p.sub_(lr * mhat / (vhat.sqrt() + 1e-8))
-        return loss, images
 
 
 def grid_loss_and_grad(grid, t_frames, geom, hp, target, sigma):

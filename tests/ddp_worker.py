@@ -27,7 +27,8 @@ def main():
     t = np.linspace(0, 1, nt)
     GM = constants.GM_c3('hr')
     target = synthetic.hotspot_movie(geos[0], t, GM)
-    hp = {'num_iters': nsteps, 'lr_init': lr, 'lr_final': 1e-4, 'seed': 1}
+    overlap = os.environ.get('BHNERF_DDP_OVERLAP') == '1'       # opt-in stale-gradient overlap of the all-reduce (TrainState)
+    hp = {'num_iters': nsteps, 'lr_init': lr, 'lr_final': 1e-4, 'seed': 1, 'overlap_allreduce': overlap}
     pred = network.NeRF_Predictor(8.0, 0.0, np.inf, np.inf, net_width=64, mode='f32', device=dev)
     step = optimization.TrainStep.image(t * units.hr, target, dtype='full')
     opt = optimization.Optimizer(hp, pred, rts)
@@ -47,7 +48,7 @@ def main():
         frames_rng = optimization.TemporalBatchedArgs(t * units.hr, [target]).sample
         rays_rng = optimization._shared_rng(1)
         eng = pred1.engine()
-        picks = []
+        picks, pending = [], None
         for it in range(nsteps):
             idx = frames_rng(batch)
             k = int(rays_rng.integers(len(rts)))
@@ -60,7 +61,14 @@ def main():
             tg = torch.as_tensor(target[idx], device=dev).reshape(batch, 1, -1)
             loss, dimg = engine.chi2_image(img, tg, torch.ones_like(tg), torch.zeros_like(tg), 1.0, 'full')
             grad = eng.render_bwd(geom, tM0, dimg)
-            st.apply_gradients(grad, grad_scale=1.0 / world)
+            if not overlap:
+                st.apply_gradients(grad, grad_scale=1.0 / world)
+            else:                               # the gradient of step k is applied after the backward of step k+1
+                if pending is not None:
+                    st.apply_gradients(pending, grad_scale=1.0 / world)
+                pending = grad.clone()
+        if pending is not None:
+            st.apply_gradients(pending, grad_scale=1.0 / world)
         diff = (st.flat.cpu() - flat).abs().numpy()
         moved = float((flat - p0.cpu()).abs().max())
         out = dict(identical=bool(identical), moved=moved, max_diff=float(diff.max()),

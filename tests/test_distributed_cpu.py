@@ -126,7 +126,7 @@ class _StubEngine:
         return out
 
 
-def _step_worker(rank, world, port, out):
+def _step_worker(rank, world, port, out, overlap=False):
     import sys
     import types
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -156,6 +156,7 @@ def _step_worker(rank, world, port, out):
     network.engine.chi2_image, network.engine.adam_step = chi2_image, adam_step
     # the state is built BEFORE the process group exists (ADVICE: the gradient buffer must follow the world size)
     state = network.TrainState(None, eng.flatten(), pred, 3, 1e-3, 1e-4)
+    state.overlap_allreduce = overlap
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         shape = (4, H, W)
@@ -171,7 +172,13 @@ def _step_worker(rank, world, port, out):
                 float(g['t_start_obs']), g['t_geos'], float(g['t_injection']), 1.0)
             losses.append(loss.numpy().copy())
             assert images.shape == (1, 2, H, W)
-        assert eng.calls == ['pack', 'render', 'bwd', 'adam(grad_scale=0.5)'] * 3, eng.calls
+        if overlap:
+            # the all-reduce of step k completes inside step k+1 (after its backward); the last one at finish_allreduce()
+            assert eng.calls == ['pack', 'render', 'bwd'] + ['pack', 'render', 'bwd', 'adam(grad_scale=0.5)'] * 2, eng.calls
+            assert state.step == 2 and np.isnan(losses[0][1 - rank]) and not np.isnan(losses[0][rank])
+            state.finish_allreduce()
+            assert eng.calls[-1] == 'adam(grad_scale=0.5)' and state._pending is None
+            losses = losses[1:]                  # steps 2 and 3 return the loss vectors of the completed steps 1 and 2
         assert state.grad.numel() == eng.nparams + world and state.step == 3
         out.put((rank, state.flat.numpy().copy(), np.array(losses)))
         dist.barrier()
@@ -213,3 +220,44 @@ def test_two_rank_training_steps_match_single_process_reference():
     assert moved > 1e-4
     assert np.abs(res[0][1] - ref).max() < 2e-3 * moved               # float32 Adam state vs the float64 reference
     assert np.allclose(res[0][2].sum(axis=1), ref_losses, rtol=2e-5)  # sum of the per-device sums = chi^2 of the batch
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_overlapped_allreduce_is_the_one_step_stale_update():
+    """overlap_allreduce (opt-in): the gradient of step k is applied after the backward of step k+1, identically on
+    both ranks, and equals a single-process run that applies the (all-frames, / world) gradient one step late."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_step_worker, args=(r, world, port, out, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([out.get(timeout=240) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert np.array_equal(res[0][1], res[1][1])                       # identical parameters on both ranks, bitwise
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import test_oracle_golden as tg
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'g5_predict_e.npz')))
+    tr, t = tg._torch_trainer(g)
+    tr.num_iters, tr.lr_init, tr.lr_final = 3, 1e-3, 1e-4
+    p0 = torch.cat([p.detach().reshape(-1) for i in range(len(tr.k)) for p in (tr.k[i], tr.b[i])]).numpy().copy()
+    shape = (4,) + g['coords'].shape[1:3]
+    tgt = {k: t(g[k + '_full']).reshape(shape) for k in ('target', 'sigma', 'offset')}
+    pending, ref_losses = None, []
+    for it in range(3):
+        idx = [[2, 0, 3, 1], [0, 1, 2, 3], [3, 2, 1, 0]][it]
+        loss, _, grads = tr.loss_and_grad(t(g['t_frames'][idx]), tgt['target'][idx], tgt['sigma'][idx], tgt['offset'][idx], 1.0, 'full')
+        ref_losses.append(float(loss))
+        if pending is not None:
+            tr.apply(pending, grad_div=world)
+        pending = [gr.detach().clone() for gr in grads]
+    tr.apply(pending, grad_div=world)
+    ref = torch.cat([p.detach().reshape(-1) for i in range(len(tr.k)) for p in (tr.k[i], tr.b[i])]).numpy()
+    moved = np.abs(ref - p0).max()
+    assert moved > 1e-4
+    assert np.abs(res[0][1] - ref).max() < 2e-3 * moved
+    # the loss vectors returned by steps 2 and 3 are those of the completed steps 1 and 2
+    assert res[0][2].shape == (2, 2) and np.allclose(res[0][2].sum(axis=1), ref_losses[:2], rtol=2e-5)

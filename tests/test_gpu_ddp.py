@@ -26,9 +26,10 @@ def need_gpu():
 
 
 @pytest.mark.timeout(600)
-def test_two_ranks_equal_single_process_mean_of_sums(tmp_path):
+@pytest.mark.parametrize('overlap', ['0', '1'])        # '1': opt-in stale-gradient overlap of the all-reduce
+def test_two_ranks_equal_single_process_mean_of_sums(tmp_path, overlap):
     out = tmp_path / 'ddp.json'
-    env = dict(os.environ, BHNERF_DDP_OUT=str(out), HSA_ENABLE_IPC_MODE_LEGACY='0', BHNERF_BATCH_SEED='7')
+    env = dict(os.environ, BHNERF_DDP_OUT=str(out), HSA_ENABLE_IPC_MODE_LEGACY='0', BHNERF_BATCH_SEED='7', BHNERF_DDP_OVERLAP=overlap)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', str(_free_port()), os.path.join(ROOT, 'tests', 'ddp_worker.py')]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=540)
