@@ -62,6 +62,12 @@ struct MlpShape {
 
 int bhn_mlp_shape(const bhn_model *m, MlpShape *s);   // validates, returns BHN_* code
 
+// bf16 networks with >= 3 hidden layers: the backward never materialises gA_{depth-1} = W_out (.) dout (.) relu' --
+// the dW job of layer depth-1 rebuilds it from h_depth and dout (TapeLayout::drop_ga), and the delta chain feeds
+// relu' (.) bf16(dout) into a transposed weight image of layer depth-1 whose columns are pre-scaled by W_out
+// (bhn_pack_weights): the same product with the factor W_out[k] moved from the B operand to the A operand.
+__host__ __device__ static inline bool bhn_folds_wout(int mode, int depth) { return mode == BHN_BF16 && depth >= 3; }
+
 // Number of compute units of a device (cached).
 int bhn_num_cus(int device);
 

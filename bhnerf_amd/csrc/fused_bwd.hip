@@ -548,9 +548,39 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
             // ---- gA_{depth-1} = wout * dout * relu'(a_{depth-1}); its last tile stays pending ---------------
             frag dl[KS];
             f32x16 pend = {};
+            unsigned last_mask = 0xffffu;            // relu bits still to be applied to the pending tile of gA_{depth-1}
             {
                 const bool keep_ga = !A.t.drop_ga;                    // else the dW kernel rebuilds gA_{depth-1}
                 char *gdst = A.tape + ga_lin + (a.depth - 1) * lin_stride + qs * MT * TB;
+                if constexpr (Pol::ELEM_BYTES == 2) {
+                    if (A.t.drop_ga) {
+                        // W_out sits in the columns of this layer's transposed weight image (bhn_folds_wout): the B operand
+                        // is relu' (.) bf16(dout) -- one packed dword ANDed with the spread relu bits, 3 VALU per pair
+                        // (building W_out . dout . relu' element by element was ~550 of the 970 VALU instructions of this
+                        // kernel's tile prologue, which all eight waves execute with the matrix pipe idle)
+                        typedef short i16x2 __attribute__((ext_vector_type(2)));
+                        const typename Pol::bf16x2 d2 = {(__bf16)dout, (__bf16)dout};
+                        const unsigned dd = __builtin_bit_cast(unsigned, d2);
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) {
+                            const unsigned mw = (cin.mtop[m >> 1] >> ((m & 1) * 16)) & 0xffffu;
+                            if (m == MT - 1 && a.depth > 1) {
+                                // the last tile stays pending as f32; the first ring step masks and packs it (TapePost)
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) pend[r] = dout;
+                                last_mask = mw;
+                                continue;
+                            }
+                            const unsigned spread = Pol::mask_spread(mw);
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) {
+                                const i16x2 on = __builtin_bit_cast(i16x2, spread << (15 - k)) >> (i16x2){15, 15};
+                                Pol::put_dword(dl[2 * m + (k >> 2)], k & 3, dd & __builtin_bit_cast(unsigned, on));
+                            }
+                        }
+                    }
+                }
+                if (!(Pol::ELEM_BYTES == 2 && A.t.drop_ga)) {
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
                     const unsigned mw = cin.mtop[m >> 1] >> ((m & 1) * 16);
@@ -572,10 +602,11 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
                         if (keep_ga) em.emit(gdst + m * TB, dl[2 * m], dl[2 * m + 1], edbg);
                     } else pend = g;
                 }
+                }
             }
             // ---- delta chain through hidden layers depth-1 .. 1: step (l, m) makes tile m of gA_{l-1} -------
             int pnd_layer = a.depth - 1;             // layer of the pending gA tile
-            unsigned pnd_mask = 0xffffu;             // its relu bits (gA_{depth-1} is masked already)
+            unsigned pnd_mask = last_mask;           // its relu bits (0xffff: gA_{depth-1} is masked already)
             unsigned mq0 = cin.q0, mq1 = cin.q1, mcur = 0u;          // MODE_CHAIN: relu-bit words in flight from the tape
             unsigned no_acc = 0u;
 #pragma nounroll
@@ -1367,7 +1398,7 @@ static void tape_layout(int depth, bool layer1_takes_enc, long long NQ, TapeLayo
         t->h_off[l] = off; off += per_tensor;
     }
     if (t->drop_h1) { t->encp_off = off; off += NQ * (long long)BG::TILE_BYTES; }
-    t->drop_ga = Pol::ELEM_BYTES == 2 && depth >= 3;
+    t->drop_ga = bhn_folds_wout(Pol::MODE, depth);
     for (int l = 0; l < depth; ++l) {
         if (l == depth - 1 && t->drop_ga) { t->ga_off[l] = -1; continue; }
         t->ga_off[l] = off; off += per_tensor;

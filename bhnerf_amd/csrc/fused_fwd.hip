@@ -101,7 +101,11 @@ __global__ void pack_weights_kernel(PackArgs a) {
             const int cb = c - a.L.n_fwd;
             const int l = 1 + cb / MT, m = cb % MT;
             const int k = 32 * m + i, o = 16 * f + ph;     // transposed image: row = input unit k, column = output unit o
-            if (f < KS && k < WT && o < WT) v = a.params[s.kernel_off[l] + (long long)k * WT + o];
+            if (f < KS && k < WT && o < WT) {
+                v = a.params[s.kernel_off[l] + (long long)k * WT + o];
+                // layer depth-1: column o carries W_out[o] (the delta chain's B operand is relu' (.) dout only; common.h)
+                if (l == D - 1 && bhn_folds_wout(a.mode, D)) v *= a.params[s.kernel_off[D] + o];
+            }
         }
         char *img = a.packed + (fwd ? a.L.fwd_off + (size_t)c * a.L.chunk_bytes
                                     : a.L.bwd_off + (size_t)(c - a.L.n_fwd) * a.L.chunk_bytes);
