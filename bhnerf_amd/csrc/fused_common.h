@@ -586,8 +586,12 @@ struct RingState {
     // larger than the 16-bit offset field of ds_read, pays one v_add per read (16 per step, round-2 ISA census).  From
     // an SGPR base it is one v_add per step and immediate offsets.
     static DEVI int opaque(int v) { asm volatile("" : "+s"(v)); return v; }
-    DEVI const char *ch() const { return ring + opaque(wrap(cur - lag) * CB); }
-    DEVI const char *chn() const { return ring + opaque(wrap(cur - lag + 1) * CB); }
+    // Without LAG the three buffer offsets a step needs (consumed, next, the one just freed) are carried as byte offsets
+    // and rotated at the step end (3 SALU) instead of being derived from `cur` each time (three wrap()s and multiplies:
+    // ~25 of the 140-190 instructions of a ring step, round-2 ISA census).
+    int o_cur, o_nxt, o_prv;
+    DEVI const char *ch() const { return ring + opaque(LAG ? wrap(cur - lag) * CB : o_cur); }
+    DEVI const char *chn() const { return ring + opaque(LAG ? wrap(cur - lag + 1) * CB : o_nxt); }
     DEVI unsigned next_src() {
         unsigned src;
         if (issue_c < NCA) src = (unsigned)issue_c * CB;
@@ -600,7 +604,7 @@ struct RingState {
     }
     DEVI DmaJob job() {
         if (dbg & 4) return DmaJob{false, 0u, nullptr, rs};
-        return DmaJob{true, next_src(), ring + wrap(cur - (LAG ? 2 : 1)) * CB, rs};
+        return DmaJob{true, next_src(), ring + (LAG ? wrap(cur - 2) * CB : o_prv), rs};
     }
     // STORES: global stores this wave is GUARANTEED to have issued after the DMA pieces of chunk c+2 (issued in the
     // middle of step c-2) other than the two younger chunks: vmcnt retires in order and counts stores, so they may
@@ -616,7 +620,12 @@ struct RingState {
             if ((threadIdx.x & 63) == 0) { ts[0] = t1; ts[1] = t3; }
             ts += 2;
         }
-        cur = (cur == NB - 1) ? 0 : cur + 1;
+        if constexpr (LAG) cur = (cur == NB - 1) ? 0 : cur + 1;
+        else {
+            o_prv = o_cur;
+            o_cur = o_nxt;
+            o_nxt = (o_nxt == (NB - 1) * CB) ? 0 : o_nxt + CB;
+        }
     }
     DEVI void idle_step() {      // a step in which this wave consumes nothing (lagging waves: first; the others: last)
         const DmaJob j = job();
@@ -628,6 +637,7 @@ struct RingState {
         off_b = b_ ? (unsigned)(b_ - a_) : 0u;                  // (the transposed image follows the forward image)
         rs = RG::resource(a_);
         dbg = dbg_; cur = 0; issue_c = 0; lag = LAG ? lag_ : 0; ts = nullptr;
+        o_cur = 0; o_nxt = CB; o_prv = (NB - 1) * CB;
 #pragma unroll
         for (int j = 0; j < DIST; ++j) RG::issue(DmaJob{true, next_src(), ring + j * CB, rs});
         RG::template wait_younger<RG::PPW * (DIST - 2)>();
