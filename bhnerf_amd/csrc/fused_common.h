@@ -414,7 +414,8 @@ struct DmaJob {
     unsigned soff;                              // byte offset of the chunk from the ring's source base
     char *dst;
     __amdgpu_buffer_rsrc_t rs;
-};
+    int wvu;                                    // the issuing wave's index, held in an SGPR by the ring (hipcc otherwise
+};                                              // re-derives it from threadIdx with v_readfirstlane + shifts in every step)
 
 // Work folded into the MFMA shadows of a ring step ("Post" objects): at(t) is called right after MFMA t of the
 // step (t is a constant after unrolling) when the layer has >= 16 k-steps, all() before the first MFMA otherwise.
@@ -532,7 +533,7 @@ struct DmaRing {
         return __builtin_amdgcn_make_buffer_rsrc(us, 0, 0x7fffffff, 0x00020000);
     }
     static DEVI void issue(const DmaJob &j) {
-        const int wvu = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        const int wvu = j.wvu;
         const int voff = (int)(threadIdx.x & 63) * 16;
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
@@ -589,7 +590,7 @@ struct RingState {
     // Without LAG the three buffer offsets a step needs (consumed, next, the one just freed) are carried as byte offsets
     // and rotated at the step end (3 SALU) instead of being derived from `cur` each time (three wrap()s and multiplies:
     // ~25 of the 140-190 instructions of a ring step, round-2 ISA census).
-    int o_cur, o_nxt, o_prv;
+    int o_cur, o_nxt, o_prv, wvu;
     DEVI const char *ch() const { return ring + opaque(LAG ? wrap(cur - lag) * CB : o_cur); }
     DEVI const char *chn() const { return ring + opaque(LAG ? wrap(cur - lag + 1) * CB : o_nxt); }
     DEVI unsigned next_src() {
@@ -603,8 +604,8 @@ struct RingState {
         return src;
     }
     DEVI DmaJob job() {
-        if (dbg & 4) return DmaJob{false, 0u, nullptr, rs};
-        return DmaJob{true, next_src(), ring + (LAG ? wrap(cur - 2) * CB : o_prv), rs};
+        if (dbg & 4) return DmaJob{false, 0u, nullptr, rs, wvu};
+        return DmaJob{true, next_src(), ring + (LAG ? wrap(cur - 2) * CB : o_prv), rs, wvu};
     }
     // STORES: global stores this wave is GUARANTEED to have issued after the DMA pieces of chunk c+2 (issued in the
     // middle of step c-2) other than the two younger chunks: vmcnt retires in order and counts stores, so they may
@@ -638,8 +639,9 @@ struct RingState {
         rs = RG::resource(a_);
         dbg = dbg_; cur = 0; issue_c = 0; lag = LAG ? lag_ : 0; ts = nullptr;
         o_cur = 0; o_nxt = CB; o_prv = (NB - 1) * CB;
+        wvu = opaque(__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)));
 #pragma unroll
-        for (int j = 0; j < DIST; ++j) RG::issue(DmaJob{true, next_src(), ring + j * CB, rs});
+        for (int j = 0; j < DIST; ++j) RG::issue(DmaJob{true, next_src(), ring + j * CB, rs, wvu});
         RG::template wait_younger<RG::PPW * (DIST - 2)>();
         lds_barrier();
     }
