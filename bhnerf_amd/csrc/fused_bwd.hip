@@ -297,17 +297,21 @@ struct TapePost {
         if constexpr (Pol::ELEM_BYTES == 2) TapeEmit<Pol>::store_native(dst, d0, d1, edbg);
         else TapeEmit<Pol>::store(dst, tr, edbg);
     }
+    unsigned w = 0;                             // the pair rounded in the previous k-step (pack_pipe)
     DEVI void at(int t) {
-        if (t == 0) elems<0, 2>();
-        if (t == 1) elems<2, 2>();
-        if (t == 2) elems<4, 2>();
-        if (t == 3) elems<6, 2>();
-        if (t == 4) elems<8, 2>();
-        if (t == 5) elems<10, 2>();
-        if (t == 6) elems<12, 2>();
-        if (t == 7) elems<14, 2>();
+        if constexpr (RELU && Pol::ELEM_BYTES == 2) pack_pipe<Pol>(t, pend, d0, d1, w, mask);     // fragments complete after k-step 8, bits after 9
+        else {
+            if (t == 0) elems<0, 2>();
+            if (t == 1) elems<2, 2>();
+            if (t == 2) elems<4, 2>();
+            if (t == 3) elems<6, 2>();
+            if (t == 4) elems<8, 2>();
+            if (t == 5) elems<10, 2>();
+            if (t == 6) elems<12, 2>();
+            if (t == 7) elems<14, 2>();
+        }
         if (Pol::ELEM_BYTES != 2 && t == 6 && !(edbg & 2)) em.load_id(id);
-        if (t == 8) bits_and_transpose();
+        if (t == 10) bits_and_transpose();
         if (t == 12) store_tile();
     }
     DEVI void all() {

@@ -65,9 +65,9 @@ struct PolBF16 {
         // v_cvt_pk + one v_pk_max_i16 instead of two v_max per element (hipcc canonicalises before every max).
         // Inline asm only on the VALU result of the convert, never on an MFMA accumulator (hazard, see relu()).
         typedef short i16x2 __attribute__((ext_vector_type(2)));
-        const bf16x2 t = {(__bf16)a, (__bf16)b};
-        unsigned w = __builtin_bit_cast(unsigned, t);
-        asm("" : "+v"(w));                 // keeps the convert one v_cvt_pk_bf16_f32 (else: two converts + v_perm)
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 ab = {a, b};           // ONE vector conversion = one v_cvt_pk_bf16_f32 (two scalar ones: two converts + v_perm)
+        const unsigned w = __builtin_bit_cast(unsigned, __builtin_convertvector(ab, bf16x2));
         // v_pk_max_i16 through the vector builtin, not as an inline-asm instruction: its result replaces fragment
         // registers that an MFMA issued just before may still be reading, and only compiler-visible writes are
         // covered by the hazard recogniser (tools/check_asm_hazard.py)
@@ -75,6 +75,26 @@ struct PolBF16 {
         put_dword(f, i, u);
         unsigned m;      // (plain VALU reading a VALU result: no hazard the compiler would have to know about; the
                          //  generic elementwise min on u16x2 expands into ~10 compare/select instructions)
+        asm("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(u), "s"(0x00010001u));
+        spread |= m << k;
+    }
+    // relu_pair in three phases for the software-pipelined pack of ring_step (one phase per k-step and pair): hipcc puts
+    // an `s_nop 0` between a VALU instruction and an inline-asm statement that reads its result in the next cycle, and
+    // relu_pair is convert -> (asm pin) -> clamp -> (asm v_pk_min_u16 / asm use marker): 16-20 s_nop per ring step
+    // (10 % of its instructions, round-2 ISA census).  With the phases one k-step apart the neighbours are independent.
+    static DEVI unsigned pack_a(float a, float b) {                       // round (ONE vector conversion = v_cvt_pk_bf16_f32;
+        typedef float f32x2 __attribute__((ext_vector_type(2)));          //  two scalar ones become two converts + v_perm)
+        const f32x2 v = {a, b};
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+    }
+    static DEVI void pack_b(frag &f, int i, int, float, float, unsigned w, unsigned &) {       // clamp
+        typedef short i16x2 __attribute__((ext_vector_type(2)));
+        // (no asm pin on w here: rounded one k-step earlier, behind a sched_barrier, the convert stays one v_cvt_pk_bf16_f32)
+        put_dword(f, i, __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, w), (i16x2){0, 0})));
+    }
+    static DEVI void pack_c(const frag &f, int i, int k, unsigned &spread) {                  // relu bits
+        const unsigned u = __builtin_bit_cast(u32x4, f)[i];
+        unsigned m;
         asm("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(u), "s"(0x00010001u));
         spread |= m << k;
     }
@@ -138,6 +158,9 @@ struct PolF32 {
         f[2 * i] = relu(a); f[2 * i + 1] = relu(b);
         code |= (a > 0.f ? 1u << k : 0u) | (b > 0.f ? 1u << (8 + k) : 0u);
     }
+    static DEVI unsigned pack_a(float, float) { return 0u; }             // (phases of the pipelined pack: see PolBF16)
+    static DEVI void pack_b(frag &f, int i, int k, float a, float b, unsigned, unsigned &code) { relu_pair(f, i, k, a, b, code); }
+    static DEVI void pack_c(const frag &, int, int, unsigned &) {}
     static DEVI void mask_pair(frag &f, int i, int k, float a, float b, unsigned code) {
         f[2 * i] = ((code >> k) & 1) ? a : 0.f; f[2 * i + 1] = ((code >> (8 + k)) & 1) ? b : 0.f;
     }
@@ -386,6 +409,25 @@ DEVI void pack_elems(const f32x16 &acc, typename Pol::frag &d0, typename Pol::fr
     if (R0 + N > 8) asm volatile("" : "+v"(d1));
 }
 
+// Software-pipelined relu + repack of a pending tile over k-steps 0..9 of a ring step (pair p = elements 2p, 2p+1):
+// k-step t rounds pair t, clamps pair t-1 into its fragment dword and takes the relu bits of pair t-2 (Pol::pack_a/b/c).
+// The fragments are complete after k-step 8, the relu bits after k-step 9.
+template <class Pol>
+DEVI void pack_pipe(int t, const f32x16 &pend, typename Pol::frag &d0, typename Pol::frag &d1, unsigned &w, unsigned &mask) {
+    if (t >= 1 && t <= 8) {
+        const int r = 2 * (t - 1);
+        Pol::pack_b(r < 8 ? d0 : d1, (r & 7) >> 1, r >> 1, pend[r], pend[r + 1], w, mask);
+    }
+    if (t <= 7) w = Pol::pack_a(pend[2 * t], pend[2 * t + 1]);
+    if (t >= 2 && t <= 9) {
+        const int r = 2 * (t - 2);
+        Pol::pack_c(r < 8 ? d0 : d1, (r & 7) >> 1, r >> 1, mask);
+    }
+    // the packed registers are "used" once, a k-step after the last write (see pack_elems; an empty asm right behind the
+    // VALU instruction that writes a packed 16-bit result costs an s_nop: hipcc's inline-asm hazard rule)
+    if (t == 10) asm volatile("" : "+v"(d0), "+v"(d1));
+}
+
 template <class Pol>
 struct APipe {                                  // fragments 0..PF-2 of the chunk about to be consumed
     static constexpr int N = Pol::LDS_PREFETCH - 1;
@@ -428,15 +470,19 @@ struct PackPost {
     typename Pol::frag &d0, &d1;
     unsigned mask;                              // relu bits of the pending tile (bit r: element r > 0)
     DEVI PackPost(const f32x16 &p, typename Pol::frag &a, typename Pol::frag &b) : pend(p), d0(a), d1(b), mask(0) {}
+    unsigned w = 0;                             // the pair rounded in the previous k-step (pack_pipe)
     DEVI void at(int t) {
-        if (t == 0) pack_elems<Pol, 0, 2>(pend, d0, d1, mask);
-        if (t == 1) pack_elems<Pol, 2, 2>(pend, d0, d1, mask);
-        if (t == 2) pack_elems<Pol, 4, 2>(pend, d0, d1, mask);
-        if (t == 3) pack_elems<Pol, 6, 2>(pend, d0, d1, mask);
-        if (t == 4) pack_elems<Pol, 8, 2>(pend, d0, d1, mask);
-        if (t == 5) pack_elems<Pol, 10, 2>(pend, d0, d1, mask);
-        if (t == 6) pack_elems<Pol, 12, 2>(pend, d0, d1, mask);
-        if (t == 7) pack_elems<Pol, 14, 2>(pend, d0, d1, mask);
+        if constexpr (Pol::ELEM_BYTES == 2) pack_pipe<Pol>(t, pend, d0, d1, w, mask);
+        else {                                  // f32: no packed converts, nothing to pipeline
+            if (t == 0) pack_elems<Pol, 0, 2>(pend, d0, d1, mask);
+            if (t == 1) pack_elems<Pol, 2, 2>(pend, d0, d1, mask);
+            if (t == 2) pack_elems<Pol, 4, 2>(pend, d0, d1, mask);
+            if (t == 3) pack_elems<Pol, 6, 2>(pend, d0, d1, mask);
+            if (t == 4) pack_elems<Pol, 8, 2>(pend, d0, d1, mask);
+            if (t == 5) pack_elems<Pol, 10, 2>(pend, d0, d1, mask);
+            if (t == 6) pack_elems<Pol, 12, 2>(pend, d0, d1, mask);
+            if (t == 7) pack_elems<Pol, 14, 2>(pend, d0, d1, mask);
+        }
     }
     DEVI void all() { pack_elems<Pol, 0, 16>(pend, d0, d1, mask); }
 };
