@@ -400,9 +400,27 @@ DEVI f32x16 bias_acc(const float *bias_lds, int m, int h) {
 template <class Pol, int R0, int N>
 DEVI void pack_elems(const f32x16 &acc, typename Pol::frag &d0, typename Pol::frag &d1, unsigned &mask) {
     static_assert(R0 % 2 == 0 && N % 2 == 0, "elements are packed in pairs");
+    if constexpr (Pol::ELEM_BYTES == 2 && N >= 4) {
+        // phase by phase over the pairs (all rounded, then all clamped, then all relu bits): pair by pair every clamp sits
+        // right behind its convert and every bit extraction right behind its clamp, an s_nop each (hipcc 7.2, gfx950)
+        unsigned w[N / 2];
 #pragma unroll
-    for (int r = R0; r < R0 + N; r += 2)       // mask: spread ReLU bits (Pol::mask_code), dead code unless recorded
-        Pol::relu_pair(r < 8 ? d0 : d1, (r & 7) >> 1, r >> 1, acc[r], acc[r + 1], mask);
+        for (int p = 0; p < N / 2; ++p) w[p] = Pol::pack_a(acc[R0 + 2 * p], acc[R0 + 2 * p + 1]);
+#pragma unroll
+        for (int p = 0; p < N / 2; ++p) {
+            const int r = R0 + 2 * p;
+            Pol::pack_b(r < 8 ? d0 : d1, (r & 7) >> 1, r >> 1, acc[r], acc[r + 1], w[p], mask);
+        }
+#pragma unroll
+        for (int p = 0; p < N / 2; ++p) {
+            const int r = R0 + 2 * p;
+            Pol::pack_c(r < 8 ? d0 : d1, (r & 7) >> 1, r >> 1, mask);
+        }
+    } else {
+#pragma unroll
+        for (int r = R0; r < R0 + N; r += 2)       // mask: spread ReLU bits (Pol::mask_code), dead code unless recorded
+            Pol::relu_pair(r < 8 ? d0 : d1, (r & 7) >> 1, r >> 1, acc[r], acc[r + 1], mask);
+    }
     // the packed registers are "used" here: without this the machine sinker moves the whole pack down to the
     // next layer's first read of the fragment, i.e. out of the MFMA shadow it was placed in
     if (R0 < 8) asm volatile("" : "+v"(d0));
