@@ -339,7 +339,13 @@ def main():
         sq = json.load(open(os.path.join(ROOT, 'profiles', PROFILE_TAG + '_sq_summary.json')))['kernels']
         if std:
             tag = {', 1>': fwd_name, ', 2>': chain_name, 'dw_kernel': 'dw_kernel', 'fused_fwd_kernel': 'fused_fwd_kernel (inference)'}
-            roofline['mfma_busy_frac_pmc'] = {n: v['mfma_busy_frac'] for k, v in sq.items() for t, n in tag.items() if t in k}
+            busy = {n: v['mfma_busy_frac'] for k, v in sq.items() for t, n in tag.items() if t in k}
+            roofline['mfma_busy_frac_pmc'] = busy
+            # matrix-pipe utilisation of the whole training step as the SQ counters see it: busy fractions of the three MLP
+            # kernels weighted by their live durations (north_star: ">= 40 % MFMA utilisation in the fused MLP")
+            tk = [fwd_name, chain_name, 'dw_kernel']
+            if all(k in busy for k in tk):
+                roofline['step_mfma_busy_frac_pmc'] = round(sum(busy[k] * kern_ms[k] for k in tk) / sum(kern_ms[k] for k in tk), 3)
     except Exception:
         pass
     roofline['mfma_tflops'] = {k: round(alg[k] * pts / (kern_ms[k] * 1e-3) / 1e12, 1) for k in alg}
