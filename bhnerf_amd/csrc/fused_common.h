@@ -34,7 +34,10 @@ struct PolBF16 {
     static constexpr int NTHREADS = NWAVES * 64;
     static constexpr int ELEM_BYTES = 2;
     static constexpr int FRAG_BYTES = 1024;     // 64 lanes x 8 bf16
-    static constexpr int LDS_PREFETCH = 4;      // A fragments in flight + 1 (ring_step); 8 measured no faster
+#ifndef BHN_LDS_PF
+#define BHN_LDS_PF 4
+#endif
+    static constexpr int LDS_PREFETCH = BHN_LDS_PF;      // A fragments in flight + 1 (ring_step); 6 / 8 measured no faster
     static constexpr bool PHASE_LAG = false;    // RingState LAG: measured 5 % slower in the render kernel, off
     using frag = bf16x8;
     static DEVI frag zero() { frag f; for (int j = 0; j < 8; ++j) f[j] = (__bf16)0.f; return f; }
