@@ -1328,41 +1328,66 @@ __global__ __launch_bounds__(Pol::NTHREADS) __attribute__((amdgpu_waves_per_eu(P
 // ---------------------------------------------------------------------------------------------
 // slab reduction -> flat dparams (flax tree order)
 // ---------------------------------------------------------------------------------------------
+// One block per slab tile (layer, A-tile row, B tile | bias tile), one float4 per thread and slab: the sum over the job's
+// workgroups runs over CONTIGUOUS 4 KiB of every slab (round 1 walked the flat parameters and gathered single floats out
+// of the tiles: 330 MB of sectors fetched for 94 MB of slabs, 0.117 ms), in workgroup order (bitwise reproducible), and
+// the result is scattered to the flat parameters (flax tree order) by inverting the tile layout
+//   idx = (m NTMAX + n) 1024 + (r >> 2) 256 + (col + 32 hh) 4 + (r & 3),  row = (r & 3) + 4 hh + 8 (r >> 2).
 template <int W, class Pol>
-__global__ void reduce_kernel(BwdArgs A) {
+struct ReduceGeom {
     using BG = BwdGeom<W, Pol>;
+    // tiles of layer l: rows x (B tiles + bias tile); the output layer is one row (slab row MT when it rides on job depth-1)
+    static __host__ __device__ int n_b(int l, unsigned skip_mask) { return (l >= 1 ? BG::MT : 0) + ((l == 0 || ((skip_mask >> l) & 1)) ? 1 : 0); }
+    static __host__ __device__ int rows(int l, int depth) { return l == depth ? 1 : BG::MT; }
+    static __host__ __device__ int blocks(int depth, unsigned skip_mask) {
+        int n = 0;
+        for (int l = 0; l <= depth; ++l) n += rows(l, depth) * (n_b(l, skip_mask) + 1);
+        return n;
+    }
+};
+
+template <int W, class Pol>
+__global__ __launch_bounds__(256) void reduce_kernel(BwdArgs A) {
+    using BG = BwdGeom<W, Pol>;
+    using RG = ReduceGeom<W, Pol>;
     constexpr int MT = BG::MT;
-    const int depth = A.f.depth;
-    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < A.nparams; t += (long long)gridDim.x * blockDim.x) {
-        int l = 0;
-        while (l < depth && t >= A.kernel_off[l + 1]) ++l;
-        const bool is_bias = t >= A.bias_off[l];
-        const int WT = A.width_true;
-        int o, kin = 0;
-        if (is_bias) o = (int)(t - A.bias_off[l]);
-        else {
-            const int outw = (l == depth) ? 1 : WT;
-            o = (int)((t - A.kernel_off[l]) % outw);
-            kin = (int)((t - A.kernel_off[l]) / outw);
-        }
-        // A-side position of output feature o
-        const int m = o >> 5, row = o & 31;
-        const int hh = (row >> 2) & 1, r = (row & 3) + 4 * (row >> 3);
-        // B-side tile / column of input feature kin
-        const bool has_h = l >= 1, has_enc = (l == 0) || ((A.f.skip_mask >> l) & 1);
-        const int nH = has_h ? MT : 0, nB = nH + (has_enc ? 1 : 0);
-        int n, col;
-        if (is_bias) { n = nB; col = 0; }
-        else if (l == 0) { n = 0; col = bhn_enc_feature_slot(kin, A.f.deg); }
-        else if (kin < WT) { n = kin >> 5; col = kin & 31; }
-        else { n = nH; col = bhn_enc_feature_slot(kin - WT, A.f.deg); }
-        // the output layer's row rides on the job of layer depth-1 (slab row MT) when gA_{depth-1} is not on the tape
-        const bool rides = l == depth && A.t.drop_ga;
-        const int jl = rides ? depth - 1 : l;
-        const long long idx = (long long)((rides ? MT : m) * BG::NTMAX + n) * 1024 + (r >> 2) * 256 + (col + 32 * hh) * 4 + (r & 3);
-        float sum = 0.f;
-        for (int wg = A.wg_begin[jl]; wg < A.wg_begin[jl + 1]; ++wg) sum += A.f.slabs[(long long)wg * BG::SLAB_FLOATS + idx];
-        A.dparams[t] = sum;
+    const int depth = A.f.depth, WT = A.width_true;
+    int b = blockIdx.x, l = 0;
+    for (; l <= depth; ++l) {
+        const int cnt = RG::rows(l, depth) * (RG::n_b(l, A.f.skip_mask) + 1);
+        if (b < cnt) break;
+        b -= cnt;
+    }
+    if (l > depth) return;
+    const bool has_h = l >= 1, has_enc = (l == 0) || ((A.f.skip_mask >> l) & 1);
+    const int nH = has_h ? MT : 0, nB = nH + (has_enc ? 1 : 0);
+    const int mi = b / (nB + 1), n = b % (nB + 1);
+    const bool out = l == depth, rides = out && A.t.drop_ga;
+    const int jl = rides ? depth - 1 : l;
+    const int mrow = out ? (rides ? MT : 0) : mi;
+    if (!out && 32 * mi >= WT) return;                              // padding rows of a narrower model
+    const int tid = threadIdx.x, g4 = tid >> 6, lane = tid & 63, hh = lane >> 5, col = lane & 31;
+    const float *src = A.f.slabs + (long long)(mrow * BG::NTMAX + n) * 1024 + g4 * 256 + lane * 4;
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    for (int wg = A.wg_begin[jl]; wg < A.wg_begin[jl + 1]; ++wg) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(src + (long long)wg * BG::SLAB_FLOATS);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sum[e] += v[e];
+    }
+    // input feature of this column
+    long long kin = -1;
+    bool is_bias = false;
+    if (n < nH) { if (32 * n + col < WT) kin = 32 * n + col; }
+    else if (n < nB) { const int fe = bhn_enc_slot_feature(col, A.f.deg); if (fe >= 0) kin = (has_h ? WT : 0) + fe; }
+    else is_bias = col == 0;
+    if (kin < 0 && !is_bias) return;
+    const int outw = out ? 1 : WT;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int r = 4 * g4 + e, row = (r & 3) + 4 * hh + 8 * (r >> 2);
+        const int o = out ? 0 : 32 * mi + row;
+        if (out ? row != 0 : o >= WT) continue;
+        A.dparams[is_bias ? A.bias_off[l] + o : A.kernel_off[l] + kin * outw + o] = sum[e];
     }
 }
 
@@ -1600,7 +1625,7 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
         BHN_HIP(hipGetLastError());
         BHN_HIP(mark(2));
     }
-    if (what != RUN_FWD_TRAIN && (g_bwd_stages & 4)) hipLaunchKernelGGL((reduce_kernel<W, Pol>), dim3(256), dim3(256), 0, st, A);
+    if (what != RUN_FWD_TRAIN && (g_bwd_stages & 4)) hipLaunchKernelGGL((reduce_kernel<W, Pol>), dim3((unsigned)ReduceGeom<W, Pol>::blocks(depth, (unsigned)A.f.skip_mask)), dim3(256), 0, st, A);
     BHN_HIP(hipGetLastError());
     if (events && n_events > 3 && events[3]) BHN_HIP(hipEventRecord((hipEvent_t)events[3], st));
     return BHN_OK;
