@@ -57,7 +57,7 @@ DEVI void wide_step(const char *ch, const char *chn, APipe<Pol> &ap, const typen
         acc0 = Pol::mma(a[t % PF], s0[t], acc0);
         acc1 = Pol::mma(a[t % PF], s1[t], acc1);
         p0.at(t); p1.at(t);
-        if (t == 9 && dma.src) RG::issue(dma.src, dma.dst);
+        if (t == 9 && dma.on) RG::issue(dma);
         if (t == 13) ap.bias = bias_acc(bias_next, 0, lane >> 5);
         __builtin_amdgcn_sched_barrier(0);
     }
