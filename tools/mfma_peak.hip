@@ -4,6 +4,8 @@
 //   mode 1: A fragment from LDS (ds_read_b128, 3 reads in flight), B in registers (= tile_matmul)
 //   mode 2: as 1, plus a workgroup barrier every 16 MFMAs (= one ring step)
 //   mode 4: registers only, two independent accumulator chains per wave
+//   mode 5/6/7: mode 0 plus 2 / 4 / 8 independent VALU instructions (v_pk_mul_f32 on private registers) behind every MFMA:
+//               does the vector ALU work of the two waves of a SIMD overlap the matrix pipe, or add to it?
 // build: hipcc -O3 --offload-arch=gfx950 tools/mfma_peak.hip -o gpurun_out/mfma_peak
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -22,10 +24,25 @@ __global__ __launch_bounds__(NW * 64) void k(float *out, int iters) {
         for (int j = 0; j < 8; ++j) b[i][j] = (__bf16)(0.01f * ((lane + i + j) & 15));
     f32x16 acc = {};
     f32x16 keep = {};
+    for (int j = 0; j < 16; ++j) keep[j] = 1.f + 0.001f * lane;
     for (int it = 0; it < iters; ++it) {
         if (MODE == 0) {
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[(ks + 1) & 15], b[ks], acc, 0, 0, 0);
+        } else if (MODE >= 5) {
+            constexpr int NV = MODE == 5 ? 2 : MODE == 6 ? 4 : 8;
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[(ks + 1) & 15], b[ks], acc, 0, 0, 0);
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    f32x2 t = {keep[2 * v], keep[2 * v + 1]};
+                    t = t * (f32x2){1.0001f, 0.9999f};
+                    keep[2 * v] = t[0]; keep[2 * v + 1] = t[1];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         } else if (MODE == 4) {        // two independent accumulator chains per wave
 #pragma unroll
             for (int ks = 0; ks < 16; ks += 2) {
@@ -95,5 +112,9 @@ int main() {
     run<1, 4>("A from LDS", 1);
     run<1, 8>("A from LDS", 1);
     run<2, 8>("A from LDS + barrier/16", 1);
+    run<5, 8>("regs only + 2 VALU per MFMA", 1);
+    run<6, 8>("regs only + 4 VALU per MFMA", 1);
+    run<7, 8>("regs only + 8 VALU per MFMA", 1);
+    run<7, 4>("regs only + 8 VALU per MFMA", 1);
     return 0;
 }
