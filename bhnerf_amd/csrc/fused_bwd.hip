@@ -299,7 +299,7 @@ struct TapePost {
     }
     unsigned w = 0;                             // the pair rounded in the previous k-step (pack_pipe)
     DEVI void at(int t) {
-        if constexpr (RELU && Pol::ELEM_BYTES == 2) pack_pipe<Pol>(t, pend, d0, d1, w, mask);     // fragments complete after k-step 8, bits after 9
+        if constexpr (RELU && Pol::ELEM_BYTES == 2) pack_pipe<Pol, true>(t, pend, d0, d1, w, mask);     // fragments complete after k-step 8, bits after 9
         else {
             if (t == 0) elems<0, 2>();
             if (t == 1) elems<2, 2>();

@@ -58,6 +58,19 @@ struct PolBF16 {
     //   mask_pair : dword = pack(a, b) & pk_ashr15(spread << (15 - k))                       (4 VALU per pair)
     // A bf16 result of +0 counts as inactive (an f32 pre-activation below 2^-133 would be active in exact arithmetic).
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    // 1 in each 16-bit half of u that is nonzero, for halves that are non-negative as signed integers (clamped bf16:
+    // <= 0x7f80): a SIGNED packed min with 1 = one v_pk_min_i16, compiler-visible.  (The unsigned form of the same
+    // builtin is turned into two compares, two selects and a v_perm; the inline-asm v_pk_min_u16 used until round 2 was
+    // opaque to the hazard recogniser -- after the pack was pipelined it landed in a SrcA register two instructions behind
+    // its MFMA, which tools/check_asm_hazard.py caught -- and cost an s_nop behind every clamp.)
+    // The (1, 1) operand is made opaque (an SGPR behind an empty asm): knowing both that the halves are clamped and that
+    // the other operand is 1, hipcc folds clamp + min into per-half compares, selects and a v_perm (100 VALU per tile).
+    static DEVI unsigned nonzero_halves(unsigned u) {
+        typedef short i16x2 __attribute__((ext_vector_type(2)));
+        unsigned one = 0x00010001u;
+        asm("" : "+s"(one));
+        return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(i16x2, u), __builtin_bit_cast(i16x2, one)));
+    }
     static DEVI void put_dword(frag &f, int i, unsigned u) {
         u32x4 w = __builtin_bit_cast(u32x4, f);
         w[i] = u;
@@ -76,14 +89,11 @@ struct PolBF16 {
         // covered by the hazard recogniser (tools/check_asm_hazard.py)
         const unsigned u = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, w), (i16x2){0, 0}));
         put_dword(f, i, u);
-        unsigned m;      // (plain VALU reading a VALU result: no hazard the compiler would have to know about; the
-                         //  generic elementwise min on u16x2 expands into ~10 compare/select instructions)
-        asm("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(u), "s"(0x00010001u));
-        spread |= m << k;
+        spread |= nonzero_halves(u) << k;
     }
     // relu_pair in three phases for the software-pipelined pack of ring_step (one phase per k-step and pair): hipcc puts
     // an `s_nop 0` between a VALU instruction and an inline-asm statement that reads its result in the next cycle, and
-    // relu_pair is convert -> (asm pin) -> clamp -> (asm v_pk_min_u16 / asm use marker): 16-20 s_nop per ring step
+    // relu_pair was convert -> (asm pin) -> clamp -> (asm v_pk_min_u16 / asm use marker): 16-20 s_nop per ring step
     // (10 % of its instructions, round-2 ISA census).  With the phases one k-step apart the neighbours are independent.
     static DEVI unsigned pack_a(float a, float b) {                       // round (ONE vector conversion = v_cvt_pk_bf16_f32;
         typedef float f32x2 __attribute__((ext_vector_type(2)));          //  two scalar ones become two converts + v_perm)
@@ -96,10 +106,7 @@ struct PolBF16 {
         put_dword(f, i, __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, w), (i16x2){0, 0})));
     }
     static DEVI void pack_c(const frag &f, int i, int k, unsigned &spread) {                  // relu bits
-        const unsigned u = __builtin_bit_cast(u32x4, f)[i];
-        unsigned m;
-        asm("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(u), "s"(0x00010001u));
-        spread |= m << k;
+        spread |= nonzero_halves(__builtin_bit_cast(u32x4, f)[i]) << k;
     }
     static DEVI void mask_pair(frag &f, int i, int k, float a, float b, unsigned spread) {
         // bits k and 16+k of `spread` moved to the sign bits of the two halves, spread by a packed arithmetic >> 15
@@ -433,7 +440,7 @@ DEVI void pack_elems(const f32x16 &acc, typename Pol::frag &d0, typename Pol::fr
 // Software-pipelined relu + repack of a pending tile over k-steps 0..9 of a ring step (pair p = elements 2p, 2p+1):
 // k-step t rounds pair t, clamps pair t-1 into its fragment dword and takes the relu bits of pair t-2 (Pol::pack_a/b/c).
 // The fragments are complete after k-step 8, the relu bits after k-step 9.
-template <class Pol>
+template <class Pol, bool BITS>
 DEVI void pack_pipe(int t, const f32x16 &pend, typename Pol::frag &d0, typename Pol::frag &d1, unsigned &w, unsigned &mask) {
     if (t >= 1 && t <= 8) {
         const int r = 2 * (t - 1);
@@ -446,7 +453,11 @@ DEVI void pack_pipe(int t, const f32x16 &pend, typename Pol::frag &d0, typename 
     }
     // the packed registers are "used" once, a k-step after the last write (see pack_elems; an empty asm right behind the
     // VALU instruction that writes a packed 16-bit result costs an s_nop: hipcc's inline-asm hazard rule)
-    if (t == 10) asm volatile("" : "+v"(d0), "+v"(d1));
+    // (BITS, the recording kernels: the relu bits as well -- else the bit extraction of an even tile sinks into the next step)
+    if (t == 10) {
+        if constexpr (BITS) asm volatile("" : "+v"(d0), "+v"(d1), "+v"(mask));
+        else asm volatile("" : "+v"(d0), "+v"(d1));
+    }
 }
 
 template <class Pol>
@@ -493,7 +504,7 @@ struct PackPost {
     DEVI PackPost(const f32x16 &p, typename Pol::frag &a, typename Pol::frag &b) : pend(p), d0(a), d1(b), mask(0) {}
     unsigned w = 0;                             // the pair rounded in the previous k-step (pack_pipe)
     DEVI void at(int t) {
-        if constexpr (Pol::ELEM_BYTES == 2) pack_pipe<Pol>(t, pend, d0, d1, w, mask);
+        if constexpr (Pol::ELEM_BYTES == 2) pack_pipe<Pol, false>(t, pend, d0, d1, w, mask);
         else {                                  // f32: no packed converts, nothing to pipeline
             if (t == 0) pack_elems<Pol, 0, 2>(pend, d0, d1, mask);
             if (t == 1) pack_elems<Pol, 2, 2>(pend, d0, d1, mask);

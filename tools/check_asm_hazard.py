@@ -4,9 +4,11 @@ inline asm is opaque to hipcc's hazard recogniser.  Measured on gfx950: an asm w
 MFMA corrupted the product; writes into SrcA three or more instructions later are what the shipped kernels do and are
 covered by the parity tests.
 
-The only opcode this code base emits through inline asm is v_pk_min_u16 (fused_common.h: relu bits; v_pk_max_i16 comes from
-a vector builtin and is visible to the compiler), so the built objects are disassembled and every such instruction is
-checked against the most recent MFMA (no other MFMA in between):
+Until round 2 the relu bits were taken with an inline-asm v_pk_min_u16 (fused_common.h); when the pack was software-
+pipelined over the k-steps this check caught that instruction two slots behind an MFMA whose SrcA it overwrote, and the
+bits are now a compiler-visible signed packed min (PolBF16::nonzero_halves, v_pk_min_i16).  No VALU instruction is emitted
+through inline asm any more; the check stays as a guard: the built objects are disassembled and every instruction with one
+of the opcodes below is checked against the most recent MFMA (no other MFMA in between):
 
     python tools/check_asm_hazard.py [objects ...]        # default: bhnerf_amd/csrc/fused_{fwd,bwd}.o
 """
