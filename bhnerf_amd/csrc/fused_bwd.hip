@@ -21,6 +21,12 @@
 #ifndef BHN_JOB1_W
 #define BHN_JOB1_W 13          // weight of the layer-1 dW job in B tiles at width 256 (measured optimum; scaled with the width)
 #endif
+#ifndef BHN_DROP_GA0
+#define BHN_DROP_GA0 0          // 1 (EXPERIMENT, measured slower: DESIGN.md 5): gA_0 not on the tape, rebuilt by the layer-0 dW job
+#endif
+#ifndef BHN_JOB0R_W
+#define BHN_JOB0R_W 24          // weight (in tiles at width 256) of the layer-0 dW job when it rebuilds gA_0 (measured optimum)
+#endif
 #ifndef BHN_JOBL_W
 #define BHN_JOBL_W 10           // extra weight (in tiles at width 256, scaled with the width) of the layer depth-1 dW job when it rebuilds gA_{depth-1} and carries the output row
 #endif
@@ -53,6 +59,10 @@ struct TapeLayout {
     // tile, and also makes dW_out from the same h_depth tiles (no separate output-layer job): -1 KB per point of
     // tape traffic (chain write + dW read of gA_{depth-1}, second dW read of h_depth)
     int drop_ga;
+    // bf16, width 256, depth >= 3: gA_0 is not on the tape: the delta chain stops at gA_1 (16 instead of 24 ring steps per
+    // tile at depth 4) and the dW job of layer 0 rebuilds gA_0 = (h_1 != 0) (.) W_1 gA_1 from the gA_1 tiles it streams
+    // instead (the same bytes), with its rows of W_1 in registers (dw_body_first_r)
+    int drop_ga0;
     long long dout_stride;                     // bytes per group of the dout region: tile (+ 32 f32 when drop_ga)
 };
 
@@ -386,14 +396,17 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
     for (int i = tid; i < W; i += Pol::NTHREADS) wout_lds[i] = reinterpret_cast<const float *>(a.packed + a.wout_off)[i];
 
     const int NCF = (MODE == MODE_CHAIN) ? 0 : PK::fwd_chunks(a.depth);
-    const int NLB = (MODE == MODE_FWD_TRAIN) ? 0 : a.depth - 1;
+    // delta chain: hidden layers depth-1 .. LEND produce gA_{l-1}; with TapeLayout::drop_ga0 it stops at gA_1 (LEND = 2)
+    const int LEND = (MODE == MODE_CHAIN && A.t.drop_ga0) ? 2 : 1;
+    const int NLB = (MODE == MODE_FWD_TRAIN) ? 0 : a.depth - LEND;
     const bool have_ring = NCF + NLB * MT > 0;
     // first tile of the sequence starts with bias (forward) or zero (delta chain) accumulators
     const float *first_bias = (MODE == MODE_CHAIN) ? zero_lds : bias_lds;
     RS rs;
     APipe<Pol> ap;
     if (have_ring) {
-        rs.start(ring, a.packed + a.fwd_off, NCF, a.packed + a.bwd_off, NLB, sdbg ? 1 : 0, 0);
+        // (the transposed images are stored layer-major from layer 1 on: the ring starts at layer LEND's)
+        rs.start(ring, a.packed + a.fwd_off, NCF, a.packed + a.bwd_off + (size_t)(LEND - 1) * MT * CB, NLB, sdbg ? 1 : 0, 0);
         ap.prime(rs.ch(), first_bias);
     } else {
         __syncthreads();
@@ -614,7 +627,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
             unsigned mq0 = cin.q0, mq1 = cin.q1, mcur = 0u;          // MODE_CHAIN: relu-bit words in flight from the tape
             unsigned no_acc = 0u;
 #pragma nounroll
-            for (int l = a.depth - 1; l >= 1; --l) {
+            for (int l = a.depth - 1; l >= LEND; --l) {
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
                     const char *ch = rs.ch(), *chn = rs.chn();
@@ -631,7 +644,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
                         mq1 = chain_word(mask_g, (a.depth - 1 - l) * MW + (m >> 1) + 2);
                     }
                     const f32x16 acc = ring_step<W, Pol, RG>(ch, chn, ap, dl, enc, false,
-                                                             (l == 1 && m == MT - 1) ? first_bias : zero_lds, post, dj, sdbg);
+                                                             (l == LEND && m == MT - 1) ? first_bias : zero_lds, post, dj, sdbg);
                     // without the gA_{depth-1} emissions the intervals around this layer's first DMA issue hold one
                     // emission less: the step ends whose window reaches back to it count one less (small widths: none)
                     if (A.t.drop_ga && l == a.depth - 1 && m <= 4) rs.template step_end<YS_L1>();
@@ -644,9 +657,9 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
 #pragma unroll
                 for (int ks = 0; ks < KS - 2; ++ks) dl[ks] = next[ks];
             }
-            if (a.depth > 1) {           // flush the last tile of gA_0 (no further step to hide it behind)
+            if (a.depth > 1) {           // flush the last tile of gA_{LEND-1} (no further step to hide it behind)
                 TapePost<Pol, false> post(pend, dl[KS - 2], dl[KS - 1], pnd_mask, em,
-                                              A.tape + ga_lin + (qs * MT + MT - 1) * TB, nullptr, nullptr, no_acc, false, false, edbg);
+                                              A.tape + ga_lin + (LEND - 1) * lin_stride + (qs * MT + MT - 1) * TB, nullptr, nullptr, no_acc, false, false, edbg);
                 post.all();
             }
         }   // MODE_CHAIN
@@ -687,8 +700,11 @@ struct TapeStream {
     long long mstride[NMIX];
     int mlds[NMIX];
     int wvu;
-    DEVI TapeStream(const char *a, long long sa, const char *h, long long sh, const char *e, long long se, const char *d, long long sd, int wave) {
+    unsigned voffA;              // global-side lane offset of the region-0 pieces (default: lane-linear)
+    DEVI TapeStream(const char *a, long long sa, const char *h, long long sh, const char *e, long long se, const char *d, long long sd, int wave,
+                    int voff_a = -1) {
         wvu = wave;
+        voffA = voff_a >= 0 ? (unsigned)voff_a : (threadIdx.x & 63) * 16;
         src[0] = a; src[1] = h; src[2] = e; src[3] = d;
         stride[0] = sa; stride[1] = sh; stride[2] = se; stride[3] = sd;
         int k = 0;
@@ -712,9 +728,10 @@ struct TapeStream {
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
         return u32x4{lo, hi & 0xffffu, 0x7fffffffu, 0x00020000u};
     }
+    // voff: the lane's byte offset on the GLOBAL side (the LDS side of a piece is lane-linear).  Any permutation of the
+    // 64 16-byte slots of a piece can be had for free by permuting these offsets (voffA, region 0).
     template <int POLICY>
-    static DEVI void dma(const u32x4 &rs, unsigned soff, unsigned m) {
-        const unsigned voff = (threadIdx.x & 63) * 16;
+    static DEVI void dma(const u32x4 &rs, unsigned soff, unsigned m, unsigned voff) {
         if constexpr (POLICY == 1)
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen nt lds" ::"s"(m), "v"(voff), "s"(rs), "s"(soff) : "memory");
         else if constexpr (POLICY == 2)
@@ -729,10 +746,10 @@ struct TapeStream {
             constexpr int r = region_of(p0), rel = (p0 - region_start(r)) * 1024;
             if constexpr (!(uniform_row(I - 1) && region_of(NW * (I - 1)) == r))      // first such row: the region's resource
                 rs[r] = rsrc(src[r] + wvu * 1024 + q * stride[r]);
-            dma<POLICY>(rs[r], (unsigned)rel, lb + (unsigned)(wvu * 1024 + region_lds(r) + rel));
+            dma<POLICY>(rs[r], (unsigned)rel, lb + (unsigned)(wvu * 1024 + region_lds(r) + rel), r == 0 ? voffA : (threadIdx.x & 63) * 16);
         } else {                                                      // a row across regions / the ragged tail
             constexpr int k = mixed_before(I);
-            dma<POLICY>(rsrc(msrc[k] + q * mstride[k]), 0u, lb + (unsigned)mlds[k]);
+            dma<POLICY>(rsrc(msrc[k] + q * mstride[k]), 0u, lb + (unsigned)mlds[k], (threadIdx.x & 63) * 16);
         }
     }
     template <int POLICY, int... I>
@@ -1291,6 +1308,156 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// dW job of layer 0 that REBUILDS gA_0 (TapeLayout::drop_ga0; bf16, one 32-feature tile per wave: MT == NWAVES).
+// The delta chain stops at gA_1; this job streams the gA_1 tiles (the bytes the plain layer-0 job spends on gA_0) and the
+// encoded inputs, and wave w makes feature tile w of
+//     gA_0 = (h_1 != 0) (.) (gA_1 W_1^T),     h_1 = relu(enc W_0 + b_0)
+// with the POINT on the MFMA row (the orientation of the h_1 recompute of layer 1's job): A = tape tiles read as plain
+// fragments (point-on-lane images ARE A fragments), B = the wave's 16 fragments of W_1 -- chunk (layer 1, tile w) of the
+// transposed weight image, whose A fragments are B fragments of the transpose -- held in registers for the whole job.
+// The accumulator then has the feature on the lane and the points in the registers in the order the transposed tape reads
+// deliver (tr_frag): masked and rounded it is the A operand of dW_0 = gA_0^T enc without leaving the registers.
+// Same products, the same k order and the same rounding as the chain's own layer-1 step: gA_0 is bit-identical to what
+// the chain recorded.  20 MFMAs per group and wave instead of 2.
+// ---------------------------------------------------------------------------------------------
+template <int W, class Pol>
+DEVI void dw_body_first_r(const BwdArgs &A, char *smem) {
+    using BG = BwdGeom<W, Pol>;
+    using PK = Pack<W, Pol>;
+    using frag = typename Pol::frag;
+    static_assert(Pol::ELEM_BYTES == 2, "bf16");
+    constexpr int MT = BG::MT, TB = BG::TILE_BYTES, KS = PK::KS;
+    static_assert(MT == Pol::NWAVES, "one feature tile per wave");
+    constexpr int OFF_E = MT * TB, OFF_P = OFF_E + TB, GB = OFF_P + TB;          // LDS group image [gA_1 tiles][enc][enc, fragment form]
+    constexpr int NBUF = 4;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int trl = tr_lane_off();
+    const int nwg = A.wg_begin[1] - A.wg_begin[0];
+    const int kb = blockIdx.x - A.wg_begin[0];
+    const long long q0 = uniform64(A.t.NQ * kb / nwg), q1 = uniform64(A.t.NQ * (kb + 1) / nwg);
+    // W_0 (layer-0 chunk of the forward image) and b_0 behind the ring, as in the layer-1 job
+    char *w0_lds = smem + NBUF * GB;
+    float *b0_lds = reinterpret_cast<float *>(w0_lds + 2 * MT * Pol::FRAG_BYTES);
+    {
+        const char *w0 = A.f.packed + A.f.fwd_off;
+        for (int i = tid; i < 2 * MT * Pol::FRAG_BYTES / 16; i += Pol::NTHREADS)
+            reinterpret_cast<u32x4 *>(w0_lds)[i] = reinterpret_cast<const u32x4 *>(w0)[i];
+        for (int i = tid; i < W; i += Pol::NTHREADS) b0_lds[i] = reinterpret_cast<const float *>(A.f.packed + A.f.bias_off)[i];
+    }
+    // this wave's fragments of W_1: chunk (layer 1, tile wv) of the transposed image, fragments 0 .. KS-1
+    frag w1[KS];
+    {
+        const char *c = A.f.packed + A.f.bwd_off + (size_t)wv * PK::CHUNK_BYTES;
+#pragma unroll
+        for (int sfr = 0; sfr < KS; ++sfr) w1[sfr] = *reinterpret_cast<const frag *>(c + sfr * Pol::FRAG_BYTES + lane * 16);
+    }
+    using Stream = TapeStream<Pol::NWAVES, MT * TB / 1024, 0, TB / 1024, TB / 1024, 0, OFF_E, OFF_P>;
+    constexpr int PPW = Stream::PPW;
+    // The gA_1 pieces are un-swizzled on their way into LDS: the tape's slot layout (made for the transposed reads of the
+    // other jobs) makes plain fragment reads 4-way bank-conflicted -- the four 4-point rows a 16-lane read group touches
+    // fall on the same banks.  DMA lane i fetches global slot (p & 3) + 4 (c & 1) + 8 (c >> 1) + 16 (p >> 2) of its 1-KiB
+    // piece (p = i & 15: point within the piece, c = i >> 4 = 2 s + h) and writes LDS slot i = p + 16 c: a fragment read
+    // then takes 16 consecutive slots per read group.  Free: only the lanes' global offsets are permuted.
+    const int dl_p = lane & 15, dl_c = lane >> 4;
+    const Stream stream(A.tape + A.t.ga_off[1], (long long)MT * TB, nullptr, 0, A.tape + A.t.enc_off, TB, A.tape + A.t.encp_off, TB, wv,
+                        16 * ((dl_p & 3) + 4 * (dl_c & 1) + 8 * (dl_c >> 1) + 16 * (dl_p >> 2)));
+    auto issue = [&](long long q, char *buf) {
+        q = q < q1 ? q : q1 - 1;
+        if (BHN_DBG(A.wrap)) q %= A.wrap;
+        stream.template issue<1>(q, buf);
+    };
+    // fragment s of a (un-swizzled) tile: lane (pt, h) reads slot (pt & 15) + 16 (2 s + h) of piece pt >> 4
+    const int nat = ((lane & 31) >> 4) * 1024 + 16 * (lane & 15) + 256 * (lane >> 5);
+    __syncthreads();
+    const frag w00 = Pol::lds_frag(w0_lds, 2 * wv, lane), w01 = Pol::lds_frag(w0_lds, 2 * wv + 1, lane);
+    const float b0 = b0_lds[32 * wv + (lane & 31)];
+    f32x16 acc0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = 0.f;
+    float bsum = 0.f;
+    if (q0 < q1) {
+#pragma unroll
+        for (int j = 0; j < NBUF - 1; ++j) issue(q0 + j, smem + j * GB);
+        int it = 0;
+        for (long long q = q0; q < q1; ++q) {
+            if (!BHN_DBG(A.debug & 2)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * PPW) : "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (!BHN_DBG(A.debug & 2)) issue(q + NBUF - 1, smem + ((it + NBUF - 1) & (NBUF - 1)) * GB);
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const char *gp = smem + it * GB;
+            if (!BHN_DBG(A.debug & 1)) {
+                // h_1 tile wv: D[point][feature] = enc W_0 + b_0 (two MFMAs, as the layer-1 job makes it)
+                f32x16 hacc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) hacc[r] = b0;
+                hacc = Pol::mma(Pol::lds_frag(gp + OFF_P, 0, lane), w00, hacc);
+                hacc = Pol::mma(Pol::lds_frag(gp + OFF_P, 1, lane), w01, hacc);
+                // gA_1 W_1^T, tile wv: K = the 256 features of layer 1, fragment s = half (s & 1) of tape tile s >> 1
+                f32x16 dacc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dacc[r] = 0.f;
+                constexpr int PFD = 6;                                      // tape fragments in flight (the reads are bank-conflicted: long latency)
+                frag af[PFD];
+#pragma unroll
+                for (int i = 0; i < PFD - 1; ++i) af[i] = *reinterpret_cast<const frag *>(gp + (i >> 1) * TB + (i & 1) * 512 + nat);
+                const frag eb0 = tr_frag(gp + OFF_E, 0, trl), eb1 = tr_frag(gp + OFF_E, 1, trl);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int sfr = 0; sfr < KS; ++sfr) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int nx = sfr + PFD - 1;
+                    if (nx < KS) af[nx % PFD] = *reinterpret_cast<const frag *>(gp + (nx >> 1) * TB + (nx & 1) * 512 + nat);
+                    dacc = Pol::mma(af[sfr % PFD], w1[sfr], dacc);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // gA_0 = (bf16(h_1) != 0) (.) bf16(dacc): the A fragments of dW_0 (fragment s = registers 8 s .. 8 s + 7)
+                frag ga[2];
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    typedef short i16x2 __attribute__((ext_vector_type(2)));
+                    const unsigned hb = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, Pol::pack_a(hacc[r], hacc[r + 1])), (i16x2){0, 0}));
+                    const i16x2 on = (i16x2){0, 0} - __builtin_bit_cast(i16x2, Pol::nonzero_halves(hb));      // 0xffff where h_1 != 0
+                    Pol::put_dword(ga[r >> 3], (r & 7) >> 1, Pol::pack_a(dacc[r], dacc[r + 1]) & __builtin_bit_cast(unsigned, on));
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    bsum = Pol::sum8(ga[s2], bsum);
+                    acc0 = Pol::mma(ga[s2], s2 ? eb1 : eb0, acc0);
+                }
+            }
+            it = (it + 1) & (NBUF - 1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    // flush: slab tile (m = wv, n = 0) and the bias column (tile (wv, 1), column 0), the layout of the plain layer-0 job
+    float *slab = A.f.slabs + (long long)blockIdx.x * BG::SLAB_FLOATS;
+    {
+        float *tp = slab + (long long)(wv * BG::NTMAX + 0) * 1024;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc0[4 * g4 + e];
+            f32x4 *dst = reinterpret_cast<f32x4 *>(tp + g4 * 256 + lane * 4);
+            if (A.accumulate) {
+                const f32x4 old = *dst;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += old[e];
+            }
+            *dst = v;
+        }
+        float v = bsum + __shfl_xor(bsum, 32, 64);
+        if (lane < 32) {
+            const int hh = (lane >> 2) & 1, r = (lane & 3) + 4 * (lane >> 3);
+            float *dst = slab + (long long)(wv * BG::NTMAX + 1) * 1024 + (r >> 2) * 256 + (32 * hh) * 4 + (r & 3);
+            if (A.accumulate) v += *dst;
+            *dst = v;
+        }
+    }
+}
+
 template <int W, class Pol>
 __global__ __launch_bounds__(Pol::NTHREADS) __attribute__((amdgpu_waves_per_eu(Pol::NWAVES == 4 ? 1 : (W <= 128 ? 4 : 2)))) void dw_kernel(BwdArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];       // NBUF x GROUP_BYTES
@@ -1303,8 +1470,12 @@ __global__ __launch_bounds__(Pol::NTHREADS) __attribute__((amdgpu_waves_per_eu(P
         if (job == depth) {                                               // (depth < 3 only)
             if (out_skip) dw_body<W, Pol, JT_OUTSKIP>(A, job, smem);
             else dw_body<W, Pol, JT_OUT>(A, job, smem);
-        } else if (job == 0) dw_body2<W, Pol, JT_FIRST>(A, job, smem);
-        else if (job == depth - 1 && A.t.drop_ga) {
+        } else if (job == 0) {
+            if constexpr (BwdGeom<W, Pol>::MT == Pol::NWAVES) {
+                if (A.t.drop_ga0) dw_body_first_r<W, Pol>(A, smem);
+                else dw_body2<W, Pol, JT_FIRST>(A, job, smem);
+            } else dw_body2<W, Pol, JT_FIRST>(A, job, smem);
+        } else if (job == depth - 1 && A.t.drop_ga) {
             if ((A.f.skip_mask >> job) & 1) {
                 if (out_skip) dw_body2<W, Pol, JT_SKIP, true, true>(A, job, smem);
                 else dw_body2<W, Pol, JT_SKIP, true>(A, job, smem);
@@ -1428,15 +1599,16 @@ static void tape_layout(int depth, bool layer1_takes_enc, long long NQ, TapeLayo
     }
     if (t->drop_h1) { t->encp_off = off; off += NQ * (long long)BG::TILE_BYTES; }
     t->drop_ga = bhn_folds_wout(Pol::MODE, depth);
+    t->drop_ga0 = BHN_DROP_GA0 && t->drop_ga && t->drop_h1 && BG::MT == Pol::NWAVES;     // (one feature tile of gA_0 per wave)
     for (int l = 0; l < depth; ++l) {
-        if (l == depth - 1 && t->drop_ga) { t->ga_off[l] = -1; continue; }
+        if ((l == depth - 1 && t->drop_ga) || (l == 0 && t->drop_ga0)) { t->ga_off[l] = -1; continue; }
         t->ga_off[l] = off; off += per_tensor;
     }
     t->lin_stride = per_tensor;
     {
         const int lmin = t->drop_h1 ? 2 : 1;
         t->h_lin = (lmin <= depth ? t->h_off[lmin] : 0) - lmin * per_tensor;
-        t->ga_lin = t->ga_off[0];
+        t->ga_lin = t->drop_ga0 ? t->ga_off[1] - per_tensor : t->ga_off[0];
     }
     t->enc_off = off; off += NQ * (long long)BG::TILE_BYTES;
     t->dout_stride = t->drop_ga ? 128 : BG::TILE_BYTES;         // 32 f32 dout per group, or dout as an A tile (row 0 = dout)
@@ -1465,8 +1637,9 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
 #ifdef BHN_DEBUG
     static const int grid_override = dbg_env_int("BHN_DEBUG_DW_GRID", 0);
     static const int job1_w = dbg_env_int("BHN_DEBUG_JOB1_W", BHN_JOB1_W), jobl_w = dbg_env_int("BHN_DEBUG_JOBL_W", BHN_JOBL_W);
+    static const int job0r_w = dbg_env_int("BHN_DEBUG_JOB0R_W", BHN_JOB0R_W);
 #else
-    constexpr int grid_override = 0, job1_w = BHN_JOB1_W, jobl_w = BHN_JOBL_W;
+    constexpr int grid_override = 0, job1_w = BHN_JOB1_W, jobl_w = BHN_JOBL_W, job0r_w = BHN_JOB0R_W;
 #endif
     const int grid_dw = grid_override > 0 ? grid_override : ncu;        // one dW workgroup per CU
     const size_t slab_bytes = align_up((size_t)grid_dw * BG::SLAB_FLOATS * 4, 256);
@@ -1535,6 +1708,7 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
             if (l == 1 && t1.drop_h1) nB = job1_w * BG::MT / 8;   // reads only the encoded inputs instead of h_1 but has the
                                                                   // same MFMA work + the recompute: not byte-bound any more
             work[l] = (double)(mtA + nB) + 0.5;
+            if (l == 0 && t1.drop_ga0) work[l] = job0r_w * BG::MT / 8.0 + 0.5;     // rebuilds gA_0: 20 MFMAs per group and wave, 16 conflicted LDS reads
             if (l == depth - 1 && t1.drop_ga) work[l] += jobl_w * BG::MT / 8.0;    // + the rebuild of gA and the output row
             if constexpr (Pol::ELEM_BYTES == 4) {
                 // f32: the jobs are MFMA-bound (a 32x32x2 MFMA is 64 cycles; one 32x32 tile product over a 32-point
