@@ -413,6 +413,7 @@ int fused_fill_args(const bhn_model *m, int32_t mode, const void *packed, const 
     a->deg = s->deg;
     for (int l = 0; l <= s->depth; ++l) a->skip_mask |= s->skip_in[l] << l;
     a->scale = m->scale;
+    a->inv_scale = (float)(1.0 / (double)m->scale);
     a->x = geom->x; a->y = geom->y; a->z = geom->z; a->Omega = geom->Omega; a->t_geo = geom->t_geo;
     a->w = geom->w; a->dom = geom->dom;
     a->R = geom->R; a->G = geom->G; a->P = geom->R * geom->G;
