@@ -125,8 +125,9 @@ def _integrate(alpha, beta, spin, inclination, distance, M, h, r_c, max_steps, t
         y_new[5] = np.where(Tn > 1e-2 * (et + a * a + lm ** 2), np.sign(y_new[5]) * np.sqrt(np.abs(Tn)), y_new[5])
         captured = ~(y_new[0] > r_hor * 1.02)              # (also catches a NaN): the step is not taken, the ray ends here
         mino_new = mino + dl
-        if targets is not None:                            # samples crossed by this step: linear in Mino time
-            ok = ~captured
+        if targets is not None:                            # samples crossed by this step: cubic Hermite in Mino time
+            ok = ~captured                                 # (value and derivative at both ends of the step: O(h^4) like
+            f_new = None                                   #  the RK4 step itself; linear interpolation left O(h^2))
             while True:
                 g_idx = idx
                 k = np.minimum(nxt[g_idx], ngeo - 1)
@@ -136,8 +137,12 @@ def _integrate(alpha, beta, spin, inclination, distance, M, h, r_c, max_steps, t
                     break
                 w = ((tgt - mino) / np.where(dl > 0, dl, 1.0))[hit]
                 rows = g_idx[hit]
+                if f_new is None:
+                    f_new = _rhs(y_new, a, lm, et, M)
+                w2, w3 = w * w, w * w * w
                 out[0, rows, k[hit]] = tgt[hit]
-                out[1:, rows, k[hit]] = y[:, hit] * (1.0 - w) + y_new[:, hit] * w
+                out[1:, rows, k[hit]] = ((2 * w3 - 3 * w2 + 1) * y[:, hit] + (w3 - 2 * w2 + w) * dl[hit] * k1[:, hit]
+                                         + (3 * w2 - 2 * w3) * y_new[:, hit] + (w3 - w2) * dl[hit] * f_new[:, hit])
                 nxt[rows] += 1
         y = np.where(captured, y, y_new)
         mino = np.where(captured, mino, mino_new)

@@ -195,8 +195,9 @@ def test_radial_motion_matches_the_published_analytic_solution(spin, inc_deg):
     """Pin for SURVEY 8 f3: the external `kgeo` package the reference calls (kgeo.py:61-62, `raytrace_ana`) implements the
     analytic Kerr solution of Gralla & Lupsasca; it is absent, so the own tracer is held to that published closed form
     instead (mpmath elliptic integrals, 30 digits): along every scattering ray the Mino time elapsed since the observer is
-    I_r(r_o) -+ I_r(r) before / after the radial turning point.  RK4 at the default step agrees to 1e-4 of the ray's total
-    Mino time and converges towards the closed form when the step is refined."""
+    I_r(r_o) -+ I_r(r) before / after the radial turning point.  RK4 with cubic-Hermite sampling agrees to 1e-9 of the
+    ray's total Mino time at the default step and converges at fourth order when the step is refined (VERDICT r1 asked
+    for 1e-8; with linear interpolation between the steps it was 4e-5 and second order)."""
     import mpmath as mp
     mp.mp.dps = 30
 
@@ -227,6 +228,6 @@ def test_radial_motion_matches_the_published_analytic_solution(spin, inc_deg):
         assert rays >= 6
         return err
 
-    coarse, fine = worst(0.02), worst(0.005)
-    assert coarse < 1e-4, coarse
-    assert fine < 1e-5 and fine < 0.5 * coarse, (coarse, fine)
+    coarse, fine = worst(0.02), worst(0.01)
+    assert coarse < 1e-9, coarse
+    assert fine < coarse / 8.0, (coarse, fine)                   # fourth order: 16x per halving
