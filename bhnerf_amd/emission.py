@@ -134,8 +134,11 @@ def image_plane_dynamics(emission_0, geos, Omega, t_frames, t_injection, J=1.0, 
             raise AttributeError('doppler=True needs traced geodesics (kgeo.image_plane_geos) or a Doppler factor geos.g')
     else:
         g = 1.0
-    if t_start_obs is None:                                                            # emission.py:274
-        t_start_obs = t_frames[0] if units.is_quantity(t_frames) else np.atleast_1d(t_frames)[0]
+    if t_start_obs is None:                                                            # emission.py:274 (a scalar frame time is its own start)
+        if units.is_quantity(t_frames):
+            t_start_obs = float(np.atleast_1d(np.asarray(t_frames.value))[0]) * t_frames.unit
+        else:
+            t_start_obs = np.atleast_1d(t_frames)[0]
     t_units = t_start_obs.unit if units.is_quantity(t_start_obs) else (t_frames.unit if units.is_quantity(t_frames) else None)
     mass = constants.sgra_mass_msun if M is None else float(getattr(M, 'value', M))
     GM_c3 = constants.GM_c3(t_units, mass) if t_units is not None else 1.0

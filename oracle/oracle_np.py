@@ -244,3 +244,26 @@ def grid_predictor_apply(grid, t_frames, coords, Omega, t_start_obs, t_geos, t_i
     emission = sigmoid(map_coordinates_linear(grid, index) - 10.0)
     emission = fill_unsupervised_emission(emission, coords, rmin, rmax, z_width)
     return np.where(valid[..., 0], emission, np.zeros_like(emission))
+
+
+def image_plane_dynamics(volume, fov, coords, Omega, t_frames, t_injection, t_geos, g, dtau, Sigma, J=1.0,
+                         t_start_obs=None, slow_light=True, GM_c3=GM_C3_SGRA_HR):
+    """emission.py:235-303 restated from the pieces above (float64): velocity warp (slow light: with t_geos, else 0,
+    emission.py:269) -> trilinear sampling of `volume` (nx,ny,nz) spanning [-fov/2, fov/2]^3 (emission.py:213-233) -> 0
+    where the warp is NaN (before the injection) -> x J -> radiative transfer.  `t_start_obs` defaults to t_frames[0]
+    (emission.py:274).  Returns (nt, [S], H, W).  Pinned to the reference's own output in fixture g8
+    (tests/test_oracle_golden.py)."""
+    volume = np.asarray(volume, dtype=np.float64)
+    t_frames = np.atleast_1d(np.asarray(t_frames, dtype=np.float64))
+    t0 = t_frames[0] if t_start_obs is None else float(t_start_obs)
+    tg = np.asarray(t_geos, dtype=np.float64) if slow_light else 0.0
+    warped = velocity_warp_coords(np.asarray(coords, dtype=np.float64), np.asarray(Omega, dtype=np.float64), t_frames, t0, tg,
+                                  float(t_injection), GM_c3=GM_c3)                    # (nt, *spatial, 3)
+    n = volume.shape
+    index = [(warped[..., i] + fov / 2.0) / fov * (n[i] - 1) for i in range(3)]
+    em = map_coordinates_linear(volume, index)
+    em = np.where(np.isnan(warped).any(axis=-1), 0.0, em)
+    if np.ndim(J) > 0:
+        em = np.asarray(J, dtype=np.float64)[None] * em[:, None]                     # (nt, S, *spatial)
+    return radiative_trasfer(em, g, dtau, Sigma)
+

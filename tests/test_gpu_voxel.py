@@ -55,3 +55,37 @@ def test_image_plane_dynamics_golden(golden):
         emission.image_plane_dynamics(Vol(), geos, g['Omega'], t, 0.0, doppler=True)       # needs geos.g
     with pytest.raises(AttributeError):
         emission.image_plane_dynamics(Vol(), geos, g['Omega'], t, 0.0, doppler=False, rot_axis=[1, 0, 0])
+
+
+def test_config1_tutorial1_forward_render_at_size():
+    """BASELINE config 1 (Tutorial1 forward render: spin 0 hotspot, 64 x 64 image, 32 samples per ray, 1 frame) at its
+    own size: Kerr geodesics from the own tracer, a 64^3 Gaussian hotspot, Keplerian Omega, Doppler factor from the traced
+    wave vectors -- the fused voxel renderer against the float64 oracle composition (pinned to the reference's output in
+    tests/test_oracle_golden.py::test_image_plane_dynamics_golden).  Then 16 frames of the orbit: flux varies, the
+    frame at t = 0 is the single-frame render."""
+    from bhnerf_amd import constants, emission, kgeo, units
+    from oracle import oracle_np as onp
+    fov_M = 16.0
+    geos = kgeo.image_plane_geos(0.0, np.deg2rad(60.0), (-fov_M / 2, fov_M / 2), (-fov_M / 2, fov_M / 2), ngeo=32, num_alpha=64, num_beta=64)
+    rr = np.sqrt(geos.x ** 2 + geos.y ** 2)
+    Omega = np.sign(1.0) * np.sqrt(geos.M) / (np.maximum(rr, 2.0) ** 1.5 + geos.spin * np.sqrt(geos.M))      # Keplerian, capped inside
+    vol = emission.generate_hotspot_xr(resolution=(64, 64, 64), rot_axis=[0, 0, 1], rot_angle=0.0, orbit_radius=6.5,
+                                       std=0.8, r_isco=constants.isco_pro(0.0), fov=(fov_M, 'GM/c^2'))
+    arr, fov = emission._grid_of(vol)
+    assert arr.shape == (64, 64, 64) and arr.max() > 0
+    g = np.asarray(kgeo.doppler_factor(geos, kgeo.azimuthal_velocity_vector(geos, Omega)), dtype=np.float64)
+    r32 = lambda v: np.asarray(v, dtype=np.float32).astype(np.float64)      # the device path holds the geometry in float32
+    coords = r32(np.array([geos.x, geos.y, geos.z]))
+    t_inj = -float(geos.r_o)
+    for dop in (False, True):
+        img = emission.image_plane_dynamics(vol, geos, Omega, 0.0 * units.hr, t_inj, J=1.0, doppler=dop)
+        want = onp.image_plane_dynamics(arr, float(fov[0]), coords, r32(Omega), [0.0], t_inj, r32(geos.t), r32(g) if dop else 1.0, r32(geos.dtau), r32(geos.Sigma))[0]
+        assert img.shape == (64, 64) and want.max() > 0
+        assert relerr(img, want) < 2e-5, (dop, relerr(img, want))
+    t = np.linspace(0.0, 1.5, 16) * units.hr
+    movie = emission.image_plane_dynamics(vol, geos, Omega, t, t_inj, J=1.0, doppler=True)
+    want = onp.image_plane_dynamics(arr, float(fov[0]), coords, r32(Omega), t.value if hasattr(t, 'value') else np.asarray(t), t_inj, r32(geos.t), r32(g), r32(geos.dtau), r32(geos.Sigma))
+    assert movie.shape == (16, 64, 64) and relerr(movie, want) < 2e-5
+    flux = movie.sum(axis=(1, 2))
+    assert flux.std() > 0.02 * flux.mean()                           # the hotspot orbits: Doppler boosting modulates the flux
+

@@ -173,3 +173,19 @@ def test_grid_predictor_golden(golden):
     assert int(g['nonzero_fd']) >= 10
     for (i, j, k), fd in zip(g['fd_idx'], g['fd_val']):
         assert abs(grad[i, j, k].item() - fd) <= 1e-6 * max(1.0, abs(fd)), ((i, j, k), grad[i, j, k].item(), fd)
+
+
+def test_image_plane_dynamics_golden(golden):
+    """The oracle's composition of emission.image_plane_dynamics (warp -> trilinear sampling -> x J -> radiative transfer)
+    against the reference's own output (fixture g8): the checker of the full-size BASELINE config-1 GPU test."""
+    g = golden('g8_dynamics')
+    fov = float(g['axis'][-1] - g['axis'][0])
+    kw = dict(t_geos=g['t_geos'], g=1.0, dtau=g['dtau'], Sigma=g['Sigma'])
+    img = onp.image_plane_dynamics(g['volume'], fov, g['coords'], g['Omega'], g['t_frames'], float(g['t_injection']), **kw)
+    assert img.shape == g['images'].shape and np.abs(img - g['images']).max() < 1e-12 * np.abs(g['images']).max()
+    imgJ = onp.image_plane_dynamics(g['volume'], fov, g['coords'], g['Omega'], g['t_frames'], float(g['t_injection']), J=g['J'], **kw)
+    assert imgJ.shape == g['images_J'].shape and np.abs(imgJ - g['images_J']).max() < 1e-12 * np.abs(g['images_J']).max()
+    fast = onp.image_plane_dynamics(g['volume'], fov, g['coords'], g['Omega'], g['t_frames'], float(g['t_injection']),
+                                    t_start_obs=0.1, slow_light=False, **kw)
+    assert np.abs(fast - g['images_fast']).max() < 1e-12 * np.abs(g['images_fast']).max()
+
