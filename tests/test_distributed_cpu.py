@@ -166,19 +166,22 @@ def _step_worker(rank, world, port, out, overlap=False):
         for it in range(3):
             idx = np.array([[2, 0, 3, 1], [0, 1, 2, 3], [3, 2, 1, 0]][it])
             tgt, sig, off, tf = batched[idx]                                          # this rank's contiguous slice
-            assert len(tf) == 2
+            assert len(tf) == 4 // world
             loss, state, images = network.gradient_step_image(
                 state, units.hr, 'full', tgt, sig, off, tf, g['coords'], g['Omega'], 1.0, g['g'], g['dtau'], g['Sigma'],
                 float(g['t_start_obs']), g['t_geos'], float(g['t_injection']), 1.0)
             losses.append(loss.numpy().copy())
-            assert images.shape == (1, 2, H, W)
+            assert images.shape == (1, 4 // world, H, W)
+        adam = 'adam(grad_scale=%g)' % (1.0 / world)
         if overlap:
             # the all-reduce of step k completes inside step k+1 (after its backward); the last one at finish_allreduce()
-            assert eng.calls == ['pack', 'render', 'bwd'] + ['pack', 'render', 'bwd', 'adam(grad_scale=0.5)'] * 2, eng.calls
-            assert state.step == 2 and np.isnan(losses[0][1 - rank]) and not np.isnan(losses[0][rank])
+            assert eng.calls == ['pack', 'render', 'bwd'] + ['pack', 'render', 'bwd', adam] * 2, eng.calls
+            assert state.step == 2 and np.isnan(losses[0][(rank + 1) % world]) and not np.isnan(losses[0][rank])
             state.finish_allreduce()
-            assert eng.calls[-1] == 'adam(grad_scale=0.5)' and state._pending is None
+            assert eng.calls[-1] == adam and state._pending is None
             losses = losses[1:]                  # steps 2 and 3 return the loss vectors of the completed steps 1 and 2
+        else:
+            assert eng.calls == ['pack', 'render', 'bwd', adam] * 3, eng.calls
         assert state.grad.numel() == eng.nparams + world and state.step == 3
         out.put((rank, state.flat.numpy().copy(), np.array(losses)))
         dist.barrier()
@@ -187,8 +190,9 @@ def _step_worker(rank, world, port, out, overlap=False):
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_training_steps_match_single_process_reference():
-    world, port = 2, _free_port()
+@pytest.mark.parametrize('world', [2, 4])
+def test_two_rank_training_steps_match_single_process_reference(world):
+    port = _free_port()
     ctx = mp.get_context('spawn')
     out = ctx.Queue()
     procs = [ctx.Process(target=_step_worker, args=(r, world, port, out)) for r in range(world)]
@@ -198,8 +202,10 @@ def test_two_rank_training_steps_match_single_process_reference():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    assert np.array_equal(res[0][1], res[1][1])                       # identical parameters on both ranks, bitwise
-    assert np.array_equal(res[0][2], res[1][2]) and res[0][2].shape == (3, 2)      # both hold every rank's loss
+    for r in res[1:]:
+        assert np.array_equal(res[0][1], r[1])                        # identical parameters on every rank, bitwise
+        assert np.array_equal(res[0][2], r[2])                        # every rank holds every rank's loss
+    assert res[0][2].shape == (3, world)
     # reference: one process, all four frames, gradient / world (pmean of per-device sums), float64
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
