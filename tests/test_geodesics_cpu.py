@@ -231,3 +231,45 @@ def test_radial_motion_matches_the_published_analytic_solution(spin, inc_deg):
     coarse, fine = worst(0.02), worst(0.01)
     assert coarse < 1e-9, coarse
     assert fine < coarse / 8.0, (coarse, fine)                   # fourth order: 16x per halving
+
+
+@pytest.mark.parametrize('spin,inc_deg', [(0.0, 60.0), (0.94, 60.0), (0.94, 17.0)])
+def test_polar_motion_matches_the_published_analytic_solution(spin, inc_deg):
+    """Second half of the f3 pin: the polar angle along every ray with eta > 0 ("ordinary" motion between the turning
+    points +-arccos sqrt(u_+)) against Gralla & Lupsasca 2020, eq. 38 (Jacobi sn; mpmath, 30 digits):
+        cos theta(tau) = -nu sqrt(u_+) sn( sqrt(-u_- a^2) (tau + nu G_o) | u_+ / u_- ),
+        G_o = -F(arcsin(cos theta_o / sqrt u_+) | u_+ / u_-) / sqrt(-u_- a^2),   u_+- = D +- sqrt(D^2 + eta / a^2),
+        D = (1 - (eta + lam^2) / a^2) / 2,   nu = sign of d theta / d tau at the observer,
+    and its a -> 0 limit cos theta = -nu sqrt(u_+) sin( sqrt(eta + lam^2) (tau + nu G_o) ), u_+ = eta / (eta + lam^2).
+    tau = Mino time elapsed since the observer.  Through several polar turning points, 1e-9 at the default step."""
+    import mpmath as mp
+    mp.mp.dps = 30
+    g = G.image_plane_geos(spin, np.deg2rad(inc_deg), (-9.0, 9.0), (-9.0, 9.0), ngeo=40, num_alpha=3, num_beta=4)
+    th_o = mp.mpf(float(g.inc))
+    err, rays, turns = 0.0, 0, 0
+    for i in range(3):
+        for j in range(4):
+            lam, eta, a = mp.mpf(float(g.lam[i, j])), mp.mpf(float(g.eta[i, j])), mp.mpf(spin)
+            th, tau = g.theta[i, j], -g.mino[i, j]
+            if eta <= 0 or not np.isfinite(th).all():
+                continue
+            nu = -1 if g.beta[i, j] > 0 else 1                  # d theta / d tau at the observer: a ray that arrives from above
+                                                                # (beta > 0) is followed back towards the pole first
+            if a == 0:
+                up, w = eta / (eta + lam ** 2), mp.sqrt(eta + lam ** 2)
+                G_o = -mp.asin(mp.cos(th_o) / mp.sqrt(up)) / w
+                f = lambda t: -nu * mp.sqrt(up) * mp.sin(w * (t + nu * G_o))
+            else:
+                D = (1 - (eta + lam ** 2) / a ** 2) / 2
+                up, um = D + mp.sqrt(D ** 2 + eta / a ** 2), D - mp.sqrt(D ** 2 + eta / a ** 2)
+                w, m = mp.sqrt(-um * a ** 2), up / um
+                G_o = -mp.re(mp.ellipf(mp.asin(mp.cos(th_o) / mp.sqrt(up)), m)) / w
+                f = lambda t: -nu * mp.sqrt(up) * mp.re(mp.ellipfun('sn', w * (t + nu * G_o), m))     # (negative parameter: mpmath returns mpc + 0j)
+            assert abs(float(f(mp.mpf(0))) - float(mp.cos(th_o))) < 1e-12
+            for k in range(len(th)):
+                err = max(err, abs(float(f(mp.mpf(float(tau[k])))) - np.cos(th[k])))
+            rays += 1
+            turns += int((np.diff(np.sign(np.diff(th))) != 0).sum())
+    assert rays >= 8 and turns >= 4                              # the rays do go through polar turning points
+    assert err < 1e-9, err
+
