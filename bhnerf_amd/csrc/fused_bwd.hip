@@ -28,7 +28,7 @@
 #define BHN_JOB0R_W 24          // weight (in tiles at width 256) of the layer-0 dW job when it rebuilds gA_0 (measured optimum)
 #endif
 #ifndef BHN_JOBL_W
-#define BHN_JOBL_W 10           // extra weight (in tiles at width 256, scaled with the width) of the layer depth-1 dW job when it rebuilds gA_{depth-1} and carries the output row
+#define BHN_JOBL_W 8            // extra weight (in tiles at width 256, scaled with the width) of the layer depth-1 dW job when it rebuilds gA_{depth-1} and carries the output row
 #endif
 // Run-time measurement switches exist only in the debug build (make debug); the release kernels see the constant 0
 #ifdef BHN_DEBUG
