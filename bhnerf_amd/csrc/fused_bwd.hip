@@ -1471,7 +1471,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) __attribute__((amdgpu_waves_per_eu(P
             if (out_skip) dw_body<W, Pol, JT_OUTSKIP>(A, job, smem);
             else dw_body<W, Pol, JT_OUT>(A, job, smem);
         } else if (job == 0) {
-            if constexpr (BwdGeom<W, Pol>::MT == Pol::NWAVES) {
+            if constexpr (BHN_DROP_GA0 != 0 && BwdGeom<W, Pol>::MT == Pol::NWAVES) {     // (experiment builds only)
                 if (A.t.drop_ga0) dw_body_first_r<W, Pol>(A, smem);
                 else dw_body2<W, Pol, JT_FIRST>(A, job, smem);
             } else dw_body2<W, Pol, JT_FIRST>(A, job, smem);
