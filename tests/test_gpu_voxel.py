@@ -89,3 +89,25 @@ def test_config1_tutorial1_forward_render_at_size():
     flux = movie.sum(axis=(1, 2))
     assert flux.std() > 0.02 * flux.mean()                           # the hotspot orbits: Doppler boosting modulates the flux
 
+
+def test_polarised_flux_tube_movie_at_size():
+    """The polarised case of the reference's light-curve notebooks at its own size (64 x 64 rays x 100 samples, Stokes I/Q/U
+    emission factors from alma.image_plane_model, slow light, 5 frames): fused voxel renderer against the oracle composition."""
+    from bhnerf_amd import alma, emission, units
+    from oracle import oracle_np as onp
+    params = dict(fov_M=40.0, z_width=4, rmin='ISCO', Q_frac=0.85, b_consts=dict(arad=0, avert=1, ator=0), Omega_dir='cw',
+                  num_alpha=64, num_beta=64, t_start_obs=9.3)
+    vol = emission.generate_tube_xr(resolution=(64, 64, 64), rot_axis=[0.0, 0.0, 1.0], phi_start=np.deg2rad(190), phi_end=np.deg2rad(270),
+                                    orbit_radius=10.0, std=1.0, r_isco=6.0, fov=(40.0, 'GM/c^2'))
+    arr, fov = emission._grid_of(vol)
+    geos, Omega, J = alma.image_plane_model(np.deg2rad(12.0), 0.0, params)
+    t = np.array([9.34056333, 9.35067, 9.36077667, 9.37088333, 9.38099])
+    t_inj = -float(geos.r_o + 40.0 / 4)
+    movie = emission.image_plane_dynamics(vol, geos, Omega, t * units.hr, t_inj, J, t_start_obs=9.3 * units.hr, doppler=False)
+    r32 = lambda v: np.asarray(v, dtype=np.float32).astype(np.float64)
+    want = onp.image_plane_dynamics(arr.astype(np.float64), float(fov[0]), r32(np.array([geos.x, geos.y, geos.z])), r32(Omega), t, t_inj,
+                                    r32(geos.t), 1.0, r32(geos.dtau), r32(geos.Sigma), J=r32(J), t_start_obs=9.3)
+    assert movie.shape == (5, 3, 64, 64) and relerr(movie, want) < 5e-5, relerr(movie, want)
+    lc, lw = movie.sum(axis=(-1, -2)), want.sum(axis=(-1, -2))
+    assert np.abs(lc / lw - 1.0).max() < 1e-4
+
