@@ -377,8 +377,9 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
     constexpr int YS_L1 = YS_L1r > 0 ? YS_L1r : 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *ring = smem;
-    float *bias_lds = reinterpret_cast<float *>(smem + RS::NB * CB);  // (depth+1) x W, then one zero row
-    float *zero_lds = bias_lds + (a.depth + 1) * W;
+    float *bias_lds = reinterpret_cast<float *>(smem + RS::NB * CB);  // depth x W + the 32 rows of the output tile, then one zero row
+    const int nbias = a.depth * W + 32;                               // (the output layer's tile is read as one 32-row tile:
+    float *zero_lds = bias_lds + nbias;                               //  a full W row for it put the f32 8x256 kernel over 160 KB)
     float *wout_lds = zero_lds + 32;
     char *id_lds = reinterpret_cast<char *>(wout_lds + W);
     char *seg_lds = id_lds + (Pol::ELEM_BYTES == 2 ? 0 : 2 * Pol::FRAG_BYTES);   // RaySum scratch (bf16 has no identity table)
@@ -390,7 +391,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
     asm volatile("" : "+s"(h_lin), "+s"(ga_lin), "+s"(lin_stride));
     TapeEmit<Pol> em;
     em.init(id_lds);
-    for (int i = tid; i < (a.depth + 1) * W; i += Pol::NTHREADS)
+    for (int i = tid; i < nbias; i += Pol::NTHREADS)
         bias_lds[i] = reinterpret_cast<const float *>(a.packed + a.bias_off)[i];
     if (tid < 32) zero_lds[tid] = 0.f;
     for (int i = tid; i < W; i += Pol::NTHREADS) wout_lds[i] = reinterpret_cast<const float *>(a.packed + a.wout_off)[i];
@@ -1740,7 +1741,7 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
         }
     }
     // ring + bias rows + zero row + output weights + identity fragments
-    const size_t lds_fixed = (size_t)(depth + 1) * W * 4 + 128 + W * 4 + (Pol::ELEM_BYTES == 2 ? 0 : 2 * Pol::FRAG_BYTES) + RaySum<Pol::NWAVES>::bytes(A.f.Sx);
+    const size_t lds_fixed = ((size_t)depth * W + 32) * 4 + 128 + W * 4 + (Pol::ELEM_BYTES == 2 ? 0 : 2 * Pol::FRAG_BYTES) + RaySum<Pol::NWAVES>::bytes(A.f.Sx);
     const size_t lds_taped = (size_t)(BG::RING_DIST_TAPED + 1) * PK::CHUNK_BYTES + lds_fixed;
     size_t lds_dw = (size_t)BG::NBUF * BG::GROUP_BYTES + (t1.drop_h1 ? (size_t)2 * BG::MT * Pol::FRAG_BYTES + W * 4 : 0);
     if (t1.drop_ga && (size_t)BG::NBUF * BG::GROUP_BYTES_LAST2 > lds_dw) lds_dw = (size_t)BG::NBUF * BG::GROUP_BYTES_LAST2;

@@ -193,7 +193,7 @@ def test_frame_group_taped_step_equals_full_step(dev, golden, dt):
                                                (128, 4, 0, 0), (256, 4, 3, 1), (64, 4, 0, 2), (128, 4, 2, 4),
                                                (100, 4, 0, 3), (48, 4, 3, 3), (200, 6, 0, 2), (20, 4, 0, 3),
                                                (64, 5, 0, 3), (128, 7, 2, 3), (32, 3, 0, 3), (64, 2, 3, 2), (256, 5, 0, 3),
-                                               (256, 8, 0, 3), (256, 8, 2, 3)])      # 8x256 f32: the LDS budget of the training forward
+                                               (256, 8, 0, 3), (256, 8, 3, 3)])      # 8x256 f32: the LDS budget of the training forward
 def test_random_problem_f32_and_bf16(dev, width, depth, S, deg):
     """Larger ragged problem (G=50 rays straddle wave tiles, several workgroup tiles, pre-injection
     and out-of-domain samples) against the float64 oracle; positional-encoding degrees 0..4 (network.py:98-122,
