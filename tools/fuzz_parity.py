@@ -1,7 +1,6 @@
 """Randomised parity sweep (not part of the test suite): tests/test_gpu_backward.py::test_random_problem_f32_and_bf16 --
 images and gradients of both arithmetic modes against the float64 oracle on a ragged problem -- for N random
-(width 1..256, depth 2..8, Stokes planes 0 / 2 / 3, posenc degree 0..4) combinations.  (One plane is left out:
-the reference squeezes the unit Stokes axis, network.py:418, and the test's targets are not shaped for that.)  The bf16
+(width 1..256, depth 2..8, Stokes planes 0..3, posenc degree 0..4) combinations.  The bf16
 bounds of the test are statistical on this tiny problem (3 x 63 rays): a few per cent of the draws exceed them by
 less than a factor of two; anything beyond that, and any f32 failure, is reported as HARD.
     python tools/fuzz_parity.py [N] [seed]"""
@@ -16,7 +15,7 @@ dev = torch.device('cuda:0')
 bad = soft = 0
 for i in range(N):
     width = int(rng.choice([int(rng.integers(1, 257)), 32, 64, 128, 256]))
-    depth, S, deg = int(rng.integers(2, 9)), int(rng.choice([0, 2, 3])), int(rng.integers(0, 5))
+    depth, S, deg = int(rng.integers(2, 9)), int(rng.integers(0, 4)), int(rng.integers(0, 5))
     try:
         T.test_random_problem_f32_and_bf16(dev, width, depth, S, deg)
     except Exception as e:                                   # noqa: BLE001 -- report and go on
