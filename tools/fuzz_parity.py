@@ -16,6 +16,12 @@ bad = soft = 0
 for i in range(N):
     width = int(rng.choice([int(rng.integers(1, 257)), 32, 64, 128, 256]))
     depth, S, deg = int(rng.integers(2, 9)), int(rng.integers(0, 4)), int(rng.integers(0, 5))
+    # ray grid, samples per ray (1 .. 140: below / at / above the 32- and 64-sample tile boundaries), frames
+    T.RANDOM_PROBLEM_SHAPE = (int(rng.integers(2, 12)), int(rng.integers(2, 10)), int(rng.choice([int(rng.integers(3, 141)), 32, 33, 64, 65, 100])),
+                              int(rng.integers(1, 5)))
+    T.RANDOM_PROBLEM_JITTER = tuple(rng.uniform(-0.05, 0.05, 3))       # no sample exactly on a domain boundary (mask ties)
+    T.RANDOM_PROBLEM_SHAPE = (max(T.RANDOM_PROBLEM_SHAPE[0], 3), max(T.RANDOM_PROBLEM_SHAPE[1], 3)) + T.RANDOM_PROBLEM_SHAPE[2:]
+    # (two rows / columns sit at alpha or beta = +-8: nothing inside the domain, all-zero images)
     try:
         T.test_random_problem_f32_and_bf16(dev, width, depth, S, deg)
     except Exception as e:                                   # noqa: BLE001 -- report and go on
@@ -23,11 +29,13 @@ for i in range(N):
         hard = True
         try:
             mode, err = e.args[0][0], float(e.args[0][1])
-            hard = mode == 'f32' or err > 2 * T.GTOL['bf16']
+            ties = e.args[0][2] if len(e.args[0]) > 2 else 0
+            # f32 with detected ReLU ties (pre-activations within rounding of 0): the documented fallback bound, a few 1e-3
+            hard = (mode == 'f32' and not (ties and err < 5e-3)) or (mode == 'bf16' and err > 2 * T.GTOL['bf16'])
         except Exception:                                    # noqa: BLE001
             pass
         soft += not hard
         bad += hard
-        print('%s width %d depth %d S %d deg %d: %s' % ('HARD' if hard else 'soft', width, depth, S, deg, msg), flush=True)
+        print('%s width %d depth %d S %d deg %d shape %s: %s' % ('HARD' if hard else 'soft', width, depth, S, deg, T.RANDOM_PROBLEM_SHAPE, msg), flush=True)
 print('%d of %d random configurations failed hard, %d exceeded a bf16 bound by less than 2x' % (bad, N, soft))
 sys.exit(1 if bad else 0)
