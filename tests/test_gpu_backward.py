@@ -25,6 +25,7 @@ GTOL = {'f32': 2e-5, 'bf16': 1.2e-1}       # max-norm
 L2TOL = {'f32': 2e-5, 'bf16': 6e-2}        # relative L2
 LOSSTOL = {'f32': 1e-5, 'bf16': 3e-2}
 RANDOM_PROBLEM_SHAPE = (9, 7, 50, 3)       # rays H x W, samples per ray, frames of test_random_problem (tools/fuzz_parity.py varies it)
+RANDOM_PROBLEM_DOMAIN = (8.0, 2.5, 8.0, 4.0)   # scale, rmin, rmax, z_width of the recovery domain (fuzz: random)
 RANDOM_PROBLEM_JITTER = (0.0, 0.0, 0.0)    # offsets of the alpha / beta / sample grids: regular grids of other shapes put samples EXACTLY
                                            # on the domain boundary (e.g. 10 x 7 rays x 64 samples: alpha^2 + beta^2 + s^2 = rmax^2),
                                            # where the f32 kernel and the f64 oracle legitimately disagree about the mask
@@ -232,7 +233,7 @@ def test_random_problem_f32_and_bf16(dev, width, depth, S, deg):
         d['kernel'] = d['kernel'].astype(np.float64)
         d['bias'] = f32r(rng.uniform(-0.1, 0.1, d['bias'].shape))
     g = dict(geo, J=(J if S else np.array(1.0)), t_frames=t_frames, t_start_obs=0.0, t_injection=t_inj,
-             hparams=np.array([8.0, 2.5, 8.0, 4.0, deg, depth, width, 1.0]))
+             hparams=np.array(list(RANDOM_PROBLEM_DOMAIN) + [deg, depth, width, 1.0]))
     for i in range(depth + 1):
         g['kernel%d' % i] = tree['MLP_0']['Dense_%d' % i]['kernel']; g['bias%d' % i] = tree['MLP_0']['Dense_%d' % i]['bias']
     tr, t = oracle_trainer(g)

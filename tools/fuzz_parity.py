@@ -20,6 +20,9 @@ for i in range(N):
     T.RANDOM_PROBLEM_SHAPE = (int(rng.integers(2, 12)), int(rng.integers(2, 10)), int(rng.choice([int(rng.integers(3, 141)), 32, 33, 64, 65, 100])),
                               int(rng.integers(1, 5)))
     T.RANDOM_PROBLEM_JITTER = tuple(rng.uniform(-0.05, 0.05, 3))       # no sample exactly on a domain boundary (mask ties)
+    # recovery domain: scale, rmin, rmax, z_width -- from "everything inside" (no compaction) to a thin shell
+    T.RANDOM_PROBLEM_DOMAIN = (float(rng.uniform(4.0, 12.0)), float(rng.choice([0.0, rng.uniform(0.5, 5.0)])),
+                               float(rng.choice([np.inf, rng.uniform(5.5, 14.0)])), float(rng.choice([np.inf, rng.uniform(1.0, 8.0)])))
     T.RANDOM_PROBLEM_SHAPE = (max(T.RANDOM_PROBLEM_SHAPE[0], 3), max(T.RANDOM_PROBLEM_SHAPE[1], 3)) + T.RANDOM_PROBLEM_SHAPE[2:]
     # (two rows / columns sit at alpha or beta = +-8: nothing inside the domain, all-zero images)
     try:
@@ -36,6 +39,6 @@ for i in range(N):
             pass
         soft += not hard
         bad += hard
-        print('%s width %d depth %d S %d deg %d shape %s: %s' % ('HARD' if hard else 'soft', width, depth, S, deg, T.RANDOM_PROBLEM_SHAPE, msg), flush=True)
+        print('%s width %d depth %d S %d deg %d shape %s domain %s: %s' % ('HARD' if hard else 'soft', width, depth, S, deg, T.RANDOM_PROBLEM_SHAPE, tuple(round(v, 2) for v in T.RANDOM_PROBLEM_DOMAIN), msg), flush=True)
 print('%d of %d random configurations failed hard, %d exceeded a bf16 bound by less than 2x' % (bad, N, soft))
 sys.exit(1 if bad else 0)
