@@ -16,9 +16,15 @@ Inputs are synthetic geodesic arrays resident in HBM before the time
 "all-active" variant (rmin=0, rmax=inf, z_width=inf, nothing pre-injection) is used so that every
 ray-sample goes through the full MLP (evaluated points == total points).
 
-Prints ONE JSON line on rank 0.  `roofline` refers to the kernel with the largest share of the step, every kernel
-timed live with HIP events on the launch stream (`bhn_render_bwd_tape_timed` records the caller's events between the
-kernels of the backward); `roofline.step_mfma_frac` is the whole step on SURVEY 8(d)'s algorithmic-flop basis;
+Prints ONE JSON line on rank 0.  `roofline` refers to the MLP kernel with the largest share of the step on SURVEY 8(d)'s
+ALGORITHMIC-FLOP basis (bound: mfma -- the fused MLP is a dense contraction; the tape bytes the design chose to move are
+reported beside it as `tape_stream`, never as the roofline), every kernel timed live with HIP events on the launch stream
+(`bhn_render_bwd_tape_timed` records the caller's events between the kernels of the backward);
+`roofline.step_mfma_frac` is the whole step on the same basis.  Keys ending in `_from_profiles` (and `traffic`) are NOT
+measured in this run: they are read from the committed rocprofv3 counter passes `profiles/<roofline.profiles_tag>_*`
+(PMC counters cannot be collected from inside the process) and are flagged `profiles_match_this_build: false` when the
+library they were collected on is not the one loaded here.  `fwd_images_per_s` is frames / time of
+`optimization.total_movie_loss` (the reference's test path, optimization.py:14-66) over the whole movie;
 `parity_mode` is the same step in the f32 (1e-5 parity) arithmetic; `cpu_baseline` is the oracle's PyTorch-CPU
 restatement timed on the host cores on a bounded sample BEFORE the GPU work starts (best of a thread-count sweep).
 """
@@ -37,7 +43,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}      # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
-PROFILE_TAG = 'r2'                                  # profiles/<tag>_pmc_traffic.json etc. (tools/collect_profiles.sh)
+PROFILE_TAG = 'r3'                                  # profiles/<tag>_pmc_traffic.json etc. (tools/collect_profiles.sh)
 
 
 def mlp_flops(depth, width, F=21):
@@ -67,6 +73,9 @@ def parse():
     ap.add_argument('--no-parity-mode', action='store_true', help='skip the f32 parity-mode block')
     ap.add_argument('--no-tutorial-domain', action='store_true',
                     help='skip the masked-domain variant (profiling runs: keeps every launch of a kernel the same shape)')
+    ap.add_argument('--other-configs', action='store_true',
+                    help='add one timed training step each at the sizes of BASELINE configs 3 (256x256x128, Stokes I/Q/U, lc), '
+                         '4 (EHT2017 visibilities, 256x256x100) and 5 (64x64x100, 4x128, lc) on this one GPU')
     ap.add_argument('--cpu-rays', type=int, default=2048, help='rays of one frame in the CPU-baseline sample')
     ap.add_argument('--cpu-seconds', type=float, default=25.0, help='time budget of the CPU-baseline thread sweep')
     return ap.parse_args()
@@ -74,7 +83,8 @@ def parse():
 
 def spawn_ranks(args):
     """`bench.py --gpus N` from a plain shell: start N ranks with torch.distributed.run and relay rank 0's line.
-    Runs before this process has initialised a GPU (device_count() does not) and never replaces itself."""
+    Runs before this process has made a HIP call of its own that creates a context, and never replaces itself: the ranks
+    are a fresh child process tree (device_count() may fall back to hipGetDeviceCount on this image; harmless here)."""
     import socket
     n = args.gpus
     one_dev = os.environ.get('BHNERF_BENCH_ONE_DEVICE') == '1'
@@ -144,6 +154,84 @@ def cpu_baseline(args, geo, GM_c3):
             'sample': '1 frame x %d rays x %d samples as one (%d, features) matrix, 4x%d MLP, float32 torch-CPU fwd+bwd+Adam, '
                       'best of 2 steps at the best of the thread counts tried (%.3f s/step at %d threads)'
                       % (nr, args.ngeo, nr * args.ngeo, args.width, dt, best)}
+
+
+def file_md5(path):
+    import hashlib
+    try:
+        return hashlib.md5(open(path, 'rb').read()).hexdigest()
+    except OSError:
+        return None
+
+
+def _hip_lib_path():
+    from bhnerf_amd import _hip
+    return os.environ.get('BHNERF_HIP_LIB') or _hip.LIB_PATH
+
+
+def other_configs(dev, mode):
+    """One timed training step (mean of 3 after 2 warm-up steps) at the sizes of BASELINE configs 3, 4 and 5 on this one
+    GPU, through the reference-shaped API (TrainStep / Optimizer): the multi-GPU configs shard frames, so the per-GPU
+    share of a step is 8 frames here as well.  Synthetic geodesics, tutorial-style recovery domains."""
+    from bhnerf_amd import constants, network, observation, optimization, synthetic, units
+    GM = constants.GM_c3('hr')
+    B = 8
+    out = {}
+
+    def time_steps(step, opt, rt, n_warm=2, n=3):
+        idx = np.arange(B)
+        for _ in range(n_warm):
+            opt.loss, opt.state, _ = step(opt.state, rt, idx)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            opt.loss, opt.state, _ = step(opt.state, rt, idx)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+
+    lc_cfgs = {'config3': dict(H=256, W=256, G=128, width=256, fov=40.0, inc=60.0, spin=0.94, rmin=2.024, rmax=20.0, z_width=4.0),
+               'config5': dict(H=64, W=64, G=100, width=128, fov=40.0, inc=12.0, spin=0.0, rmin=6.0, rmax=20.0, z_width=4.0)}
+    for name, c in lc_cfgs.items():
+        geo = synthetic.synthetic_geodesics(c['H'], c['W'], c['G'], fov_M=c['fov'], inc_deg=c['inc'], spin=c['spin'], S=3, seed=3)
+        t_frames = np.linspace(0.0, 1.7, 128)[:B]
+        pred = network.NeRF_Predictor(c['rmax'], c['rmin'], c['rmax'], c['z_width'], net_depth=4, net_width=c['width'], mode=mode, device=dev)
+        rt = network.raytracing_args(dict(x=geo['coords'][0], y=geo['coords'][1], z=geo['coords'][2], dtau=geo['dtau'], Sigma=geo['Sigma'],
+                                          t=geo['t_geos'], g=geo['g']), geo['Omega'], geo['t_injection'], 0.0 * units.hr, J=geo['J'])
+        target = np.random.default_rng(5).uniform(0.5, 1.5, (B, 3)).astype(np.float32)
+        step = optimization.TrainStep.image(t_frames * units.hr, target, sigma=0.1, dtype='lc')
+        opt = optimization.Optimizer({'num_iters': 100, 'lr_init': 1e-4, 'lr_final': 1e-6}, pred, rt)
+        dt = time_steps(step, opt, rt)
+        gm = pred.geometry(rt['coords'], rt['Omega'], rt['t_geos'], rt['J'], rt['g'], rt['dtau'], rt['Sigma'])
+        n = B * c['H'] * c['W'] * c['G']
+        out[name] = {'workload': '%dx%d rays x %d samples, Stokes I/Q/U, loss lc, 4x%d MLP, %d frames/step' % (c['H'], c['W'], c['G'], c['width'], B),
+                     'dtype': mode, 'ms_per_step': round(1e3 * dt, 3), 'value': round(n / dt, 1), 'unit': 'ray-samples/s',
+                     'active_fraction': round(gm.active_fraction, 4), 'visited_fraction': round(gm.visited_fraction, 4),
+                     'tape_frame_group': (B if pred.engine().fits_tape(B, gm.P_eff) else pred.engine().tape_group(B, gm.P_eff))}
+        del opt, pred, gm, rt
+        torch.cuda.empty_cache()
+    # config 4: EHT2017 (u, v) tracks from the reference's station file (fixture g11: data, made by tests/golden/make_eht2017.py)
+    NPIX, G4, FOV = 256, 100, 16.0
+    g11 = np.load(os.path.join(ROOT, 'tests', 'golden', 'g11_eht2017.npz'))
+    frames = np.arange(0, 64, 64 // B)
+    t_hr = g11['t_hr'][frames]
+    geo = synthetic.synthetic_geodesics(NPIX, NPIX, G4, fov_M=FOV, inc_deg=60.0, seed=0)
+    rad_per_M = 5.03e-6 / 3600.0 * np.pi / 180.0
+    A = np.stack([observation.dft_matrix(g11['uv'][f], FOV * rad_per_M, NPIX) for f in frames])
+    rng = np.random.default_rng(4)
+    target = (rng.normal(size=A.shape[:2]) + 1j * rng.normal(size=A.shape[:2])).astype(np.complex64)
+    sigma = g11['sigma'][frames].astype(np.float32)
+    rt = network.raytracing_args(dict(x=geo['coords'][0], y=geo['coords'][1], z=geo['coords'][2], dtau=geo['dtau'], Sigma=geo['Sigma'],
+                                      t=geo['t_geos'], g=geo['g']), geo['Omega'], geo['t_injection'], 0.0 * units.hr)
+    pred = network.NeRF_Predictor(FOV / 2, 2.0, FOV / 2, 4.0, net_depth=4, net_width=256, mode=mode, device=dev)
+    step = optimization.TrainStep.eht_arrays(t_hr * units.hr, target, sigma, A, dtype='vis')
+    opt = optimization.Optimizer({'num_iters': 100, 'lr_init': 1e-4, 'lr_final': 1e-6}, pred, rt)
+    dt = time_steps(step, opt, rt)
+    gm = pred.geometry(rt['coords'], rt['Omega'], rt['t_geos'], None, rt['g'], rt['dtau'], rt['Sigma'])
+    n = B * NPIX * NPIX * G4
+    out['config4'] = {'workload': "EHT2017 complex-visibility loss ('vis', 28 baselines, direct-DFT A), %dx%d rays x %d samples, 4x256 MLP, %d frames/step" % (NPIX, NPIX, G4, B),
+                      'dtype': mode, 'ms_per_step': round(1e3 * dt, 3), 'value': round(n / dt, 1), 'unit': 'ray-samples/s',
+                      'active_fraction': round(gm.active_fraction, 4), 'visited_fraction': round(gm.visited_fraction, 4)}
+    return out
 
 
 class HipEvents:
@@ -231,14 +319,23 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     import torch.distributed as dist
-    if world > 1:
+    # BHNERF_BENCH_FORCE_DIST=1 with --gpus 1: a process group of ONE rank over RCCL, so that a 1-GPU box runs the shipped
+    # multi-GPU path (init_process_group('nccl', device_id=...), the flat all-reduce on the device, then Adam)
+    force_dist = world == 1 and os.environ.get('BHNERF_BENCH_FORCE_DIST') == '1'
+    if world > 1 or force_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        if force_dist and 'MASTER_PORT' not in os.environ:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(('127.0.0.1', 0))
+                os.environ['MASTER_PORT'] = str(sk.getsockname()[1])
         if one_dev:
             dist.init_process_group('gloo', rank=rank, world_size=world)
         else:
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
         assert dist.get_world_size() == args.gpus
+    backend = dist.get_backend() if dist.is_initialized() else None
 
     from bhnerf_amd import engine, network, optimization, units
     t_frames = np.linspace(0.0, 1.0, nt)
@@ -266,9 +363,11 @@ def main():
         torch.cuda.synchronize()
 
     run_steps(opt, args.warmup)
+    opt.state.finish_allreduce()
     barrier()
     t0 = time.perf_counter()
     run_steps(opt, args.steps)
+    opt.state.finish_allreduce()        # (--overlap-allreduce: the last gradient's all-reduce + Adam belong to the K steps)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -320,40 +419,67 @@ def main():
             tiles += 0.5                                                   # the 1 KiB piece that starts with the group's 32 f32 dout
     tape_bpp = tiles * (32 * 32 * elem) / 32.0
     std = H == 128 and G == 64 and args.frames_per_gpu == 8 and args.width == 256 and args.depth == 4 and args.mode == 'bf16' and not args.masked
-    try:      # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (profiles/)
-        pmc = json.load(open(os.path.join(ROOT, 'profiles', PROFILE_TAG + '_pmc_traffic.json')))['kernels']
-        traffic = pmc.get(dom_k, {}).get('hbm_bytes') if std else None
-    except Exception:
-        traffic = None
-    if dom_k == 'dw_kernel':      # a stream over the tape: HBM-bound
-        gbs = tape_bpp * pts / (kern_ms[dom_k] * 1e-3) / 1e9
-        roofline = {'bound': 'hbm', 'kernel': dom_k, 'achieved': round(gbs, 1), 'peak': 8000.0, 'unit': 'GB/s',
-                    'frac': round(gbs / 8000.0, 4), 'traffic': traffic}
-    else:
-        achieved = alg[dom_k] * pts / (kern_ms[dom_k] * 1e-3) / 1e12
-        roofline = {'bound': 'mfma', 'kernel': dom_k, 'achieved': round(achieved, 2), 'peak': PEAK_TFLOPS[args.mode],
-                    'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_TFLOPS[args.mode], 4), 'traffic': traffic}
-    roofline['kernel_ms'] = {k: round(v, 4) for k, v in kern_ms.items()}
-    roofline['kernel_ms_sum'] = round(sum(v for k, v in kern_ms.items() if 'inference' not in k), 4)
-    try:      # matrix-pipe busy fraction of SIMD cycles from the committed SQ counter passes
-        sq = json.load(open(os.path.join(ROOT, 'profiles', PROFILE_TAG + '_sq_summary.json')))['kernels']
-        if std:
-            tag = {', 1>': fwd_name, ', 2>': chain_name, 'dw_kernel': 'dw_kernel', 'fused_fwd_kernel': 'fused_fwd_kernel (inference)'}
-            busy = {n: v['mfma_busy_frac'] for k, v in sq.items() for t, n in tag.items() if t in k}
-            roofline['mfma_busy_frac_pmc'] = busy
-            # matrix-pipe utilisation of the whole training step as the SQ counters see it: busy fractions of the three MLP
-            # kernels weighted by their live durations (north_star: ">= 40 % MFMA utilisation in the fused MLP")
-            tk = [fwd_name, chain_name, 'dw_kernel']
-            if all(k in busy for k in tk):
-                roofline['step_mfma_busy_frac_pmc'] = round(sum(busy[k] * kern_ms[k] for k in tk) / sum(kern_ms[k] for k in tk), 3)
+    # what the committed counter passes say about this workload (NOT measured in this run; see the module docstring)
+    lib_md5 = file_md5(_hip_lib_path())
+    prof = {'tag': PROFILE_TAG, 'pmc': {}, 'sq': {}, 'match': None}
+    try:
+        j = json.load(open(os.path.join(ROOT, 'profiles', PROFILE_TAG + '_pmc_traffic.json')))
+        prof['pmc'] = j['kernels'] if std else {}
+        prof['match'] = (j.get('lib_md5') == lib_md5) if j.get('lib_md5') else None
     except Exception:
         pass
+    try:
+        prof['sq'] = json.load(open(os.path.join(ROOT, 'profiles', PROFILE_TAG + '_sq_summary.json')))['kernels'] if std else {}
+    except Exception:
+        pass
+    # the dominant kernel of the step on SURVEY 8(d)'s algorithmic-flop basis: the fused MLP is MFMA-bound by its
+    # arithmetic intensity; what the tape design streams through HBM is reported as `tape_stream`
+    achieved = alg[dom_k] * pts / (kern_ms[dom_k] * 1e-3) / 1e12
+    roofline = {'bound': 'mfma', 'kernel': dom_k, 'achieved': round(achieved, 2), 'peak': PEAK_TFLOPS[args.mode],
+                'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_TFLOPS[args.mode], 4),
+                'traffic': prof['pmc'].get(dom_k, {}).get('hbm_bytes'),
+                'traffic_source': 'profiles/%s_pmc_traffic.json (rocprofv3 --pmc passes, not measured in this run)' % PROFILE_TAG,
+                'profiles_tag': PROFILE_TAG, 'profiles_match_this_build': prof['match'],
+                'algorithmic_flop_per_point': alg[dom_k], 'points_per_launch': int(pts)}
+    gbs = tape_bpp * pts / (kern_ms['dw_kernel'] * 1e-3) / 1e9
+    roofline['tape_stream'] = {'kernel': 'dw_kernel', 'GB_per_s': round(gbs, 1), 'frac_of_8TBs': round(gbs / 8000.0, 4),
+                               'bytes_per_point': round(tape_bpp, 1),
+                               'hbm_bytes_from_profiles': prof['pmc'].get('dw_kernel', {}).get('hbm_bytes')}
+    roofline['kernel_ms'] = {k: round(v, 4) for k, v in kern_ms.items()}
+    roofline['kernel_ms_sum'] = round(sum(v for k, v in kern_ms.items() if 'inference' not in k), 4)
+    roofline['kernel_ms_note'] = 'each kernel timed separately from the step loop (HIP events around / between the launches)'
+    if prof['sq']:    # matrix-pipe busy fraction of SIMD cycles from the committed SQ counter passes
+        tag = {', 1>': fwd_name, ', 2>': chain_name, 'dw_kernel': 'dw_kernel', 'fused_fwd_kernel': 'fused_fwd_kernel (inference)'}
+        busy = {n: v['mfma_busy_frac'] for k, v in prof['sq'].items() for t, n in tag.items() if t in k}
+        roofline['mfma_busy_frac_from_profiles'] = busy
+        # matrix-pipe utilisation of the whole training step as the SQ counters saw it: busy fractions of the three MLP
+        # kernels weighted by the durations recorded WITH them in the profile (not by this run's)
+        tk = [fwd_name, chain_name, 'dw_kernel']
+        pms = {n: v.get('ms') for k, v in prof['sq'].items() for t, n in tag.items() if t in k}
+        if all(k in busy and pms.get(k) for k in tk):
+            roofline['step_mfma_busy_frac_from_profiles'] = round(sum(busy[k] * pms[k] for k in tk) / sum(pms[k] for k in tk), 3)
     roofline['mfma_tflops'] = {k: round(alg[k] * pts / (kern_ms[k] * 1e-3) / 1e12, 1) for k in alg}
     roofline['mfma_tflops']['fused_fwd_kernel (inference)'] = round(f_fwd * pts / (kern_ms['fused_fwd_kernel (inference)'] * 1e-3) / 1e12, 1)
     roofline['mfma_frac'] = {k: round(v / PEAK_TFLOPS[args.mode], 4) for k, v in roofline['mfma_tflops'].items()}
     step_tflops = f_train * value * geom.visited_fraction / 1e12 / world
     roofline['step_algorithmic_tflops'] = round(step_tflops, 2)
     roofline['step_mfma_frac'] = round(step_tflops / PEAK_TFLOPS[args.mode], 4)      # 1,234,944 flop/point at 4x256
+
+    # ---- fwd images/sec: frames / time of the reference's test path over the whole movie (optimization.py:14-66) ----
+    fwd_path = None
+    if world == 1:
+        optimization.total_movie_loss(args.frames_per_gpu, opt.state, train_step, rt_args)        # warm-up
+        torch.cuda.synchronize()
+        reps_f = 3
+        t0 = time.perf_counter()
+        for _ in range(reps_f):
+            movie_loss = optimization.total_movie_loss(args.frames_per_gpu, opt.state, train_step, rt_args)
+        torch.cuda.synchronize()
+        dt_f = (time.perf_counter() - t0) / reps_f
+        fwd_path = {'value': round(nt / dt_f, 1), 'unit': 'images/s', 'frames': nt, 'batch': args.frames_per_gpu,
+                    'ms_per_movie': round(1e3 * dt_f, 3), 'movie_loss': movie_loss,
+                    'path': 'optimization.total_movie_loss -> TrainStep(update_state=False) -> pack, fused render, chi^2 per batch',
+                    'kernel_only_images_per_s': round(args.frames_per_gpu / (kern_ms['fused_fwd_kernel (inference)'] * 1e-3), 1)}
 
     # ---- the same step in the f32 parity arithmetic (the mode that meets north_star's 1e-5), single GPU ----------
     parity = None
@@ -432,15 +558,20 @@ def main():
         'dtype': args.mode, 'data': 'synthetic',
         'config': {'workload': 'Tutorial3 image-plane recovery: %dx%d rays x %d samples, %d frames, %dx%d MLP, loss full'
                                % (H, W, G, nt, args.depth, args.width),
-                   'frames_per_step': batch, 'frames_per_gpu': args.frames_per_gpu, 'parallelism': 'dp%d (time-frames)' % world + (', stale-gradient all-reduce overlap' if (args.overlap_allreduce and world > 1) else ''),
+                   'frames_per_step': batch, 'frames_per_gpu': args.frames_per_gpu, 'parallelism': 'dp%d (time-frames)' % world + (', process group %s' % backend if backend else '') + (', stale-gradient all-reduce overlap' if (args.overlap_allreduce and world > 1) else ''),
                    'active_fraction': round(geom.active_fraction, 4), 'visited_fraction': round(geom.visited_fraction, 4),
                    'tape_frame_group': group,
                    'loss': loss_now},
         'roofline': roofline,
         'rt_scan': rt_scan,
         'eht_loss': eht_loss,
-        'fwd_images_per_s': round(args.frames_per_gpu / (kern_ms['fused_fwd_kernel (inference)'] * 1e-3), 1),
+        'fwd_images_per_s': fwd_path['value'] if fwd_path else None,
+        'fwd_path': fwd_path,
     }
+    if args.other_configs and world == 1:
+        del opt
+        torch.cuda.empty_cache()
+        out['other_configs'] = other_configs(dev, args.mode)
     if parity:
         out['parity_mode'] = parity
     if tutorial_domain:

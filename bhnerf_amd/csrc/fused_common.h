@@ -519,6 +519,24 @@ struct PackPost {
     DEVI void all() { pack_elems<Pol, 0, 16>(pend, d0, d1, mask); }
 };
 
+// EXPERIMENT (-DBHN_PRIO_MODE=n, round 3): issue priority of the two waves of a SIMD inside a ring step.  With equal
+// priority the older wave of a SIMD wins every arbitration: per-step stamps show it finishing its MFMAs ~500 cycles before
+// its partner and then waiting at the barrier.  1: static s_setprio 1 for waves NW/2.. (set once, RingState::start);
+// 2 / 3 / 4: the two halves swap priority every 1 / 2 / 4 k-steps.
+#ifndef BHN_PRIO_MODE
+#define BHN_PRIO_MODE 0
+#endif
+DEVI void prio_flip(int t, int wvu) {
+    if constexpr (BHN_PRIO_MODE >= 2) {
+        constexpr int P = BHN_PRIO_MODE == 2 ? 1 : BHN_PRIO_MODE == 3 ? 2 : 4;
+        if (t % P == 0) {
+            const bool up = ((t / P) & 1) != 0;
+            if (wvu >= 4) { if (up) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+            else { if (up) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
+        }
+    }
+}
+
 // One output tile of a hidden / output / delta-chain layer: acc = ap.bias + sum_ks A[ks] . src[ks] (+ the enc
 // block when with_enc), A streamed from the ring chunk `ch`; reads the head of the next chunk `chn` and the bias
 // rows `bias_next` of the next tile before returning (both consumed after the barrier).
@@ -537,6 +555,7 @@ DEVI f32x16 ring_step(const char *ch, const char *chn, APipe<Pol> &ap, const typ
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < KS; ++t) {
+        prio_flip(t, dma.wvu);
         a[(t + PF - 1) % PF] = stream_frag<Pol, NF>(ch, chn, t + PF - 1, lane);
         if (do_mma) acc = Pol::mma(a[t % PF], src[t], acc);
         if (do_post && KS >= 16) post.at(t);
@@ -718,6 +737,7 @@ struct RingState {
         dbg = dbg_; cur = 0; issue_c = 0; lag = LAG ? lag_ : 0; ts = nullptr;
         o_cur = 0; o_nxt = CB; o_prv = (NB - 1) * CB;
         wvu = opaque(__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)));
+        if constexpr (BHN_PRIO_MODE == 1) { if (wvu >= 4) __builtin_amdgcn_s_setprio(1); }
 #pragma unroll
         for (int j = 0; j < DIST; ++j) RG::issue(DmaJob{true, next_src(), ring + j * CB, rs, wvu});
         RG::template wait_younger<RG::PPW * (DIST - 2)>();

@@ -119,16 +119,14 @@ class TrainState:
     def exchange_overlapped(self, buf, n, loss, rank, world):
         """Stale-gradient data parallelism (overlap_allreduce): start this step's all-reduce asynchronously, then complete
         the PREVIOUS step's (it ran under this step's forward and backward) and apply its gradient.  Returns the loss
-        vector of the completed step (first step: this rank's own loss, NaN elsewhere; no update yet)."""
+        vector of the completed step (first step: this rank's own loss in every slot; no update yet)."""
         import torch.distributed as dist
         prev = self._pending
         buf[n:].zero_()
         buf[n + rank] = loss.reshape(-1)[0]
         self._pending = (dist.all_reduce(buf, async_op=True), buf)
-        if prev is None:
-            out = torch.full((world,), float('nan'), dtype=torch.float32, device=buf.device)
-            out[rank] = loss.reshape(-1)[0]
-            return out
+        if prev is None:                        # no completed step yet: this rank's own loss in every slot (a NaN filler
+            return loss.reshape(-1)[:1].expand(world).clone()      # would reach Optimizer.loss, the log functions and every mean)
         prev[0].wait()                          # the compute stream waits for the collective; the host does not block
         self.apply_gradients(prev[1][:n], grad_scale=1.0 / world)
         return prev[1][n:].clone()
@@ -193,9 +191,14 @@ class TrainState:
         return self.from_state_dict(sd)
 
 
+def _dist_on():
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
+
+
 def _world():
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized():
+    if _dist_on():
         return dist.get_rank(), dist.get_world_size()
     return 0, 1
 
@@ -447,10 +450,10 @@ def dp_allreduce(buf, n, loss, rank, world):
     of its per-device chi^2 SUM; slots ``buf[n:n+world]`` carry the per-rank losses so that a single
     all-reduce(sum) returns both.  The caller divides the gradient by ``world`` (mean over devices,
     the reference's pmean).  Returns the vector of per-rank losses (shape (world,))."""
-    if world == 1:
+    if world == 1 and not _dist_on():
         return loss
-    import torch.distributed as dist
-    buf[n:].zero_()
+    import torch.distributed as dist        # (an initialised process group of ONE rank still runs the collective: the RCCL
+    buf[n:].zero_()                         #  path of a single-GPU box, tests/test_gpu_ddp.py)
     buf[n + rank] = loss.reshape(-1)[0]
     dist.all_reduce(buf)                                  # RCCL over xGMI on GPUs; gloo in the CPU tests
     return buf[n:].clone()
@@ -458,7 +461,7 @@ def dp_allreduce(buf, n, loss, rank, world):
 
 def _exchange_and_apply(state, buf, n, loss, rank, world):
     """jax.lax.pmean(grads) + apply_gradients (network.py:620-621): one all-reduce, Adam with grad / world."""
-    if world > 1 and getattr(state, 'overlap_allreduce', False):
+    if (world > 1 or _dist_on()) and getattr(state, 'overlap_allreduce', False):
         return state.exchange_overlapped(buf, n, loss, rank, world)
     loss_vec = dp_allreduce(buf, n, loss, rank, world)
     state.apply_gradients(buf[:n], grad_scale=1.0 / world)

@@ -80,7 +80,7 @@ def total_movie_loss(batchsize, state, train_step, raytracing_args, return_frame
     total, movie = 0.0, []
     for inds in _movie_chunks(nt, batchsize, ndev):
         loss, state, images = train_step(state, raytracing_args, inds, update_state=False)
-        total += float(loss.sum())
+        total = total + loss.sum()                            # stays on the device: ONE host sync per movie, not per batch
         if not return_frames:
             continue
         if ndev > 1:                                          # every rank rendered its slice of the chunk
@@ -90,7 +90,7 @@ def total_movie_loss(batchsize, state, train_step, raytracing_args, return_frame
             images = torch.cat(parts, dim=0)
         keep = 3 if polarised else 2                          # trailing ([S],H,W) axes of one frame
         movie.append(images.reshape((-1,) + tuple(images.shape[-keep:])).cpu().numpy())
-    mean_loss = total / nt
+    mean_loss = float(total) / nt
     return (mean_loss, np.concatenate(movie)[:nt]) if return_frames else mean_loss
 
 
@@ -144,9 +144,12 @@ class Optimizer(object):
                 self.loss = loss.as_subclass(HostReadable) if isinstance(loss, torch.Tensor) else loss
                 self.log()
                 self.save_checkpoint()
-            self.state.finish_allreduce()
         except KeyboardInterrupt:
-            return
+            pass
+        finally:
+            # overlap_allreduce: the gradient still in flight is completed and applied on every exit path (Ctrl-C
+            # included), so that opt.params / a later save never lag one update behind
+            self.state.finish_allreduce()
 
     @property
     def params(self):

@@ -16,9 +16,16 @@ sys.path.insert(0, ROOT)
 
 def main():
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
-    dist.init_process_group('gloo', rank=rank, world_size=world)
     torch.cuda.set_device(0)
     dev = torch.device('cuda:0')
+    # BHNERF_DDP_BACKEND=nccl (world size 1 on a 1-GPU box): the process group of the shipped multi-GPU design -- RCCL --
+    # with its device-side all-reduce and the stream semantics of the async work handle (TrainState.exchange_overlapped)
+    backend = os.environ.get('BHNERF_DDP_BACKEND', 'gloo')
+    if backend == 'nccl':
+        assert world == 1, 'every rank of this worker uses cuda:0; RCCL needs one device per rank'
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
     from bhnerf_amd import constants, engine, network, optimization, synthetic, units
     H = W = 16; G = 32; nt = 8; nsteps = 3; batch = 4; lr = 1e-3
     geos = [synthetic.synthetic_geodesics(H, W, G, seed=s) for s in (1, 2, 3)]          # three "sub-pixel" ray sets
@@ -35,9 +42,10 @@ def main():
     p0 = opt.state.flat.clone()
     opt.run(batch, step, rts)
     losses = torch.as_tensor(opt.loss).cpu().numpy()
-    flat = opt.state.flat.cpu()
+    flat = opt.state.flat if backend == 'nccl' else opt.state.flat.cpu()
     gathered = [torch.empty_like(flat) for _ in range(world)]
     dist.all_gather(gathered, flat)
+    flat, gathered = flat.cpu(), [g.cpu() for g in gathered]
     out = None
     if rank == 0:
         identical = all(torch.equal(g, gathered[0]) for g in gathered)
@@ -73,7 +81,8 @@ def main():
         moved = float((flat - p0.cpu()).abs().max())
         out = dict(identical=bool(identical), moved=moved, max_diff=float(diff.max()),
                    frac_off=float((diff > 1e-3 * moved).mean()), picks=picks, loss_vector=[float(v) for v in losses],
-                   last_loss_single=float(loss.item()), world=world)
+                   last_loss_single=float(loss.item()), world=world, backend=dist.get_backend(),
+                   bitwise_equal_single=bool(torch.equal(st.flat.cpu(), flat)))
         with open(os.environ['BHNERF_DDP_OUT'], 'w') as f:
             json.dump(out, f)
     dist.barrier()

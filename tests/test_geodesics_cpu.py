@@ -376,3 +376,66 @@ def test_azimuth_and_time_match_quadratures_along_the_analytic_solution(spin, in
     assert rays >= 3
     assert err_phi < 1e-8 and err_t < 1e-9, (err_phi, err_t)          # observed 1.6e-10 rad / 1.2e-10
 
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# f3 pinned to the REFERENCE'S OWN functions (round 3): fixture g12_gr = outputs of /root/reference/bhnerf/kgeo.py:91-593
+# executed unmodified by tests/golden/make_gr.py (named-dimension stand-in for xarray: tests/golden/xr_standin.py) on
+# geodesics of the own tracer, spins 0 (inclination 12 deg) and 0.94 (60 deg), a 7 x 6 image of 32 samples per ray.
+# ---------------------------------------------------------------------------------------------------------------
+GR_FIELDS = ('r', 'theta', 'affine', 'mino', 'R', 'Theta', 'Delta', 'Sigma', 'Xi', 'omega', 'alpha', 'beta', 'lam', 'E', 'M', 'spin', 'inc')
+GR_TOL = 1e-10
+
+
+def _gr_close(got, want, what):
+    got, want = np.asarray(got), np.asarray(want)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    assert np.array_equal(np.isnan(got), np.isnan(want)), (what, 'NaN pattern')
+    fin = np.isfinite(want)
+    assert np.array_equal(np.isfinite(got), fin), (what, 'inf pattern')
+    scale = (np.abs(want[fin]).max() if fin.any() else 0.0) or 1.0          # (spin 0: g_tph is identically zero)
+    err = np.abs(got[fin] - want[fin]).max() / scale if fin.any() else 0.0
+    assert err <= GR_TOL, (what, err)
+
+
+@pytest.mark.parametrize('tag', ['s0', 's94'])
+def test_gr_helpers_match_the_reference_functions(golden, tag):
+    f = golden('g12_gr')
+    ref = lambda k: f['%s_%s' % (tag, k)]
+    mu_last = lambda v: np.moveaxis(v, 0, -1)                  # the reference's concat puts the component index FIRST
+    g = G.Geodesics({k: ref('geo_' + k) for k in GR_FIELDS})
+    with np.errstate(all='ignore'):
+        umu = K.azimuthal_velocity_vector(g, ref('Omega'))                                             # kgeo.py:199-223
+        _gr_close(umu, mu_last(ref('umu')), 'umu')
+        assert np.isnan(umu).any()                                                                    # the super-luminal patch
+        _gr_close(K.doppler_factor(g, umu), ref('g'), 'doppler factor')                               # kgeo.py:225-248
+        _gr_close(K.doppler_factor(g, umu, fillna=False), ref('g_nan'), 'doppler factor, NaNs kept')
+        _gr_close(K.wave_vector(g), ref('k_mu'), 'wave vector')                                       # kgeo.py:92-116
+        gm, gi = K.spacetime_metric(g), K.spacetime_inv_metric(g)                                     # kgeo.py:118-173
+        for c in ('tt', 'rr', 'thth', 'phph', 'tph'):
+            _gr_close(gm[c], ref('g_' + c), 'g_' + c)
+            _gr_close(gi[c], ref('ginv_' + c), 'ginv_' + c)
+        _gr_close(K.raise_or_lower_indices(gm, umu), mu_last(ref('u_lower')), 'lowered velocity')    # kgeo.py:175-197
+        _gr_close(K.fluid_frame_tetrad(g, umu), ref('e_mu'), 'fluid-frame tetrad')                    # kgeo.py:310-345
+        for i, (arad, avert, ator) in enumerate(ref('field')):
+            b = K.magnetic_field_fluid_frame(g, umu, arad, avert, ator)                               # kgeo.py:274-308
+            _gr_close(b, ref('b%d' % i), 'fluid-frame field %d' % i)
+            J = K.parallel_transport(g, umu, ref('g'), b, Q_frac=0.85, V_frac=0)                      # kgeo.py:438-519
+            assert J.shape[0] == 3
+            _gr_close(J, ref('J%d_q85' % i), 'J (I, Q, U) %d' % i)
+            _gr_close(K.parallel_transport(g, umu, ref('g'), b, Q_frac=0.2, V_frac=0.01, spectral_index=1), ref('J%d_v' % i), 'J (I, Q, U, V) %d' % i)
+        beta_v, chi = ref('zamo')
+        _gr_close(K.zamo_frame_velocity(g, beta_v, chi), mu_last(ref('u_zamo')), 'ZAMO velocity')     # kgeo.py:408-436
+        _gr_close(K.zamo_frame_tetrad(g, beta_v, chi), ref('e_zamo'), 'ZAMO tetrad')                  # kgeo.py:347-406
+        _gr_close(K.magnetic_field_spherical(g, 0.2, -0.7, 0.5), ref('b_sph'), 'spherical field')     # kgeo.py:250-272
+        # the ray-LIST form of the dataset (dims (pix, geo), alpha / beta per ray): the form parallel_transport_zamo is
+        # written for (kgeo.py:562 pads a 3-D array), and the one in which no dimension-order question can arise
+        flat = lambda v: v.reshape((-1,) + v.shape[2:]) if np.ndim(v) >= 2 else v
+        gp = G.Geodesics({k: flat(ref('geo_' + k)) for k in GR_FIELDS})
+        up = K.azimuthal_velocity_vector(gp, flat(ref('Omega')))
+        bp = K.magnetic_field_fluid_frame(gp, up, 0.3, 0.5, 0.8)
+        _gr_close(K.parallel_transport(gp, up, flat(ref('g')), bp, Q_frac=0.85, V_frac=0), ref('J1_q85_pix'), 'J, ray-list form')
+        bz = K.magnetic_field_spherical(gp, 0.2, -0.7, 0.5)
+        _gr_close(K.parallel_transport_zamo(gp, beta_v, chi, flat(ref('g')), bz, Q_frac=0.6), ref('J_zamo_pix'), 'J, ZAMO frame')   # kgeo.py:521-593
+    # both forms of the dataset give the same Stokes factors
+    assert np.array_equal(np.nan_to_num(ref('J1_q85').reshape(ref('J1_q85_pix').shape)), np.nan_to_num(ref('J1_q85_pix')))

@@ -9,8 +9,10 @@ Tolerances (error / largest gradient entry, and relative L2), set from what the 
 accumulation, and only 100-500 points per fixture to average the rounding over -- the full-size test holds 2e-2).
 A ReLU-net gradient is discontinuous: where a pre-activation lies within f32 rounding of zero, f32 and f64 may
 disagree on relu' for that (point, unit) and every layer below changes by that one point's contribution.  Such cases
-are DETECTED (conftest.relu_tie_count on the float64 reference forward) and only then the f32 bound falls back to 1e-3;
-none of the committed fixtures has one."""
+are DETECTED (conftest.relu_tie_count on the float64 reference forward) and ADJUDICATED, not waved through: the same
+problem is re-run with every weight nudged by a random relative 1e-6 (then 1e-5 ... 1e-3) until the float64 forward has
+no tie left, and the f32 gradient must then meet the SAME 2e-5 bounds -- otherwise the disagreement was not a tie and the
+test fails (round 3; rounds 1-2 fell back to a 1e-3 bound).  None of the committed fixtures has a tie."""
 import numpy as np
 import pytest
 import torch
@@ -29,7 +31,7 @@ RANDOM_PROBLEM_DOMAIN = (8.0, 2.5, 8.0, 4.0)   # scale, rmin, rmax, z_width of t
 RANDOM_PROBLEM_JITTER = (0.0, 0.0, 0.0)    # offsets of the alpha / beta / sample grids: regular grids of other shapes put samples EXACTLY
                                            # on the domain boundary (e.g. 10 x 7 rays x 64 samples: alpha^2 + beta^2 + s^2 = rmax^2),
                                            # where the f32 kernel and the f64 oracle legitimately disagree about the mask
-TIE_FALLBACK = 1e-3                        # f32 bound when the fixture has a ReLU tie (detected, see the module docstring)
+TIE_NUDGES = (1e-6, 1e-5, 1e-4, 1e-3)      # relative weight nudges tried to move detected ReLU ties off zero (module docstring)
 
 
 def l2err(a, b):
@@ -107,7 +109,8 @@ def test_gradient_vs_oracle_and_reference_fd(dev, golden, tag, dt, mode):
     gmax = np.abs(gref).max()
     assert gmax > 0
     ties = relu_tie_count(g) if mode == 'f32' else 0
-    gtol, l2tol = (TIE_FALLBACK, TIE_FALLBACK) if ties else (GTOL[mode], L2TOL[mode])
+    assert ties == 0                          # the committed fixtures have no pre-activation within f32 rounding of zero
+    gtol, l2tol = GTOL[mode], L2TOL[mode]
     err = np.abs(gdev - gref).max() / gmax
     assert err < gtol, (err, ties)
     assert l2err(gdev, gref) < l2tol, (l2err(gdev, gref), ties)
@@ -205,7 +208,35 @@ def test_random_problem_f32_and_bf16(dev, width, depth, S, deg):
     `NeRF_Predictor.posenc_deg`); hidden widths that are not 32/64/128/256 run zero-padded on the next kernel width
     (the flat parameters and gradients keep the model's width); odd depths (and depth 2) with do_skip feed the
     skip-concat into the OUTPUT layer (network.py:59-62)."""
-    from bhnerf_amd import network, units
+    prob = random_problem(width, depth, S, deg)
+    for mode in ('f32', 'bf16'):
+        ierr, gerr, l2 = random_problem_errors(prob, mode, dev)
+        tol_img = {'f32': 1e-5, 'bf16': 1e-2}[mode]
+        assert ierr < tol_img, (mode, ierr)
+        ties = prob['ties']
+        if mode == 'f32' and ties and not (gerr < GTOL[mode] and l2 < L2TOL[mode]):
+            adjudicate_relu_ties(width, depth, S, deg, dev, gerr, ties)        # raises unless the ties explain it
+            continue
+        assert gerr < GTOL[mode], (mode, gerr, ties)
+        assert l2 < L2TOL[mode], (mode, l2, ties)
+
+
+def adjudicate_relu_ties(width, depth, S, deg, dev, gerr, ties):
+    """A detected ReLU tie is only an explanation if the SAME problem with the ties moved off zero meets the f32 bounds:
+    nudge every weight by a random relative amount (1e-6, then 10x more, until the float64 forward has no tie left) and
+    require 2e-5 of the nudged problem's own float64 gradient.  Anything else is reported as a failure of the original."""
+    for nudge in TIE_NUDGES:
+        prob = random_problem(width, depth, S, deg, nudge=nudge)
+        if prob['ties']:
+            continue
+        ierr, g2, l2 = random_problem_errors(prob, 'f32', dev)
+        assert ierr < 1e-5 and g2 < GTOL['f32'] and l2 < L2TOL['f32'], ('f32', gerr, ties, 'NOT a tie: nudged %g -> %g / %g' % (nudge, g2, l2))
+        print('relu ties adjudicated: %d ties, gradient error %.2e; weights nudged by %g: no tie, error %.2e (L2 %.2e)' % (ties, gerr, nudge, g2, l2))
+        return
+    raise AssertionError(('f32', gerr, ties, 'ties persist under every nudge: cannot adjudicate'))
+
+
+def random_problem(width, depth, S, deg, nudge=0.0):
     rng = np.random.default_rng(width + depth)
     H, Wd, G, B = RANDOM_PROBLEM_SHAPE
     ja, jb, js = RANDOM_PROBLEM_JITTER
@@ -228,10 +259,14 @@ def test_random_problem_f32_and_bf16(dev, width, depth, S, deg):
     geo = {k: f32r(v) for k, v in geo.items()}
     J = f32r(J) if S else None
     tree = onp.he_uniform_params(rng, depth, width, 3 + 6 * deg, dtype=np.float32)
+    nrng = np.random.default_rng(977)
     for i in range(depth + 1):
         d = tree['MLP_0']['Dense_%d' % i]
         d['kernel'] = d['kernel'].astype(np.float64)
         d['bias'] = f32r(rng.uniform(-0.1, 0.1, d['bias'].shape))
+        if nudge:                            # tie adjudication: every weight moved by a random relative amount <= nudge
+            d['kernel'] = f32r(d['kernel'] * (1.0 + nudge * nrng.uniform(-1, 1, d['kernel'].shape)))
+            d['bias'] = f32r(d['bias'] * (1.0 + nudge * nrng.uniform(-1, 1, d['bias'].shape)))
     g = dict(geo, J=(J if S else np.array(1.0)), t_frames=t_frames, t_start_obs=0.0, t_injection=t_inj,
              hparams=np.array(list(RANDOM_PROBLEM_DOMAIN) + [deg, depth, width, 1.0]))
     for i in range(depth + 1):
@@ -242,25 +277,28 @@ def test_random_problem_f32_and_bf16(dev, width, depth, S, deg):
     loss_ref, img_ref, grads_ref = tr.loss_and_grad(t(t_frames), t(target), t(sigma), t(offset), 1.0, 'full')
     n = len(tr.k)
     gref = np.concatenate([np.concatenate([grads_ref[i].numpy().ravel(), grads_ref[n + i].numpy().ravel()]) for i in range(n)])
-    ties = relu_tie_count(g)
-    for mode in ('f32', 'bf16'):
-        pred, rt = device_setup(g, mode, dev)
-        params = pred.engine().flatten(golden_tree(g)).requires_grad_(True)
-        ptree = network.ParamTree(); ptree.flat = params
-        # one Stokes plane: the reference squeezes the unit axis (network.py:418), so its images -- and the targets a caller
-        # pairs them with -- are (B, H, W); the oracle trainer keeps the axis
-        sq = (lambda v: v[:, 0]) if S == 1 else (lambda v: v)
-        loss, [images] = network.loss_fn_image(ptree, pred.apply, sq(target), sq(sigma), sq(offset), t_frames, rt['coords'], rt['Omega'],
-                                               rt['J'], rt['g'], rt['dtau'], rt['Sigma'], 0.0, rt['t_geos'], t_inj, 1.0,
-                                               units.hr, 'full')
-        loss.backward()
-        tol_img = {'f32': 1e-5, 'bf16': 1e-2}[mode]
-        ierr = np.abs(images.detach().cpu().numpy().reshape(img_ref.shape) - img_ref.numpy()).max() / img_ref.abs().max().item()
-        assert ierr < tol_img, (mode, ierr)
-        gtol, l2tol = (TIE_FALLBACK, TIE_FALLBACK) if (ties and mode == 'f32') else (GTOL[mode], L2TOL[mode])
-        gerr = np.abs(params.grad.cpu().numpy() - gref).max() / np.abs(gref).max()
-        assert gerr < gtol, (mode, gerr, ties)
-        assert l2err(params.grad.cpu().numpy(), gref) < l2tol, (mode, l2err(params.grad.cpu().numpy(), gref), ties)
+    return dict(g=g, S=S, t_frames=t_frames, t_inj=t_inj, target=target, sigma=sigma, offset=offset, img_ref=img_ref, gref=gref,
+                ties=relu_tie_count(g))
+
+
+def random_problem_errors(prob, mode, dev):
+    """(image error / image maximum, gradient max error / largest entry, gradient relative L2) of the HIP path against the
+    float64 oracle on a random_problem()."""
+    from bhnerf_amd import network, units
+    g, S, img_ref, gref = prob['g'], prob['S'], prob['img_ref'], prob['gref']
+    pred, rt = device_setup(g, mode, dev)
+    params = pred.engine().flatten(golden_tree(g)).requires_grad_(True)
+    ptree = network.ParamTree(); ptree.flat = params
+    # one Stokes plane: the reference squeezes the unit axis (network.py:418), so its images -- and the targets a caller
+    # pairs them with -- are (B, H, W); the oracle trainer keeps the axis
+    sq = (lambda v: v[:, 0]) if S == 1 else (lambda v: v)
+    loss, [images] = network.loss_fn_image(ptree, pred.apply, sq(prob['target']), sq(prob['sigma']), sq(prob['offset']), prob['t_frames'],
+                                           rt['coords'], rt['Omega'], rt['J'], rt['g'], rt['dtau'], rt['Sigma'], 0.0, rt['t_geos'],
+                                           prob['t_inj'], 1.0, units.hr, 'full')
+    loss.backward()
+    ierr = np.abs(images.detach().cpu().numpy().reshape(img_ref.shape) - img_ref.numpy()).max() / img_ref.abs().max().item()
+    gdev = params.grad.cpu().numpy()
+    return ierr, np.abs(gdev - gref).max() / np.abs(gref).max(), l2err(gdev, gref)
 
 
 @pytest.mark.parametrize('mode', ['f32', 'bf16'])

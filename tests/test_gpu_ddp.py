@@ -43,6 +43,40 @@ def test_two_ranks_equal_single_process_mean_of_sums(tmp_path, overlap):
     assert r['moved'] > 0 and r['frac_off'] < 2e-3 and r['max_diff'] <= 2.5 * r['moved'], r
 
 
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize('overlap', ['0', '1'])
+def test_rccl_process_group_of_one_rank(tmp_path, overlap):
+    """The shipped multi-GPU design is one process per GPU over RCCL (backend 'nccl'); a 1-GPU box can run it at world
+    size 1: init_process_group('nccl', device_id=...), the flat all-reduce on the device (synchronous, and the async work
+    handle + stream wait of overlap_allreduce), then Adam -- bitwise equal to the step without a process group."""
+    out = tmp_path / 'ddp.json'
+    env = dict(os.environ, BHNERF_DDP_OUT=str(out), HSA_ENABLE_IPC_MODE_LEGACY='0', BHNERF_BATCH_SEED='7', BHNERF_DDP_OVERLAP=overlap,
+               BHNERF_DDP_BACKEND='nccl')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'tests', 'ddp_worker.py')]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=540)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    r = json.load(open(out))
+    assert r['world'] == 1 and r['backend'] == 'nccl' and r['identical'], r
+    assert len(r['loss_vector']) == 1 and r['moved'] > 0
+    assert r['bitwise_equal_single'] and r['max_diff'] == 0.0, r
+
+
+@pytest.mark.timeout(600)
+def test_bench_forced_process_group_runs_rccl_on_one_gpu():
+    """bench.py --gpus 1 with BHNERF_BENCH_FORCE_DIST=1 goes through init_process_group('nccl') + the flat all-reduce."""
+    env = dict(os.environ, BHNERF_BENCH_FORCE_DIST='1')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1', '--image', '32',
+           '--ngeo', '32', '--frames', '8', '--frames-per-gpu', '2', '--width', '64', '--no-cpu-baseline', '--no-parity-mode',
+           '--no-tutorial-domain']
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=540)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    r = json.loads([l for l in res.stdout.splitlines() if l.startswith('{"metric"')][-1])
+    assert r['n_gpus'] == 1 and 'nccl' in r['config']['parallelism'] and r['value'] > 0
+
+
 @pytest.mark.timeout(900)
 def test_bench_gpus_flag_spawns_the_ranks():
     env = dict(os.environ, BHNERF_BENCH_ONE_DEVICE='1')

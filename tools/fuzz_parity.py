@@ -2,7 +2,9 @@
 images and gradients of both arithmetic modes against the float64 oracle on a ragged problem -- for N random
 (width 1..256, depth 2..8, Stokes planes 0..3, posenc degree 0..4) combinations.  The bf16
 bounds of the test are statistical on this tiny problem (3 x 63 rays): a few per cent of the draws exceed them by
-less than a factor of two; anything beyond that, and any f32 failure, is reported as HARD.
+less than a factor of two; anything beyond that, and any f32 failure, is reported as HARD (exit code 1).  f32 draws with
+detected ReLU ties are adjudicated by the test itself (tests/test_gpu_backward.py::adjudicate_relu_ties) and print a
+"relu ties adjudicated" line.
     python tools/fuzz_parity.py [N] [seed]"""
 import os, sys, traceback
 import numpy as np, torch
@@ -32,9 +34,9 @@ for i in range(N):
         hard = True
         try:
             mode, err = e.args[0][0], float(e.args[0][1])
-            ties = e.args[0][2] if len(e.args[0]) > 2 else 0
-            # f32 with detected ReLU ties (pre-activations within rounding of 0): the documented fallback bound, a few 1e-3
-            hard = (mode == 'f32' and not (ties and err < 5e-3)) or (mode == 'bf16' and err > 2 * T.GTOL['bf16'])
+            # every f32 failure is HARD: detected ReLU ties are adjudicated inside the test (weights nudged until the float64
+            # forward has no tie; the f32 gradient must then meet 2e-5) and only un-explained ones get here
+            hard = mode == 'f32' or (mode == 'bf16' and err > 2 * T.GTOL['bf16'])
         except Exception:                                    # noqa: BLE001
             pass
         soft += not hard

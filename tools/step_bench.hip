@@ -184,7 +184,157 @@ void run(const char *name, bool random_weights) {
     hipFree(d); hipFree(img);
 }
 
-int main() {
+
+// ---- the same ring step on v_mfma_f32_16x16x32_bf16 (round 3 experiment; MI355X_MICROARCH.md DVFS give-back item 7) ----
+// Fragment t of a chunk = (32-feature k-block t>>1, 16-row block t&1); it feeds the two 16-point column blocks, whose B
+// fragments are src[2(t>>1)] and src[2(t>>1)+1]; accumulator registers [4M, 4M+4) / [8+4M, 8+4M+4) = (row block M, column
+// block 0 / 1), so registers 8b..8b+7 of the finished tile are the B fragment of column block b for the next layer --
+// the pack code is unchanged.  Timing only (the weight image is random, results are not checked).
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+DEVI f32x16 mma16_pair(const bf16x8 &a, const bf16x8 &b0, const bf16x8 &b1, f32x16 acc, int M) {
+    f32x4v c0, c1;
+    if (M == 0) { c0 = __builtin_shufflevector(acc, acc, 0, 1, 2, 3); c1 = __builtin_shufflevector(acc, acc, 8, 9, 10, 11); }
+    else { c0 = __builtin_shufflevector(acc, acc, 4, 5, 6, 7); c1 = __builtin_shufflevector(acc, acc, 12, 13, 14, 15); }
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b0, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b1, c1, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { acc[4 * M + i] = c0[i]; acc[8 + 4 * M + i] = c1[i]; }
+    return acc;
+}
+
+template <int W, class Pol, class RG, class Post>
+DEVI f32x16 ring_step16(const char *ch, const char *chn, APipe<Pol> &ap, const typename Pol::frag (&src)[W / 16],
+                        const typename Pol::frag (&enc)[2], bool with_enc, const float *bias_next, Post &post, DmaJob dma) {
+    const int lane = threadIdx.x & 63;
+    constexpr int KS = W / 16, NF = KS + 2, PF = Pol::LDS_PREFETCH;
+    typename Pol::frag a[PF];
+#pragma unroll
+    for (int i = 0; i < PF - 1; ++i) a[i] = ap.f[i];
+    f32x16 acc = ap.bias;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < KS; ++t) {
+        a[(t + PF - 1) % PF] = stream_frag<Pol, NF>(ch, chn, t + PF - 1, lane);
+        acc = mma16_pair(a[t % PF], src[2 * (t >> 1)], src[2 * (t >> 1) + 1], acc, t & 1);
+        post.at(t);
+        if (t == 9 && dma.on) RG::issue(dma);
+        if (t == 13) ap.bias = bias_acc(bias_next, 0, lane >> 5);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int t = KS; t < NF; ++t) {
+        a[(t + PF - 1) % PF] = stream_frag<Pol, NF>(ch, chn, t + PF - 1, lane);
+        if (with_enc) acc = mma16_pair(a[t % PF], enc[0], enc[1], acc, t & 1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int i = 0; i < PF - 1; ++i) ap.f[i] = a[(NF + i) % PF];
+    return acc;
+}
+
+template <int W, class Pol, class RG, class RS>
+DEVI void hidden_layer16(RS &rs, APipe<Pol> &ap, typename Pol::frag (&src)[W / 16], typename Pol::frag (&dst)[W / 16],
+                         const typename Pol::frag (&enc)[2], bool sk, const float *bl, f32x16 &pend) {
+    constexpr int KS = W / 16, MT = W / 32;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const char *ch = rs.ch(), *chn = rs.chn();
+        const DmaJob dj = rs.job();
+        PackPost<Pol> post(pend, m == 0 ? src[KS - 2] : dst[2 * (m > 0 ? m - 1 : 0)], m == 0 ? src[KS - 1] : dst[2 * (m > 0 ? m - 1 : 0) + 1]);
+        const f32x16 acc = ring_step16<W, Pol, RG>(ch, chn, ap, src, enc, sk, bl + 32 * (m + 1), post, dj);
+        rs.step_end();
+        pend = acc;
+    }
+}
+
+// MODE bits: 1 pending-tile pack, 2 weight DMA, 8 skip block (18 fragments per step)
+template <int MODE, int SHAPE>
+__global__ __launch_bounds__(512) void k2(const char *img, const bf16x8 *bsrc, float *out, unsigned long long *clk, int steps) {
+    using Pol = PolBF16;
+    constexpr int W = 256, KS = 16, CB = 18 * 1024, DIST = 4;
+    using RG = DmaRing<CB, 8>;
+    using RS = RingState<RG, CB, DIST, false>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *bias_lds = reinterpret_cast<float *>(smem + RS::NB * CB);
+    for (int i = threadIdx.x; i < 5 * W; i += 512) bias_lds[i] = 0.001f * i;
+    RS rs;
+    rs.start(smem, img, 26, nullptr, 0, (MODE & 2) ? 0 : 4, 0);
+    APipe<Pol> ap;
+    ap.prime(rs.ch(), bias_lds);
+    Pol::frag act[KS], next[KS], enc[2];
+    for (int i = 0; i < KS; ++i) { act[i] = bsrc[(size_t)(blockIdx.x * 512 + threadIdx.x) * 18 + i]; next[i] = act[i]; }
+    enc[0] = bsrc[(size_t)(blockIdx.x * 512 + threadIdx.x) * 18 + 16]; enc[1] = bsrc[(size_t)(blockIdx.x * 512 + threadIdx.x) * 18 + 17];
+    f32x16 pend = {};
+    unsigned long long t0 = 0, r0 = 0;
+    for (int it = -32; it < steps; it += 16) {
+        if (it == 0) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+        if constexpr (SHAPE == 16) {
+            hidden_layer16<W, Pol, RG>(rs, ap, act, next, enc, (MODE & 8) != 0, bias_lds + W, pend);
+            hidden_layer16<W, Pol, RG>(rs, ap, next, act, enc, (MODE & 8) != 0, bias_lds + 2 * W, pend);
+        } else {
+            hidden_layer<W, Pol, RG>(rs, ap, act, next, enc, (MODE & 8) != 0, bias_lds + W, pend);
+            hidden_layer<W, Pol, RG>(rs, ap, next, act, enc, (MODE & 8) != 0, bias_lds + 2 * W, pend);
+        }
+        if (!(MODE & 1)) {      // without the pack the activations would be dead: keep them random
+            for (int i = 0; i < KS; ++i) asm volatile("" : "+v"(act[i]), "+v"(next[i]));
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; }
+    rs.idle_step();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float s = 0;
+    for (int j = 0; j < 16; ++j) s += pend[j];
+    for (int i = 0; i < KS; ++i) s += (float)act[i][0] + (float)next[i][3];
+    if (s == 12345.678f) out[threadIdx.x] = s;
+}
+
+#include <algorithm>
+#include <vector>
+template <int MODE, int SHAPE>
+void run2(const char *name) {
+    const int steps = 16 * 4000, grid = 256;
+    std::vector<unsigned short> hi(26 * 9 * 1024), hb((size_t)grid * 512 * 18 * 8);
+    unsigned x = 12345u;
+    auto rnd = [&](float amp) { x = x * 1664525u + 1013904223u; const float f = ((x >> 8) * (1.0f / 16777216.0f) - 0.5f) * 2.f * amp; unsigned u; memcpy(&u, &f, 4); return (unsigned short)(u >> 16); };
+    for (auto &v : hi) v = rnd(0.108f);          // he-uniform limit of a 256-input layer: sqrt(6/256) = 0.153 (std 0.088); kept a little lower
+    for (auto &v : hb) v = rnd(1.0f);
+    char *img; bf16x8 *bs; float *d; unsigned long long *clk;
+    hipMalloc(&img, hi.size() * 2); hipMemcpy(img, hi.data(), hi.size() * 2, hipMemcpyHostToDevice);
+    hipMalloc(&bs, hb.size() * 2); hipMemcpy(bs, hb.data(), hb.size() * 2, hipMemcpyHostToDevice);
+    hipMalloc(&d, 4096); hipMalloc(&clk, grid * 16);
+    const size_t lds = 6 * 18 * 1024 + 5 * 256 * 4;
+    hipFuncSetAttribute((const void *)k2<MODE, SHAPE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    k2<MODE, SHAPE><<<grid, 512, lds>>>(img, bs, d, clk, 64);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    k2<MODE, SHAPE><<<grid, 512, lds>>>(img, bs, d, clk, steps);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    std::vector<unsigned long long> hc(grid * 2);
+    hipMemcpy(hc.data(), clk, grid * 16, hipMemcpyDeviceToHost);
+    std::vector<double> ghz(grid), cyc(grid);
+    for (int i = 0; i < grid; ++i) { ghz[i] = (double)hc[2 * i] / (double)hc[2 * i + 1] * 0.1; cyc[i] = (double)hc[2 * i] / steps; }
+    std::sort(ghz.begin(), ghz.end()); std::sort(cyc.begin(), cyc.end());
+    const int nf = (MODE & 8) ? 18 : 16;
+    const double flops = (double)grid * 8 * (double)(steps + 32) * nf * 32768.0;
+    printf("ring_step shape %2d %-28s %8.2f ms  %6.0f TFLOP/s  clock %.3f GHz  %.0f cycles/step\n", SHAPE, name, ms, flops / ms * 1e-9, ghz[grid / 2], cyc[grid / 2]);
+    hipFree(img); hipFree(bs); hipFree(d); hipFree(clk);
+}
+
+int main(int argc, char **argv) {
+    if (argc > 1) {      // round 3: MFMA shape A/B on the library's ring step, random weights AND random activations
+        for (int r = 0; r < 3; ++r) {
+            run2<3, 32>("pack + DMA"); run2<3, 16>("pack + DMA");
+            run2<11, 32>("pack + DMA + skip block"); run2<11, 16>("pack + DMA + skip block");
+            run2<2, 32>("DMA only"); run2<2, 16>("DMA only");
+        }
+        return 0;
+    }
     for (int r = 0; r < 2; ++r) {
         run<0>("steps only (reads, MFMAs, barrier)", r);
         run<1>("+ pack", r);
