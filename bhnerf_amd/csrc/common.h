@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <mutex>
 #include <stdio.h>
 #include <string.h>
@@ -68,20 +69,29 @@ int bhn_mlp_shape(const bhn_model *m, MlpShape *s);   // validates, returns BHN_
 // (bhn_pack_weights): the same product with the factor W_out[k] moved from the B operand to the A operand.
 __host__ __device__ static inline bool bhn_folds_wout(int mode, int depth) { return mode == BHN_BF16 && depth >= 3; }
 
-// Number of compute units of a device (cached).
+// Number of compute units of a device (cached); 0 for a device id outside [0, BHN_MAX_DEVICES) -- callers turn that into
+// BHN_EINVAL (BHN_CHECK_DEVICE), the same answer DeviceOnce::run gives for such an id.
 int bhn_num_cus(int device);
 
 // Per-device one-time setup of a kernel (hipFuncSetAttribute applies to the device that is current when it is
 // called; a process may drive several devices, from several threads): run `f` once per device, remember its result.
+// Only SUCCESS is remembered: a transient failure (e.g. an earlier sticky asynchronous error on that device) is returned
+// to the caller and the set-up is tried again by the next call, under the mutex.
 #define BHN_MAX_DEVICES 64
+#define BHN_CHECK_DEVICE(dev) BHN_CHECK_ARG((dev) >= 0 && (dev) < BHN_MAX_DEVICES, "device %d outside [0, %d)", (int)(dev), BHN_MAX_DEVICES)
 struct DeviceOnce {
-    std::once_flag flag[BHN_MAX_DEVICES];
-    hipError_t rc[BHN_MAX_DEVICES];
+    std::mutex mu;
+    std::atomic<bool> done[BHN_MAX_DEVICES];
     int value[BHN_MAX_DEVICES];
+    DeviceOnce() { for (auto &d : done) d.store(false, std::memory_order_relaxed); }
     template <class F>
     hipError_t run(int dev, F &&f) {
         if (dev < 0 || dev >= BHN_MAX_DEVICES) return hipErrorInvalidDevice;
-        std::call_once(flag[dev], [&] { rc[dev] = f(value[dev]); });
-        return rc[dev];
+        if (done[dev].load(std::memory_order_acquire)) return hipSuccess;
+        std::lock_guard<std::mutex> lock(mu);
+        if (done[dev].load(std::memory_order_relaxed)) return hipSuccess;
+        const hipError_t rc = f(value[dev]);
+        if (rc == hipSuccess) done[dev].store(true, std::memory_order_release);
+        return rc;
     }
 };

@@ -734,11 +734,11 @@ struct TapeStream {
     template <int POLICY>
     static DEVI void dma(const u32x4 &rs, unsigned soff, unsigned m, unsigned voff) {
         if constexpr (POLICY == 1)
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen nt lds" ::"s"(m), "v"(voff), "s"(rs), "s"(soff) : "memory");
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen nt lds" ::"s"(m), "v"(voff), "s"(rs), "s"(soff) : "memory", "m0");
         else if constexpr (POLICY == 2)
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen sc1 lds" ::"s"(m), "v"(voff), "s"(rs), "s"(soff) : "memory");
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen sc1 lds" ::"s"(m), "v"(voff), "s"(rs), "s"(soff) : "memory", "m0");
         else
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(m), "v"(voff), "s"(rs), "s"(soff) : "memory");
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(m), "v"(voff), "s"(rs), "s"(soff) : "memory", "m0");
     }
     template <int POLICY, int I>
     DEVI void row(long long q, unsigned lb, u32x4 (&rs)[4]) const {
@@ -1634,6 +1634,7 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
                    int device, void *const *events = nullptr, int n_events = 0) {
     using BG = BwdGeom<W, Pol>;
     using PK = Pack<W, Pol>;
+    BHN_CHECK_DEVICE(device);
     const int ncu = bhn_num_cus(device);
 #ifdef BHN_DEBUG
     static const int grid_override = dbg_env_int("BHN_DEBUG_DW_GRID", 0);

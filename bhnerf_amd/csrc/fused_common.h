@@ -599,7 +599,8 @@ DEVI void dma_1k(const char *src, char *dst) {
 // it knows to be in flight -- s_waitcnt vmcnt(0) in front of the first read of each group, i.e. no prefetch at all
 // (measured: dW kernel 5.3 -> 7.5 ms).  Issued from inline asm the DMA is invisible to that pass; its completion is
 // ordered by the kernel's own counted vmcnt waits + barrier, exactly as for the builtin form.  M0 = LDS byte address
-// of the wave's first lane (the compiler never keeps M0 live: it is not an allocatable register).
+// of the wave's first lane; M0 is declared clobbered (the builtin LDS-DMA form and movrel / gpr_idx indexing use M0 too:
+// without the clobber LLVM may hoist or merge its own M0 initialisations across this statement).
 template <int POLICY = 0>      // 0 default, 1 nt (bytes one CU reads once from HBM), 2 sc1 (bytes another CU has just written)
 DEVI void dma_1k_asm(const char *src, char *dst) {
     const unsigned long long u = reinterpret_cast<unsigned long long>(src);
@@ -610,11 +611,11 @@ DEVI void dma_1k_asm(const char *src, char *dst) {
     const unsigned m = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<unsigned long long>(dst));
     const unsigned voff = (threadIdx.x & 63) * 16;
     if constexpr (POLICY == 1)
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen nt lds" ::"s"(m), "v"(voff), "s"(rs) : "memory");
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen nt lds" ::"s"(m), "v"(voff), "s"(rs) : "memory", "m0");
     else if constexpr (POLICY == 2)
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen sc1 lds" ::"s"(m), "v"(voff), "s"(rs) : "memory");
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen sc1 lds" ::"s"(m), "v"(voff), "s"(rs) : "memory", "m0");
     else
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(m), "v"(voff), "s"(rs) : "memory");
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(m), "v"(voff), "s"(rs) : "memory", "m0");
 }
 
 template <int CHUNK_BYTES, int NWAVES>

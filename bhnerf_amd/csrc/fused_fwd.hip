@@ -449,6 +449,7 @@ static int launch_fwd_wide(FusedArgs &a, hipStream_t st) {
     auto kern = fused_fwd_wide_kernel<W, Pol, 3, RENDER>;
     int dev = 0;
     BHN_HIP(hipGetDevice(&dev));
+    BHN_CHECK_DEVICE(dev);
     static DeviceOnce once;
     BHN_HIP(once.run(dev, [&](int &occ) {
         occ = 1;
@@ -473,6 +474,7 @@ static int launch_fwd_w(FusedArgs &a, hipStream_t st) {
     auto kern = fused_fwd_kernel<W, Pol, 3, RENDER, DBG>;
     int dev = 0;
     BHN_HIP(hipGetDevice(&dev));
+    BHN_CHECK_DEVICE(dev);
     static DeviceOnce once;                 // per template instantiation and device: LDS attribute + occupancy
     BHN_HIP(once.run(dev, [&](int &occ) {
         occ = 1;

@@ -22,7 +22,7 @@ extern "C" const char *bhn_last_error(void) { return g_err; }
 
 int bhn_num_cus(int device) {
     static DeviceOnce once;
-    if (device < 0 || device >= BHN_MAX_DEVICES) return 256;
+    if (device < 0 || device >= BHN_MAX_DEVICES) return 0;        // callers: BHN_CHECK_DEVICE
     (void)once.run(device, [&](int &n) {
         n = 0;
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || n <= 0) n = 256;
@@ -359,7 +359,7 @@ extern "C" int bhn_adam_step(float *params, const float *grads, float *m, float 
 // the R axis is split until the grid has >= ~2048 blocks; stage 2 (eht_loss_kernel) adds the RS partial sums of a row in
 // a fixed order -- no atomics, bitwise reproducible.  16-byte loads (two complex64 per lane).
 __global__ __launch_bounds__(256) void eht_vis_kernel(const float *__restrict__ images, const float2 *__restrict__ A,
-                                                      int C, int nvis, int64_t R, int RS, float2 *__restrict__ part) {
+                                                      int C, int nvis, int64_t R, int RS, float2 *__restrict__ part, int wide) {
     __shared__ float red[4];
     const int64_t row = blockIdx.x;                         // (n, c, k)
     const int64_t n = row / ((int64_t)C * nvis);
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256) void eht_vis_kernel(const float *__restrict__ 
     const float2 *a = A + row * R;
     const float *img = images + n * R;
     float re = 0.f, im = 0.f;
-    if ((R & 1) == 0) {
+    if (wide) {                // R even AND A 16-byte / images 8-byte aligned (bhn_chi2_eht checks the caller's pointers)
         for (int64_t r = r0 + 2 * threadIdx.x; r < r1; r += 512) {      // r0, r1, R even: (r, r + 1) is a whole pair
             const float4 v = *reinterpret_cast<const float4 *>(a + r);       // (re0, im0, re1, im1)
             const float2 x = *reinterpret_cast<const float2 *>(img + r);
@@ -486,8 +486,11 @@ extern "C" int bhn_chi2_eht(const float *images, const float *A, const float *ta
     float2 *vis = reinterpret_cast<float2 *>(vis_ws), *part = vis + rows;
     float *loss_part = vis_ws + 2 * rows * (1 + RS);
     const unsigned nblk = (unsigned)((tot + 255) / 256);
+    // 16-byte loads of A and 8-byte loads of the images only when the caller's buffers allow them (a C caller may hand over
+    // a 4- or 8-byte-aligned sub-view; torch allocations and row offsets are aligned): otherwise the scalar path
+    const int wide = (R % 2 == 0) && (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(images) & 7) == 0;
     hipLaunchKernelGGL(eht_vis_kernel, dim3((unsigned)rows, (unsigned)RS), dim3(256), 0, st, images,
-                       reinterpret_cast<const float2 *>(A), C, nvis, R, RS, part);
+                       reinterpret_cast<const float2 *>(A), C, nvis, R, RS, part, wide);
     BHN_HIP(hipGetLastError());
     hipLaunchKernelGGL(eht_loss_kernel, dim3(nblk), dim3(256), 0, st, vis, part, RS, target, sigma, scale, dtype, (int64_t)N,
                        C, nvis, loss_part, dimages ? 1 : 0);

@@ -50,12 +50,13 @@ def mask_tie_points(g, t_frames=None):
     return static[None] | dyn
 
 
-def relu_tie_count(g, rel=64 * F32_EPS):
+def relu_tie_count(g, rel=64 * F32_EPS, return_points=False):
     """Number of (frame, point, hidden unit) pre-activations of the float64 reference forward that lie within f32
     rounding of zero: |a| <= 64 eps_f32 (|x| @ |W| + |b|) -- the error band of a 32..288-term f32 dot product whose inputs
     carry the rounding of the layers before (4 ulp of the RESULT would ignore the cancellation that makes it small).
     There f32 and f64 may disagree on relu' and the parameter gradient, which is discontinuous at that point, changes by
-    that one point's contribution."""
+    that one point's contribution.  return_points: also the boolean (*spatial, G) array of the ray samples that have such
+    a pre-activation in any frame (the tests adjudicate a tie by taking exactly these samples out of the problem)."""
     from oracle import oracle_np as onp
     hp = g['hparams']
     tree = golden_tree(g)['MLP_0']
@@ -65,13 +66,16 @@ def relu_tie_count(g, rel=64 * F32_EPS):
     valid = np.isfinite(warped)
     x0 = onp.posenc(np.where(valid, warped, 0.0) / hp[0], int(hp[4]))
     x, ties = x0, 0
+    points = np.zeros(valid.shape[:-1], dtype=bool)
     skip_layer = depth // 2
     for i in range(depth):
         k, b = tree['Dense_%d' % i]['kernel'].astype(np.float64), tree['Dense_%d' % i]['bias'].astype(np.float64)
         a = x @ k + b
         mag = np.abs(x) @ np.abs(k) + np.abs(b)
-        ties += int((np.abs(a) <= rel * mag)[valid[..., 0]].sum())
+        near = (np.abs(a) <= rel * mag) & valid[..., :1]
+        ties += int(near.sum())
+        points |= near.any(axis=-1)
         x = np.maximum(a, 0.0)
         if i % skip_layer == 0 and i > 0:
             x = np.concatenate([x, x0], axis=-1)
-    return ties
+    return (ties, points.any(axis=0)) if return_points else ties

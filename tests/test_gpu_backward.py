@@ -9,10 +9,14 @@ Tolerances (error / largest gradient entry, and relative L2), set from what the 
 accumulation, and only 100-500 points per fixture to average the rounding over -- the full-size test holds 2e-2).
 A ReLU-net gradient is discontinuous: where a pre-activation lies within f32 rounding of zero, f32 and f64 may
 disagree on relu' for that (point, unit) and every layer below changes by that one point's contribution.  Such cases
-are DETECTED (conftest.relu_tie_count on the float64 reference forward) and ADJUDICATED, not waved through: the same
-problem is re-run with every weight nudged by a random relative 1e-6 (then 1e-5 ... 1e-3) until the float64 forward has
-no tie left, and the f32 gradient must then meet the SAME 2e-5 bounds -- otherwise the disagreement was not a tie and the
-test fails (round 3; rounds 1-2 fell back to a 1e-3 bound).  None of the committed fixtures has a tie."""
+are DETECTED (conftest.relu_tie_count on the float64 reference forward) and ADJUDICATED, not waved through (round 3;
+rounds 1-2 fell back to a 1e-3 bound): the gradient is a sum over ray samples, so the same problem is re-run with exactly
+the samples that have a tie taken out (their Doppler weight g set to 0 on both sides: they no longer reach the image) and
+the f32 gradient must then meet the SAME 2e-5 bounds -- otherwise the disagreement was not a tie and the test fails.  Where
+the ties are few, nudging every weight by a random relative 1e-6 ... 1e-3 until none is left does the same (fixtures:
+their finite-difference reference is tied to the weights, so only the oracle comparison is repeated).  A random problem
+with 14 M pre-activations has ~10^2 of them inside the detection band at ANY weights, which is why the ray samples, not
+the weights, are what the random-problem test moves."""
 import numpy as np
 import pytest
 import torch
@@ -108,10 +112,32 @@ def test_gradient_vs_oracle_and_reference_fd(dev, golden, tag, dt, mode):
     assert abs(loss.item() - loss_ref.item()) <= LOSSTOL[mode] * abs(loss_ref.item())
     gmax = np.abs(gref).max()
     assert gmax > 0
-    ties = relu_tie_count(g) if mode == 'f32' else 0
-    assert ties == 0                          # the committed fixtures have no pre-activation within f32 rounding of zero
+    ties = relu_tie_count(g) if mode == 'f32' else 0          # (fixture b has one pre-activation inside the f32 rounding band)
     gtol, l2tol = GTOL[mode], L2TOL[mode]
     err = np.abs(gdev - gref).max() / gmax
+    if mode == 'f32' and ties and not (err < gtol and l2err(gdev, gref) < l2tol):
+        # a detected tie only excuses the original if the same fixture with its weights nudged off the tie meets the bounds
+        for nudge in TIE_NUDGES:
+            nrng = np.random.default_rng(977)
+            g2 = dict(g)
+            for i in range(int(g['hparams'][5]) + 1):
+                for k in ('kernel%d' % i, 'bias%d' % i):
+                    g2[k] = (g[k] * (1.0 + nudge * nrng.uniform(-1, 1, g[k].shape))).astype(np.float32).astype(np.float64)
+            if relu_tie_count(g2):
+                continue
+            tr2, _ = oracle_trainer(g2)
+            _, _, gr2 = tr2.loss_and_grad(t(g['t_frames']), t(tg['target']), t(tg['sigma']), t(tg['offset']), scale, dt)
+            gref2 = np.concatenate([np.concatenate([gr2[i].numpy().ravel(), gr2[n + i].numpy().ravel()]) for i in range(n)])
+            p2 = pred.engine().flatten(golden_tree(g2)).requires_grad_(True)
+            tree2 = network.ParamTree(); tree2.flat = p2
+            loss2, _ = network.loss_fn_image(tree2, pred.apply, tg['target'], tg['sigma'], tg['offset'], g['t_frames'], rt['coords'], rt['Omega'],
+                                             rt['J'], rt['g'], rt['dtau'], rt['Sigma'], rt['t_start_obs'], rt['t_geos'], rt['t_injection'], scale, units.hr, dt)
+            loss2.backward()
+            gd2 = p2.grad.cpu().numpy().astype(np.float64)
+            e2 = np.abs(gd2 - gref2).max() / np.abs(gref2).max()
+            assert e2 < gtol and l2err(gd2, gref2) < l2tol, ('f32', err, ties, 'NOT a tie: nudged %g -> %g' % (nudge, e2))
+            return
+        raise AssertionError(('f32', err, ties, 'ties persist under every nudge'))
     assert err < gtol, (err, ties)
     assert l2err(gdev, gref) < l2tol, (l2err(gdev, gref), ties)
     if dt == 'full':      # finite differences of the reference's own loss_fn_image (float64)
@@ -222,21 +248,18 @@ def test_random_problem_f32_and_bf16(dev, width, depth, S, deg):
 
 
 def adjudicate_relu_ties(width, depth, S, deg, dev, gerr, ties):
-    """A detected ReLU tie is only an explanation if the SAME problem with the ties moved off zero meets the f32 bounds:
-    nudge every weight by a random relative amount (1e-6, then 10x more, until the float64 forward has no tie left) and
-    require 2e-5 of the nudged problem's own float64 gradient.  Anything else is reported as a failure of the original."""
-    for nudge in TIE_NUDGES:
-        prob = random_problem(width, depth, S, deg, nudge=nudge)
-        if prob['ties']:
-            continue
-        ierr, g2, l2 = random_problem_errors(prob, 'f32', dev)
-        assert ierr < 1e-5 and g2 < GTOL['f32'] and l2 < L2TOL['f32'], ('f32', gerr, ties, 'NOT a tie: nudged %g -> %g / %g' % (nudge, g2, l2))
-        print('relu ties adjudicated: %d ties, gradient error %.2e; weights nudged by %g: no tie, error %.2e (L2 %.2e)' % (ties, gerr, nudge, g2, l2))
-        return
-    raise AssertionError(('f32', gerr, ties, 'ties persist under every nudge: cannot adjudicate'))
+    """A detected ReLU tie is only an explanation if the SAME problem without the tied ray samples meets the f32 bounds:
+    those samples get Doppler weight g = 0 on both sides (no contribution to the image, hence none to the gradient), every
+    other sample keeps its inputs and its forward values.  Anything else is reported as a failure of the original."""
+    prob = random_problem(width, depth, S, deg, drop_ties=True)
+    assert prob['ties_left'] == 0 and 0 < prob['dropped'] <= ties
+    ierr, g2, l2 = random_problem_errors(prob, 'f32', dev)
+    assert ierr < 1e-5 and g2 < GTOL['f32'] and l2 < L2TOL['f32'], ('f32', gerr, ties, 'NOT a tie: without the %d tied samples %g / %g' % (prob['dropped'], g2, l2))
+    print('relu ties adjudicated: %d ties on %d ray samples, gradient error %.2e; without those samples: error %.2e (L2 %.2e)'
+          % (ties, prob['dropped'], gerr, g2, l2))
 
 
-def random_problem(width, depth, S, deg, nudge=0.0):
+def random_problem(width, depth, S, deg, nudge=0.0, drop_ties=False):
     rng = np.random.default_rng(width + depth)
     H, Wd, G, B = RANDOM_PROBLEM_SHAPE
     ja, jb, js = RANDOM_PROBLEM_JITTER
@@ -271,6 +294,11 @@ def random_problem(width, depth, S, deg, nudge=0.0):
              hparams=np.array(list(RANDOM_PROBLEM_DOMAIN) + [deg, depth, width, 1.0]))
     for i in range(depth + 1):
         g['kernel%d' % i] = tree['MLP_0']['Dense_%d' % i]['kernel']; g['bias%d' % i] = tree['MLP_0']['Dense_%d' % i]['bias']
+    ties, tied = relu_tie_count(g, return_points=True)
+    dropped = 0
+    if drop_ties:                            # tie adjudication: the tied ray samples no longer reach the image
+        g['g'] = np.where(tied, 0.0, g['g'])
+        dropped = int(tied.sum())
     tr, t = oracle_trainer(g)
     shape = (B, S, H, Wd) if S else (B, H, Wd)
     target = rng.uniform(0, 1e-3, shape); sigma = rng.uniform(0.5, 2.0, shape); offset = np.zeros(shape)
@@ -278,7 +306,7 @@ def random_problem(width, depth, S, deg, nudge=0.0):
     n = len(tr.k)
     gref = np.concatenate([np.concatenate([grads_ref[i].numpy().ravel(), grads_ref[n + i].numpy().ravel()]) for i in range(n)])
     return dict(g=g, S=S, t_frames=t_frames, t_inj=t_inj, target=target, sigma=sigma, offset=offset, img_ref=img_ref, gref=gref,
-                ties=relu_tie_count(g))
+                ties=ties, dropped=dropped, ties_left=0 if drop_ties else ties)
 
 
 def random_problem_errors(prob, mode, dev):

@@ -142,3 +142,48 @@ def test_trainstep_eht_arrays_at_config4_size(dev, setup):
     # pixel for rays of <= 129 samples in f32 mode, RaySum in fused_common.h), chi^2 / visibilities / dW in fixed order
     assert torch.equal(finals[0][1], finals[1][1]) and torch.equal(finals[0][0], finals[1][0])
     assert float((finals[0][0] - s['params'].flat).abs().max()) > 0
+
+
+def test_config4_network_4x256_bf16_against_f32_and_oracle(dev, setup):
+    """SURVEY 8's table quotes config 4 with the 4x256 network in bf16 arithmetic (the fixture above is 4x128 f32): the
+    visibility chi-square and its parameter gradient on the same 256x256x100 geometry, 8 frames -- the bf16 step against
+    the f32 step of the same network (images 1e-2 of the maximum, loss 3e-2, gradient 5e-2 relative L2: the bf16 bounds
+    of tests/test_gpu_backward.py), the f32 image chi-square against the NumPy oracle's loss_eht, bitwise reproducibility
+    of the bf16 step, and TrainStep.eht_arrays moving the parameters."""
+    from bhnerf_amd import engine, network, optimization, units
+    from oracle import oracle_np as onp
+    s = setup
+    res = {}
+    for mode in ('f32', 'bf16'):
+        pred = network.NeRF_Predictor(FOV_M / 2, 2.0, FOV_M / 2, 4.0, net_depth=4, net_width=256, mode=mode, device=dev)
+        params = pred.init_params(s['rt'], seed=7)
+        with torch.no_grad():
+            tree = pred.engine().unflatten(params.flat)
+            tree['MLP_0']['Dense_4']['bias'] += 6.0
+        flat = params.flat.detach().clone().requires_grad_(True)
+        ptree = network.ParamTree(); ptree.flat = flat
+        loss, [images] = network.loss_fn_eht(ptree, pred.apply, s['target'], s['sigma'], s['A'], s['t_hr'], *s['rt'].values(), 1.0, units.hr, 'vis')
+        loss.backward()
+        res[mode] = (float(loss), images.detach().clone(), flat.grad.detach().clone(), pred, params)
+        if mode == 'f32':      # the image-domain chi-square of the rendered frames against the oracle
+            ref = onp.loss_eht(images.detach().cpu().numpy().astype(np.float64).reshape(NT, NPIX, NPIX), s['target'].astype(np.complex128),
+                               s['sigma'].astype(np.float64), s['A'].astype(np.complex128), 1.0, 'vis')
+            assert abs(float(loss) - ref) <= 2e-5 * abs(ref)
+    (l32, i32, g32, _, _), (l16, i16, g16, pred16, params16) = res['f32'], res['bf16']
+    assert float(i32.max()) > 0
+    assert float((i16 - i32).abs().max()) <= 1e-2 * float(i32.abs().max())
+    assert abs(l16 - l32) <= 3e-2 * abs(l32)
+    assert float((g16 - g32).norm() / g32.norm()) <= 5e-2
+    # the bf16 training step through the reference-shaped API: reproducible bit for bit, and it moves the parameters
+    step = optimization.TrainStep.eht_arrays(s['t_hr'] * units.hr, s['target'], s['sigma'], s['A'], dtype='vis')
+    finals = []
+    for rep in range(2):
+        opt = optimization.Optimizer({'num_iters': 10, 'lr_init': 1e-4, 'lr_final': 1e-5, 'seed': 7}, pred16, s['rt'])
+        with torch.no_grad():
+            opt.state.flat.copy_(params16.flat)
+        loss0, state, imgs = step(opt.state, s['rt'], np.arange(NT))
+        assert imgs.shape == (1, NT, NPIX, NPIX) and state.step == 1
+        assert abs(float(loss0.sum()) - l16) <= 1e-4 * abs(l16)
+        finals.append((state.flat.clone(), state.grad[:state.flat.numel()].clone()))
+    assert torch.equal(finals[0][0], finals[1][0]) and torch.equal(finals[0][1], finals[1][1])
+    assert float((finals[0][0] - params16.flat).abs().max()) > 0

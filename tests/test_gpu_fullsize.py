@@ -4,6 +4,10 @@ forward routes (fused render vs predictor + stand-alone ray sum), linearity and 
 gradient, the two backward routes (recorded tape vs bhn_render_bwd), run-to-run bitwise reproducibility, and the
 oracle's gradient on a problem restricted to the same subset of rays.
 
+Every test runs on two recovery domains: the tutorial-style masked one (rmin 2, rmax 8, |z| <= 4: point-compacted layout,
+ray sums combined per workgroup tile) and the ALL-ACTIVE one of bench.py's headline line (rmin 0, rmax = z_width = inf:
+dense layout, every sample through the MLP, per-tile-atomic ray sums) -- the exact variant the benchmark times.
+
 Tolerances: f32 mode 1e-5 relative on images (north-star parity mode); bf16 mode 2e-2 of the image maximum
 (bf16 activations, measured 3e-3); gradients: bf16 5e-2 relative L2 against the f64 oracle on 256 rays."""
 import numpy as np
@@ -40,36 +44,50 @@ def problem(dev):
     return dict(geo=geo, t_frames=t_frames, tree=tree, tM0=tM0, GM_c3=constants.GM_c3('hr'))
 
 
-def setup(problem, mode, dev):
+DOMAINS = {'masked': (8.0, 2.0, 8.0, 4.0),                    # scale, rmin, rmax, z_width: tutorial-style recovery domain
+           'all_active': (8.0, 0.0, np.inf, np.inf)}          # bench.py's headline variant
+
+
+@pytest.fixture(params=['masked', 'all_active'])
+def domain(request):
+    return request.param
+
+
+def setup(problem, mode, dev, domain='masked'):
     from bhnerf_amd import network
     geo = problem['geo']
-    pred = network.NeRF_Predictor(8.0, 2.0, 8.0, 4.0, net_depth=4, net_width=256, mode=mode, device=dev)   # tutorial-style domain
+    pred = network.NeRF_Predictor(*DOMAINS[domain], net_depth=4, net_width=256, mode=mode, device=dev)
     eng = pred.engine()
     geom = pred.geometry(geo['coords'], geo['Omega'], geo['t_geos'], None, geo['g'], geo['dtau'], geo['Sigma'])
     eng.pack(eng.flatten(problem['tree']))
+    if domain == 'all_active':
+        assert geom.visited_fraction == 1.0 and geom.active_fraction > 0.99        # dense layout, (nearly) every sample live
+    else:
+        assert geom.visited_fraction < 0.9                                          # point-compacted layout
     return pred, eng, geom
 
 
-def oracle_images(problem, rays):
+def oracle_images(problem, rays, domain='masked'):
     geo = problem['geo']
+    scale, rmin, rmax, z_width = DOMAINS[domain]
     # (as a 12 x 8 "image": the reference's squeeze / broadcast conventions, which the oracle keeps, assume no
     #  singleton spatial axis)
     sub = lambda v: v.reshape((-1, G))[rays].reshape(12, 8, G).astype(np.float64)
     coords = np.stack([sub(geo['coords'][i]) for i in range(3)])
     tree = {'MLP_0': {k: {kk: np.asarray(vv, dtype=np.float64) for kk, vv in v.items()} for k, v in problem['tree']['MLP_0'].items()}}
     e = onp.predictor_apply(tree, problem['t_frames'], coords, sub(geo['Omega']), 0.0, sub(geo['t_geos']), float(geo['t_injection']),
-                            GM_c3=problem['GM_c3'], scale=8.0, rmin=2.0, rmax=8.0, z_width=4.0)
+                            GM_c3=problem['GM_c3'], scale=scale, rmin=rmin, rmax=rmax, z_width=z_width)
     return onp.image_plane_prediction(e, 1.0, sub(geo['g']), sub(geo['dtau']), sub(geo['Sigma'])).reshape(B, 96)      # (B, nrays)
 
 
 @pytest.mark.parametrize('mode,tol', [('f32', 1e-5), ('bf16', 1e-2)])
-def test_forward_full_size_against_oracle_on_a_ray_subset_and_both_routes(dev, problem, mode, tol):
+def test_forward_full_size_against_oracle_on_a_ray_subset_and_both_routes(dev, problem, mode, tol, domain):
     from bhnerf_amd import kgeo
-    pred, eng, geom = setup(problem, mode, dev)
+    pred, eng, geom = setup(problem, mode, dev, domain)
     images = eng.render(geom, problem['tM0'])[:, 0]                                   # (B, R)
     assert images.shape == (B, H * W) and float(images.max()) > 0
     rays = np.random.default_rng(11).choice(H * W, size=96, replace=False)
-    ref = oracle_images(problem, rays)
+    ref = oracle_images(problem, rays, domain)
     got = images[:, torch.as_tensor(rays, device=dev)].cpu().numpy()
     assert np.abs(got - ref).max() <= tol * np.abs(ref).max(), np.abs(got - ref).max() / np.abs(ref).max()
     # route 2: emission (B,P) from the predictor kernel, integrated by the stand-alone ray-sum kernel
@@ -83,8 +101,8 @@ def test_forward_full_size_against_oracle_on_a_ray_subset_and_both_routes(dev, p
     assert float((images3 - images).abs().max()) <= 2e-6 * float(images.abs().max())
 
 
-def test_backward_full_size_properties_bf16(dev, problem):
-    pred, eng, geom = setup(problem, 'bf16', dev)
+def test_backward_full_size_properties_bf16(dev, problem, domain):
+    pred, eng, geom = setup(problem, 'bf16', dev, domain)
     tM0 = problem['tM0']
     gen = torch.Generator(device=dev).manual_seed(3)
     d1 = torch.rand((B, 1, geom.R), device=dev, generator=gen) - 0.5
@@ -112,10 +130,11 @@ def test_backward_full_size_properties_bf16(dev, problem):
     assert float((parts - g1).abs().max()) <= 1e-5 * scale + 1e-3 * float((parts - g1).abs().mean() + 1e-30) + 2e-6 * scale
 
 
-def test_gradient_full_width_against_oracle_on_a_ray_subset(dev, problem):
+def test_gradient_full_width_against_oracle_on_a_ray_subset(dev, problem, domain):
     """4x256 network, 256 rays of the full geometry x 64 samples x 8 frames: chi^2 gradient vs torch.autograd on the f64 oracle."""
     from bhnerf_amd import network, units
     geo = problem['geo']
+    scale, rmin, rmax, z_width = DOMAINS[domain]
     rays = np.sort(np.random.default_rng(12).choice(H * W, size=256, replace=False))
     sub = lambda v: np.ascontiguousarray(v.reshape((-1, G))[rays].reshape(16, 16, G))
     g = dict(coords=np.stack([sub(geo['coords'][i]) for i in range(3)]), Omega=sub(geo['Omega']), t_geos=sub(geo['t_geos']),
@@ -126,13 +145,13 @@ def test_gradient_full_width_against_oracle_on_a_ray_subset(dev, problem):
     ks, bs = ot.tree_to_lists(problem['tree'], torch.float64)
     geom_t = dict(coords=t64(g['coords']), Omega=t64(g['Omega']), t_geos=t64(g['t_geos']), g=t64(g['g']), dtau=t64(g['dtau']),
                   Sigma=t64(g['Sigma']), J=None, t_start_obs=0.0, t_injection=float(geo['t_injection']))
-    hp = dict(GM_c3=problem['GM_c3'], scale=8.0, rmin=2.0, rmax=8.0, z_width=4.0, posenc_deg=3, net_depth=4)
+    hp = dict(GM_c3=problem['GM_c3'], scale=scale, rmin=rmin, rmax=rmax, z_width=z_width, posenc_deg=3, net_depth=4)
     tr = ot.CpuTrainer(ks, bs, geom_t, hp)
     loss_ref, _, grads_ref = tr.loss_and_grad(t64(problem['t_frames']), t64(target), t64(sigma), t64(offset), 1.0, 'full')
     n = len(tr.k)
     gref = np.concatenate([np.concatenate([grads_ref[i].numpy().ravel(), grads_ref[n + i].numpy().ravel()]) for i in range(n)])
     for mode, l2tol in (('f32', 2e-5), ('bf16', 2e-2)):
-        pred = network.NeRF_Predictor(8.0, 2.0, 8.0, 4.0, net_depth=4, net_width=256, mode=mode, device=dev)
+        pred = network.NeRF_Predictor(scale, rmin, rmax, z_width, net_depth=4, net_width=256, mode=mode, device=dev)
         params = pred.engine().flatten(problem['tree']).requires_grad_(True)
         tree = network.ParamTree()
         tree.flat = params
@@ -145,11 +164,11 @@ def test_gradient_full_width_against_oracle_on_a_ray_subset(dev, problem):
         assert err < l2tol, (mode, err)
 
 
-def test_taped_step_is_bitwise_stable_under_hbm_contention(dev, problem):
+def test_taped_step_is_bitwise_stable_under_hbm_contention(dev, problem, domain):
     """The weight / tape rings use counted s_waitcnt vmcnt (in-order completion of the LDS-DMA loads and the tape stores,
     DESIGN.md 4.2-4.3).  A wait that is one operation too lax shows up as run-to-run differences once the memory system
     is perturbed: every second repetition runs against a copy stream that saturates HBM."""
-    pred, eng, geom = setup(problem, 'bf16', dev)
+    pred, eng, geom = setup(problem, 'bf16', dev, domain)
     tM0 = problem['tM0']
     gen = torch.Generator(device=dev).manual_seed(9)
     d = torch.rand((B, 1, geom.R), device=dev, generator=gen) - 0.4

@@ -289,6 +289,86 @@ __global__ __launch_bounds__(512) void k2(const char *img, const bf16x8 *bsrc, f
     if (s == 12345.678f) out[threadIdx.x] = s;
 }
 
+
+// ---- round 3: the ring step WITH the training forward's tape emission at its real byte rate -----------------------------
+// Per step and wave: relu + relu bits + repack of the pending tile (pack_pipe<BITS>), two 16-byte-per-lane non-temporal
+// stores of the finished tile (2 KiB per wave and step = the h-tile stream of chain_kernel<MODE_FWD_TRAIN>, 1.5 KB / point
+// at 4x256) and one relu-bit word per two steps; the counted vmcnt of the step end lets 12 stores stay in flight (DIST 7),
+// as in the library.  What this loop sustains is the ceiling of the training forward's hidden steps under the chip's
+// power management: no per-tile prologue / epilogue, no layer 0, no output layer.
+template <class Pol>
+struct TapeLikePost {
+    const f32x16 &pend;
+    typename Pol::frag &d0, &d1;
+    unsigned mask = 0, w = 0;
+    char *dst;
+    unsigned *mword;
+    bool stores;
+    DEVI TapeLikePost(const f32x16 &p, typename Pol::frag &a, typename Pol::frag &b, char *dst_, unsigned *mw, bool st) : pend(p), d0(a), d1(b), dst(dst_), mword(mw), stores(st) {}
+    DEVI void at(int t) {
+        pack_pipe<Pol, true>(t, pend, d0, d1, w, mask);
+        if (t == 10 && mword) __builtin_nontemporal_store(Pol::mask_code(mask), mword);
+        if (t == 12 && stores) {
+            const int lane = threadIdx.x & 63;
+            __builtin_nontemporal_store(d0, reinterpret_cast<typename Pol::frag *>(dst + lane * 16));
+            __builtin_nontemporal_store(d1, reinterpret_cast<typename Pol::frag *>(dst + 1024 + lane * 16));
+        }
+    }
+    DEVI void all() {}
+};
+
+// MODE bits: 1 tape stores, 8 skip block
+template <int MODE>
+__global__ __launch_bounds__(512) void k3(const char *img, const bf16x8 *bsrc, float *out, unsigned long long *clk, char *tape, long long tape_per_wg, int steps) {
+    using Pol = PolBF16;
+    constexpr int W = 256, KS = 16, MT = 8, CB = 18 * 1024, DIST = 7;
+    using RG = DmaRing<CB, 8>;
+    using RS = RingState<RG, CB, DIST, false>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *bias_lds = reinterpret_cast<float *>(smem + RS::NB * CB);
+    for (int i = threadIdx.x; i < 5 * W; i += 512) bias_lds[i] = 0.001f * i;
+    const int wvu = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    RS rs;
+    rs.start(smem, img, 26, nullptr, 0, 0, 0);
+    APipe<Pol> ap;
+    ap.prime(rs.ch(), bias_lds);
+    Pol::frag act[KS], next[KS], enc[2];
+    for (int i = 0; i < KS; ++i) { act[i] = bsrc[(size_t)(blockIdx.x * 512 + threadIdx.x) * 18 + i]; next[i] = act[i]; }
+    enc[0] = bsrc[(size_t)(blockIdx.x * 512 + threadIdx.x) * 18 + 16]; enc[1] = bsrc[(size_t)(blockIdx.x * 512 + threadIdx.x) * 18 + 17];
+    f32x16 pend = {};
+    char *wbase = tape + (long long)blockIdx.x * tape_per_wg;
+    long long off = (long long)wvu * 2048;                     // wave w of step s writes [s][w][2 KiB]
+    unsigned *mbase = reinterpret_cast<unsigned *>(wbase + tape_per_wg - (1 << 20));
+    unsigned long long t0 = 0, r0 = 0;
+    auto layer = [&](Pol::frag (&src)[KS], Pol::frag (&dst)[KS], const float *bl) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const char *ch = rs.ch(), *chn = rs.chn();
+            const DmaJob dj = rs.job();
+            TapeLikePost<Pol> post(pend, m == 0 ? src[KS - 2] : dst[2 * (m > 0 ? m - 1 : 0)], m == 0 ? src[KS - 1] : dst[2 * (m > 0 ? m - 1 : 0) + 1],
+                                   wbase + off, (m & 1) ? mbase + (threadIdx.x & 511) : nullptr, (MODE & 1) != 0);
+            const f32x16 acc = ring_step<W, Pol, RG>(ch, chn, ap, src, enc, (MODE & 8) != 0, bl + 32 * (m + 1), post, dj, 0);
+            if (MODE & 1) rs.template step_end<12>(); else rs.template step_end<0>();
+            pend = acc;
+            off += 8 * 2048;
+            if (off >= tape_per_wg - (2 << 20)) off = (long long)wvu * 2048;
+        }
+    };
+    for (int it = -32; it < steps; it += 16) {
+        if (it == 0) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+        layer(act, next, bias_lds + W);
+        layer(next, act, bias_lds + 2 * W);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; }
+    rs.idle_step();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float s = 0;
+    for (int j = 0; j < 16; ++j) s += pend[j];
+    for (int i = 0; i < KS; ++i) s += (float)act[i][0] + (float)next[i][3];
+    if (s == 12345.678f) out[threadIdx.x] = s;
+}
+
 #include <algorithm>
 #include <vector>
 template <int MODE, int SHAPE>
@@ -326,7 +406,67 @@ void run2(const char *name) {
     hipFree(img); hipFree(bs); hipFree(d); hipFree(clk);
 }
 
+#include <chrono>
+#include <ctime>
+// runs kernel k3<MODE> back to back for `seconds` (power / clock telemetry is sampled from outside meanwhile)
+template <int MODE>
+void run3(const char *name, double seconds) {
+    const int steps = 16 * 4000, grid = 256;
+    std::vector<unsigned short> hi(26 * 9 * 1024), hb((size_t)grid * 512 * 18 * 8);
+    unsigned x = 12345u;
+    auto rnd = [&](float amp) { x = x * 1664525u + 1013904223u; const float f = ((x >> 8) * (1.0f / 16777216.0f) - 0.5f) * 2.f * amp; unsigned u; memcpy(&u, &f, 4); return (unsigned short)(u >> 16); };
+    for (auto &v : hi) v = rnd(0.108f);
+    for (auto &v : hb) v = rnd(1.0f);
+    char *img, *tape; bf16x8 *bs; float *d; unsigned long long *clk;
+    const long long tape_per_wg = 64ll << 20;
+    hipMalloc(&img, hi.size() * 2); hipMemcpy(img, hi.data(), hi.size() * 2, hipMemcpyHostToDevice);
+    hipMalloc(&bs, hb.size() * 2); hipMemcpy(bs, hb.data(), hb.size() * 2, hipMemcpyHostToDevice);
+    hipMalloc(&d, 4096); hipMalloc(&clk, grid * 16);
+    if (hipMalloc(&tape, tape_per_wg * grid) != hipSuccess) { printf("tape alloc failed\n"); return; }
+    const size_t lds = 8 * 18 * 1024 + 5 * 256 * 4;
+    hipFuncSetAttribute((const void *)k3<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    k3<MODE><<<grid, 512, lds>>>(img, bs, d, clk, tape, tape_per_wg, 64);
+    hipDeviceSynchronize();
+    const auto w0 = std::chrono::system_clock::now();
+    double ms_sum = 0; int n = 0;
+    std::vector<double> ghz_all, cyc_all;
+    while (std::chrono::duration<double>(std::chrono::system_clock::now() - w0).count() < seconds) {
+        hipEventRecord(e0);
+        k3<MODE><<<grid, 512, lds>>>(img, bs, d, clk, tape, tape_per_wg, steps);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        ms_sum += ms; ++n;
+        std::vector<unsigned long long> hc(grid * 2);
+        hipMemcpy(hc.data(), clk, grid * 16, hipMemcpyDeviceToHost);
+        std::vector<double> ghz(grid), cyc(grid);
+        for (int i = 0; i < grid; ++i) { ghz[i] = (double)hc[2 * i] / (double)hc[2 * i + 1] * 0.1; cyc[i] = (double)hc[2 * i] / steps; }
+        std::sort(ghz.begin(), ghz.end()); std::sort(cyc.begin(), cyc.end());
+        ghz_all.push_back(ghz[grid / 2]); cyc_all.push_back(cyc[grid / 2]);
+    }
+    const double t_end = std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count();
+    const double t_beg = std::chrono::duration<double>(w0.time_since_epoch()).count();
+    std::sort(ghz_all.begin(), ghz_all.end()); std::sort(cyc_all.begin(), cyc_all.end());
+    const int nf = (MODE & 8) ? 18 : 16;
+    const double flops = (double)grid * 8 * (double)(steps + 32) * nf * 32768.0 * n;
+    const double bytes = (MODE & 1) ? (double)grid * 8 * (double)(steps + 32) * 2048.0 * n : 0.0;
+    printf("%-44s unix %.1f .. %.1f  %d launches  %8.2f ms each  %6.0f TFLOP/s  tape writes %5.2f TB/s  in-kernel clock %.3f GHz  %.0f cycles/step\n", name, t_beg, t_end, n,
+           ms_sum / n, flops / ms_sum * 1e-9, bytes / ms_sum * 1e-9, ghz_all[ghz_all.size() / 2], cyc_all[cyc_all.size() / 2]);
+    fflush(stdout);
+    hipFree(img); hipFree(bs); hipFree(d); hipFree(clk); hipFree(tape);
+}
+
 int main(int argc, char **argv) {
+    if (argc > 2 && !strcmp(argv[1], "ceiling")) {      // round 3: ring-step ceiling with the tape stores, under telemetry
+        const double sec = atof(argv[2]);
+        run3<0>("ring step + pack + relu bits + DMA", sec);
+        run3<1>("... + tape stores (2 KiB / wave / step)", sec);
+        run3<8>("ring step + skip block", sec);
+        run3<9>("... + skip block + tape stores", sec);
+        return 0;
+    }
     if (argc > 1) {      // round 3: MFMA shape A/B on the library's ring step, random weights AND random activations
         for (int r = 0; r < 3; ++r) {
             run2<3, 32>("pack + DMA"); run2<3, 16>("pack + DMA");
