@@ -191,6 +191,22 @@ class TrainState:
         return self.from_state_dict(sd)
 
 
+def _fingerprint(v):
+    """Cache key of one ray-tracing argument (NeRF_Predictor.geometry): identity + what an in-place edit would change."""
+    if v is None or np.isscalar(v):
+        return v
+    if isinstance(v, torch.Tensor):
+        return (id(v), tuple(v.shape), v._version)
+    if isinstance(v, (list, tuple)):
+        return tuple(_fingerprint(x) for x in v)
+    a = np.asarray(v)
+    if a.size == 0:
+        return (id(v), a.shape, str(a.dtype))
+    step = max(1, a.size // 256)
+    sample = a.flat[::step]
+    return (id(v), a.shape, str(a.dtype), hash(np.ascontiguousarray(sample).tobytes()), hash(a.flat[a.size - 1].tobytes()))
+
+
 def _dist_on():
     import torch.distributed as dist
     return dist.is_available() and dist.is_initialized()
@@ -235,10 +251,12 @@ class NeRF_Predictor:
         return self._engine
 
     def geometry(self, coords, Omega, t_geos, J=None, g=None, dtau=None, Sigma=None):
-        """Prepared RayGeometry for these arrays, cached on the IDENTITY of the inputs (the reference's ray-tracing
-        arguments are immutable jax arrays): an in-place edit of an array is not seen -- pass a new array, or call
-        ``clear_geometry_cache()``."""
-        key = tuple(id(v) for v in (coords, Omega, t_geos, J, g, dtau, Sigma)) + (self.rmin, self.rmax, self.z_width)
+        """Prepared RayGeometry for these arrays, cached on the identity of the inputs AND a fingerprint of their
+        contents (the reference's ray-tracing arguments are immutable jax arrays; NumPy arrays and tensors are not):
+        torch tensors by their in-place version counter (exact), NumPy arrays by shape, dtype and a strided sample of
+        257 elements -- an in-place edit that touches none of the sampled elements is not seen: pass a new array, or
+        call ``clear_geometry_cache()``."""
+        key = tuple(_fingerprint(v) for v in (coords, Omega, t_geos, J, g, dtau, Sigma)) + (self.rmin, self.rmax, self.z_width)
         hit = self._geoms.get(key)
         if hit is not None:
             self._geoms.move_to_end(key)            # LRU: logging geometries must not evict the training ray sets

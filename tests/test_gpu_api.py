@@ -223,3 +223,26 @@ def test_edge_cases_empty_domain_pre_injection_and_single_sample_ray(dev, mode):
     opt = optimization.Optimizer({'num_iters': 2, 'lr_init': 1e-3, 'lr_final': 1e-4}, pred, rt1)
     opt.run(1, step1, rt1)
     assert np.isfinite(float(np.mean(opt.loss))) and opt.state.step == 2
+
+
+def test_geometry_cache_sees_in_place_edits(dev, problem):
+    """NeRF_Predictor.geometry caches the prepared ray geometry per set of ray-tracing arrays; the key holds a fingerprint of
+    the CONTENTS (NumPy: strided sample; tensors: version counter), so an in-place edit of an array gives a new geometry
+    instead of silently re-using the stale one (round 2: keyed on id() only)."""
+    from bhnerf_amd import network
+    geo = {k: (np.array(v, copy=True) if isinstance(v, np.ndarray) else v) for k, v in problem['geo'].items()}
+    pred = network.NeRF_Predictor(8.0, 1.0, 8.0, 4.0, net_depth=4, net_width=64, mode='f32', device=dev)
+    args = (geo['coords'], geo['Omega'], geo['t_geos'], None, geo['g'], geo['dtau'], geo['Sigma'])
+    g1 = pred.geometry(*args)
+    assert pred.geometry(*args) is g1                                  # unchanged arrays: cache hit
+    w_before = g1.w.clone()
+    geo['g'] *= 2.0                                                    # in place: same object, new contents
+    g2 = pred.geometry(*args)
+    assert g2 is not g1
+    assert torch.allclose(g2.w, 4.0 * w_before)                        # w = g^2 dtau Sigma
+    t = torch.as_tensor(np.ascontiguousarray(geo['Omega'], dtype=np.float32), device=dev)
+    args_t = (geo['coords'], t, geo['t_geos'], None, geo['g'], geo['dtau'], geo['Sigma'])
+    g3 = pred.geometry(*args_t)
+    assert pred.geometry(*args_t) is g3
+    t.mul_(0.5)                                                        # tensors: exact, through the version counter
+    assert pred.geometry(*args_t) is not g3

@@ -129,3 +129,54 @@ def test_polarised_lightcurve_gradient_properties(dev, name):
     loss, _, frames = step(opt.state, rt, np.arange(B), update_state=False)
     want = float((((lc - torch.as_tensor(target, device=dev)) / sigma) ** 2).sum())
     assert abs(float(torch.as_tensor(loss).sum()) - want) <= 2e-2 * want
+
+
+def test_config3_render_with_reference_pinned_J(dev):
+    """BASELINE config 3's polarised render with REAL Kerr factors instead of synthetic ones: spin-0.94 geodesics of the own
+    tracer (60 deg, 40 M field of view, 64 x 64 rays x 128 samples), Doppler factor and Stokes factors J = (I, Q, U) from
+    bhnerf_amd/kgeo.py -- the functions fixture g12 pins to the reference's own kgeo.py:199-519 -- through the fused HIP
+    render against the float64 oracle on 96 rays, both arithmetic modes."""
+    from bhnerf_amd import constants, engine, geodesics, kgeo, network
+    spin, inc, fov, NA, NG = 0.94, np.deg2rad(60.0), 40.0, 64, 128
+    geos = geodesics.image_plane_geos(spin, inc, (-fov / 2, fov / 2), (-fov / 2, fov / 2), ngeo=NG, num_alpha=NA, num_beta=NA)
+    r = np.asarray(geos.r)
+    Omega = 1.0 / (np.maximum(r, 2.1) ** 1.5 + spin)                                    # prograde Keplerian (utils-style), capped inside the ISCO
+    with np.errstate(all='ignore'):
+        umu = kgeo.azimuthal_velocity_vector(geos, Omega)
+        g = kgeo.doppler_factor(geos, umu)
+        b = kgeo.magnetic_field_fluid_frame(geos, umu, 0.0, 1.0, 0.0)
+        domain = (np.abs(geos.z) < 4.0) & (r > 2.024) & (r < fov / 2)                    # unit mean field strength over the recovery
+        b = b / np.sqrt((b[domain] ** 2).sum(axis=-1)).mean()                            # domain, as alma.py:52-54 normalises it
+        J = np.nan_to_num(kgeo.parallel_transport(geos, umu, g, b, Q_frac=0.85, V_frac=0), 0.0)
+    assert J.shape == (3, NA, NA, NG) and np.abs(J[1][domain]).max() > 0.1 and np.abs(J[2][domain]).max() > 0.1
+    f32 = lambda v: np.ascontiguousarray(np.nan_to_num(np.asarray(v, dtype=np.float64)), dtype=np.float32)
+    coords = np.stack([f32(geos.x), f32(geos.y), f32(geos.z)])
+    arrs = dict(Omega=f32(Omega), t_geos=f32(geos.t), g=f32(g), dtau=f32(geos.dtau), Sigma=f32(geos.Sigma), J=f32(J))
+    t_frames = np.linspace(0.0, 1.7, 128)[:B]
+    t_inj = -float(geos.r_o + fov / 4)
+    GM = constants.GM_c3('hr')
+    rng = np.random.default_rng(33)
+    tree = onp.he_uniform_params(rng, 4, 256, 21, dtype=np.float32)
+    for i in range(5):
+        d = tree['MLP_0']['Dense_%d' % i]
+        d['bias'] = rng.uniform(-0.05, 0.05, d['bias'].shape).astype(np.float32)
+    tree['MLP_0']['Dense_4']['bias'] = tree['MLP_0']['Dense_4']['bias'] + 9.0
+    rmin, rmax, zw = 2.024, fov / 2, 4.0
+    rays = np.random.default_rng(34).choice(NA * NA, size=96, replace=False)
+    sub = lambda v: v.reshape((-1, NG))[rays].reshape(12, 8, NG).astype(np.float64)
+    tree64 = {'MLP_0': {k: {kk: np.asarray(vv, dtype=np.float64) for kk, vv in v.items()} for k, v in tree['MLP_0'].items()}}
+    e = onp.predictor_apply(tree64, t_frames, np.stack([sub(coords[i]) for i in range(3)]), sub(arrs['Omega']), 0.0, sub(arrs['t_geos']), t_inj,
+                            GM_c3=GM, scale=rmax, rmin=rmin, rmax=rmax, z_width=zw)
+    ref = onp.image_plane_prediction(e, np.stack([sub(arrs['J'][s]) for s in range(3)]), sub(arrs['g']), sub(arrs['dtau']),
+                                     sub(arrs['Sigma'])).reshape(B, 3, 96)
+    assert np.abs(ref[:, 0]).max() > 0 and np.abs(ref[:, 1]).max() > 0
+    tM0 = engine.frame_offsets(t_frames, 0.0, t_inj, GM, dev)
+    for mode, tol in (('f32', 1e-5), ('bf16', 2e-2)):
+        pred = network.NeRF_Predictor(rmax, rmin, rmax, zw, net_depth=4, net_width=256, mode=mode, device=dev)
+        eng = pred.engine()
+        geom = pred.geometry(coords, arrs['Omega'], arrs['t_geos'], arrs['J'], arrs['g'], arrs['dtau'], arrs['Sigma'])
+        eng.pack(eng.flatten(tree))
+        got = eng.render(geom, tM0)[:, :, torch.as_tensor(rays, device=dev)].cpu().numpy()
+        for s in range(3):
+            err = np.abs(got[:, s] - ref[:, s]).max() / np.abs(ref[:, s]).max()
+            assert err <= tol, (mode, s, err)

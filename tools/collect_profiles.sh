@@ -5,9 +5,12 @@
 #   <tag>_f32_kernel_stats.csv    the same for `bench.py --mode f32` (the parity mode)
 #   <tag>_pmc_traffic.json        HBM traffic per launch (FETCH_SIZE / WRITE_SIZE, separate --pmc passes, gfx950 x2 on FETCH_SIZE)
 #   <tag>_sq_counters.txt / <tag>_sq_summary.json   SQ counter passes of tools/pmc_run.py (MFMA busy, waits, LDS conflicts)
+#   <tag>_ring_ceiling_microbench.txt + <tag>_telemetry_ceiling.txt   tools/step_bench.hip `ceiling`: the library's ring step
+#                                 with and without the tape stores, in-kernel clock, board power / SMI clock sampled beside it
+#   <tag>_telemetry_bench.txt     board power / SMI clock during 400 training steps of bench.py (tools/smi_sample.py)
 # The files land in gpurun_out/profiles/ (merged back by gpurun); copy them to profiles/ and commit.
 set -euo pipefail
-TAG=${1:-r2}
+TAG=${1:-r3}
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/profiles
@@ -23,9 +26,12 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pm_$c; rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pm_$c -o p -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity-mode --no-tutorial-domain > /tmp/pm_$c.log 2>&1
   f=$(find /tmp/pm_$c -name "*counter_collection.csv" | head -1); need "$f"; cp "$f" /tmp/pm_$c.csv
 done
+LIBMD5=$(md5sum $R/bhnerf_amd/csrc/libbhnerf_hip.so | cut -d" " -f1)
+export LIBMD5
 python3 - > $O/${TAG}_pmc_traffic.json <<'PY'
-import csv, json, collections
+import csv, json, collections, os
 out = collections.OrderedDict()
+ms = collections.defaultdict(list)
 def short(k):
     if 'chain_kernel' in k: return 'chain_kernel<MODE_FWD_TRAIN>' if ', 1>' in k else 'chain_kernel<MODE_CHAIN>' if ', 2>' in k else None
     for n in ('dw_kernel', 'reduce_kernel', 'rt_kernel', 'adam_kernel', 'chi2_image_kernel', 'pack_weights_kernel', 'eht_vis_kernel', 'eht_bwd_kernel'):
@@ -36,19 +42,22 @@ for c in ('FETCH_SIZE', 'WRITE_SIZE'):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open('/tmp/pm_%s.csv' % c)):
         n = short(r['Kernel_Name'])
-        if n and r['Counter_Name'] == c: acc[n].append(float(r['Counter_Value']))
+        if n and r['Counter_Name'] == c:
+            acc[n].append(float(r['Counter_Value']))
+            ms[n].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) * 1e-6)
     for n, v in acc.items():
         out.setdefault(n, {})[c + '_KiB'] = round(sum(v) / len(v), 1)
 for n, d in out.items():
     d['hbm_bytes'] = int((2 * d.get('FETCH_SIZE_KiB', 0) + d.get('WRITE_SIZE_KiB', 0)) * 1024)
-print(json.dumps({'note': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace) of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity-mode --no-tutorial-domain`; averages per launch in KiB as reported; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 with the gfx950 correction (FETCH_SIZE reports half of wide coalesced reads, MI355X_MICROARCH.md HBM section)', 'kernels': out}, indent=1))
+    d['ms_under_profiler'] = round(sum(ms[n]) / len(ms[n]), 4)
+print(json.dumps({'lib_md5': os.environ.get('LIBMD5'), 'note': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace) of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity-mode --no-tutorial-domain`; averages per launch in KiB as reported; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 with the gfx950 correction (FETCH_SIZE reports half of wide coalesced reads, MI355X_MICROARCH.md HBM section)', 'kernels': out}, indent=1))
 PY
 need $O/${TAG}_pmc_traffic.json
 bash $R/tools/pmc_collect.sh > /tmp/sq.log 2>&1
 ls $R/gpurun_out/pmc/pass*.txt > /dev/null
 cat $R/gpurun_out/pmc/pass*.txt > $O/${TAG}_sq_counters.txt
 python3 - $O/${TAG}_sq_counters.txt > $O/${TAG}_sq_summary.json <<'PY'
-import sys, json, re, collections
+import sys, json, re, collections, os
 k = None; d = collections.OrderedDict()
 for l in open(sys.argv[1]):
     if not l.startswith(' '):
@@ -65,10 +74,20 @@ for k, c in d.items():
                   'wave_wait_any_frac': round(c['SQ_WAIT_ANY'] / c['SQ_WAVE_CYCLES'], 3),
                   'wave_wait_inst_frac': round(c['SQ_WAIT_INST_ANY'] / c['SQ_WAVE_CYCLES'], 3),
                   'lds_bank_conflict_frac': round(c['SQ_LDS_BANK_CONFLICT'] / max(c['SQ_LDS_IDX_ACTIVE'], 1), 3),
-                  'cu_cycles_per_cu': round(cu / 256)}
+                  'mfma_coexec_frac_of_mfma_busy': round(c.get('SQ_VALU_MFMA_COEXEC_CYCLES', 0.0) / max(c['SQ_VALU_MFMA_BUSY_CYCLES'], 1), 3),
+                  'cu_cycles_per_cu': round(cu / 256), 'ms': c.get('duration_ms')}
     except KeyError:
         pass
-print(json.dumps({'note': 'from sq_counters.txt (rocprofv3 --pmc SQ_* passes of tools/pmc_run.py, one launch each): mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES) = fraction of SIMD cycles with the matrix pipe busy', 'kernels': out}, indent=1))
+print(json.dumps({'lib_md5': os.environ.get('LIBMD5'), 'note': 'from sq_counters.txt (rocprofv3 --pmc SQ_* passes of tools/pmc_run.py, one launch each): mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES) = fraction of SIMD cycles with the matrix pipe busy', 'kernels': out}, indent=1))
 PY
 need $O/${TAG}_sq_summary.json
+hipcc -O3 -std=c++17 --offload-arch=gfx950 -I$R/bhnerf_amd/csrc -I$R/include $R/tools/step_bench.hip -o /tmp/step_bench > /tmp/step_bench.log 2>&1
+python3 $R/tools/smi_sample.py > $O/${TAG}_telemetry_ceiling.txt & SMI=$!
+sleep 2; /tmp/step_bench ceiling 8 > $O/${TAG}_ring_ceiling_microbench.txt 2>&1; sleep 1; kill $SMI
+need $O/${TAG}_ring_ceiling_microbench.txt
+python3 $R/tools/smi_sample.py > $O/${TAG}_telemetry_bench.txt & SMI=$!
+sleep 2; date +"# bench.py --steps 400 starts %s" >> $O/${TAG}_telemetry_bench.txt
+python3 $R/bench.py --steps 400 --warmup 5 --no-cpu-baseline --no-parity-mode --no-tutorial-domain > /tmp/bench400.json 2> /tmp/bench400.err
+date +"# bench.py ends %s" >> $O/${TAG}_telemetry_bench.txt; sleep 1; kill $SMI
+python3 -c "import json; d=json.load(open('/tmp/bench400.json')); print('# bench.py --steps 400: ms_per_step %.3f' % d['ms_per_step'])" >> $O/${TAG}_telemetry_bench.txt
 ls -la $O

@@ -24,6 +24,7 @@ for r in rows:
     if not any(s in k for s in ('chain_kernel', 'dw_kernel', 'fused_fwd_kernel')): continue
     d = agg.setdefault(k, collections.OrderedDict())
     d.setdefault(r['Counter_Name'], []).append(float(r['Counter_Value']))
+    d.setdefault('duration_ms', []).append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) * 1e-6)
 for k, d in agg.items():
     print(k)
     for c, v in d.items():
