@@ -57,8 +57,8 @@ def mlp_flops(depth, width, F=21):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--mode', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--image', type=int, default=128)
     ap.add_argument('--ngeo', type=int, default=64)
@@ -73,9 +73,10 @@ def parse():
     ap.add_argument('--no-parity-mode', action='store_true', help='skip the f32 parity-mode block')
     ap.add_argument('--no-tutorial-domain', action='store_true',
                     help='skip the masked-domain variant (profiling runs: keeps every launch of a kernel the same shape)')
-    ap.add_argument('--other-configs', action='store_true',
-                    help='add one timed training step each at the sizes of BASELINE configs 3 (256x256x128, Stokes I/Q/U, lc), '
-                         '4 (EHT2017 visibilities, 256x256x100) and 5 (64x64x100, 4x128, lc) on this one GPU')
+    ap.add_argument('--no-other-configs', dest='other_configs', action='store_false',
+                    help='skip the block with one timed training step each at the sizes of BASELINE configs 3 (256x256x128, Stokes '
+                         'I/Q/U, lc), 4 (EHT2017 visibilities, 256x256x100) and 5 (64x64x100, 4x128, lc) on this one GPU (N = 1 only)')
+    ap.add_argument('--other-configs', dest='other_configs', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--cpu-rays', type=int, default=2048, help='rays of one frame in the CPU-baseline sample')
     ap.add_argument('--cpu-seconds', type=float, default=25.0, help='time budget of the CPU-baseline thread sweep')
     return ap.parse_args()
@@ -568,7 +569,7 @@ def main():
         'fwd_images_per_s': fwd_path['value'] if fwd_path else None,
         'fwd_path': fwd_path,
     }
-    if args.other_configs and world == 1:
+    if args.other_configs and world == 1 and args.mode == 'bf16' and std:
         del opt
         torch.cuda.empty_cache()
         out['other_configs'] = other_configs(dev, args.mode)
