@@ -199,12 +199,12 @@ def _fingerprint(v):
         return (id(v), tuple(v.shape), v._version)
     if isinstance(v, (list, tuple)):
         return tuple(_fingerprint(x) for x in v)
-    a = np.asarray(v)
+    a = v if type(v) is np.ndarray else np.asarray(v)
     if a.size == 0:
-        return (id(v), a.shape, str(a.dtype))
-    step = max(1, a.size // 256)
-    sample = a.flat[::step]
-    return (id(v), a.shape, str(a.dtype), hash(np.ascontiguousarray(sample).tobytes()), hash(a.flat[a.size - 1].tobytes()))
+        return (id(v), a.shape, a.dtype.str)
+    step = max(1, (a.size - 1) // 256)                              # 257 samples from the first element to (nearly) the last
+    flat = a.reshape(-1) if a.flags.c_contiguous else a.flat       # (a view: ~2.5 us per array and step)
+    return (id(v), a.shape, a.dtype.str, hash(flat[::step].tobytes()))
 
 
 def _dist_on():
@@ -254,7 +254,7 @@ class NeRF_Predictor:
         """Prepared RayGeometry for these arrays, cached on the identity of the inputs AND a fingerprint of their
         contents (the reference's ray-tracing arguments are immutable jax arrays; NumPy arrays and tensors are not):
         torch tensors by their in-place version counter (exact), NumPy arrays by shape, dtype and a strided sample of
-        257 elements -- an in-place edit that touches none of the sampled elements is not seen: pass a new array, or
+        ~257 elements -- an in-place edit that touches none of the sampled elements is not seen: pass a new array, or
         call ``clear_geometry_cache()``."""
         key = tuple(_fingerprint(v) for v in (coords, Omega, t_geos, J, g, dtau, Sigma)) + (self.rmin, self.rmax, self.z_width)
         hit = self._geoms.get(key)
