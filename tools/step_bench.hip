@@ -319,7 +319,7 @@ struct TapeLikePost {
 
 // MODE bits: 1 tape stores, 8 skip block
 template <int MODE>
-__global__ __launch_bounds__(512) void k3(const char *img, const bf16x8 *bsrc, float *out, unsigned long long *clk, char *tape, long long tape_per_wg, int steps) {
+__global__ __launch_bounds__(512) void k3(const char *img, const bf16x8 *bsrc, float *out, unsigned long long *clk, char *tape, long long tape_per_wg, long long window, int steps) {
     using Pol = PolBF16;
     constexpr int W = 256, KS = 16, MT = 8, CB = 18 * 1024, DIST = 7;
     using RG = DmaRing<CB, 8>;
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(512) void k3(const char *img, const bf16x8 *bsrc, f
             if (MODE & 1) rs.template step_end<12>(); else rs.template step_end<0>();
             pend = acc;
             off += 8 * 2048;
-            if (off >= tape_per_wg - (2 << 20)) off = (long long)wvu * 2048;
+            if (off >= window) off = (long long)wvu * 2048;
         }
     };
     for (int it = -32; it < steps; it += 16) {
@@ -409,8 +409,10 @@ void run2(const char *name) {
 #include <chrono>
 #include <ctime>
 // runs kernel k3<MODE> back to back for `seconds` (power / clock telemetry is sampled from outside meanwhile)
+// window: bytes per workgroup the tile stores cycle through (the whole 62 MB slice: every store goes to HBM; 128 KB: the
+// 32 MB of all workgroups stay in the Infinity Cache; 16 KB: in the XCD's L2)
 template <int MODE>
-void run3(const char *name, double seconds) {
+void run3(const char *name, double seconds, long long window = (64ll << 20) - (2 << 20)) {
     const int steps = 16 * 4000, grid = 256;
     std::vector<unsigned short> hi(26 * 9 * 1024), hb((size_t)grid * 512 * 18 * 8);
     unsigned x = 12345u;
@@ -427,14 +429,14 @@ void run3(const char *name, double seconds) {
     hipFuncSetAttribute((const void *)k3<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    k3<MODE><<<grid, 512, lds>>>(img, bs, d, clk, tape, tape_per_wg, 64);
+    k3<MODE><<<grid, 512, lds>>>(img, bs, d, clk, tape, tape_per_wg, window, 64);
     hipDeviceSynchronize();
     const auto w0 = std::chrono::system_clock::now();
     double ms_sum = 0; int n = 0;
     std::vector<double> ghz_all, cyc_all;
     while (std::chrono::duration<double>(std::chrono::system_clock::now() - w0).count() < seconds) {
         hipEventRecord(e0);
-        k3<MODE><<<grid, 512, lds>>>(img, bs, d, clk, tape, tape_per_wg, steps);
+        k3<MODE><<<grid, 512, lds>>>(img, bs, d, clk, tape, tape_per_wg, window, steps);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -465,6 +467,8 @@ int main(int argc, char **argv) {
         run3<1>("... + tape stores (2 KiB / wave / step)", sec);
         run3<8>("ring step + skip block", sec);
         run3<9>("... + skip block + tape stores", sec);
+        run3<1>("tape stores into a 128 KB window / WG (MALL)", sec, 128 << 10);
+        run3<1>("tape stores into a 16 KB window / WG (L2)", sec, 16 << 10);
         return 0;
     }
     if (argc > 1) {      // round 3: MFMA shape A/B on the library's ring step, random weights AND random activations
