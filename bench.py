@@ -57,8 +57,8 @@ def mlp_flops(depth, width, F=21):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=100)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=300)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--mode', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--image', type=int, default=128)
     ap.add_argument('--ngeo', type=int, default=64)
