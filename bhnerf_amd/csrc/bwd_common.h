@@ -1,0 +1,61 @@
+// Declarations shared by the backward translation units (fused_bwd.hip: generic tape backward; fused_bwd128.hip: the
+// fused delta-chain + weight-gradient kernel of width-128 networks).
+#pragma once
+#include "fused_common.h"
+
+struct TapeLayout {
+    long long NQ;                              // 32-point groups on the tape
+    long long h_off[BHN_MAX_LAYERS + 1];       // h_l, l = 1..depth  (inputs of layer l)
+    long long ga_off[BHN_MAX_LAYERS];          // gA_l, l = 0..depth-1
+    long long enc_off, dout_off, mask_off, e_off, total;   // mask: relu bits [group][layer][word][lane]; e: [group][32] f32
+    // the recorded h_l / gA_l tensors are equally spaced: h_off[l] = h_lin + l * lin_stride, ga_off[l] = ga_lin + l * lin_stride.
+    // The producers address them this way: indexing the offset ARRAYS with the run-time layer made the compiler fetch
+    // the entry from the kernel-argument segment in every ring step (s_load + s_waitcnt lgkmcnt(0), which also drains
+    // the LDS prefetch queue).
+    long long h_lin, ga_lin, lin_stride;
+    // bf16: h_1 = relu(W_0^T enc + b_0) is NOT on the tape; the dW job of layer 1 recomputes it from the encoded
+    // inputs kept a second time in their forward (point-on-lane) fragment form -- 64 B instead of 512 B per point
+    long long encp_off;
+    int drop_h1;
+    // bf16, depth >= 3: gA_{depth-1} = relu'(a_{depth-1}) * W_out * dout is NOT on the tape either; the dW job of layer
+    // depth-1 rebuilds it from the h_depth tiles (relu bits = "!= 0"), W_out and dout kept in f32 behind the dout
+    // tile, and also makes dW_out from the same h_depth tiles (no separate output-layer job): -1 KB per point of
+    // tape traffic (chain write + dW read of gA_{depth-1}, second dW read of h_depth)
+    int drop_ga;
+    // bf16, width 256, depth >= 3: gA_0 is not on the tape: the delta chain stops at gA_1 (16 instead of 24 ring steps per
+    // tile at depth 4) and the dW job of layer 0 rebuilds gA_0 = (h_1 != 0) (.) W_1 gA_1 from the gA_1 tiles it streams
+    // instead (the same bytes), with its rows of W_1 in registers (dw_body_first_r)
+    int drop_ga0;
+    long long dout_stride;                     // bytes per group of the dout region: tile (+ 32 f32 when drop_ga)
+    // width-128 bf16 networks of depth <= 4 (fused_bwd128.hip): the tape holds only what the FORWARD knows -- h_1 .. h_depth,
+    // the encoded inputs (slot 31 set to 1: the bias column of the fused dW GEMMs) and e; no relu bits (the fused
+    // backward reads them off the h tiles), no gA, no dout
+    int fused128;
+};
+
+struct BwdArgs {
+    FusedArgs f;
+    char *tape;
+    TapeLayout t;
+    // dW jobs: job j = layer j (0..depth), workgroups [wg_begin[j], wg_begin[j+1])
+    int wg_begin[BHN_MAX_LAYERS + 2];
+    int accumulate;                            // 1: add to what the slabs already hold
+    int debug;                                 // measurement aid: 1 skip MFMA work, 2 skip tape loads
+    long long *ts_buf;                         // measurement aid: ring-step time stamps (debug bit 9)
+    long long wrap;                            // measurement aid (debug build): tape tile addresses wrap after this many groups
+    int policy;                                // measurement aid (debug build): 0 nt, 1 plain, 2 sc1 tape stores / loads
+    float *dparams;
+    long long kernel_off[BHN_MAX_LAYERS + 1], bias_off[BHN_MAX_LAYERS + 1];
+    int in_dim[BHN_MAX_LAYERS + 1];
+    int F;
+    int width_true;                            // the model's hidden width (flat parameter layout); W is the kernel width
+    long long nparams;
+};
+
+
+// fused_bwd128.hip: the fused delta-chain + weight-gradient backward of width-128 bf16 networks (depth 4)
+bool bwd128_supported(int mode, int kernel_width, int depth);
+size_t bwd128_slab_bytes(int grid);
+void bwd128_tape_layout(int depth, long long NQ, TapeLayout *t);
+int bwd128_launch(const BwdArgs &A, int depth, int grid, hipStream_t st);
+int reduce128_launch(const BwdArgs &A, int depth, int nslabs, hipStream_t st);

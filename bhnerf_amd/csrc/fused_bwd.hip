@@ -14,6 +14,7 @@
 //   reduce_kernel sums the slabs of each layer's workgroups into the flat dparams (flax tree order).
 #include <utility>
 #include "fused_common.h"
+#include "bwd_common.h"
 
 #ifndef BHN_CHAIN_STAMPS
 #define BHN_CHAIN_STAMPS 0      // 1: ring-step time stamps in the chain kernels (tools/dbg_chain_steps.py needs this build)
@@ -39,51 +40,6 @@
 #ifndef BHN_TAPED_DIST
 #define BHN_TAPED_DIST 7         // weight chunks in flight in the training-forward / delta-chain kernels (bf16; 4 measured 2 % slower)
 #endif
-
-struct TapeLayout {
-    long long NQ;                              // 32-point groups on the tape
-    long long h_off[BHN_MAX_LAYERS + 1];       // h_l, l = 1..depth  (inputs of layer l)
-    long long ga_off[BHN_MAX_LAYERS];          // gA_l, l = 0..depth-1
-    long long enc_off, dout_off, mask_off, e_off, total;   // mask: relu bits [group][layer][word][lane]; e: [group][32] f32
-    // the recorded h_l / gA_l tensors are equally spaced: h_off[l] = h_lin + l * lin_stride, ga_off[l] = ga_lin + l * lin_stride.
-    // The producers address them this way: indexing the offset ARRAYS with the run-time layer made the compiler fetch
-    // the entry from the kernel-argument segment in every ring step (s_load + s_waitcnt lgkmcnt(0), which also drains
-    // the LDS prefetch queue).
-    long long h_lin, ga_lin, lin_stride;
-    // bf16: h_1 = relu(W_0^T enc + b_0) is NOT on the tape; the dW job of layer 1 recomputes it from the encoded
-    // inputs kept a second time in their forward (point-on-lane) fragment form -- 64 B instead of 512 B per point
-    long long encp_off;
-    int drop_h1;
-    // bf16, depth >= 3: gA_{depth-1} = relu'(a_{depth-1}) * W_out * dout is NOT on the tape either; the dW job of layer
-    // depth-1 rebuilds it from the h_depth tiles (relu bits = "!= 0"), W_out and dout kept in f32 behind the dout
-    // tile, and also makes dW_out from the same h_depth tiles (no separate output-layer job): -1 KB per point of
-    // tape traffic (chain write + dW read of gA_{depth-1}, second dW read of h_depth)
-    int drop_ga;
-    // bf16, width 256, depth >= 3: gA_0 is not on the tape: the delta chain stops at gA_1 (16 instead of 24 ring steps per
-    // tile at depth 4) and the dW job of layer 0 rebuilds gA_0 = (h_1 != 0) (.) W_1 gA_1 from the gA_1 tiles it streams
-    // instead (the same bytes), with its rows of W_1 in registers (dw_body_first_r)
-    int drop_ga0;
-    long long dout_stride;                     // bytes per group of the dout region: tile (+ 32 f32 when drop_ga)
-};
-
-struct BwdArgs {
-    FusedArgs f;
-    char *tape;
-    TapeLayout t;
-    // dW jobs: job j = layer j (0..depth), workgroups [wg_begin[j], wg_begin[j+1])
-    int wg_begin[BHN_MAX_LAYERS + 2];
-    int accumulate;                            // 1: add to what the slabs already hold
-    int debug;                                 // measurement aid: 1 skip MFMA work, 2 skip tape loads
-    long long *ts_buf;                         // measurement aid: ring-step time stamps (debug bit 9)
-    long long wrap;                            // measurement aid (debug build): tape tile addresses wrap after this many groups
-    int policy;                                // measurement aid (debug build): 0 nt, 1 plain, 2 sc1 tape stores / loads
-    float *dparams;
-    long long kernel_off[BHN_MAX_LAYERS + 1], bias_off[BHN_MAX_LAYERS + 1];
-    int in_dim[BHN_MAX_LAYERS + 1];
-    int F;
-    int width_true;                            // the model's hidden width (flat parameter layout); W is the kernel width
-    long long nparams;
-};
 
 template <int W, class Pol>
 struct BwdGeom {
@@ -458,7 +414,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
         const bool inb = (MODE != MODE_CHAIN) ? in.inb : cin.inb;
         const long long q = tile * Pol::NWAVES + wvu;                    // 32-point group on the tape
         const long long qs = BHN_DBG(A.wrap) ? q % A.wrap : q;           // (debug: h / gA tiles wrap into a cache-resident window)
-        unsigned *mask_g = reinterpret_cast<unsigned *>(A.tape + A.t.mask_off) + q * (long long)(a.depth * MW * 64);
+        unsigned *mask_g = A.t.fused128 ? nullptr : reinterpret_cast<unsigned *>(A.tape + A.t.mask_off) + q * (long long)(a.depth * MW * 64);
         float *e_g = reinterpret_cast<float *>(A.tape + A.t.e_off) + q * 32;
         frag enc[2], act[KS], next[KS];
         bool live = false;
@@ -467,7 +423,13 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
         if constexpr (MODE != MODE_CHAIN) {
             point_prologue<Pol, DEG>(a, in, enc, live);
             // the encoded inputs are the B operand of dW_0 and of the skip layer
-            em.emit(A.tape + A.t.enc_off + q * TB, enc[0], enc[1], edbg);
+            if (A.t.fused128) {
+                // slot 31 (k-step 1, lane half 1, element 7; an unused slot: zero weight rows) carries 1 on the tape: against
+                // it the fused dW GEMMs of fused_bwd128.hip produce the bias gradients
+                frag e1 = enc[1];
+                if (h) Pol::set(e1, 7, 1.f);
+                em.emit(A.tape + A.t.enc_off + q * TB, enc[0], e1, edbg);
+            } else em.emit(A.tape + A.t.enc_off + q * TB, enc[0], enc[1], edbg);
             const bool drop_h1 = A.t.drop_h1;
             if (drop_h1 && !(edbg & 2)) {        // ... and, as they are, the A operand from which dW_1 recomputes h_1
                 __builtin_nontemporal_store(enc[0], reinterpret_cast<frag *>(A.tape + A.t.encp_off + q * TB + lane * 16));
@@ -491,7 +453,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
                     }
                     if (dst) em.emit(dst + (long long)m * TB, d0, d1, edbg);
                 }
-            } l0{em, drop_h1 ? nullptr : A.tape + h_lin + lin_stride + qs * MT * TB, mask_g + lane,
+            } l0{em, drop_h1 ? nullptr : A.tape + h_lin + lin_stride + qs * MT * TB, mask_g ? mask_g + lane : nullptr,
                  nullptr, 0u, edbg};
             f32x16 pend;
             layer0_step<W, Pol, RG, YS0>(rs, ap, enc, act, bias_lds, h, pend, l0);
@@ -514,7 +476,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
                     const int widx = (pl_layer * MW + (pm >> 1)) * 64 + lane;
                     const bool no_h = drop_h1 && pl_layer == 0;     // layer 0's last tile: relu bits only
                     TapePost<Pol, true> post(pend, d0, d1, 0u, em, A.tape + h_lin + (pl_layer + 1) * lin_stride + (qs * MT + pm) * TB,
-                                                 mask_g + widx, nullptr,
+                                                 mask_g ? mask_g + widx : nullptr, nullptr,
                                                  macc, pm & 1, pm == MT - 1, no_h ? (edbg | 2) : edbg);
                     // bias rows of the next tile: (l, m+1), or the first tile of the next sequence part
                     const float *bn = (out || (m == MT - 1 && l + 1 > a.depth)) ? nullptr : bl + 32 * (m + 1);
@@ -1644,20 +1606,28 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
     constexpr int grid_override = 0, job1_w = BHN_JOB1_W, jobl_w = BHN_JOBL_W, job0r_w = BHN_JOB0R_W;
 #endif
     const int grid_dw = grid_override > 0 ? grid_override : ncu;        // one dW workgroup per CU
-    const size_t slab_bytes = align_up((size_t)grid_dw * BG::SLAB_FLOATS * 4, 256);
+    MlpShape s;
+    {
+        const int rcq = bhn_mlp_shape(m, &s);
+        if (rcq != BHN_OK) return rcq;
+    }
+    // width 128, bf16, depth 4 (the reference's default network): delta chain and weight gradients fused in one kernel, the
+    // gradient accumulated on chip, a tape of h_l / enc / e only (fused_bwd128.hip)
+    const bool f128 = bwd128_supported(Pol::MODE, W, s.depth);
+    const size_t slab_bytes = align_up(f128 ? bwd128_slab_bytes(ncu) : (size_t)grid_dw * BG::SLAB_FLOATS * 4, 256);
+    auto layout = [&](long long NQ, TapeLayout *t) {
+        if (f128) bwd128_tape_layout(s.depth, NQ, t);
+        else tape_layout<W, Pol>(s.depth, s.depth >= 2 && s.skip_in[1], NQ, t);
+    };
     if (what == RUN_QUERY) {
         const long long tiles = (query_P + Pol::NWAVES * 32 - 1) / (Pol::NWAVES * 32) * query_B;
         TapeLayout t;
-        MlpShape sq;
-        const int rcq = bhn_mlp_shape(m, &sq);
-        if (rcq != BHN_OK) return rcq;
-        tape_layout<W, Pol>(sq.depth, sq.depth >= 2 && sq.skip_in[1], tiles * Pol::NWAVES, &t);
+        layout(tiles * Pol::NWAVES, &t);
         *query_bytes = slab_bytes + (size_t)t.total;
         return BHN_OK;
     }
     BwdArgs A;
     memset(&A, 0, sizeof(A));
-    MlpShape s;
     int rc = fused_fill_args(m, mode, packed, geom, fr, true, &A.f, &s, Pol::NWAVES);
     if (rc != BHN_OK) return rc;
     BHN_CHECK_ARG(workspace, "null workspace");
@@ -1666,8 +1636,7 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
     // frames per pass so that the tape fits the workspace (same layout function as the size query)
     const long long groups_per_frame = (long long)A.f.tiles_per_frame * Pol::NWAVES;
     TapeLayout t1;
-    const bool l1enc = depth >= 2 && s.skip_in[1];
-    tape_layout<W, Pol>(depth, l1enc, groups_per_frame, &t1);
+    layout(groups_per_frame, &t1);
     if (workspace_bytes < slab_bytes + (size_t)t1.total) {
         bhn_set_error("render_bwd workspace too small: %zu bytes, need >= %zu (slabs %zu + one frame of tape %lld)",
                       workspace_bytes, slab_bytes + (size_t)t1.total, slab_bytes, t1.total);
@@ -1676,7 +1645,7 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
     long long fpp = 1;
     while (fpp < A.f.B) {
         TapeLayout tn;
-        tape_layout<W, Pol>(depth, l1enc, groups_per_frame * (fpp + 1), &tn);
+        layout(groups_per_frame * (fpp + 1), &tn);
         if (slab_bytes + (size_t)tn.total > workspace_bytes) break;
         ++fpp;
     }
@@ -1760,6 +1729,7 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
     BHN_CHECK_ARG(lds_taped <= 160 * 1024 && lds_dw <= 160 * 1024, "LDS budget exceeded (chain %zu, dw %zu)", lds_taped, lds_dw);
     const int B_total = A.f.B;
     const double *tM0 = A.f.tM0;
+    int nslabs128 = 0;
     if (what == RUN_FWD_TRAIN)
         BHN_HIP(hipMemsetAsync(images, 0, sizeof(float) * (size_t)B_total * A.f.Sx * A.f.R, st));
     for (int b0 = 0, pass = 0; b0 < B_total; b0 += (int)fpp, ++pass) {
@@ -1768,7 +1738,7 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
         A.f.tM0 = tM0 + b0;
         A.f.dimages = dimages ? dimages + (long long)b0 * A.f.Sx * A.f.R : nullptr;
         A.f.total_tiles = (long long)A.f.tiles_per_frame * nb;
-        tape_layout<W, Pol>(depth, l1enc, A.f.total_tiles * Pol::NWAVES, &A.t);
+        layout(A.f.total_tiles * Pol::NWAVES, &A.t);
         A.accumulate = pass > 0;
         A.debug = g_bwd_debug;
 #ifdef BHN_DEBUG
@@ -1788,6 +1758,20 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
             return (events && i < n_events && events[i] && pass == 0) ? hipEventRecord((hipEvent_t)events[i], st) : hipSuccess;
         };
         BHN_HIP(mark(0));
+        if (f128) {                          // kernel slot 0 = the fused chain + dW kernel, slot 1 empty
+            if (what == RUN_RECOMPUTE) {
+                hipLaunchKernelGGL(k_fwd, dim3((unsigned)grid), dim3(Pol::NTHREADS), lds_taped, st, A);
+                BHN_HIP(hipGetLastError());
+            }
+            long long g128 = A.t.NQ / 4;
+            if (g128 > ncu) g128 = ncu;
+            if ((int)g128 > nslabs128) nslabs128 = (int)g128;
+            const int rc128 = bwd128_launch(A, depth, (int)g128, st);
+            if (rc128 != BHN_OK) return rc128;
+            BHN_HIP(mark(1));
+            BHN_HIP(mark(2));
+            continue;
+        }
         if (g_bwd_stages & 1) {
             if (what == RUN_RECOMPUTE) {     // forward again (tape only: A.f.images is null), then the chain
                 hipLaunchKernelGGL(k_fwd, dim3((unsigned)grid), dim3(Pol::NTHREADS), lds_taped, st, A);
@@ -1801,7 +1785,10 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
         BHN_HIP(hipGetLastError());
         BHN_HIP(mark(2));
     }
-    if (what != RUN_FWD_TRAIN && (g_bwd_stages & 4)) hipLaunchKernelGGL((reduce_kernel<W, Pol>), dim3((unsigned)ReduceGeom<W, Pol>::blocks(depth, (unsigned)A.f.skip_mask)), dim3(256), 0, st, A);
+    if (what != RUN_FWD_TRAIN && f128) {
+        const int rcr = reduce128_launch(A, depth, nslabs128, st);
+        if (rcr != BHN_OK) return rcr;
+    } else if (what != RUN_FWD_TRAIN && (g_bwd_stages & 4)) hipLaunchKernelGGL((reduce_kernel<W, Pol>), dim3((unsigned)ReduceGeom<W, Pol>::blocks(depth, (unsigned)A.f.skip_mask)), dim3(256), 0, st, A);
     BHN_HIP(hipGetLastError());
     if (events && n_events > 3 && events[3]) BHN_HIP(hipEventRecord((hipEvent_t)events[3], st));
     return BHN_OK;

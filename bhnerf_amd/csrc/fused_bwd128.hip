@@ -1,0 +1,554 @@
+// Fused backward of width-128 bf16 networks (the reference's default MLP, network.py:19-20): delta chain AND weight-gradient
+// GEMMs in ONE kernel, with the gradient of every layer accumulated in the registers of the workgroup.
+//
+// Why a kernel of its own.  At width 256 the weight gradient of all layers (833 KB of f32) does not fit a compute unit, so
+// the generic backward (fused_bwd.hip) sends every layer input h_l AND every pre-activation gradient gA_l through an HBM
+// tape to a second kernel whose workgroups own one layer each: 3.3 KB per point and step.  At width 128 the whole
+// gradient is 57,344 + 128 floats = 225 KB: it fits the 512 KB register file of one CU (4 waves x 256 accumulator
+// registers), so gA_l never leaves the chip and the tape shrinks to what the forward knows (h_l, encoded inputs, e:
+// 1.1 KB per point, written once and read once).
+//
+// Structure (one workgroup = 4 waves, one per SIMD, 512 registers each; one workgroup per CU, persistent).  A workgroup
+// iteration takes 128 points (four 32-point tape groups).  Activations live in LDS as [point][feature] images whose 256-byte
+// rows are stored in 16-byte chunks with the XOR swizzle that makes BOTH access patterns conflict-free
+// (cdna_hip_programming.md T10, "one image for row reads and transposed reads", form (b)):
+//     off(row, ch) = 256 row + 16 (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)))
+//   * row reads  (ds_read_b128): lane (point, half) takes chunk 2 ks + half = the B fragment of k-step ks of a product that
+//     sums over FEATURES (the delta chain  gA_{l-1} = relu' (.) W_l gA_l);
+//   * transposed reads (ds_read_b64_tr_b16): lane = feature, 8 points in the registers = the A / B fragments of a product
+//     that sums over POINTS (dW_l^T = gA_l^T [h_l | enc]).
+// The 8 features of a chunk are in the forward's canonical fragment order (fused_common.h), so a chunk IS the fragment the
+// producer holds: the forward's tape tiles are copied in by LDS-DMA with the lanes' global offsets permuted (free), the
+// chain's output tiles are written as they leave the accumulators (two ds_write_b128 per tile).  Feature positions inside a
+// 32-feature tile are therefore permuted ("virtual" position v = 8 (2 s + h) + e holds feature 16 s + 4 h + (e & 3) +
+// 8 (e >> 2)) identically for every operand; reduce128_kernel undoes the permutation when it writes the flat gradient.
+//
+// Per layer l = depth-1 .. 1, wave (i, j):
+//   chain   tiles m in {2i, 2i+1} x point blocks {2j, 2j+1} of gA_{l-1}: A = its 16 fragments of the transposed weight image
+//           (registers, loaded from L2 one phase ahead), B = row reads of gA_l: every B fragment feeds two MFMAs;
+//   dW_l    accumulator tiles m in {2i, 2i+1} x n in {2j, 2j+1} of gA_l^T h_l plus (m = 2i + j) x the encoded-input tile:
+//           the encoded inputs carry a 1 in slot 31, so that tile's column 31 is the bias gradient of EVERY layer and its
+//           other columns the skip layer's encoded-input rows (discarded for the other layers); K = the 128 points.
+// Layer 0: dW_0 = gA_0^T enc, one tile per wave.  Output layer: dW_out = sum_p dout_p h_depth by v_dot2 on transposed reads;
+// gA_{depth-1} = relu' (.) bf16(dout) with W_out folded into the weight image and applied to dW_{depth-1} at the reduce
+// (bhn_folds_wout: the same arithmetic as the generic path).
+// 16 accumulator tiles (256 registers) per wave at depth 4; deeper networks use the generic path.
+#include <type_traits>
+#include "bwd_common.h"
+
+namespace {
+
+constexpr int W128 = 128, MT = 4, KS = 8, TB = 2048;
+constexpr int IMG = 32768;                                         // 128 points x 128 features, bf16
+constexpr int OFF_GA = 0, OFF_H = 2 * IMG, OFF_E = 4 * IMG;         // two gA images, two h images, two encoded-input images (8 KiB)
+constexpr int ENC_IMG = 8192;
+constexpr int OFF_DOUT = OFF_E + 2 * ENC_IMG;                       // f32 dout of the 128 points
+constexpr int OFF_DPK = OFF_DOUT + 512;                             // the same as bf16 (dW_out operand)
+constexpr int LDS_BYTES = OFF_DPK + 256;
+constexpr int CB = (KS + 2) * 1024;                                 // chunk bytes of the packed weight images (fused_common.h Pack<128>)
+constexpr int SLAB_TILES = 65;                                      // 60 hidden tiles + 4 layer-0 tiles + the output layer's row / biases
+constexpr int SLAB_FLOATS128 = SLAB_TILES * 1024;
+
+typedef PolBF16 Pol;
+typedef Pol::frag frag;
+
+DEVI frag lds_row(const char *smem, unsigned off) { return *reinterpret_cast<const frag *>(smem + off); }
+DEVI void lds_put(char *smem, unsigned off, const frag &f) { *reinterpret_cast<frag *>(smem + off) = f; }
+
+// two transposed reads = one K = points fragment (8 points of one feature per lane)
+DEVI frag tr2(const char *smem, unsigned off_a, unsigned off_b) {
+    typedef s16x4 __attribute__((address_space(3))) * lds_v4;
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(smem + off_a));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(smem + off_b));
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(frag, v);
+}
+
+DEVI u32x4 make_rsrc(const char *p) {
+    const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return u32x4{lo, hi & 0xffffu, 0x7fffffffu, 0x00020000u};
+}
+// one wave copies 1 KiB global -> LDS: lane i's 16 bytes come from rs.base + soff + voff(i) and land at lds + 16 i
+DEVI void dma_piece(const u32x4 &rs, unsigned soff, unsigned lds, unsigned voff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen nt lds" ::"s"(lds), "v"(voff), "s"(rs), "s"(soff) : "memory", "m0");
+}
+
+// 0xffff in every 16-bit half of u that is a nonzero bf16 (u: non-negative bf16 pairs, i.e. relu outputs)
+DEVI unsigned nz_mask(unsigned u) {
+    typedef short i16x2 __attribute__((ext_vector_type(2)));
+    const unsigned sgn = u + 0x7fff7fffu;                          // sets the half's sign bit iff it is nonzero; no carry between halves
+    return __builtin_bit_cast(unsigned, __builtin_bit_cast(i16x2, sgn) >> (i16x2){15, 15});
+}
+
+
+// SKIPL: the hidden layer whose input is concat[h, enc] (network.py:59-61; 3 at depth 4 with do_skip), or 0 for none
+template <int DEPTH, int SKIPL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void bwd128_kernel(BwdArgs A) {
+    static_assert(DEPTH >= 2 && DEPTH <= 4, "14 accumulator tiles per wave at depth 4");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const FusedArgs &a = A.f;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wv >> 1, wj = wv & 1;
+    const int pl = lane & 31, hh = lane >> 5;
+
+    // ---- per-lane address parts (bytes) ------------------------------------------------------------------------------
+    // row access of point block 2j + pi: 256 (32 pb + n) + 16 ((half ^ swz) & 15); chunk pair C (even) is reached by ^ 16 C
+    unsigned rowb[2];
+    {
+        const int swz = ((pl & 3) << 2) | ((pl >> 2) & 3);
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi) rowb[pi] = 256u * (32 * (2 * wj + pi) + pl) + 16u * ((hh ^ swz) & 15);
+    }
+    // transposed read of feature tile T: first / second 4-point block of the lane's 8 points of a 16-point k-step
+    const int tg = lane >> 4, tcg = tg & 1, tkh = tg >> 1, tq = (lane & 15) >> 2, tp = lane & 3;
+    auto tr_first = [&](int T) -> unsigned {
+        const int lc = 2 * tcg + (tp >> 1), swa = (tq << 2) | (2 * tkh);
+        return 256u * (8 * tkh + tq) + 16u * (((4 * T) ^ lc ^ swa) & 15) + 8u * (tp & 1);
+    };
+    auto tr_second = [&](int T) -> unsigned {
+        const int lc = 2 * tcg + (tp >> 1), swb = (tq << 2) | (2 * tkh) | 1;
+        return 256u * (8 * tkh + tq + 4) + 16u * (((4 * T) ^ lc ^ swb) & 15) + 8u * (tp & 1);
+    };
+    // this wave's tiles: chain / dW rows m0 = 2i, m1 = 2i + 1; dW columns n0 = 2j, n1 = 2j + 1; enc tile with m_e = 2i + j;
+    // layer 0 and the output layer: tile wv
+    const unsigned trA_m0 = tr_first(2 * wi), trB_m0 = tr_second(2 * wi), trA_m1 = tr_first(2 * wi + 1), trB_m1 = tr_second(2 * wi + 1);
+    const unsigned trA_n0 = tr_first(2 * wj), trB_n0 = tr_second(2 * wj), trA_n1 = tr_first(2 * wj + 1), trB_n1 = tr_second(2 * wj + 1);
+    const unsigned trA_w = tr_first(wv), trB_w = tr_second(wv);
+    const unsigned trE = 64u * (8 * tkh + tq) + 32u * tcg + 8u * tp;      // encoded-input image: 64-byte rows, no swizzle
+
+    // LDS-DMA lane offsets on the GLOBAL side (tape tiles are in the producer's slot layout, TapeEmit::native_off)
+    const unsigned voffH = 2048u * ((((lane & 15) >> 2) ^ (lane >> 4)) & 3) + 64u * (((lane & 3) ^ wv) & 3) + 16u * (lane >> 4);
+    const unsigned voffE = 16u * ((lane >> 2) & 3) + 64u * (lane & 3) + 256u * (lane >> 4);
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<unsigned long long>(smem));
+
+    const long long nquads = A.t.NQ >> 2;
+    const long long h_stride = A.t.lin_stride;
+    // image of h_l (l = 1..DEPTH) of quad Q -> H buffer hb (0 / 1): 32 pieces of 4 rows, wave w issues pieces w + 4 t
+    auto dma_h = [&](int l, long long Q, int hb) {
+        const u32x4 rs = make_rsrc(A.tape + A.t.h_lin + (long long)l * h_stride + Q * (4ll * MT * TB));
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int pb = t >> 1, kk = wv + 4 * (t & 1), k = wv + 4 * t;
+            dma_piece(rs, (unsigned)(pb * (MT * TB) + 256 * kk), lds0 + OFF_H + hb * IMG + 1024 * k, voffH);
+        }
+    };
+    auto dma_enc = [&](long long Q, int eb) {
+        const u32x4 rs = make_rsrc(A.tape + A.t.enc_off + Q * (4ll * TB));
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int e = wv + 4 * t, pb = e >> 1, half = e & 1;
+            dma_piece(rs, (unsigned)(pb * TB + 1024 * half), lds0 + OFF_E + eb * ENC_IMG + 1024 * e, voffE);
+        }
+    };
+    // dout of point pl of group 4 Q + wv: dout128_kernel has turned the tape's e into dout = dE e (1 - e) in place
+    const float *dout_g = reinterpret_cast<const float *>(A.tape + A.t.e_off);
+    auto point_dout = [&](long long Q) -> float { return dout_g[(4 * Q + wv) * 32 + pl]; };
+    auto put_dout = [&](float d) {
+        if (lane < 32) {
+            reinterpret_cast<float *>(smem + OFF_DOUT)[32 * wv + pl] = d;
+            reinterpret_cast<__bf16 *>(smem + OFF_DPK)[32 * wv + pl] = (__bf16)d;
+        }
+    };
+    // this wave's 16 fragments of the transposed weight image of hidden layer l (rows m0, m1), plain loads from L2
+    const char *wimg = a.packed + a.bwd_off + (size_t)(2 * wi) * CB + lane * 16;
+    auto load_w = [&](int l, frag (&wf)[2][KS]) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                wf[mi][ks] = *reinterpret_cast<const frag *>(wimg + (size_t)((l - 1) * MT + mi) * CB + ks * 1024);
+    };
+    auto use_w = [&](frag (&wf)[2][KS]) {          // the loads have landed (the compiler waits here, at a drain point of the schedule)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ks = 0; ks < KS; ks += 4) asm volatile("" : "+v"(wf[mi][ks]), "+v"(wf[mi][ks + 1]), "+v"(wf[mi][ks + 2]), "+v"(wf[mi][ks + 3]));
+    };
+    auto drain_and_barrier = [&]() {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+
+    // ---- accumulators: hidden layer l = 1..DEPTH-1: (m0,n0) (m0,n1) (m1,n0) (m1,n1); the skip layer's (m_e, enc) tile;
+    //      layer 0: (wv, enc).  The enc tile's column 31 is the bias gradient (slot 31 of the recorded inputs is 1); the
+    //      other hidden layers sum their bias from the A fragments (v_dot2 against (1, 1): bsum) ----
+    f32x16 acc[DEPTH - 1][4], acc_e, acc0;
+#pragma unroll
+    for (int l = 0; l < DEPTH - 1; ++l)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { const f32x16 z = {}; acc[l][t] = z; }
+    { const f32x16 z = {}; acc_e = z; acc0 = z; }
+    float bsum[DEPTH - 1];
+#pragma unroll
+    for (int l = 0; l < DEPTH - 1; ++l) bsum[l] = 0.f;
+    float orow = 0.f, bout = 0.f;
+
+    // ---- phases ------------------------------------------------------------------------------------------------------
+    // delta chain through hidden layer l, point block 2j + pi: tiles m0, m1 of W_l gA_l (ga_in: image offset of gA_l) ...
+    auto chain_mma = [&](const frag (&wf)[2][KS], unsigned ga_in, int pi, f32x16 (&c)[2]) {
+        { const f32x16 z = {}; c[0] = z; c[1] = z; }
+        frag bq[3];
+        bq[0] = lds_row(smem, ga_in + rowb[pi]);
+        bq[1] = lds_row(smem, ga_in + (rowb[pi] ^ 32u));
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks + 2 < KS) bq[(ks + 2) % 3] = lds_row(smem, ga_in + (rowb[pi] ^ (32u * (ks + 2))));
+            __builtin_amdgcn_sched_barrier(0);
+            c[0] = Pol::mma(wf[0][ks], bq[ks % 3], c[0]);
+            c[1] = Pol::mma(wf[1][ks], bq[ks % 3], c[1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // ... and their epilogue: gA_{l-1} = relu'(a_{l-1}) (.) c, relu' read off the h_l image (h_l = relu(a_{l-1}) as bf16)
+    auto chain_post = [&](const f32x16 (&c)[2], int pi, unsigned h_img, unsigned ga_out) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const unsigned off = rowb[pi] ^ (16u * (4 * (2 * wi + mi) + 2 * s2));
+                const u32x4 hv = __builtin_bit_cast(u32x4, lds_row(smem, h_img + off));
+                u32x4 o;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) o[d] = Pol::pack_a(c[mi][8 * s2 + 2 * d], c[mi][8 * s2 + 2 * d + 1]) & nz_mask(hv[d]);
+                lds_put(smem, ga_out + off, __builtin_bit_cast(frag, o));
+            }
+    };
+    // dW of a hidden layer: t[0..3] += gA^T h over the wave's 2 x 2 tiles; ENC: te += gA[m_e]^T enc, else bs += the bias of
+    // row tile m_e (sum over the points of the A fragments); K = the 128 points
+    auto dw_phase = [&](auto enc_tag, unsigned ga_img, unsigned h_img, unsigned e_img, f32x16 (&t)[4], f32x16 &te, float &bs) {
+        constexpr bool ENC = decltype(enc_tag)::value;
+        struct KF { frag a0, a1, b0, b1, be; };
+        auto fetch = [&](int k) {
+            KF f;
+            const unsigned ko = 4096u * k;
+            f.a0 = tr2(smem, ga_img + trA_m0 + ko, ga_img + trB_m0 + ko);
+            f.a1 = tr2(smem, ga_img + trA_m1 + ko, ga_img + trB_m1 + ko);
+            f.b0 = tr2(smem, h_img + trA_n0 + ko, h_img + trB_n0 + ko);
+            f.b1 = tr2(smem, h_img + trA_n1 + ko, h_img + trB_n1 + ko);
+            if constexpr (ENC) f.be = tr2(smem, e_img + trE + 1024u * k, e_img + trE + 1024u * k + 256u);
+            else f.be = f.b0;
+            return f;
+        };
+        KF cur = fetch(0);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            KF nx = cur;
+            if (k + 1 < 8) nx = fetch(k + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            t[0] = Pol::mma(cur.a0, cur.b0, t[0]);
+            t[1] = Pol::mma(cur.a0, cur.b1, t[1]);
+            t[2] = Pol::mma(cur.a1, cur.b0, t[2]);
+            t[3] = Pol::mma(cur.a1, cur.b1, t[3]);
+            const frag ae = wj ? cur.a1 : cur.a0;
+            if constexpr (ENC) te = Pol::mma(ae, cur.be, te);
+            else bs = Pol::sum8(ae, bs);
+            __builtin_amdgcn_sched_barrier(0);
+            cur = nx;
+        }
+    };
+    // dW of layer 0: tile m = wv of gA_0^T enc
+    auto dw0_phase = [&](unsigned ga_img, unsigned e_img) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const unsigned ko = 4096u * k;
+            const frag af = tr2(smem, ga_img + trA_w + ko, ga_img + trB_w + ko);
+            const frag be = tr2(smem, e_img + trE + 1024u * k, e_img + trE + 1024u * k + 256u);
+            acc0 = Pol::mma(af, be, acc0);
+        }
+    };
+    // front: gA_{depth-1} (without W_out, common.h bhn_folds_wout) = relu'(a_{depth-1}) (.) bf16(dout) from the h_depth image;
+    // the output layer's row: dW_out[f] += sum_p dout_p h_depth[p][f] (feature tile wv)
+    auto front = [&](unsigned h_img, unsigned ga_out) {
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi) {
+            const float d = reinterpret_cast<const float *>(smem + OFF_DOUT)[32 * (2 * wj + pi) + pl];
+            const Pol::bf16x2 d2 = {(__bf16)d, (__bf16)d};
+            const unsigned dd = __builtin_bit_cast(unsigned, d2);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const unsigned off = rowb[pi] ^ (16u * (4 * (2 * wi + mi) + 2 * s2));
+                    const u32x4 hv = __builtin_bit_cast(u32x4, lds_row(smem, h_img + off));
+                    u32x4 o;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o[k] = dd & nz_mask(hv[k]);
+                    lds_put(smem, ga_out + off, __builtin_bit_cast(frag, o));
+                }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const frag hf = tr2(smem, h_img + trA_w + 4096u * k, h_img + trB_w + 4096u * k);
+            const frag dp = *reinterpret_cast<const frag *>(smem + OFF_DPK + 2 * (16 * k + 8 * (lane >> 5)));   // the lane's 8 points
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const Pol::bf16x2 hp = {hf[2 * i], hf[2 * i + 1]}, dq = {dp[2 * i], dp[2 * i + 1]};
+                orow = __builtin_amdgcn_fdot2_f32_bf16(hp, dq, orow, false);
+            }
+        }
+    };
+
+    // ---- prelude: the first quad's h_depth, h_{depth-1}, enc; its dout; the top layer's weights --------------------------
+    long long Q = blockIdx.x;
+    frag wf[2][KS];
+    float dnext = 0.f;
+    int eb = 0;
+    if (Q < nquads) {
+        dma_h(DEPTH, Q, 0);
+        dma_h(DEPTH - 1, Q, 1);
+        dma_enc(Q, 0);
+        dnext = point_dout(Q);
+        load_w(DEPTH - 1, wf);
+        use_w(wf);
+    }
+    for (; Q < nquads; Q += gridDim.x) {
+        // the accumulators stay in the AGPRs, in place, across the back edge (hipcc otherwise shuffles them through VGPRs)
+#pragma unroll
+        for (int l = 0; l < DEPTH - 1; ++l) asm volatile("" : "+a"(acc[l][0]), "+a"(acc[l][1]), "+a"(acc[l][2]), "+a"(acc[l][3]));
+        asm volatile("" : "+a"(acc_e), "+a"(acc0));
+        const long long Qn = (Q + gridDim.x < nquads) ? Q + gridDim.x : Q;     // the last iteration re-loads its own quad (unused)
+        const unsigned e_img = OFF_E + eb * ENC_IMG;
+        {
+            const float d = dnext;
+            if (lane < 32) bout += d;
+            put_dout(d);
+        }
+        drain_and_barrier();                                   // dout visible; h_depth (H0) landed for every wave
+        // ---- top: gA_{D-1} -> GA0, dW_out ----
+        front(OFF_H + 0 * IMG, OFF_GA + 0 * IMG);
+        drain_and_barrier();                                   // GA0 complete; h_{D-1} (H1) and enc landed; H0 free
+        // Layers D-1 .. 1.  Buffers alternate: gA_l in GA[(D-1-l) & 1], h_l in H[(D-l) & 1]; the h image that the mask of
+        // layer l+1 has just released takes h_{l-1} (or the next quad's h_D).
+#pragma unroll
+        for (int l = DEPTH - 1; l >= 1; --l) {
+            const int gi = (DEPTH - 1 - l) & 1, hi = (DEPTH - l) & 1;
+            const unsigned ga_in = OFF_GA + gi * IMG, ga_out = OFF_GA + (gi ^ 1) * IMG, h_img = OFF_H + hi * IMG;
+            if (l - 1 >= 1) dma_h(l - 1, Q, hi ^ 1);
+            else dma_h(DEPTH, Qn, hi ^ 1);                     // l == 1: next quad's h_D
+            if (l == 1) dnext = point_dout(Qn);                // load issued here, consumed behind this layer's dW phase
+#pragma unroll
+            for (int pi = 0; pi < 2; ++pi) {                   // (one point block at a time: 32 chain accumulators beside the 224 of dW)
+                f32x16 c[2];
+                chain_mma(wf, ga_in, pi, c);
+                chain_post(c, pi, h_img, ga_out);
+            }
+            if (l - 1 >= 1) load_w(l - 1, wf);                 // next layer's weights fly under the dW phase
+            else load_w(DEPTH - 1, wf);
+            if (l == SKIPL) dw_phase(std::true_type{}, ga_in, h_img, e_img, acc[l - 1], acc_e, bsum[l - 1]);
+            else dw_phase(std::false_type{}, ga_in, h_img, e_img, acc[l - 1], acc_e, bsum[l - 1]);
+            use_w(wf);
+            drain_and_barrier();                               // gA_{l-1} complete; the h image issued above has landed
+        }
+        // ---- layer 0: dW_0 = gA_0^T enc; the images of the next quad fly under it ----
+        {
+            const int gi0 = (DEPTH - 1) & 1, hfree = (DEPTH - 1) & 1;          // gA_0 image; H image that held h_1
+            dma_h(DEPTH - 1, Qn, hfree);
+            dma_enc(Qn, eb ^ 1);
+            dw0_phase(OFF_GA + gi0 * IMG, e_img);
+        }
+        eb ^= 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- flush: slab[tile][r >> 2][lane][r & 3] (the layout reduce128_kernel reads) -------------------------------------
+    float *slab = a.slabs + (long long)blockIdx.x * SLAB_FLOATS128;
+    auto flush_tile = [&](int tile, const f32x16 &t) {
+        float *tp = slab + (long long)tile * 1024;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = t[4 * g4 + e];
+            f32x4 *dst = reinterpret_cast<f32x4 *>(tp + g4 * 256 + lane * 4);
+            if (A.accumulate) {
+                const f32x4 old = *dst;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += old[e];
+            }
+            *dst = v;
+        }
+    };
+#pragma unroll
+    for (int l = 1; l < DEPTH; ++l) {
+        const int base = (l - 1) * 20;                          // tile (l, m, n) = (l-1) 20 + 5 m + n
+        flush_tile(base + 5 * (2 * wi) + 2 * wj, acc[l - 1][0]);
+        flush_tile(base + 5 * (2 * wi) + 2 * wj + 1, acc[l - 1][1]);
+        flush_tile(base + 5 * (2 * wi + 1) + 2 * wj, acc[l - 1][2]);
+        flush_tile(base + 5 * (2 * wi + 1) + 2 * wj + 1, acc[l - 1][3]);
+        if (l == SKIPL) flush_tile(base + 5 * (2 * wi + wj) + 4, acc_e);
+        else {
+            // bias of row tile m_e: virtual row (lane & 31), halves added; stored as column 31 of row (lane & 31) of tile (l, m_e, 4):
+            // the place the enc tile's bias column has (register r of lane 31 + 32 h holds row (r & 3) + 8 (r >> 2) + 4 h)
+            float v = bsum[l - 1] + __shfl_xor(bsum[l - 1], 32, 64);
+            float *tp = slab + (long long)(base + 5 * (2 * wi + wj) + 4) * 1024;
+            if (lane < 32) {
+                const int row = lane, h2 = (row >> 2) & 1, r = (row & 3) + 4 * (row >> 3);
+                float *dst = tp + (r >> 2) * 256 + (31 + 32 * h2) * 4 + (r & 3);
+                if (A.accumulate) v += *dst;
+                *dst = v;
+            }
+        }
+    }
+    flush_tile(60 + wv, acc0);
+    {   // tile 64: [0..127] the output layer's row by virtual feature position, [128 + wv] this wave's share of its bias
+        float *tp = slab + 64ll * 1024;
+        float v = orow + __shfl_xor(orow, 32, 64);
+        if (lane < 32) {
+            float *dst = tp + 32 * wv + lane;
+            if (A.accumulate) v += *dst;
+            *dst = v;
+        }
+        float bs = bout;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) bs += __shfl_xor(bs, o, 64);
+        if (lane == 0) {
+            float *dst = tp + 128 + wv;
+            if (A.accumulate) bs += *dst;
+            *dst = bs;
+        }
+    }
+}
+
+// dout = dE e (1 - e) per point, in place over the e the forward recorded (sigmoid'(out - 10) = e (1 - e); dE = sum_s dimg w)
+__global__ __launch_bounds__(256) void dout128_kernel(BwdArgs A) {
+    const FusedArgs &a = A.f;
+    const long long n = A.t.NQ * 32;
+    float *eg = reinterpret_cast<float *>(A.tape + A.t.e_off);
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const long long q = i >> 5;
+        int b; long long p; bool inb;
+        tile_point<8>(a, q >> 3, (int)(q & 7), (int)(i & 31), b, p, inb);
+        const float e = eg[i];
+        float d = 0.f;
+        if (inb && e != 0.f) {
+            const long long ray = a.ray_idx ? (long long)a.ray_idx[p] : (long long)a.fd_G.div((unsigned)p);
+            float dE = 0.f;
+            for (int s = 0; s < a.Sx; ++s) dE += a.dimages[((long long)b * a.Sx + s) * a.R + ray] * a.w[(long long)s * a.P + p];
+            d = dE * e * (1.f - e);
+        }
+        eg[i] = d;
+    }
+}
+
+// feature of virtual position v (0..31) of a 32-feature tile: chunk (s, h) = v >> 3, element e = v & 7 of the canonical fragment
+__host__ __device__ inline int virt_feature(int v) { return 16 * ((v >> 4) & 1) + 4 * ((v >> 3) & 1) + (v & 3) + 8 * ((v >> 2) & 1); }
+
+// Sum the slabs of all workgroups (fixed order: bitwise reproducible) and write the flat gradient (flax tree order).
+// One block per slab tile; thread (g4, lane) owns the float4 at [g4][lane] of the tile: accumulator registers 4 g4 .. 4 g4 + 3 of
+// lane `lane`, i.e. rows (virtual output position) e + 8 g4 + 4 (lane >> 5), column (virtual input position) lane & 31.
+template <int DEPTH>
+__global__ __launch_bounds__(256) void reduce128_kernel(BwdArgs A, int nslabs) {
+    const int tile = blockIdx.x, tid = threadIdx.x, g4 = tid >> 6, lane = tid & 63, hh = lane >> 5, col = lane & 31;
+    const float *src = A.f.slabs + (long long)tile * 1024 + g4 * 256 + lane * 4;
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    for (int wg = 0; wg < nslabs; ++wg) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(src + (long long)wg * SLAB_FLOATS128);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sum[e] += v[e];
+    }
+    const int WT = A.width_true;
+    const float *wout = reinterpret_cast<const float *>(A.f.packed + A.f.wout_off);
+    if (tile == 64) {                                            // output layer: float index 256 g4 + 4 lane + e of the tile
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = 256 * g4 + 4 * lane + e;
+            if (idx < 128) {
+                const int f = 32 * (idx >> 5) + virt_feature(idx & 31);
+                if (f < WT) A.dparams[A.kernel_off[DEPTH] + f] = sum[e];
+            }
+        }
+        if (tid == 32) {                                         // floats 128..131: the four waves' shares of the bias
+            A.dparams[A.bias_off[DEPTH]] = (sum[0] + sum[1]) + (sum[2] + sum[3]);
+        }
+        return;
+    }
+    int l, m, n;
+    if (tile >= 60) { l = 0; m = tile - 60; n = 4; }
+    else { l = 1 + tile / 20; m = (tile % 20) / 5; n = tile % 5; }
+    if (l >= DEPTH) return;
+    const bool skip = (A.f.skip_mask >> l) & 1;
+    const bool fold = l == DEPTH - 1 && bhn_folds_wout(BHN_BF16, DEPTH);
+    // input of this column
+    long long kin = -1;
+    bool is_bias = false;
+    if (n < 4) {
+        const int k = 32 * n + virt_feature(col);
+        if (k < WT) kin = k;
+    } else {
+        const int slot = virt_feature(col);
+        if (slot == 31) is_bias = true;
+        else {
+            const int fe = bhn_enc_slot_feature(slot, A.f.deg);
+            if (fe >= 0 && (l == 0 || skip)) kin = (l == 0 ? 0 : WT) + fe;
+        }
+    }
+    if (kin < 0 && !is_bias) return;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int v = e + 8 * g4 + 4 * hh;                       // row of the accumulator = virtual output position
+        const int o = 32 * m + virt_feature(v);
+        if (o >= WT) continue;
+        float val = sum[e];
+        if (fold) val *= wout[o];
+        A.dparams[is_bias ? A.bias_off[l] + o : A.kernel_off[l] + kin * WT + o] = val;
+    }
+}
+
+}   // namespace
+
+// ---- host side (called from bwd_run of fused_bwd.hip) --------------------------------------------------------------------
+bool bwd128_supported(int mode, int kernel_width, int depth) {
+#ifdef BHN_NO_FUSED128
+    return false;
+#else
+    return mode == BHN_BF16 && kernel_width == 128 && depth == 4;
+#endif
+}
+
+size_t bwd128_slab_bytes(int grid) { return (size_t)grid * SLAB_FLOATS128 * 4; }
+
+void bwd128_tape_layout(int depth, long long NQ, TapeLayout *t) {
+    memset(t, 0, sizeof(*t));
+    t->NQ = NQ;
+    t->fused128 = 1;
+    const long long per_tensor = NQ * (long long)MT * TB;
+    long long off = 0;
+    for (int l = 1; l <= depth; ++l) { t->h_off[l] = off; off += per_tensor; }
+    for (int l = 0; l < depth; ++l) t->ga_off[l] = -1;
+    t->lin_stride = per_tensor;
+    t->h_lin = -per_tensor;                                      // h_off[l] = h_lin + l * lin_stride
+    t->enc_off = off; off += NQ * (long long)TB;
+    t->e_off = off; off += NQ * 128;
+    t->mask_off = -1; t->dout_off = -1; t->encp_off = -1;
+    t->total = (long long)(((size_t)off + 1024 + 255) / 256 * 256);
+}
+
+int bwd128_launch(const BwdArgs &A, int depth, int grid, hipStream_t st) {
+    static DeviceOnce once;
+    int dev = 0;
+    BHN_HIP(hipGetDevice(&dev));
+    BHN_CHECK_DEVICE(dev);
+    BHN_HIP(once.run(dev, [&](int &) {
+        return hipFuncSetAttribute((const void *)&bwd128_kernel<4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }));
+    BHN_CHECK_ARG(depth == 4 && (A.t.NQ & 3) == 0, "fused width-128 backward: depth %d, %lld groups", depth, A.t.NQ);
+    {
+        long long nb = (A.t.NQ * 32 + 255) / 256;
+        if (nb > 4096) nb = 4096;
+        hipLaunchKernelGGL(dout128_kernel, dim3((unsigned)nb), dim3(256), 0, st, A);
+        BHN_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL((bwd128_kernel<4, 3>), dim3((unsigned)grid), dim3(256), LDS_BYTES, st, A);
+    BHN_HIP(hipGetLastError());
+    return BHN_OK;
+}
+
+int reduce128_launch(const BwdArgs &A, int depth, int nslabs, hipStream_t st) {
+    BHN_CHECK_ARG(depth == 4, "fused width-128 backward: depth %d", depth);
+    hipLaunchKernelGGL(reduce128_kernel<4>, dim3(SLAB_TILES), dim3(256), 0, st, A, nslabs);
+    BHN_HIP(hipGetLastError());
+    return BHN_OK;
+}
