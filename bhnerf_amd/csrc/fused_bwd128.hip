@@ -72,14 +72,20 @@ DEVI u32x4 make_rsrc(const char *p) {
 }
 // one wave copies 1 KiB global -> LDS: lane i's 16 bytes come from rs.base + soff + voff(i) and land at lds + 16 i
 DEVI void dma_piece(const u32x4 &rs, unsigned soff, unsigned lds, unsigned voff) {
+#ifdef BHN_B128_ABL
+    if (BHN_B128_ABL & 8) return;
+#endif
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen nt lds" ::"s"(lds), "v"(voff), "s"(rs), "s"(soff) : "memory", "m0");
 }
 
-// 0xffff in every 16-bit half of u that is a nonzero bf16 (u: non-negative bf16 pairs, i.e. relu outputs)
-DEVI unsigned nz_mask(unsigned u) {
+// g with every 16-bit half zeroed whose half of h is zero (h: non-negative bf16 pairs, i.e. relu outputs).  Three instructions
+// per pair of elements: h + 0x7fff7fff sets a half's sign bit iff it is nonzero (no carry between halves), a packed arithmetic
+// >> 15 spreads it, and.  (min(h, 1) * g as packed 16-bit integers would be two, but hipcc 7.2 expands the packed unsigned min
+// into compares and selects: measured slower.)
+DEVI unsigned keep_where_nz(unsigned g, unsigned h) {
     typedef short i16x2 __attribute__((ext_vector_type(2)));
-    const unsigned sgn = u + 0x7fff7fffu;                          // sets the half's sign bit iff it is nonzero; no carry between halves
-    return __builtin_bit_cast(unsigned, __builtin_bit_cast(i16x2, sgn) >> (i16x2){15, 15});
+    const unsigned sgn = h + 0x7fff7fffu;
+    return g & __builtin_bit_cast(unsigned, __builtin_bit_cast(i16x2, sgn) >> (i16x2){15, 15});
 }
 
 
@@ -117,6 +123,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const unsigned trA_m0 = tr_first(2 * wi), trB_m0 = tr_second(2 * wi), trA_m1 = tr_first(2 * wi + 1), trB_m1 = tr_second(2 * wi + 1);
     const unsigned trA_n0 = tr_first(2 * wj), trB_n0 = tr_second(2 * wj), trA_n1 = tr_first(2 * wj + 1), trB_n1 = tr_second(2 * wj + 1);
     const unsigned trA_w = tr_first(wv), trB_w = tr_second(wv);
+    const unsigned trA_me = tr_first(2 * wi + wj), trB_me = tr_second(2 * wi + wj);
     const unsigned trE = 64u * (8 * tkh + tq) + 32u * tcg + 8u * tp;      // encoded-input image: 64-byte rows, no swizzle
 
     // LDS-DMA lane offsets on the GLOBAL side (tape tiles are in the producer's slot layout, TapeEmit::native_off)
@@ -134,6 +141,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int pb = t >> 1, kk = wv + 4 * (t & 1), k = wv + 4 * t;
             dma_piece(rs, (unsigned)(pb * (MT * TB) + 256 * kk), lds0 + OFF_H + hb * IMG + 1024 * k, voffH);
         }
+    };
+    // the same, one piece at a time (issued from the MFMA shadows of the phases): rs from h_rsrc(l, Q)
+    auto h_rsrc = [&](int l, long long Q) { return make_rsrc(A.tape + A.t.h_lin + (long long)l * h_stride + Q * (4ll * MT * TB)); };
+    auto dma_h_piece = [&](const u32x4 &rs, int hb, int t) {
+        const int pb = t >> 1, kk = wv + 4 * (t & 1), k = wv + 4 * t;
+        dma_piece(rs, (unsigned)(pb * (MT * TB) + 256 * kk), lds0 + OFF_H + hb * IMG + 1024 * k, voffH);
     };
     auto dma_enc = [&](long long Q, int eb) {
         const u32x4 rs = make_rsrc(A.tape + A.t.enc_off + Q * (4ll * TB));
@@ -153,13 +166,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     };
     // this wave's 16 fragments of the transposed weight image of hidden layer l (rows m0, m1), plain loads from L2
-    const char *wimg = a.packed + a.bwd_off + (size_t)(2 * wi) * CB + lane * 16;
+    // (buffer loads: one resource over the image, the fragment as a scalar offset, 16 lane -- no 64-bit address per fragment:
+    //  with plain pointers hipcc kept fourteen of them across the loop, in scratch)
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(a.packed + a.bwd_off + (size_t)(2 * wi) * CB), 0, 0x7fffffff, 0x00020000);
+    auto load_w1 = [&](int l, int mi, int ks) -> frag {
+        return __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane * 16, ((l - 1) * MT + mi) * CB + ks * 1024, 0));
+    };
     auto load_w = [&](int l, frag (&wf)[2][KS]) {
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-                wf[mi][ks] = *reinterpret_cast<const frag *>(wimg + (size_t)((l - 1) * MT + mi) * CB + ks * 1024);
+            for (int ks = 0; ks < KS; ++ks) wf[mi][ks] = load_w1(l, mi, ks);
     };
     auto use_w = [&](frag (&wf)[2][KS]) {          // the loads have landed (the compiler waits here, at a drain point of the schedule)
 #pragma unroll
@@ -167,10 +185,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int ks = 0; ks < KS; ks += 4) asm volatile("" : "+v"(wf[mi][ks]), "+v"(wf[mi][ks + 1]), "+v"(wf[mi][ks + 2]), "+v"(wf[mi][ks + 3]));
     };
+#ifndef BHN_B128_ABL
+#define BHN_B128_ABL 0              // measurement builds (results wrong): 1 no dW MFMAs, 2 dW fragments read once per phase, 4 no chain MFMAs, 8 no tape DMA, 16 no chain epilogue, 32 no front, 64 no barriers
+#endif
+#ifndef BHN_B128_STAMPS
+#define BHN_B128_STAMPS 0           // 1 (measurement build): s_memtime stamps of one iteration of workgroup 0 -> slab tile 64 (tools/dbg_bwd128_stamps.py)
+#endif
+    long long *ts = nullptr;
+    int ts_i = 0;
+    auto stamp = [&]() {
+        if constexpr (BHN_B128_STAMPS != 0) {
+            if (ts) { const long long t = __builtin_readcyclecounter(); if (lane == 0) ts[ts_i] = t; ++ts_i; }
+        }
+    };
     auto drain_and_barrier = [&]() {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        stamp();
+        if (!(BHN_B128_ABL & 64)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        stamp();
     };
 
     // ---- accumulators: hidden layer l = 1..DEPTH-1: (m0,n0) (m0,n1) (m1,n0) (m1,n1); the skip layer's (m_e, enc) tile;
@@ -189,21 +222,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // ---- phases ------------------------------------------------------------------------------------------------------
     // delta chain through hidden layer l, point block 2j + pi: tiles m0, m1 of W_l gA_l (ga_in: image offset of gA_l) ...
-    auto chain_mma = [&](const frag (&wf)[2][KS], unsigned ga_in, int pi, f32x16 (&c)[2]) {
+    // `side(ks)`: work of other phases issued in the shadow of this step's MFMAs (one wave per SIMD: nothing else hides it)
+    auto chain_mma = [&](const frag (&wf)[2][KS], unsigned ga_in, int pi, f32x16 (&c)[2], auto &&side) {
         { const f32x16 z = {}; c[0] = z; c[1] = z; }
-        frag bq[3];
-        bq[0] = lds_row(smem, ga_in + rowb[pi]);
-        bq[1] = lds_row(smem, ga_in + (rowb[pi] ^ 32u));
+#ifndef BHN_B128_CPF
+#define BHN_B128_CPF 3              // chain B fragments in flight
+#endif
+        constexpr int CPF = BHN_B128_CPF;
+        frag bq[CPF + 1];
+#pragma unroll
+        for (int i = 0; i < CPF; ++i) bq[i] = lds_row(smem, ga_in + (rowb[pi] ^ (32u * i)));
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            if (ks + 2 < KS) bq[(ks + 2) % 3] = lds_row(smem, ga_in + (rowb[pi] ^ (32u * (ks + 2))));
+            if (ks + CPF < KS) bq[(ks + CPF) % (CPF + 1)] = lds_row(smem, ga_in + (rowb[pi] ^ (32u * (ks + CPF))));
             __builtin_amdgcn_sched_barrier(0);
-            c[0] = Pol::mma(wf[0][ks], bq[ks % 3], c[0]);
-            c[1] = Pol::mma(wf[1][ks], bq[ks % 3], c[1]);
+            if constexpr (BHN_B128_ABL & 4) { asm volatile("" :: "v"(bq[ks % (CPF + 1)])); }
+            else {
+            c[0] = Pol::mma(wf[0][ks], bq[ks % (CPF + 1)], c[0]);
+            c[1] = Pol::mma(wf[1][ks], bq[ks % (CPF + 1)], c[1]);
+            }
+            side(ks);
             __builtin_amdgcn_sched_barrier(0);
         }
+        asm volatile("" : "+v"(c[0]), "+v"(c[1]));     // the epilogue is VALU work: keep the tile out of the AGPRs (2 v_accvgpr_read per pair)
     };
     // ... and their epilogue: gA_{l-1} = relu'(a_{l-1}) (.) c, relu' read off the h_l image (h_l = relu(a_{l-1}) as bf16)
+    // the same epilogue in eight slices (slice j: row tile j >> 2, k-step (j >> 1) & 1, half j & 1 of its eight elements),
+    // issued from the MFMA shadows of the following phase; the h chunk of a slice pair is read one slice ahead
+    u32x4 ps_hv, ps_hvn, ps_o;
+    auto post_off = [&](int pi, int jp) -> unsigned { return rowb[pi] ^ (16u * (4 * (2 * wi + (jp >> 1)) + 2 * (jp & 1))); };
+    auto post_begin = [&](int pi, unsigned h_img) { ps_hvn = __builtin_bit_cast(u32x4, lds_row(smem, h_img + post_off(pi, 0))); };
+    auto post_slice = [&](const f32x16 (&c)[2], int pi, unsigned h_img, unsigned ga_out, int j) {
+        const int mi = j >> 2, s2 = (j >> 1) & 1, half = j & 1;
+        if (half == 0) ps_hv = ps_hvn;
+        else if (j + 1 < 8) ps_hvn = __builtin_bit_cast(u32x4, lds_row(smem, h_img + post_off(pi, (j + 1) >> 1)));
+#pragma unroll
+        for (int d = 2 * half; d < 2 * half + 2; ++d) ps_o[d] = keep_where_nz(Pol::pack_a(c[mi][8 * s2 + 2 * d], c[mi][8 * s2 + 2 * d + 1]), ps_hv[d]);
+        if (half == 1) lds_put(smem, ga_out + post_off(pi, j >> 1), __builtin_bit_cast(frag, ps_o));
+    };
     auto chain_post = [&](const f32x16 (&c)[2], int pi, unsigned h_img, unsigned ga_out) {
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
@@ -213,15 +269,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 const u32x4 hv = __builtin_bit_cast(u32x4, lds_row(smem, h_img + off));
                 u32x4 o;
 #pragma unroll
-                for (int d = 0; d < 4; ++d) o[d] = Pol::pack_a(c[mi][8 * s2 + 2 * d], c[mi][8 * s2 + 2 * d + 1]) & nz_mask(hv[d]);
+                for (int d = 0; d < 4; ++d) o[d] = keep_where_nz(Pol::pack_a(c[mi][8 * s2 + 2 * d], c[mi][8 * s2 + 2 * d + 1]), hv[d]);
                 lds_put(smem, ga_out + off, __builtin_bit_cast(frag, o));
             }
     };
     // dW of a hidden layer: t[0..3] += gA^T h over the wave's 2 x 2 tiles; ENC: te += gA[m_e]^T enc, else bs += the bias of
     // row tile m_e (sum over the points of the A fragments); K = the 128 points
-    auto dw_phase = [&](auto enc_tag, unsigned ga_img, unsigned h_img, unsigned e_img, f32x16 (&t)[4], f32x16 &te, float &bs) {
+    auto dw_phase = [&](auto enc_tag, unsigned ga_img, unsigned h_img, unsigned e_img, f32x16 (&t)[4], f32x16 &te, float &bs, auto &&side) {
         constexpr bool ENC = decltype(enc_tag)::value;
-        struct KF { frag a0, a1, b0, b1, be; };
+        // ae: row tile m_e = 2i + j once more, read through its own address (a select between a0 and a1 costs four v_cndmask
+        // per k-step; a wave-uniform branch around the MFMA made hipcc wait for the MFMA and move the accumulator: 3.7k cycles
+        // per phase against 1.7k)
+        struct KF { frag a0, a1, b0, b1, ae, be; };
         auto fetch = [&](int k) {
             KF f;
             const unsigned ko = 4096u * k;
@@ -229,67 +288,99 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             f.a1 = tr2(smem, ga_img + trA_m1 + ko, ga_img + trB_m1 + ko);
             f.b0 = tr2(smem, h_img + trA_n0 + ko, h_img + trB_n0 + ko);
             f.b1 = tr2(smem, h_img + trA_n1 + ko, h_img + trB_n1 + ko);
+            f.ae = tr2(smem, ga_img + trA_me + ko, ga_img + trB_me + ko);
             if constexpr (ENC) f.be = tr2(smem, e_img + trE + 1024u * k, e_img + trE + 1024u * k + 256u);
             else f.be = f.b0;
             return f;
         };
+#ifndef BHN_B128_DWDB
+#define BHN_B128_DWDB 0             // 1: the next k-step's fragments are fetched BEFORE this step's MFMAs (a second fragment set: 24 registers)
+#endif
         KF cur = fetch(0);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             KF nx = cur;
-            if (k + 1 < 8) nx = fetch(k + 1);
+            if constexpr (BHN_B128_DWDB != 0) { if (k + 1 < 8) nx = fetch(k + 1); }
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (BHN_B128_ABL & 1) { asm volatile("" :: "v"(cur.a0), "v"(cur.a1), "v"(cur.b0), "v"(cur.b1), "v"(cur.be), "v"(cur.ae)); }
+            else {
             t[0] = Pol::mma(cur.a0, cur.b0, t[0]);
             t[1] = Pol::mma(cur.a0, cur.b1, t[1]);
             t[2] = Pol::mma(cur.a1, cur.b0, t[2]);
             t[3] = Pol::mma(cur.a1, cur.b1, t[3]);
-            const frag ae = wj ? cur.a1 : cur.a0;
-            if constexpr (ENC) te = Pol::mma(ae, cur.be, te);
-            else bs = Pol::sum8(ae, bs);
+            }
+            if constexpr (BHN_B128_ABL & 1) {}
+            else if constexpr (ENC) te = Pol::mma(cur.ae, cur.be, te);
+            else bs = Pol::sum8(cur.ae, bs);
+            // the next k-step's fragments are fetched BEHIND this step's MFMAs (160 cycles of matrix work cover the LDS
+            // latency; a second fragment set in flight costs 40 registers this kernel does not have)
+            if constexpr (BHN_B128_DWDB != 0) cur = nx;
+            else if (k + 1 < 8 && !(BHN_B128_ABL & 2)) cur = fetch(k + 1);
+            side(k);
             __builtin_amdgcn_sched_barrier(0);
-            cur = nx;
         }
     };
     // dW of layer 0: tile m = wv of gA_0^T enc
-    auto dw0_phase = [&](unsigned ga_img, unsigned e_img) {
+    auto dw0_phase = [&](unsigned ga_img, unsigned e_img, auto &&side) {
+        frag af = tr2(smem, ga_img + trA_w, ga_img + trB_w);
+        frag be = tr2(smem, e_img + trE, e_img + trE + 256u);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const unsigned ko = 4096u * k;
-            const frag af = tr2(smem, ga_img + trA_w + ko, ga_img + trB_w + ko);
-            const frag be = tr2(smem, e_img + trE + 1024u * k, e_img + trE + 1024u * k + 256u);
+            frag afn = af, ben = be;
+            if (k + 1 < 8) {
+                const unsigned ko = 4096u * (k + 1);
+                afn = tr2(smem, ga_img + trA_w + ko, ga_img + trB_w + ko);
+                ben = tr2(smem, e_img + trE + 1024u * (k + 1), e_img + trE + 1024u * (k + 1) + 256u);
+            }
+            __builtin_amdgcn_sched_barrier(0);
             acc0 = Pol::mma(af, be, acc0);
+            side(k);
+            __builtin_amdgcn_sched_barrier(0);
+            af = afn; be = ben;
         }
     };
     // front: gA_{depth-1} (without W_out, common.h bhn_folds_wout) = relu'(a_{depth-1}) (.) bf16(dout) from the h_depth image;
     // the output layer's row: dW_out[f] += sum_p dout_p h_depth[p][f] (feature tile wv)
     auto front = [&](unsigned h_img, unsigned ga_out) {
+        // (all LDS reads of a part first: one wave per SIMD has nobody to hide a read-use round trip behind)
+        u32x4 hv[2][2][2];
+        float dv[2];
 #pragma unroll
         for (int pi = 0; pi < 2; ++pi) {
-            const float d = reinterpret_cast<const float *>(smem + OFF_DOUT)[32 * (2 * wj + pi) + pl];
-            const Pol::bf16x2 d2 = {(__bf16)d, (__bf16)d};
+            dv[pi] = reinterpret_cast<const float *>(smem + OFF_DOUT)[32 * (2 * wj + pi) + pl];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+                    hv[pi][mi][s2] = __builtin_bit_cast(u32x4, lds_row(smem, h_img + (rowb[pi] ^ (16u * (4 * (2 * wi + mi) + 2 * s2)))));
+        }
+        frag hf[8], dp[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            hf[k] = tr2(smem, h_img + trA_w + 4096u * k, h_img + trB_w + 4096u * k);
+            dp[k] = *reinterpret_cast<const frag *>(smem + OFF_DPK + 2 * (16 * k + 8 * (lane >> 5)));   // the lane's 8 points
+        }
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi) {
+            const Pol::bf16x2 d2 = {(__bf16)dv[pi], (__bf16)dv[pi]};
             const unsigned dd = __builtin_bit_cast(unsigned, d2);
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
-                    const unsigned off = rowb[pi] ^ (16u * (4 * (2 * wi + mi) + 2 * s2));
-                    const u32x4 hv = __builtin_bit_cast(u32x4, lds_row(smem, h_img + off));
                     u32x4 o;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) o[k] = dd & nz_mask(hv[k]);
-                    lds_put(smem, ga_out + off, __builtin_bit_cast(frag, o));
+                    for (int k = 0; k < 4; ++k) o[k] = keep_where_nz(dd, hv[pi][mi][s2][k]);
+                    lds_put(smem, ga_out + (rowb[pi] ^ (16u * (4 * (2 * wi + mi) + 2 * s2))), __builtin_bit_cast(frag, o));
                 }
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const frag hf = tr2(smem, h_img + trA_w + 4096u * k, h_img + trB_w + 4096u * k);
-            const frag dp = *reinterpret_cast<const frag *>(smem + OFF_DPK + 2 * (16 * k + 8 * (lane >> 5)));   // the lane's 8 points
+        for (int k = 0; k < 8; ++k)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const Pol::bf16x2 hp = {hf[2 * i], hf[2 * i + 1]}, dq = {dp[2 * i], dp[2 * i + 1]};
+                const Pol::bf16x2 hp = {hf[k][2 * i], hf[k][2 * i + 1]}, dq = {dp[k][2 * i], dp[k][2 * i + 1]};
                 orow = __builtin_amdgcn_fdot2_f32_bf16(hp, dq, orow, false);
             }
-        }
     };
 
     // ---- prelude: the first quad's h_depth, h_{depth-1}, enc; its dout; the top layer's weights --------------------------
@@ -311,15 +402,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int l = 0; l < DEPTH - 1; ++l) asm volatile("" : "+a"(acc[l][0]), "+a"(acc[l][1]), "+a"(acc[l][2]), "+a"(acc[l][3]));
         asm volatile("" : "+a"(acc_e), "+a"(acc0));
         const long long Qn = (Q + gridDim.x < nquads) ? Q + gridDim.x : Q;     // the last iteration re-loads its own quad (unused)
+        if constexpr (BHN_B128_STAMPS != 0) {
+            ts = (blockIdx.x == 0 && Q == blockIdx.x + 100ll * gridDim.x) ? reinterpret_cast<long long *>(a.slabs + 64 * 1024 + 256) + 64 * wv : nullptr;
+            ts_i = 0;
+            stamp();
+        }
         const unsigned e_img = OFF_E + eb * ENC_IMG;
         {
             const float d = dnext;
             if (lane < 32) bout += d;
             put_dout(d);
         }
-        drain_and_barrier();                                   // dout visible; h_depth (H0) landed for every wave
+        // dout visible.  h_depth (H0) landed behind layer 1's barrier; the ten pieces issued under the layer-0 phase (h_{D-1},
+        // enc of this quad) stay in flight until the barrier behind the top phase
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        stamp();
+        if (!(BHN_B128_ABL & 64)) __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        stamp();
         // ---- top: gA_{D-1} -> GA0, dW_out ----
-        front(OFF_H + 0 * IMG, OFF_GA + 0 * IMG);
+        if (!(BHN_B128_ABL & 32)) front(OFF_H + 0 * IMG, OFF_GA + 0 * IMG);
+        stamp();
         drain_and_barrier();                                   // GA0 complete; h_{D-1} (H1) and enc landed; H0 free
         // Layers D-1 .. 1.  Buffers alternate: gA_l in GA[(D-1-l) & 1], h_l in H[(D-l) & 1]; the h image that the mask of
         // layer l+1 has just released takes h_{l-1} (or the next quad's h_D).
@@ -327,28 +430,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int l = DEPTH - 1; l >= 1; --l) {
             const int gi = (DEPTH - 1 - l) & 1, hi = (DEPTH - l) & 1;
             const unsigned ga_in = OFF_GA + gi * IMG, ga_out = OFF_GA + (gi ^ 1) * IMG, h_img = OFF_H + hi * IMG;
-            if (l - 1 >= 1) dma_h(l - 1, Q, hi ^ 1);
-            else dma_h(DEPTH, Qn, hi ^ 1);                     // l == 1: next quad's h_D
+            // the h image that layer l+1 has released takes h_{l-1} (l == 1: the next quad's h_D), piece by piece under the
+            // first chain step's MFMAs; the epilogue of point block 0 runs under the MFMAs of point block 1, that of point block
+            // 1 and the loads of the next layer's weights under the dW MFMAs
+            const u32x4 rs_h = (l - 1 >= 1) ? h_rsrc(l - 1, Q) : h_rsrc(DEPTH, Qn);
             if (l == 1) dnext = point_dout(Qn);                // load issued here, consumed behind this layer's dW phase
-#pragma unroll
-            for (int pi = 0; pi < 2; ++pi) {                   // (one point block at a time: 32 chain accumulators beside the 224 of dW)
-                f32x16 c[2];
-                chain_mma(wf, ga_in, pi, c);
-                chain_post(c, pi, h_img, ga_out);
+            stamp();
+            f32x16 c0[2], c1[2];
+            chain_mma(wf, ga_in, 0, c0, [&](int ks) { dma_h_piece(rs_h, hi ^ 1, ks); });
+            stamp();
+            if constexpr (BHN_B128_ABL & 16) {
+                chain_mma(wf, ga_in, 1, c1, [&](int) {});
+            } else {
+                post_begin(0, h_img);
+                chain_mma(wf, ga_in, 1, c1, [&](int ks) { post_slice(c0, 0, h_img, ga_out, ks); });
+                post_begin(1, h_img);
             }
-            if (l - 1 >= 1) load_w(l - 1, wf);                 // next layer's weights fly under the dW phase
-            else load_w(DEPTH - 1, wf);
-            if (l == SKIPL) dw_phase(std::true_type{}, ga_in, h_img, e_img, acc[l - 1], acc_e, bsum[l - 1]);
-            else dw_phase(std::false_type{}, ga_in, h_img, e_img, acc[l - 1], acc_e, bsum[l - 1]);
+            stamp();
+            const int ln = (l - 1 >= 1) ? l - 1 : DEPTH - 1;  // next layer's weights (this layer's are dead behind the chain MFMAs)
+            auto side_dw = [&](int k) {
+                if constexpr (!(BHN_B128_ABL & 16)) post_slice(c1, 1, h_img, ga_out, k);
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) wf[mi][k] = load_w1(ln, mi, k);
+            };
+            if (l == SKIPL) dw_phase(std::true_type{}, ga_in, h_img, e_img, acc[l - 1], acc_e, bsum[l - 1], side_dw);
+            else dw_phase(std::false_type{}, ga_in, h_img, e_img, acc[l - 1], acc_e, bsum[l - 1], side_dw);
+            stamp();
             use_w(wf);
+            if (l == 1) asm volatile("" : "+v"(dnext));        // (the compiler's wait for this load belongs here, at a drain point)
+            stamp();
             drain_and_barrier();                               // gA_{l-1} complete; the h image issued above has landed
         }
         // ---- layer 0: dW_0 = gA_0^T enc; the images of the next quad fly under it ----
         {
             const int gi0 = (DEPTH - 1) & 1, hfree = (DEPTH - 1) & 1;          // gA_0 image; H image that held h_1
-            dma_h(DEPTH - 1, Qn, hfree);
+            const u32x4 rs_h = h_rsrc(DEPTH - 1, Qn);
             dma_enc(Qn, eb ^ 1);
-            dw0_phase(OFF_GA + gi0 * IMG, e_img);
+            stamp();
+            dw0_phase(OFF_GA + gi0 * IMG, e_img, [&](int k) { dma_h_piece(rs_h, hfree, k); });
+            stamp();
         }
         eb ^= 1;
     }

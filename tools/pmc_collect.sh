@@ -1,7 +1,8 @@
 #!/bin/bash
 # rocprofv3 SQ counter passes over tools/pmc_run.py; summaries -> gpurun_out/pmc/pass*.txt
-#   bash tools/pmc_collect.sh [bf16|f32]
+#   bash tools/pmc_collect.sh [bf16|f32] [width]
 MODE=${1:-bf16}
+WIDTH=${2:-256}
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $R/gpurun_out/pmc
@@ -12,7 +13,7 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_
            "SQ_BUSY_CU_CYCLES SQ_IFETCH SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_ANY SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_CYCLES"; do
   i=$((i+1))
   rm -rf /tmp/pmc_$i
-  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d /tmp/pmc_$i -o p -- python3 $R/tools/pmc_run.py $MODE > /tmp/pmc_$i.log 2>&1
+  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d /tmp/pmc_$i -o p -- python3 $R/tools/pmc_run.py $MODE $WIDTH > /tmp/pmc_$i.log 2>&1
   grep -i -E "error|traceback|exception" /tmp/pmc_$i.log | head -5; ls -R /tmp/pmc_$i | head -8; f=$(find /tmp/pmc_$i -name "*counter_collection.csv" | head -1)
   echo "pass $i: $f"
   [ -n "$f" ] && python3 - "$f" > $R/gpurun_out/pmc/pass$i.txt <<'PY'
@@ -21,7 +22,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 agg = collections.OrderedDict()
 for r in rows:
     k = r['Kernel_Name'][:60]
-    if not any(s in k for s in ('chain_kernel', 'dw_kernel', 'fused_fwd_kernel')): continue
+    if not any(s in k for s in ('chain_kernel', 'dw_kernel', 'fused_fwd_kernel', 'bwd128_kernel', 'fwd128')): continue
     d = agg.setdefault(k, collections.OrderedDict())
     d.setdefault(r['Counter_Name'], []).append(float(r['Counter_Value']))
     d.setdefault('duration_ms', []).append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) * 1e-6)
