@@ -43,7 +43,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}      # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
-PROFILE_TAG = 'r3'                                  # profiles/<tag>_pmc_traffic.json etc. (tools/collect_profiles.sh)
+PROFILE_TAG = 'r4'                                  # profiles/<tag>_pmc_traffic.json etc. (tools/collect_profiles.sh)
 
 
 def mlp_flops(depth, width, F=21):
@@ -71,6 +71,7 @@ def parse():
                     help='N > 1: run the all-reduce of step k under step k+1 (one-step-stale gradients; NOT the reference semantics, off by default)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity-mode', action='store_true', help='skip the f32 parity-mode block')
+    ap.add_argument('--no-width128', action='store_true', help='skip the block with the same step on the reference-default 4x128 network')
     ap.add_argument('--no-tutorial-domain', action='store_true',
                     help='skip the masked-domain variant (profiling runs: keeps every launch of a kernel the same shape)')
     ap.add_argument('--no-other-configs', dest='other_configs', action='store_false',
@@ -135,8 +136,8 @@ def cpu_baseline(args, geo, GM_c3):
     default_threads = torch.get_num_threads()
     sweep, t_start = {}, time.perf_counter()
     for nthr in sorted({n for n in (8, 16, 32, 64, 128, ncores) if n <= ncores} or {ncores}):
-        if sweep and time.perf_counter() - t_start > args.cpu_seconds:
-            break
+        if sweep and (time.perf_counter() - t_start > args.cpu_seconds or sweep[max(sweep)] > 1.05 * min(sweep.values())):
+            break                              # out of budget, or the last (larger) count was already slower than the best
         torch.set_num_threads(nthr)
         ks, bs = ot.tree_to_lists(tree, torch.float32)
         tr = ot.CpuTrainer(ks, bs, geom, hp, num_iters=1000)
@@ -235,6 +236,61 @@ def other_configs(dev, mode):
     return out
 
 
+def strong_scaling_share(dev, mode='bf16'):
+    """The per-GPU share of the reference's own 8-device runs -- b = 8 frames split over 8 devices = ONE frame per GPU and step
+    (optimization.py:289-291, 360-362) -- at the shapes of BASELINE configs 3 and 5, on this one GPU (the all-reduce of the
+    gradient is not in these numbers).  Per shape: wall ms per step of the eager Python driver, wall ms per step with the
+    step captured into a HIP graph (hparams['hip_graph'], optimization.GraphedImageStep), and the GPU time of one graph
+    replay (HIP events around back-to-back replays: the kernels of the step and the gaps between them)."""
+    from bhnerf_amd import network, optimization, synthetic, units
+    out = {}
+    cfgs = {'config3': dict(H=256, W=256, G=128, width=256, fov=40.0, inc=60.0, spin=0.94, rmin=2.024, rmax=20.0, z_width=4.0),
+            'config5': dict(H=64, W=64, G=100, width=128, fov=40.0, inc=12.0, spin=0.0, rmin=6.0, rmax=20.0, z_width=4.0)}
+    for name, c in cfgs.items():
+        geo = synthetic.synthetic_geodesics(c['H'], c['W'], c['G'], fov_M=c['fov'], inc_deg=c['inc'], spin=c['spin'], S=3, seed=3)
+        nt = 128
+        t_frames = np.linspace(0.0, 1.7, nt)
+        rt = network.raytracing_args(dict(x=geo['coords'][0], y=geo['coords'][1], z=geo['coords'][2], dtau=geo['dtau'], Sigma=geo['Sigma'],
+                                          t=geo['t_geos'], g=geo['g']), geo['Omega'], geo['t_injection'], 0.0 * units.hr, J=geo['J'])
+        target = np.random.default_rng(5).uniform(0.5, 1.5, (nt, 3)).astype(np.float32)
+        res = {'workload': '%dx%d rays x %d samples, Stokes I/Q/U, loss lc, 4x%d MLP, 1 frame per GPU and step' % (c['H'], c['W'], c['G'], c['width']),
+               'dtype': mode}
+        for graph in (False, True):
+            pred = network.NeRF_Predictor(c['rmax'], c['rmin'], c['rmax'], c['z_width'], net_depth=4, net_width=c['width'], mode=mode, device=dev)
+            step = optimization.TrainStep.image(t_frames * units.hr, target, sigma=0.1, dtype='lc')
+            step.use_graph = graph
+            opt = optimization.Optimizer({'num_iters': 1000, 'lr_init': 1e-4, 'lr_final': 1e-6}, pred, rt)
+            frames = step.args[0]
+            n = 200 if c['H'] <= 64 else 40
+            for _ in range(5):
+                opt.loss, opt.state, _ = step(opt.state, rt, frames.sample(1))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                opt.loss, opt.state, _ = step(opt.state, rt, frames.sample(1))
+            torch.cuda.synchronize()
+            res['wall_ms_per_step_' + ('hip_graph' if graph else 'eager')] = round(1e3 * (time.perf_counter() - t0) / n, 4)
+            if graph:
+                g = [v for v in step._graphs.values() if v]
+                if g:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(n):
+                        g[0].graph.replay()
+                    e1.record(); torch.cuda.synchronize()
+                    res['gpu_ms_per_graph_replay'] = round(e0.elapsed_time(e1) / n, 4)
+                    gm = g[0].geom
+                    res['active_fraction'] = round(gm.active_fraction, 4)
+            del opt, pred, step
+            torch.cuda.empty_cache()
+        if 'gpu_ms_per_graph_replay' in res:
+            res['wall_over_gpu_hip_graph'] = round(res['wall_ms_per_step_hip_graph'] / res['gpu_ms_per_graph_replay'], 3)
+            res['wall_over_gpu_eager'] = round(res['wall_ms_per_step_eager'] / res['gpu_ms_per_graph_replay'], 3)
+        res['ray_samples_per_s_hip_graph'] = round(c['H'] * c['W'] * c['G'] / (res['wall_ms_per_step_hip_graph'] * 1e-3), 1)
+        out[name] = res
+    return out
+
+
 class HipEvents:
     """Raw HIP events (ctypes on the runtime the process already has loaded) for bhn_render_bwd_tape_timed."""
 
@@ -258,7 +314,7 @@ def kernel_times(eng, geom, tM0, dimg, reps=5):
     from bhnerf_amd import _hip
     lib = _hip.lib()
     nk = 3
-    names = [lib.bhn_render_bwd_tape_kernel_name(i).decode() for i in range(nk)]
+    names = [lib.bhn_render_bwd_tape_kernel_name_for(C.byref(eng.model), eng.mode, i).decode() for i in range(nk)]
     B = int(tM0.numel())
     taped = eng.fits_tape(B, geom.P_eff)
     group = B if taped else eng.tape_group(B, geom.P_eff)
@@ -286,7 +342,122 @@ def kernel_times(eng, geom, tM0, dimg, reps=5):
         acc['chain_kernel<MODE_FWD_TRAIN>'] += a.elapsed_time(b) / reps
         for i, n in enumerate(names):
             acc[n] += sets[k].elapsed(i, i + 1) / reps
+    acc.pop('-', None)                              # (an empty kernel slot of the fused width-128 backward)
     return acc, group
+
+
+FWD_NAME, CHAIN_NAME, FUSED_NAME = 'chain_kernel<MODE_FWD_TRAIN>', 'chain_kernel<MODE_CHAIN>', 'bwd128_kernel'
+
+
+def tape_bytes_per_point(depth, width, mode, fused):
+    """ALGORITHMIC tape bytes per evaluated point that each MLP kernel of the step moves through HBM: what the
+    design chose to stream, written once and read once -- no re-reads in these figures."""
+    elem = 2 if mode == 'bf16' else 4
+    row = width * elem                                   # one layer's activations of one point
+    mt = width // 32
+    if fused:                                            # width 128, bf16, depth 4: h_2 .. h_depth, encoded inputs, e
+        b = (depth - 1) * row + 32 * elem + 4
+        return {FWD_NAME: b, FUSED_NAME: b + 4}          # (+ dout written over e by the small pre-kernel)
+    skip_layer = depth // 2 + 1 if depth >= 4 else None  # the layer that consumes concat[h, enc] (do_skip)
+    rides = mode == 'bf16' and depth >= 3                # gA_{depth-1} and the dout tile are not on the tape (DESIGN.md 3)
+    drop_h1 = mode == 'bf16' and depth >= 2 and skip_layer != 1
+    bits = depth * ((mt + 1) // 2) * 8                   # relu-bit words: 4 B per lane and pair of tiles, per 32 points
+    fwd = (depth - (1 if drop_h1 else 0)) * row + (2 if drop_h1 else 1) * 32 * elem + bits + 4
+    chain = (depth - (1 if rides else 0)) * row + bits + 4 + (4 if rides else 32 * elem)
+    tiles = (mt + 1) + (0 if rides else 1 + mt)          # dW reads per 32-point group and layer job: layer 0, output layer
+    for l in range(1, depth):
+        recomputed = l == 1 and drop_h1
+        tiles += mt + (1 if recomputed else mt) + (1 if l == skip_layer else 0)
+        if rides and l == depth - 1:
+            tiles += 0.5                                 # the 1 KiB piece that starts with the group's 32 f32 dout
+    return {FWD_NAME: fwd, CHAIN_NAME: chain, 'dw_kernel': tiles * (32 * 32 * elem) / 32.0}
+
+
+def roofline_block(eng, geom, tM0, dimg, depth, width, mode, frames_per_gpu, std):
+    """Live per-kernel timings (HIP events on the launch stream) of one rank's share of a step, and for each MLP kernel both
+    roofline fractions: MFMA (SURVEY 8(d)'s algorithmic flops / dense peak) and HBM (algorithmic tape bytes / 8 TB/s).  The
+    kernel with the largest share of the step is `roofline`; its `bound` is the resource it sits closer to."""
+    from bhnerf_amd import _hip
+    kern_ms, group = kernel_times(eng, geom, tM0, dimg)
+    fused = FUSED_NAME in kern_ms
+
+    def timed(fn, reps=5):
+        fn(); torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for a, b in ev:
+            a.record(); fn(); b.record()
+        torch.cuda.synchronize()
+        return float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    kern_ms['fused_fwd_kernel (inference)'] = timed(lambda: eng.render(geom, tM0))
+    pts = frames_per_gpu * geom.P * geom.visited_fraction     # points that go through the MLP
+    f_fwd, f_chain, f_dw, f_train = mlp_flops(depth, width)
+    alg = {FWD_NAME: f_fwd, FUSED_NAME: f_chain + f_dw} if fused else {FWD_NAME: f_fwd, CHAIN_NAME: f_chain, 'dw_kernel': f_dw}
+    bpp = tape_bytes_per_point(depth, width, mode, fused)
+    peak = PEAK_TFLOPS[mode]
+    per = {}
+    for k in alg:
+        tf = alg[k] * pts / (kern_ms[k] * 1e-3) / 1e12
+        gb = bpp[k] * pts / (kern_ms[k] * 1e-3) / 1e9
+        per[k] = {'ms': round(kern_ms[k], 4), 'mfma_tflops': round(tf, 1), 'mfma_frac': round(tf / peak, 4),
+                  'tape_GB_per_s': round(gb, 1), 'hbm_frac': round(gb / 8000.0, 4), 'tape_bytes_per_point': round(bpp[k], 1),
+                  'bound': 'hbm' if gb / 8000.0 > tf / peak else 'mfma'}
+    dom_k = max(alg, key=lambda k: kern_ms[k])
+    d = per[dom_k]
+    # what the committed counter passes say about this workload (NOT measured in this run; see the module docstring)
+    lib_md5 = file_md5(_hip_lib_path())
+    prof = {'pmc': {}, 'sq': {}, 'stats': {}, 'match': None}
+    try:
+        j = json.load(open(os.path.join(ROOT, 'profiles', PROFILE_TAG + '_pmc_traffic.json')))
+        prof['pmc'] = j['kernels'] if std else {}
+        prof['match'] = (j.get('lib_md5') == lib_md5) if j.get('lib_md5') else None
+    except Exception:
+        pass
+    try:
+        prof['sq'] = json.load(open(os.path.join(ROOT, 'profiles', PROFILE_TAG + '_sq_summary.json')))['kernels'] if std else {}
+    except Exception:
+        pass
+    try:                                             # rocprofv3 --kernel-trace --stats averages of the same workload
+        import csv
+        tagn = {', 1>': FWD_NAME, ', 2>': CHAIN_NAME, 'dw_kernel': 'dw_kernel', 'bwd128_kernel': FUSED_NAME}
+        for r in csv.DictReader(open(os.path.join(ROOT, 'profiles', PROFILE_TAG + '_bench_kernel_stats.csv'))):
+            for t, n in tagn.items():
+                if t in r['Name'] and std:
+                    prof['stats'][n] = float(r['AverageNs']) * 1e-6
+    except Exception:
+        pass
+    if d['bound'] == 'hbm':
+        roofline = {'bound': 'hbm', 'kernel': dom_k, 'achieved': d['tape_GB_per_s'], 'peak': 8000.0, 'unit': 'GB/s', 'frac': d['hbm_frac'],
+                    'algorithmic_bytes_per_point': d['tape_bytes_per_point'], 'mfma_frac_of_this_kernel': d['mfma_frac']}
+    else:
+        roofline = {'bound': 'mfma', 'kernel': dom_k, 'achieved': d['mfma_tflops'], 'peak': peak, 'unit': 'TFLOP/s', 'frac': d['mfma_frac'],
+                    'algorithmic_flop_per_point': alg[dom_k], 'hbm_frac_of_this_kernel': d['hbm_frac']}
+    roofline.update({'points_per_launch': int(pts),
+                     'traffic': prof['pmc'].get(dom_k, {}).get('hbm_bytes'),
+                     'traffic_source': 'profiles/%s_pmc_traffic.json (rocprofv3 --pmc passes, not measured in this run)' % PROFILE_TAG,
+                     'profiles_tag': PROFILE_TAG, 'profiles_match_this_build': prof['match']})
+    if dom_k in prof['stats']:                       # the same fraction on the rocprofv3 average duration of the committed profile
+        ms_p = prof['stats'][dom_k]
+        roofline['frac_from_profiles'] = round((d['hbm_frac'] if d['bound'] == 'hbm' else d['mfma_frac']) * kern_ms[dom_k] / ms_p, 4)
+        roofline['kernel_ms_from_profiles'] = round(ms_p, 4)
+    roofline['kernels'] = per
+    roofline['kernel_ms'] = {k: round(v, 4) for k, v in kern_ms.items()}
+    roofline['kernel_ms_sum'] = round(sum(v for k, v in kern_ms.items() if 'inference' not in k), 4)
+    roofline['kernel_ms_note'] = 'each kernel timed separately from the step loop (HIP events around / between the launches)'
+    if prof['sq']:    # matrix-pipe busy fraction of SIMD cycles from the committed SQ counter passes
+        tag = {', 1>': FWD_NAME, ', 2>': CHAIN_NAME, 'dw_kernel': 'dw_kernel', 'bwd128_kernel': FUSED_NAME, 'fused_fwd_kernel': 'fused_fwd_kernel (inference)'}
+        busy = {n: v['mfma_busy_frac'] for k, v in prof['sq'].items() for t, n in tag.items() if t in k}
+        roofline['mfma_busy_frac_from_profiles'] = busy
+        tk = [k for k in alg]
+        pms = {n: v.get('ms') for k, v in prof['sq'].items() for t, n in tag.items() if t in k}
+        if all(k in busy and pms.get(k) for k in tk):
+            roofline['step_mfma_busy_frac_from_profiles'] = round(sum(busy[k] * pms[k] for k in tk) / sum(pms[k] for k in tk), 3)
+    inf_tf = f_fwd * pts / (kern_ms['fused_fwd_kernel (inference)'] * 1e-3) / 1e12
+    roofline['inference_forward'] = {'ms': round(kern_ms['fused_fwd_kernel (inference)'], 4), 'mfma_tflops': round(inf_tf, 1), 'mfma_frac': round(inf_tf / peak, 4)}
+    roofline['_std'] = std
+    roofline['_alg'] = alg
+    return roofline, kern_ms, group
+
 
 
 def main():
@@ -396,72 +567,13 @@ def main():
         torch.cuda.synchronize()
         return float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
-    kern_ms, group = kernel_times(eng, geom, tM0, dimg)
-    fwd_name, chain_name = 'chain_kernel<MODE_FWD_TRAIN>', 'chain_kernel<MODE_CHAIN>'
-    kern_ms['fused_fwd_kernel (inference)'] = timed(lambda: eng.render(geom, tM0))
-    pts = args.frames_per_gpu * geom.P * geom.visited_fraction     # points that go through the MLP
-    f_fwd, f_chain, f_dw, f_train = mlp_flops(args.depth, args.width)
-    alg = {fwd_name: f_fwd, chain_name: f_chain, 'dw_kernel': f_dw}
-    dom_k = max(alg, key=lambda k: kern_ms[k])
-    # tape bytes per point the dW stream reads once: per 32-point group and layer job the gA tiles (dout for
-    # the output layer) + the input tiles (encoded inputs for layer 0, for a skip layer in addition, and -- bf16 -- INSTEAD
-    # of h_1 for layer 1, which that job recomputes)
-    elem = 2 if args.mode == 'bf16' else 4
-    mt = args.width // 32
-    skip_layer = args.depth // 2 + 1 if args.depth >= 4 else None          # the layer that consumes concat[h, enc] (do_skip)
-    # bf16, depth >= 3: gA_{depth-1} is not on the tape either -- the job of layer depth-1 reads the h_depth tiles instead
-    # (rebuilds gA from them, W_out and dout) and makes the output layer's row from the same tiles: no output-layer job
-    rides = args.mode == 'bf16' and args.depth >= 3
-    tiles = (mt + 1) + (0 if rides else 1 + mt)                            # layer 0, output layer
-    for l in range(1, args.depth):
-        recomputed = l == 1 and args.mode == 'bf16' and l != skip_layer
-        tiles += mt + (1 if recomputed else mt) + (1 if l == skip_layer else 0)
-        if rides and l == args.depth - 1:
-            tiles += 0.5                                                   # the 1 KiB piece that starts with the group's 32 f32 dout
-    tape_bpp = tiles * (32 * 32 * elem) / 32.0
-    std = H == 128 and G == 64 and args.frames_per_gpu == 8 and args.width == 256 and args.depth == 4 and args.mode == 'bf16' and not args.masked
-    # what the committed counter passes say about this workload (NOT measured in this run; see the module docstring)
-    lib_md5 = file_md5(_hip_lib_path())
-    prof = {'tag': PROFILE_TAG, 'pmc': {}, 'sq': {}, 'match': None}
-    try:
-        j = json.load(open(os.path.join(ROOT, 'profiles', PROFILE_TAG + '_pmc_traffic.json')))
-        prof['pmc'] = j['kernels'] if std else {}
-        prof['match'] = (j.get('lib_md5') == lib_md5) if j.get('lib_md5') else None
-    except Exception:
-        pass
-    try:
-        prof['sq'] = json.load(open(os.path.join(ROOT, 'profiles', PROFILE_TAG + '_sq_summary.json')))['kernels'] if std else {}
-    except Exception:
-        pass
-    # the dominant kernel of the step on SURVEY 8(d)'s algorithmic-flop basis: the fused MLP is MFMA-bound by its
-    # arithmetic intensity; what the tape design streams through HBM is reported as `tape_stream`
-    achieved = alg[dom_k] * pts / (kern_ms[dom_k] * 1e-3) / 1e12
-    roofline = {'bound': 'mfma', 'kernel': dom_k, 'achieved': round(achieved, 2), 'peak': PEAK_TFLOPS[args.mode],
-                'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_TFLOPS[args.mode], 4),
-                'traffic': prof['pmc'].get(dom_k, {}).get('hbm_bytes'),
-                'traffic_source': 'profiles/%s_pmc_traffic.json (rocprofv3 --pmc passes, not measured in this run)' % PROFILE_TAG,
-                'profiles_tag': PROFILE_TAG, 'profiles_match_this_build': prof['match'],
-                'algorithmic_flop_per_point': alg[dom_k], 'points_per_launch': int(pts)}
-    gbs = tape_bpp * pts / (kern_ms['dw_kernel'] * 1e-3) / 1e9
-    roofline['tape_stream'] = {'kernel': 'dw_kernel', 'GB_per_s': round(gbs, 1), 'frac_of_8TBs': round(gbs / 8000.0, 4),
-                               'bytes_per_point': round(tape_bpp, 1),
-                               'hbm_bytes_from_profiles': prof['pmc'].get('dw_kernel', {}).get('hbm_bytes')}
-    roofline['kernel_ms'] = {k: round(v, 4) for k, v in kern_ms.items()}
-    roofline['kernel_ms_sum'] = round(sum(v for k, v in kern_ms.items() if 'inference' not in k), 4)
-    roofline['kernel_ms_note'] = 'each kernel timed separately from the step loop (HIP events around / between the launches)'
-    if prof['sq']:    # matrix-pipe busy fraction of SIMD cycles from the committed SQ counter passes
-        tag = {', 1>': fwd_name, ', 2>': chain_name, 'dw_kernel': 'dw_kernel', 'fused_fwd_kernel': 'fused_fwd_kernel (inference)'}
-        busy = {n: v['mfma_busy_frac'] for k, v in prof['sq'].items() for t, n in tag.items() if t in k}
-        roofline['mfma_busy_frac_from_profiles'] = busy
-        # matrix-pipe utilisation of the whole training step as the SQ counters saw it: busy fractions of the three MLP
-        # kernels weighted by the durations recorded WITH them in the profile (not by this run's)
-        tk = [fwd_name, chain_name, 'dw_kernel']
-        pms = {n: v.get('ms') for k, v in prof['sq'].items() for t, n in tag.items() if t in k}
-        if all(k in busy and pms.get(k) for k in tk):
-            roofline['step_mfma_busy_frac_from_profiles'] = round(sum(busy[k] * pms[k] for k in tk) / sum(pms[k] for k in tk), 3)
-    roofline['mfma_tflops'] = {k: round(alg[k] * pts / (kern_ms[k] * 1e-3) / 1e12, 1) for k in alg}
-    roofline['mfma_tflops']['fused_fwd_kernel (inference)'] = round(f_fwd * pts / (kern_ms['fused_fwd_kernel (inference)'] * 1e-3) / 1e12, 1)
-    roofline['mfma_frac'] = {k: round(v / PEAK_TFLOPS[args.mode], 4) for k, v in roofline['mfma_tflops'].items()}
+    roofline, kern_ms, group = roofline_block(eng, geom, tM0, dimg, args.depth, args.width, args.mode, args.frames_per_gpu,
+                                              std=(H == 128 and G == 64 and args.frames_per_gpu == 8 and args.width == 256 and args.depth == 4
+                                                   and args.mode == 'bf16' and not args.masked))
+    std = roofline.pop('_std')
+    f_train = mlp_flops(args.depth, args.width)[3]
+    pts = args.frames_per_gpu * geom.P * geom.visited_fraction
+    alg = roofline.pop('_alg')
     step_tflops = f_train * value * geom.visited_fraction / 1e12 / world
     roofline['step_algorithmic_tflops'] = round(step_tflops, 2)
     roofline['step_mfma_frac'] = round(step_tflops / PEAK_TFLOPS[args.mode], 4)      # 1,234,944 flop/point at 4x256
@@ -469,6 +581,7 @@ def main():
     # ---- fwd images/sec: frames / time of the reference's test path over the whole movie (optimization.py:14-66) ----
     fwd_path = None
     if world == 1:
+      try:
         optimization.total_movie_loss(args.frames_per_gpu, opt.state, train_step, rt_args)        # warm-up
         torch.cuda.synchronize()
         reps_f = 3
@@ -481,6 +594,8 @@ def main():
                     'ms_per_movie': round(1e3 * dt_f, 3), 'movie_loss': movie_loss,
                     'path': 'optimization.total_movie_loss -> TrainStep(update_state=False) -> pack, fused render, chi^2 per batch',
                     'kernel_only_images_per_s': round(args.frames_per_gpu / (kern_ms['fused_fwd_kernel (inference)'] * 1e-3), 1)}
+      except Exception as exc:                       # a side block must never cost the headline line
+        fwd_path = {'error': repr(exc)}
 
     # ---- the same step in the f32 parity arithmetic (the mode that meets north_star's 1e-5), single GPU ----------
     parity = None
@@ -503,10 +618,42 @@ def main():
                   'steps': n_p, 'step_algorithmic_tflops': round(tf32, 2), 'step_mfma_frac': round(tf32 / PEAK_TFLOPS['f32'], 4),
                   'peak_tflops': PEAK_TFLOPS['f32'], 'tape_frame_group': grp,
                   'kernel_ms': {k: round(v, 3) for k, v in kms.items()},
-                  'mfma_frac': {k: round(alg[k] * pts / (kms[k] * 1e-3) / 1e12 / PEAK_TFLOPS['f32'], 4) for k in alg},
+                  'mfma_frac': {k: round(v * pts / (kms[k] * 1e-3) / 1e12 / PEAK_TFLOPS['f32'], 4)
+                                for k, v in zip((FWD_NAME, CHAIN_NAME, 'dw_kernel'), mlp_flops(args.depth, args.width)[:3])},
                   'loss': float(torch.as_tensor(opt_p.loss).float().mean())}
         del opt_p, pred_p, eng_p, geom_p
         torch.cuda.empty_cache()
+
+    # ---- the reference's DEFAULT network, 4x128 (network.py:19-20, every tutorial and fit script): the same config-2 geometry,
+    #      frames and loss; bf16; its own kernel path (fused delta chain + dW) ----------
+    width128 = None
+    if world == 1 and std and not args.no_width128:
+      try:
+        pred_w = network.NeRF_Predictor(*dom, net_depth=4, net_width=128, mode='bf16', device=dev)
+        opt_w = optimization.Optimizer(hparams, pred_w, rt_args)
+        run_steps(opt_w, max(args.warmup, 3))
+        torch.cuda.synchronize()
+        n_w = max(10, args.steps // 2)
+        t0 = time.perf_counter()
+        run_steps(opt_w, n_w)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n_w
+        eng_w = pred_w.engine()
+        geom_w = pred_w.geometry(rt_args['coords'], rt_args['Omega'], rt_args['t_geos'], None, rt_args['g'], rt_args['dtau'], rt_args['Sigma'])
+        eng_w.pack(opt_w.state.flat)
+        roof_w, _, grp_w = roofline_block(eng_w, geom_w, tM0, dimg, 4, 128, 'bf16', args.frames_per_gpu, std=False)
+        roof_w.pop('_std'); roof_w.pop('_alg')
+        f_train_w = mlp_flops(4, 128)[3]
+        tfw = f_train_w * samples_step / dt / 1e12
+        roof_w['step_algorithmic_tflops'] = round(tfw, 2)
+        roof_w['step_mfma_frac'] = round(tfw / PEAK_TFLOPS['bf16'], 4)          # 322,560 flop/point at 4x128
+        width128 = {'workload': 'config-2 geometry (%dx%d rays x %d samples, %d frames/step, loss full), 4x128 MLP' % (H, W, G, batch),
+                    'dtype': 'bf16', 'ms_per_step': round(1e3 * dt, 3), 'value': round(samples_step / dt, 1), 'unit': 'ray-samples/s',
+                    'steps': n_w, 'tape_frame_group': grp_w, 'roofline': roof_w, 'loss': float(torch.as_tensor(opt_w.loss).float().mean())}
+        del opt_w, pred_w, eng_w, geom_w
+        torch.cuda.empty_cache()
+      except Exception as exc:
+        width128 = {'error': repr(exc)}
 
     # ---- stand-alone radiative-transfer scan (kgeo.radiative_trasfer, HBM-bound): achieved GB/s ---------
     # measured at the size SURVEY 8d quotes (config 3: 256x256 rays x 128 samples, B*S = 8*3 planes, ~1 GB)
@@ -569,10 +716,20 @@ def main():
         'fwd_images_per_s': fwd_path['value'] if fwd_path else None,
         'fwd_path': fwd_path,
     }
+    if width128:
+        out['width128'] = width128
+    if world == 1 and std and args.other_configs:
+        try:
+            out['strong_scaling_share'] = strong_scaling_share(dev, args.mode)
+        except Exception as exc:
+            out['strong_scaling_share'] = {'error': repr(exc)}
     if args.other_configs and world == 1 and args.mode == 'bf16' and std:
         del opt
         torch.cuda.empty_cache()
-        out['other_configs'] = other_configs(dev, args.mode)
+        try:
+            out['other_configs'] = other_configs(dev, args.mode)
+        except Exception as exc:                     # (an OOM or a missing fixture here must not cost the headline line)
+            out['other_configs'] = {'error': repr(exc)}
     if parity:
         out['parity_mode'] = parity
     if tutorial_domain:

@@ -75,8 +75,11 @@ SIGNATURES = {
     'bhn_grid_render_fwd': (C.c_int, [_GP, _FP, _P, _I32, _F, _P, _P]),
     'bhn_grid_render_bwd': (C.c_int, [_GP, _FP, _P, _I32, _F, _P, _P, _P]),
     'bhn_adam_step': (C.c_int, [_P, _P, _P, _P, _I64, _I64, _F, _F, _F, _F, _F, _P]),
+    'bhn_adam_hyper': (C.c_int, [_I64, _F, _F, _F, C.POINTER(C.c_float)]),
+    'bhn_adam_step_dev': (C.c_int, [_P, _P, _P, _P, _I64, _P, _F, _F, _F, _F, _P]),
     'bhn_render_bwd_tape_timed': (C.c_int, [_MP, _I32, _P, _GP, _FP, _P, _P, _P, _SZ, _P, C.POINTER(C.c_void_p), _I32]),
     'bhn_render_bwd_tape_kernel_name': (C.c_char_p, [_I32]),
+    'bhn_render_bwd_tape_kernel_name_for': (C.c_char_p, [_MP, _I32, _I32]),
     'bhn_selftest': (C.c_int, [C.POINTER(_I32), _P, _SZ]),
 }
 

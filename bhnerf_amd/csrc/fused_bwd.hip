@@ -431,7 +431,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
                 em.emit(A.tape + A.t.enc_off + q * TB, enc[0], e1, edbg);
             } else em.emit(A.tape + A.t.enc_off + q * TB, enc[0], enc[1], edbg);
             const bool drop_h1 = A.t.drop_h1;
-            if (drop_h1 && !(edbg & 2)) {        // ... and, as they are, the A operand from which dW_1 recomputes h_1
+            if (drop_h1 && !A.t.fused128 && !(edbg & 2)) {        // ... and, as they are, the A operand from which dW_1 recomputes h_1
                 __builtin_nontemporal_store(enc[0], reinterpret_cast<frag *>(A.tape + A.t.encp_off + q * TB + lane * 16));
                 __builtin_nontemporal_store(enc[1], reinterpret_cast<frag *>(A.tape + A.t.encp_off + q * TB + Pol::FRAG_BYTES + lane * 16));
             }
@@ -1861,6 +1861,17 @@ extern "C" int bhn_render_bwd_tape_timed(const bhn_model *m, int32_t mode, const
     BHN_CHECK_ARG(events && n_events >= 1 && n_events <= BHN_BWD_TAPE_KERNELS + 1, "events: 1..%d HIP events", BHN_BWD_TAPE_KERNELS + 1);
     return bwd_entry(RUN_BWD_TAPE, m, mode, packed, geom, fr, dimages, nullptr, dparams, workspace, workspace_bytes, stream,
                      events, n_events);
+}
+
+extern "C" const char *bhn_render_bwd_tape_kernel_name(int32_t i);
+extern "C" const char *bhn_render_bwd_tape_kernel_name_for(const bhn_model *m, int32_t mode, int32_t i) {
+    MlpShape s;
+    if (!m || bhn_mlp_shape(m, &s) != BHN_OK) return nullptr;
+    if (bwd128_supported(mode, s.width, s.depth)) {
+        static const char *const names[BHN_BWD_TAPE_KERNELS] = {"bwd128_kernel", "-", "reduce128_kernel"};
+        return (i >= 0 && i < BHN_BWD_TAPE_KERNELS) ? names[i] : nullptr;
+    }
+    return bhn_render_bwd_tape_kernel_name(i);
 }
 
 extern "C" const char *bhn_render_bwd_tape_kernel_name(int32_t i) {

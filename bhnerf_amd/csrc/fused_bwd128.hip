@@ -44,7 +44,9 @@ constexpr int OFF_GA = 0, OFF_H = 2 * IMG, OFF_E = 4 * IMG;         // two gA im
 constexpr int ENC_IMG = 8192;
 constexpr int OFF_DOUT = OFF_E + 2 * ENC_IMG;                       // f32 dout of the 128 points
 constexpr int OFF_DPK = OFF_DOUT + 512;                             // the same as bf16 (dW_out operand)
-constexpr int LDS_BYTES = OFF_DPK + 256;
+constexpr int OFF_W0 = OFF_DPK + 256;                              // layer 0's forward weight fragments (8 KiB) and bias (h_1 recompute)
+constexpr int OFF_B0 = OFF_W0 + 8192;
+constexpr int LDS_BYTES = OFF_B0 + 512;
 constexpr int CB = (KS + 2) * 1024;                                 // chunk bytes of the packed weight images (fused_common.h Pack<128>)
 constexpr int SLAB_TILES = 65;                                      // 60 hidden tiles + 4 layer-0 tiles + the output layer's row / biases
 constexpr int SLAB_FLOATS128 = SLAB_TILES * 1024;
@@ -383,6 +385,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
     };
 
+    // ---- h_1 = relu(W_0^T enc + b_0) recomputed into an h image (same operands, same order, same rounding as the forward's layer
+    //      0: bit-identical to the tile the forward held): wave (i, j) makes row tiles 2i, 2i+1 of point blocks 2j, 2j+1 ----
+    for (int i = tid; i < 8192 / 16; i += 256)
+        reinterpret_cast<u32x4 *>(smem + OFF_W0)[i] = reinterpret_cast<const u32x4 *>(a.packed + a.fwd_off)[i];
+    if (tid < 128) reinterpret_cast<float *>(smem + OFF_B0)[tid] = reinterpret_cast<const float *>(a.packed + a.bias_off)[tid];
+    auto make_h1 = [&](unsigned e_img, unsigned h_out) {
+        frag eb[2][2], wa[2][2];
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) eb[pi][ks] = lds_row(smem, e_img + 64u * (32 * (2 * wj + pi) + pl) + 16u * (2 * ks + hh));
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) wa[mi][ks] = lds_row(smem, OFF_W0 + 1024u * (2 * (2 * wi + mi) + ks) + 16u * lane);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const f32x16 b0 = bias_acc(reinterpret_cast<const float *>(smem + OFF_B0), 2 * wi + mi, hh);
+#pragma unroll
+            for (int pi = 0; pi < 2; ++pi) {
+                f32x16 t = b0;
+                t = Pol::mma(wa[mi][0], eb[pi][0], t);
+                t = Pol::mma(wa[mi][1], eb[pi][1], t);
+                asm volatile("" : "+v"(t));
+                frag o[2];
+                unsigned unused = 0;
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) Pol::relu_pair(o[r >> 3], (r & 7) >> 1, r >> 1, t[r], t[r + 1], unused);
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) lds_put(smem, h_out + (rowb[pi] ^ (16u * (4 * (2 * wi + mi) + 2 * s2))), o[s2]);
+            }
+        }
+    };
+
     // ---- prelude: the first quad's h_depth, h_{depth-1}, enc; its dout; the top layer's weights --------------------------
     long long Q = blockIdx.x;
     frag wf[2][KS];
@@ -433,11 +469,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             // the h image that layer l+1 has released takes h_{l-1} (l == 1: the next quad's h_D), piece by piece under the
             // first chain step's MFMAs; the epilogue of point block 0 runs under the MFMAs of point block 1, that of point block
             // 1 and the loads of the next layer's weights under the dW MFMAs
-            const u32x4 rs_h = (l - 1 >= 1) ? h_rsrc(l - 1, Q) : h_rsrc(DEPTH, Qn);
+            const u32x4 rs_h = (l - 1 >= 2) ? h_rsrc(l - 1, Q) : h_rsrc(DEPTH, Qn);
+            if (l == 2) make_h1(e_img, OFF_H + (hi ^ 1) * IMG);          // (the image h_3 has left; published by this layer's barrier)
             if (l == 1) dnext = point_dout(Qn);                // load issued here, consumed behind this layer's dW phase
             stamp();
             f32x16 c0[2], c1[2];
-            chain_mma(wf, ga_in, 0, c0, [&](int ks) { dma_h_piece(rs_h, hi ^ 1, ks); });
+            chain_mma(wf, ga_in, 0, c0, [&](int ks) { if (l != 2) dma_h_piece(rs_h, hi ^ 1, ks); });
             stamp();
             if constexpr (BHN_B128_ABL & 16) {
                 chain_mma(wf, ga_in, 1, c1, [&](int) {});
@@ -636,10 +673,12 @@ void bwd128_tape_layout(int depth, long long NQ, TapeLayout *t) {
     t->fused128 = 1;
     const long long per_tensor = NQ * (long long)MT * TB;
     long long off = 0;
-    for (int l = 1; l <= depth; ++l) { t->h_off[l] = off; off += per_tensor; }
+    t->drop_h1 = 1;                                              // h_1 = relu(W_0^T enc + b_0) is recomputed by the backward (2 MFMAs per tile)
+    t->h_off[1] = -1;
+    for (int l = 2; l <= depth; ++l) { t->h_off[l] = off; off += per_tensor; }
     for (int l = 0; l < depth; ++l) t->ga_off[l] = -1;
     t->lin_stride = per_tensor;
-    t->h_lin = -per_tensor;                                      // h_off[l] = h_lin + l * lin_stride
+    t->h_lin = -2 * per_tensor;                                  // h_off[l] = h_lin + l * lin_stride, l >= 2
     t->enc_off = off; off += NQ * (long long)TB;
     t->e_off = off; off += NQ * 128;
     t->mask_off = -1; t->dout_off = -1; t->encp_off = -1;

@@ -348,6 +348,40 @@ extern "C" int bhn_adam_step(float *params, const float *grads, float *m, float 
     return BHN_OK;
 }
 
+// The same update with lr and the two bias corrections read from DEVICE memory (hyper = {lr, 1 - b1^t, 1 - b2^t}, written by
+// the host through bhn_adam_hyper): the launch carries no per-step scalar, so a whole training step can be captured into a
+// HIP graph and replayed (optimization.GraphedImageStep).  Same arithmetic as adam_kernel: bitwise-equal parameters.
+__global__ void adam_dev_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                                float *__restrict__ v, int64_t n, const float *__restrict__ hyper, float b1, float b2, float eps, float gs) {
+    const float lr = hyper[0], c1 = hyper[1], c2 = hyper[2];
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * gs;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= lr * (mi / c1) / (sqrtf(vi / c2) + eps);
+    }
+}
+
+extern "C" int bhn_adam_hyper(int64_t t, float lr, float b1, float b2, float *hyper_host) {
+    BHN_CHECK_ARG(hyper_host && t >= 1, "bad adam hyper arguments");
+    hyper_host[0] = lr;
+    hyper_host[1] = (float)(1.0 - pow((double)b1, (double)t));
+    hyper_host[2] = (float)(1.0 - pow((double)b2, (double)t));
+    return BHN_OK;
+}
+
+extern "C" int bhn_adam_step_dev(float *params, const float *grads, float *m, float *v, int64_t n, const float *hyper_dev,
+                                 float b1, float b2, float eps, float grad_scale, void *stream) {
+    BHN_CHECK_ARG(params && grads && m && v && hyper_dev && n > 0, "bad adam arguments");
+    const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, n, hyper_dev, b1, b2, eps,
+                       grad_scale);
+    BHN_HIP(hipGetLastError());
+    return BHN_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // loss_fn_eht (network.py:541-564): visibilities = A . image, chi^2 on 'vis' | 'amp' | 'cphase'.
 // A is complex64 (interleaved re,im), shape (N, C, nvis, R): C = 1 for vis/amp, 3 for closure

@@ -470,3 +470,19 @@ def adam_step(params, grads, m, v, t, lr, b1=0.9, b2=0.999, eps=1e-8, grad_scale
         _hip.check(_hip.lib().bhn_adam_step(_hip.ptr(params), _hip.ptr(grads), _hip.ptr(m), _hip.ptr(v), params.numel(),
                                             int(t), float(lr), b1, b2, eps, float(grad_scale),
                                             _hip.stream_ptr(params.device)))
+
+
+def adam_hyper(t, lr, b1=0.9, b2=0.999):
+    """(lr, 1 - b1^t, 1 - b2^t) as float32, computed by the library exactly as bhn_adam_step does (host)."""
+    h = (C.c_float * 3)()
+    _hip.check(_hip.lib().bhn_adam_hyper(int(t), float(lr), b1, b2, h))
+    return np.array(list(h), dtype=np.float32)
+
+
+def adam_step_dev(params, grads, m, v, hyper_dev, b1=0.9, b2=0.999, eps=1e-8, grad_scale=1.0):
+    """Adam with lr / bias corrections read from device memory (hyper_dev: 3 float32): no per-step scalar in the launch, so the
+    step can sit inside a HIP graph.  Bitwise equal to adam_step given adam_hyper's values."""
+    assert hyper_dev.dtype == torch.float32 and hyper_dev.numel() >= 3 and hyper_dev.is_cuda
+    with torch.cuda.device(params.device):
+        _hip.check(_hip.lib().bhn_adam_step_dev(_hip.ptr(params), _hip.ptr(grads), _hip.ptr(m), _hip.ptr(v), params.numel(),
+                                                _hip.ptr(hyper_dev), b1, b2, eps, float(grad_scale), _hip.stream_ptr(params.device)))

@@ -114,6 +114,7 @@ class Optimizer(object):
             lr_inject=hparams.get('lr_inject', None), checkpoint_dir=checkpoint_dir)
         # opt-in: all-reduce of step k under the forward / backward of step k+1 (one-step-stale gradients; network.TrainState)
         self.state.overlap_allreduce = bool(hparams.get('overlap_allreduce', False))
+        self.hip_graph = hparams.get('hip_graph', None)       # None: leave the TrainStep's own setting (BHNERF_HIP_GRAPH)
         if checkpoint_dir and network._world()[0] == 0:
             predictor.save_params(checkpoint_dir)
 
@@ -136,6 +137,8 @@ class Optimizer(object):
         self.final_step = self.init_step + self.num_iters
         self.log_fns = list(np.atleast_1d(log_fns))
         self.train_step, self.raytracing_args = train_step, raytracing_args
+        if self.hip_graph is not None:
+            train_step.use_graph = bool(self.hip_graph)
         frames = train_step.args[0]
         bar = tqdm(range(self.init_step, self.final_step), desc='iteration', disable=network._world()[0] != 0)
         try:
@@ -162,6 +165,104 @@ def _shared_rng(stream):
     return np.random.default_rng([int(os.environ.get('BHNERF_BATCH_SEED', '0')), int(stream)])
 
 
+class GraphedImageStep:
+    """One `gradient_step_image` (pack -> training forward -> chi^2 -> fused backward -> Adam) for a fixed ray set and batch
+    size, captured ONCE into a HIP graph and replayed per step.  Everything that changes from step to step lives in device
+    buffers the graph reads: the frame indices (the batch of target / sigma / offset is gathered inside the graph), the frame
+    time offsets tM0, and Adam's learning rate and bias corrections (bhn_adam_step_dev).  Per step the host fills one pinned
+    staging buffer, issues three small asynchronous copies and one graph launch -- instead of ~25 Python-level launches --
+    which is what a GPU needs when its share of a step is a single small frame (the reference's b = 8 on 8 devices,
+    optimization.py:289-291).  With a process group the graph ends at the gradient; the all-reduce and Adam follow eagerly.
+    The arithmetic is the un-captured step's, kernel for kernel: parameters are bitwise equal (tests/test_gpu_api.py)."""
+
+    def __init__(self, state, args, dtype, scale, rt, n_local):
+        from . import engine, _hip
+        pred = state.predictor
+        eng = pred.engine()
+        self.state, self.eng, self.args, self.dtype, self.scale = state, eng, args, dtype, float(scale)
+        dev = eng.device
+        self.geom = geom = pred.geometry(rt['coords'], rt['Omega'], rt['t_geos'], network._stokes_or_none(rt['J']), rt['g'], rt['dtau'], rt['Sigma'])
+        B = self.B = int(n_local)
+        if not eng.fits_tape(B, geom.P_eff):
+            raise ValueError('the tape of %d frames does not fit the workspace: no graph for this step' % B)
+        t_start, t_units = rt['t_start_obs'], args.t_units
+        if units.is_quantity(t_start):
+            t_units, t_start = t_start.unit, float(t_start.value)
+        from . import constants
+        self.GM = constants.GM_c3(t_units) if t_units is not None else 1.0
+        self.t_start, self.t_inj = float(t_start), float(rt['t_injection'])
+        args[np.arange(min(args.num_frames, network._world()[1]))]            # (makes the device-resident copies of the per-frame arrays)
+        self.full = [engine._hip.as_f32(a, dev) for a in args._dev[:3]]         # whole-movie target, sigma, offset
+        self.tshape = (B, geom.Sx, geom.R) if dtype == 'full' else (B, geom.Sx)
+        # per-step inputs: one pinned staging buffer, three device buffers the graph reads
+        self.h_idx = torch.zeros(B, dtype=torch.int64).pin_memory()
+        self.h_tM0 = torch.zeros(B, dtype=torch.float64).pin_memory()
+        self.h_hyp = torch.zeros(3, dtype=torch.float32).pin_memory()
+        self.d_idx = torch.zeros(B, dtype=torch.int64, device=dev)
+        self.d_tM0 = torch.zeros(B, dtype=torch.float64, device=dev)
+        self.d_hyp = torch.ones(3, dtype=torch.float32, device=dev)
+        self.images = torch.empty((B, geom.Sx, geom.R), dtype=torch.float32, device=dev)
+        self.n = eng.nparams
+        self.with_adam = not network._dist_on()                               # (a process group: exchange + Adam stay outside the graph)
+        self.graph = None
+        self.loss = None
+
+    def _body(self):
+        from . import engine
+        st, eng, geom = self.state, self.eng, self.geom
+        eng.pack(st.flat)
+        tgt, sig, off = (a.index_select(0, self.d_idx).reshape(self.tshape) for a in self.full)
+        images = eng.render_train(geom, self.d_tM0, out=self.images)
+        loss, dimg = engine.chi2_image(images, tgt, sig, off, self.scale, self.dtype)
+        buf = st.grad_buffer()
+        eng.render_bwd_tape(geom, self.d_tM0, dimg, out=buf[:self.n])
+        if self.with_adam:
+            engine.adam_step_dev(st.flat, buf[:self.n], st.m, st.v, self.d_hyp, grad_scale=1.0)
+        return loss, buf
+
+    def _stage(self, key):
+        from . import engine
+        st = self.state
+        self.h_idx.copy_(torch.as_tensor(np.asarray(key, dtype=np.int64)))
+        tM0 = (self.args.t_values[key] - self.t_start) / self.GM - self.t_inj          # engine.frame_offsets, float64
+        self.h_tM0.copy_(torch.as_tensor(np.asarray(tM0, dtype=np.float64)))
+        self.h_hyp.copy_(torch.as_tensor(engine.adam_hyper(st.step + 1, st.learning_rate())))
+        self.d_idx.copy_(self.h_idx, non_blocking=True)
+        self.d_tM0.copy_(self.h_tM0, non_blocking=True)
+        self.d_hyp.copy_(self.h_hyp, non_blocking=True)
+
+    def __call__(self, key):
+        """key: this rank's frame indices of the step (length B).  Returns (loss vector, state, images (1, B, [S], H, W))."""
+        st, geom = self.state, self.geom
+        assert len(key) == self.B
+        self._stage(key)
+        if self.graph is None:
+            # two eager steps' worth of kernels on a side stream first (lazy allocations, kernel attributes), on a COPY of
+            # the optimiser state; then the capture
+            keep = [t.clone() for t in (st.flat, st.m, st.v)]
+            s = torch.cuda.Stream(device=self.eng.device)
+            s.wait_stream(torch.cuda.current_stream(self.eng.device))
+            with torch.cuda.stream(s):
+                self._body()
+            torch.cuda.current_stream(self.eng.device).wait_stream(s)
+            for t, k in zip((st.flat, st.m, st.v), keep):
+                t.copy_(k)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.loss, self.buf = self._body()
+            for t, k in zip((st.flat, st.m, st.v), keep):                          # (capture does not execute, but stay safe)
+                t.copy_(k)
+        self.graph.replay()
+        rank, world = network._world()
+        if self.with_adam:
+            st.step += 1
+            loss_vec = self.loss
+        else:
+            loss_vec = network._exchange_and_apply(st, self.buf, self.n, self.loss, rank, world)
+        out = self.images.reshape((1, self.B) + ((geom.S,) if geom.S else ()) + geom.spatial)
+        return loss_vec, st, out
+
+
 class TrainStep(object):
     """Container of per-loss step functions (optimization.py:145-272)."""
 
@@ -179,6 +280,22 @@ class TrainStep(object):
         # the sub-pixel ray set of a training step is ONE choice for all devices (optimization.py:169 runs once in the
         # reference's single process): every rank draws it from a generator seeded like TemporalBatchedArgs._rng
         self._rng = _shared_rng(1)
+        # opt-in (hparams['hip_graph'] / BHNERF_HIP_GRAPH=1): training steps of a single image-plane loss are captured into
+        # one HIP graph per (ray set, batch size) -- GraphedImageStep
+        self.use_graph = os.environ.get('BHNERF_HIP_GRAPH') == '1'
+        self._graphs = {}
+
+    def _graphed(self, state, rt, indices):
+        key = shard(np.atleast_1d(np.asarray(indices)))
+        gkey = (id(rt), len(key), id(state))
+        g = self._graphs.get(gkey)
+        if g is None:
+            try:
+                g = GraphedImageStep(state, self.args[0], str(self.dtype[0]), float(self.scale[0]), rt, len(key))
+            except ValueError:
+                g = False                                  # (tape does not fit: this step stays eager)
+            self._graphs[gkey] = g
+        return g(key) if g else None
 
     def __call__(self, state, raytracing_args, indices, update_state=True):
         """One pass over the losses.  Training picks ONE ray set at random (stochastic sub-pixel sampling,
@@ -187,6 +304,12 @@ class TrainStep(object):
         if update_state:
             ray_sets = [ray_sets[int(self._rng.integers(len(ray_sets)))]]
         fns = self.grad_pmap if update_state else self.test_pmap
+        if (update_state and self.use_graph and self.num_losses == 1 and fns[0] is network.gradient_step_image
+                and torch.cuda.is_available() and not getattr(state, 'overlap_allreduce', False)
+                and type(state.predictor) is network.NeRF_Predictor):
+            res = self._graphed(state, ray_sets[0], indices)
+            if res is not None:
+                return res
         loss_acc = images_acc = 0.0
         for rt in ray_sets:
             for k in range(self.num_losses):

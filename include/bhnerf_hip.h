@@ -193,6 +193,14 @@ int bhn_grid_render_bwd(const bhn_geom *geom, const bhn_frames *fr, const float 
 int bhn_adam_step(float *params, const float *grads, float *m, float *v, int64_t n, int64_t t, float lr,
                   float b1, float b2, float eps, float grad_scale, void *stream);
 
+/* The same update for a step that is captured into a HIP graph: lr and the two bias corrections come from DEVICE memory
+ * (hyper_dev[3] = {lr, 1 - b1^t, 1 - b2^t}), so the launch carries no per-step scalar.  bhn_adam_hyper fills the three floats on
+ * the HOST exactly as bhn_adam_step computes them (the caller copies them to hyper_dev before each replay): parameters
+ * bitwise equal to bhn_adam_step's. */
+int bhn_adam_hyper(int64_t t, float lr, float b1, float b2, float *hyper_host);
+int bhn_adam_step_dev(float *params, const float *grads, float *m, float *v, int64_t n, const float *hyper_dev,
+                      float b1, float b2, float eps, float grad_scale, void *stream);
+
 /* bhn_render_bwd_tape with the caller's HIP events recorded on `stream` at its kernel boundaries, so that each kernel
  * of the backward can be timed live (bench.py's roofline): events[0] before the first kernel, events[i] behind kernel
  * i - 1 (i = 1..BHN_BWD_TAPE_KERNELS); n_events <= BHN_BWD_TAPE_KERNELS + 1, NULL entries are skipped.  The events are
@@ -203,6 +211,10 @@ int bhn_render_bwd_tape_timed(const bhn_model *m, int32_t mode, const void *pack
                               const bhn_frames *fr, const float *dimages, float *dparams, void *workspace,
                               size_t workspace_bytes, void *stream, void *const *events, int32_t n_events);
 const char *bhn_render_bwd_tape_kernel_name(int32_t i);
+/* The same for the path a given network takes: width-128 bf16 networks of depth 4 (the reference's default MLP, network.py:19-20)
+ * run the delta chain and the weight-gradient GEMMs as ONE kernel (slot 0: "bwd128_kernel", behind a small per-point
+ * "dout128_kernel"; slot 1 is empty: "-"; slot 2: "reduce128_kernel"). */
+const char *bhn_render_bwd_tape_kernel_name_for(const bhn_model *m, int32_t mode, int32_t i);
 
 /* Device self-checks of the MFMA / LDS-transpose / LDS-DMA lane maps the kernels rely on (exact integer
  * data).  results: 8 int32 mismatch counts on the host, all 0 when the maps hold.  scratch_dev: caller-owned device

@@ -126,6 +126,16 @@ class _StubEngine:
         return out
 
 
+def _frames_for(world):
+    rep = max(1, world // 4)
+    return 4 * rep, rep
+
+
+def _batch_indices(it, nf):
+    base = np.array([[2, 0, 3, 1], [0, 1, 2, 3], [3, 2, 1, 0]][it])
+    return np.concatenate([base + 4 * r for r in range(nf // 4)]) if nf > 4 else base
+
+
 def _step_worker(rank, world, port, out, overlap=False):
     import sys
     import types
@@ -160,18 +170,19 @@ def _step_worker(rank, world, port, out, overlap=False):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         shape = (4, H, W)
-        arrs = [g[k + '_full'].reshape(shape).astype(np.float32) for k in ('target', 'sigma', 'offset')]
-        batched = optimization.TemporalBatchedArgs(g['t_frames'] * units.hr, arrs)
+        nf, rep = _frames_for(world)            # world 8: the fixture's four frames twice (one frame per rank)
+        arrs = [np.concatenate([g[k + '_full'].reshape(shape).astype(np.float32)] * rep) for k in ('target', 'sigma', 'offset')]
+        batched = optimization.TemporalBatchedArgs(np.concatenate([g['t_frames']] * rep) * units.hr, arrs)
         losses = []
         for it in range(3):
-            idx = np.array([[2, 0, 3, 1], [0, 1, 2, 3], [3, 2, 1, 0]][it])
+            idx = _batch_indices(it, nf)
             tgt, sig, off, tf = batched[idx]                                          # this rank's contiguous slice
-            assert len(tf) == 4 // world
+            assert len(tf) == nf // world
             loss, state, images = network.gradient_step_image(
                 state, units.hr, 'full', tgt, sig, off, tf, g['coords'], g['Omega'], 1.0, g['g'], g['dtau'], g['Sigma'],
                 float(g['t_start_obs']), g['t_geos'], float(g['t_injection']), 1.0)
             losses.append(loss.numpy().copy())
-            assert images.shape == (1, 4 // world, H, W)
+            assert images.shape == (1, nf // world, H, W)
         adam = 'adam(grad_scale=%g)' % (1.0 / world)
         if overlap:
             # the all-reduce of step k completes inside step k+1 (after its backward); the last one at finish_allreduce()
@@ -190,7 +201,7 @@ def _step_worker(rank, world, port, out, overlap=False):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize('world', [2, 4])
+@pytest.mark.parametrize('world', [2, 4, 8])
 def test_two_rank_training_steps_match_single_process_reference(world):
     port = _free_port()
     ctx = mp.get_context('spawn')
@@ -215,11 +226,13 @@ def test_two_rank_training_steps_match_single_process_reference(world):
     tr.num_iters, tr.lr_init, tr.lr_final = 3, 1e-3, 1e-4
     p0 = torch.cat([p.detach().reshape(-1) for i in range(len(tr.k)) for p in (tr.k[i], tr.b[i])]).numpy().copy()
     shape = (4,) + g['coords'].shape[1:3]
-    tgt = {k: t(g[k + '_full']).reshape(shape) for k in ('target', 'sigma', 'offset')}
+    nf, rep = _frames_for(world)
+    tgt = {k: torch.cat([t(g[k + '_full']).reshape(shape)] * rep) for k in ('target', 'sigma', 'offset')}
+    t_all = np.concatenate([g['t_frames']] * rep)
     ref_losses = []
     for it in range(3):
-        idx = [[2, 0, 3, 1], [0, 1, 2, 3], [3, 2, 1, 0]][it]
-        loss, _ = tr.step(t(g['t_frames'][idx]), tgt['target'][idx], tgt['sigma'][idx], tgt['offset'][idx], 1.0, 'full', grad_div=world)
+        idx = _batch_indices(it, nf)
+        loss, _ = tr.step(t(t_all[idx]), tgt['target'][idx], tgt['sigma'][idx], tgt['offset'][idx], 1.0, 'full', grad_div=world)
         ref_losses.append(float(loss))
     ref = torch.cat([p.detach().reshape(-1) for i in range(len(tr.k)) for p in (tr.k[i], tr.b[i])]).numpy()
     moved = np.abs(ref - p0).max()

@@ -93,3 +93,20 @@ def test_bench_gpus_flag_spawns_the_ranks():
     # --gpus and WORLD_SIZE must agree
     bad = subprocess.run(cmd[:2] + ['--gpus', '2', '--no-cpu-baseline'], env=dict(env, WORLD_SIZE='1', RANK='0'), capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and 'WORLD_SIZE' in (bad.stderr + bad.stdout)
+
+
+@pytest.mark.timeout(1500)
+def test_bench_with_eight_ranks_on_one_device():
+    """The driver's 8-GPU launch shape, `bench.py --gpus 8` (8 ranks x 8 frames = 64 frames per step, one all-reduce), with every
+    rank on cuda:0 over gloo (BHNERF_BENCH_ONE_DEVICE=1): rank counts beyond 1 / 2 / 4 have no other coverage on a 1-GPU box."""
+    env = dict(os.environ, BHNERF_BENCH_ONE_DEVICE='1')
+    env.pop('WORLD_SIZE', None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '2', '--warmup', '1', '--image', '32',
+           '--ngeo', '32', '--frames', '64', '--frames-per-gpu', '8', '--width', '64', '--no-cpu-baseline']
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1400)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(line) == 1
+    r = json.loads(line[0])
+    assert r['n_gpus'] == 8 and r['config']['frames_per_step'] == 64 and r['config']['parallelism'].startswith('dp8')
+    assert r['value'] > 0 and r['scaling'] == 'weak'
