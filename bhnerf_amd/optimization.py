@@ -194,10 +194,11 @@ class GraphedImageStep:
         args[np.arange(min(args.num_frames, network._world()[1]))]            # (makes the device-resident copies of the per-frame arrays)
         self.full = [engine._hip.as_f32(a, dev) for a in args._dev[:3]]         # whole-movie target, sigma, offset
         self.tshape = (B, geom.Sx, geom.R) if dtype == 'full' else (B, geom.Sx)
-        # per-step inputs: one pinned staging buffer, three device buffers the graph reads
-        self.h_idx = torch.zeros(B, dtype=torch.int64).pin_memory()
-        self.h_tM0 = torch.zeros(B, dtype=torch.float64).pin_memory()
-        self.h_hyp = torch.zeros(3, dtype=torch.float32).pin_memory()
+        # per-step inputs: a ring of pinned staging slots (the host runs ahead of the GPU: a slot is rewritten only after the
+        # copies issued from it have executed), three device buffers the graph reads
+        self.slots = [dict(idx=torch.zeros(B, dtype=torch.int64).pin_memory(), tM0=torch.zeros(B, dtype=torch.float64).pin_memory(),
+                           hyp=torch.zeros(3, dtype=torch.float32).pin_memory(), done=None) for _ in range(8)]
+        self.slot_i = 0
         self.d_idx = torch.zeros(B, dtype=torch.int64, device=dev)
         self.d_tM0 = torch.zeros(B, dtype=torch.float64, device=dev)
         self.d_hyp = torch.ones(3, dtype=torch.float32, device=dev)
@@ -223,13 +224,20 @@ class GraphedImageStep:
     def _stage(self, key):
         from . import engine
         st = self.state
-        self.h_idx.copy_(torch.as_tensor(np.asarray(key, dtype=np.int64)))
+        sl = self.slots[self.slot_i]
+        self.slot_i = (self.slot_i + 1) % len(self.slots)
+        if sl['done'] is not None:
+            sl['done'].synchronize()                       # (only when the GPU is a whole ring behind the host)
+        sl['idx'].copy_(torch.as_tensor(np.asarray(key, dtype=np.int64)))
         tM0 = (self.args.t_values[key] - self.t_start) / self.GM - self.t_inj          # engine.frame_offsets, float64
-        self.h_tM0.copy_(torch.as_tensor(np.asarray(tM0, dtype=np.float64)))
-        self.h_hyp.copy_(torch.as_tensor(engine.adam_hyper(st.step + 1, st.learning_rate())))
-        self.d_idx.copy_(self.h_idx, non_blocking=True)
-        self.d_tM0.copy_(self.h_tM0, non_blocking=True)
-        self.d_hyp.copy_(self.h_hyp, non_blocking=True)
+        sl['tM0'].copy_(torch.as_tensor(np.asarray(tM0, dtype=np.float64)))
+        sl['hyp'].copy_(torch.as_tensor(engine.adam_hyper(st.step + 1, st.learning_rate())))
+        self.d_idx.copy_(sl['idx'], non_blocking=True)
+        self.d_tM0.copy_(sl['tM0'], non_blocking=True)
+        self.d_hyp.copy_(sl['hyp'], non_blocking=True)
+        if sl['done'] is None:
+            sl['done'] = torch.cuda.Event()
+        sl['done'].record()
 
     def __call__(self, key):
         """key: this rank's frame indices of the step (length B).  Returns (loss vector, state, images (1, B, [S], H, W))."""
