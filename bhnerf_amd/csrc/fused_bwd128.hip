@@ -246,7 +246,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             side(ks);
             __builtin_amdgcn_sched_barrier(0);
         }
-        asm volatile("" : "+v"(c[0]), "+v"(c[1]));     // the epilogue is VALU work: keep the tile out of the AGPRs (2 v_accvgpr_read per pair)
+        // (hipcc places these two tiles in the 32 AGPRs the dW accumulators leave free and reads them out for the epilogue, 32
+        //  v_accvgpr_read per point block; forcing them into VGPRs inside the loop made it copy back and forth every k-step)
+        asm volatile("" : "+v"(c[0]), "+v"(c[1]));
     };
     // ... and their epilogue: gA_{l-1} = relu'(a_{l-1}) (.) c, relu' read off the h_l image (h_l = relu(a_{l-1}) as bf16)
     // the same epilogue in eight slices (slice j: row tile j >> 2, k-step (j >> 1) & 1, half j & 1 of its eight elements),

@@ -10,7 +10,7 @@
 #   <tag>_telemetry_bench.txt     board power / SMI clock during 400 training steps of bench.py (tools/smi_sample.py)
 # The files land in gpurun_out/profiles/ (merged back by gpurun); copy them to profiles/ and commit.
 set -euo pipefail
-TAG=${1:-r3}
+TAG=${1:-r4}
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/profiles
@@ -22,25 +22,34 @@ rm -rf /tmp/kt; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt 
 f=$(find /tmp/kt -name "*kernel_stats.csv" | head -1); need "$f"; cp "$f" $O/${TAG}_bench_kernel_stats.csv
 rm -rf /tmp/ktf; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ktf -o kt -- python3 $R/bench.py --mode f32 --steps 3 --warmup 1 --no-cpu-baseline --no-tutorial-domain --no-other-configs --no-width128 > /tmp/ktf.log 2>&1
 f=$(find /tmp/ktf -name "*kernel_stats.csv" | head -1); need "$f"; cp "$f" $O/${TAG}_f32_kernel_stats.csv
+rm -rf /tmp/ktw; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ktw -o kt -- python3 $R/bench.py --width 128 --steps 5 --warmup 2 --no-cpu-baseline --no-parity-mode --no-tutorial-domain --no-other-configs --no-width128 > /tmp/ktw.log 2>&1
+f=$(find /tmp/ktw -name "*kernel_stats.csv" | head -1); need "$f"; cp "$f" $O/${TAG}_w128_kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pm_$c; rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pm_$c -o p -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity-mode --no-tutorial-domain --no-other-configs --no-width128 > /tmp/pm_$c.log 2>&1
   f=$(find /tmp/pm_$c -name "*counter_collection.csv" | head -1); need "$f"; cp "$f" /tmp/pm_$c.csv
 done
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pw_$c; rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pw_$c -o p -- python3 $R/bench.py --width 128 --steps 3 --warmup 1 --no-cpu-baseline --no-parity-mode --no-tutorial-domain --no-other-configs --no-width128 > /tmp/pw_$c.log 2>&1
+  f=$(find /tmp/pw_$c -name "*counter_collection.csv" | head -1); need "$f"; cp "$f" /tmp/pw_$c.csv
+done
 LIBMD5=$(md5sum $R/bhnerf_amd/csrc/libbhnerf_hip.so | cut -d" " -f1)
 export LIBMD5
-python3 - > $O/${TAG}_pmc_traffic.json <<'PY'
+for W in 256 128; do
+export PMC_W=$W
+python3 - > $O/${TAG}_pmc_traffic$( [ $W = 128 ] && echo _w128 ).json <<'PY'
 import csv, json, collections, os
+PFX = '/tmp/pm_' if os.environ.get('PMC_W') == '256' else '/tmp/pw_'
 out = collections.OrderedDict()
 ms = collections.defaultdict(list)
 def short(k):
     if 'chain_kernel' in k: return 'chain_kernel<MODE_FWD_TRAIN>' if ', 1>' in k else 'chain_kernel<MODE_CHAIN>' if ', 2>' in k else None
-    for n in ('dw_kernel', 'reduce_kernel', 'rt_kernel', 'adam_kernel', 'chi2_image_kernel', 'pack_weights_kernel', 'eht_vis_kernel', 'eht_bwd_kernel'):
+    for n in ('bwd128_kernel', 'dout128_kernel', 'reduce128_kernel', 'dw_kernel', 'reduce_kernel', 'rt_kernel', 'adam_kernel', 'chi2_image_kernel', 'pack_weights_kernel', 'eht_vis_kernel', 'eht_bwd_kernel'):
         if n in k: return n
     if 'fused_fwd_kernel' in k: return 'fused_fwd_kernel (inference)'
     return None
 for c in ('FETCH_SIZE', 'WRITE_SIZE'):
     acc = collections.defaultdict(list)
-    for r in csv.DictReader(open('/tmp/pm_%s.csv' % c)):
+    for r in csv.DictReader(open(PFX + '%s.csv' % c)):
         n = short(r['Kernel_Name'])
         if n and r['Counter_Name'] == c:
             acc[n].append(float(r['Counter_Value']))
@@ -52,11 +61,15 @@ for n, d in out.items():
     d['ms_under_profiler'] = round(sum(ms[n]) / len(ms[n]), 4)
 print(json.dumps({'lib_md5': os.environ.get('LIBMD5'), 'note': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace) of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity-mode --no-tutorial-domain --no-other-configs --no-width128`; averages per launch in KiB as reported; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 with the gfx950 correction (FETCH_SIZE reports half of wide coalesced reads, MI355X_MICROARCH.md HBM section)', 'kernels': out}, indent=1))
 PY
+done
 need $O/${TAG}_pmc_traffic.json
-bash $R/tools/pmc_collect.sh > /tmp/sq.log 2>&1
+need $O/${TAG}_pmc_traffic_w128.json
+for W in 256 128; do
+SFX=$( [ $W = 128 ] && echo _w128 || true )
+bash $R/tools/pmc_collect.sh bf16 $W > /tmp/sq.log 2>&1
 ls $R/gpurun_out/pmc/pass*.txt > /dev/null
-cat $R/gpurun_out/pmc/pass*.txt > $O/${TAG}_sq_counters.txt
-python3 - $O/${TAG}_sq_counters.txt > $O/${TAG}_sq_summary.json <<'PY'
+cat $R/gpurun_out/pmc/pass*.txt > $O/${TAG}${SFX}_sq_counters.txt
+python3 - $O/${TAG}${SFX}_sq_counters.txt > $O/${TAG}${SFX}_sq_summary.json <<'PY'
 import sys, json, re, collections, os
 k = None; d = collections.OrderedDict()
 for l in open(sys.argv[1]):
@@ -80,14 +93,18 @@ for k, c in d.items():
         pass
 print(json.dumps({'lib_md5': os.environ.get('LIBMD5'), 'note': 'from sq_counters.txt (rocprofv3 --pmc SQ_* passes of tools/pmc_run.py, one launch each): mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES) = fraction of SIMD cycles with the matrix pipe busy', 'kernels': out}, indent=1))
 PY
+done
 need $O/${TAG}_sq_summary.json
+need $O/${TAG}_w128_sq_summary.json
 hipcc -O3 -std=c++17 --offload-arch=gfx950 -I$R/bhnerf_amd/csrc -I$R/include $R/tools/step_bench.hip -o /tmp/step_bench > /tmp/step_bench.log 2>&1
-python3 $R/tools/smi_sample.py > $O/${TAG}_telemetry_ceiling.txt & SMI=$!
-sleep 2; /tmp/step_bench ceiling 8 > $O/${TAG}_ring_ceiling_microbench.txt 2>&1; sleep 1; kill $SMI
+: > $O/${TAG}_telemetry_ceiling.txt
+python3 $R/tools/smi_sample.py >> $O/${TAG}_telemetry_ceiling.txt & SMI=$!
+sleep 2; /tmp/step_bench ceiling 8 > $O/${TAG}_ring_ceiling_microbench.txt 2>&1; sleep 1; kill $SMI || true
 need $O/${TAG}_ring_ceiling_microbench.txt
-python3 $R/tools/smi_sample.py > $O/${TAG}_telemetry_bench.txt & SMI=$!
+: > $O/${TAG}_telemetry_bench.txt
+python3 $R/tools/smi_sample.py >> $O/${TAG}_telemetry_bench.txt & SMI=$!
 sleep 2; date +"# bench.py --steps 400 starts %s" >> $O/${TAG}_telemetry_bench.txt
 python3 $R/bench.py --steps 400 --warmup 5 --no-cpu-baseline --no-parity-mode --no-tutorial-domain --no-other-configs --no-width128 > /tmp/bench400.json 2> /tmp/bench400.err
-date +"# bench.py ends %s" >> $O/${TAG}_telemetry_bench.txt; sleep 1; kill $SMI
+date +"# bench.py ends %s" >> $O/${TAG}_telemetry_bench.txt; sleep 1; kill $SMI || true
 python3 -c "import json; d=json.load(open('/tmp/bench400.json')); print('# bench.py --steps 400: ms_per_step %.3f' % d['ms_per_step'])" >> $O/${TAG}_telemetry_bench.txt
 ls -la $O
