@@ -693,6 +693,8 @@ struct TapeStream {
     }
     // voff: the lane's byte offset on the GLOBAL side (the LDS side of a piece is lane-linear).  Any permutation of the
     // 64 16-byte slots of a piece can be had for free by permuting these offsets (voffA, region 0).
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"      // (only: "inline asm clobber list contains reserved registers: M0")
     template <int POLICY>
     static DEVI void dma(const u32x4 &rs, unsigned soff, unsigned m, unsigned voff) {
         if constexpr (POLICY == 1)
@@ -702,6 +704,7 @@ struct TapeStream {
         else
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(m), "v"(voff), "s"(rs), "s"(soff) : "memory", "m0");
     }
+#pragma clang diagnostic pop
     template <int POLICY, int I>
     DEVI void row(long long q, unsigned lb, u32x4 (&rs)[4]) const {
         constexpr int p0 = NW * I;

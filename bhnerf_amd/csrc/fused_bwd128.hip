@@ -72,6 +72,8 @@ DEVI u32x4 make_rsrc(const char *p) {
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
     return u32x4{lo, hi & 0xffffu, 0x7fffffffu, 0x00020000u};
 }
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"      // (only: "inline asm clobber list contains reserved registers: M0")
 // one wave copies 1 KiB global -> LDS: lane i's 16 bytes come from rs.base + soff + voff(i) and land at lds + 16 i
 DEVI void dma_piece(const u32x4 &rs, unsigned soff, unsigned lds, unsigned voff) {
 #ifdef BHN_B128_ABL
@@ -79,6 +81,7 @@ DEVI void dma_piece(const u32x4 &rs, unsigned soff, unsigned lds, unsigned voff)
 #endif
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen nt lds" ::"s"(lds), "v"(voff), "s"(rs), "s"(soff) : "memory", "m0");
 }
+#pragma clang diagnostic pop
 
 // g with every 16-bit half zeroed whose half of h is zero (h: non-negative bf16 pairs, i.e. relu outputs).  Three instructions
 // per pair of elements: h + 0x7fff7fff sets a half's sign bit iff it is nonzero (no carry between halves), a packed arithmetic

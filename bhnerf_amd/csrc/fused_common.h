@@ -601,6 +601,8 @@ DEVI void dma_1k(const char *src, char *dst) {
 // ordered by the kernel's own counted vmcnt waits + barrier, exactly as for the builtin form.  M0 = LDS byte address
 // of the wave's first lane; M0 is declared clobbered (the builtin LDS-DMA form and movrel / gpr_idx indexing use M0 too:
 // without the clobber LLVM may hoist or merge its own M0 initialisations across this statement).
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"      // (only: "inline asm clobber list contains reserved registers: M0")
 template <int POLICY = 0>      // 0 default, 1 nt (bytes one CU reads once from HBM), 2 sc1 (bytes another CU has just written)
 DEVI void dma_1k_asm(const char *src, char *dst) {
     const unsigned long long u = reinterpret_cast<unsigned long long>(src);
@@ -617,6 +619,7 @@ DEVI void dma_1k_asm(const char *src, char *dst) {
     else
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(m), "v"(voff), "s"(rs) : "memory", "m0");
 }
+#pragma clang diagnostic pop
 
 template <int CHUNK_BYTES, int NWAVES>
 struct DmaRing {

@@ -192,9 +192,13 @@ class TrainState:
 
 
 def _fingerprint(v):
-    """Cache key of one ray-tracing argument (NeRF_Predictor.geometry): identity + what an in-place edit would change."""
-    if v is None or np.isscalar(v):
+    """Cache key of one ray-tracing argument (NeRF_Predictor.geometry): identity + what an in-place edit would change.
+    BEST EFFORT for NumPy arrays (a strided 257-element sample: an edit that touches none of the sampled elements is not
+    seen -- pass a new array or call clear_geometry_cache()); exact for torch tensors (in-place version counter)."""
+    if v is None:
         return v
+    if np.isscalar(v):
+        return ('nan',) if (isinstance(v, float) and v != v) else v      # (a NaN never compares equal: it would rebuild the geometry every step)
     if isinstance(v, torch.Tensor):
         return (id(v), tuple(v.shape), v._version)
     if isinstance(v, (list, tuple)):

@@ -196,12 +196,21 @@ class GraphedImageStep:
         self.tshape = (B, geom.Sx, geom.R) if dtype == 'full' else (B, geom.Sx)
         # per-step inputs: a ring of pinned staging slots (the host runs ahead of the GPU: a slot is rewritten only after the
         # copies issued from it have executed), three device buffers the graph reads
-        self.slots = [dict(idx=torch.zeros(B, dtype=torch.int64).pin_memory(), tM0=torch.zeros(B, dtype=torch.float64).pin_memory(),
-                           hyp=torch.zeros(3, dtype=torch.float32).pin_memory(), done=None) for _ in range(8)]
-        self.slot_i = 0
-        self.d_idx = torch.zeros(B, dtype=torch.int64, device=dev)
-        self.d_tM0 = torch.zeros(B, dtype=torch.float64, device=dev)
-        self.d_hyp = torch.ones(3, dtype=torch.float32, device=dev)
+        # (one buffer [idx: B int64 | tM0: B float64 | lr, 1-b1^t, 1-b2^t, pad: 4 float32] = ONE copy per step; the host writes
+        #  it through NumPy views: every torch call here costs the driver microseconds it does not have at one frame per GPU)
+        nbytes = 16 * B + 16
+        self.slots = []
+        for _ in range(8):
+            h = torch.zeros(nbytes, dtype=torch.uint8).pin_memory()
+            a = h.numpy()
+            self.slots.append(dict(buf=h, idx=a[:8 * B].view(np.int64), tM0=a[8 * B:16 * B].view(np.float64),
+                                   hyp=a[16 * B:16 * B + 12].view(np.float32), done=torch.cuda.Event()))
+        self.slot_i, self.slot_used = 0, 0
+        self.d_buf = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        self.d_idx = self.d_buf[:8 * B].view(torch.int64)
+        self.d_tM0 = self.d_buf[8 * B:16 * B].view(torch.float64)
+        self.d_hyp = self.d_buf[16 * B:16 * B + 16].view(torch.float32)
+        self.d_hyp.fill_(1.0)
         self.images = torch.empty((B, geom.Sx, geom.R), dtype=torch.float32, device=dev)
         self.n = eng.nparams
         self.with_adam = not network._dist_on()                               # (a process group: exchange + Adam stay outside the graph)
@@ -226,17 +235,13 @@ class GraphedImageStep:
         st = self.state
         sl = self.slots[self.slot_i]
         self.slot_i = (self.slot_i + 1) % len(self.slots)
-        if sl['done'] is not None:
-            sl['done'].synchronize()                       # (only when the GPU is a whole ring behind the host)
-        sl['idx'].copy_(torch.as_tensor(np.asarray(key, dtype=np.int64)))
-        tM0 = (self.args.t_values[key] - self.t_start) / self.GM - self.t_inj          # engine.frame_offsets, float64
-        sl['tM0'].copy_(torch.as_tensor(np.asarray(tM0, dtype=np.float64)))
-        sl['hyp'].copy_(torch.as_tensor(engine.adam_hyper(st.step + 1, st.learning_rate())))
-        self.d_idx.copy_(sl['idx'], non_blocking=True)
-        self.d_tM0.copy_(sl['tM0'], non_blocking=True)
-        self.d_hyp.copy_(sl['hyp'], non_blocking=True)
-        if sl['done'] is None:
-            sl['done'] = torch.cuda.Event()
+        if self.slot_used >= len(self.slots):
+            sl['done'].synchronize()                       # (waits only when the GPU is a whole ring behind the host)
+        self.slot_used += 1
+        sl['idx'][:] = key
+        sl['tM0'][:] = (self.args.t_values[key] - self.t_start) / self.GM - self.t_inj          # engine.frame_offsets, float64
+        sl['hyp'][:] = engine.adam_hyper(st.step + 1, st.learning_rate())
+        self.d_buf.copy_(sl['buf'], non_blocking=True)
         sl['done'].record()
 
     def __call__(self, key):

@@ -295,10 +295,13 @@ def random_problem(width, depth, S, deg, nudge=0.0, drop_ties=False):
     for i in range(depth + 1):
         g['kernel%d' % i] = tree['MLP_0']['Dense_%d' % i]['kernel']; g['bias%d' % i] = tree['MLP_0']['Dense_%d' % i]['bias']
     ties, tied = relu_tie_count(g, return_points=True)
-    dropped = 0
+    dropped, ties_left = 0, ties
     if drop_ties:                            # tie adjudication: the tied ray samples no longer reach the image
         g['g'] = np.where(tied, 0.0, g['g'])
         dropped = int(tied.sum())
+        # re-run the detection on the MODIFIED problem: tied samples that still reach the image (Doppler weight != 0)
+        _, tied2 = relu_tie_count(g, return_points=True)
+        ties_left = int((tied2 & (np.broadcast_to(g['g'], tied2.shape) != 0)).sum())
     tr, t = oracle_trainer(g)
     shape = (B, S, H, Wd) if S else (B, H, Wd)
     target = rng.uniform(0, 1e-3, shape); sigma = rng.uniform(0.5, 2.0, shape); offset = np.zeros(shape)
@@ -306,7 +309,7 @@ def random_problem(width, depth, S, deg, nudge=0.0, drop_ties=False):
     n = len(tr.k)
     gref = np.concatenate([np.concatenate([grads_ref[i].numpy().ravel(), grads_ref[n + i].numpy().ravel()]) for i in range(n)])
     return dict(g=g, S=S, t_frames=t_frames, t_inj=t_inj, target=target, sigma=sigma, offset=offset, img_ref=img_ref, gref=gref,
-                ties=ties, dropped=dropped, ties_left=0 if drop_ties else ties)
+                ties=ties, dropped=dropped, ties_left=ties_left)
 
 
 def random_problem_errors(prob, mode, dev):
