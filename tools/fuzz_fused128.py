@@ -1,0 +1,65 @@
+"""Randomised check of the fused width-128 backward (csrc/fused_bwd128.hip) against the generic three-kernel backward on the
+SAME inputs: N random problems of the shapes the fused path takes (hidden width 97..128 -> kernel width 128, depth 4, bf16;
+with / without the skip connection, 0..3 Stokes planes, posenc degree 0..4, random ray grids / samples per ray / frames, random
+recovery domains incl. point compaction and empty groups).  Two processes, because a process loads one library:
+    BHNERF_HIP_LIB=.../libbhnerf_hip_nof128.so python tools/fuzz_fused128.py save N seed     (generic path: -DBHN_NO_FUSED128)
+    python tools/fuzz_fused128.py check N seed                                             (product library)
+Both arithmetic paths round the same bf16 operands and accumulate in f32; they differ in summation order only: the check
+demands 2e-5 of the largest gradient entry per problem (observed <= 1e-6), for the recompute route AND the recorded-tape route."""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bhnerf_amd import engine, network, synthetic, constants
+
+dev = torch.device('cuda:0')
+what, N, seed = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+rng = np.random.default_rng(seed)
+out = {}
+for i in range(N):
+    width = int(rng.integers(97, 129)) if rng.random() < 0.5 else 128
+    S, deg, skip = int(rng.integers(0, 4)), int(rng.integers(0, 5)), bool(rng.integers(0, 2))
+    H, W, G, B = int(rng.integers(3, 20)), int(rng.integers(3, 20)), int(rng.choice([int(rng.integers(3, 141)), 32, 33, 64, 65, 100])), int(rng.integers(1, 5))
+    dom = (float(rng.uniform(4.0, 12.0)), float(rng.choice([0.0, rng.uniform(0.5, 5.0)])), float(rng.choice([np.inf, rng.uniform(5.5, 14.0)])),
+           float(rng.choice([np.inf, rng.uniform(1.0, 8.0)])))
+    gseed, wseed = int(rng.integers(1 << 30)), int(rng.integers(1 << 30))
+    geo = synthetic.synthetic_geodesics(H, W, G, S=S, seed=gseed)
+    pred = network.NeRF_Predictor(*dom, posenc_deg=deg, net_depth=4, net_width=width, do_skip=skip, mode='bf16', device=dev)
+    eng = pred.engine()
+    geom = pred.geometry(geo['coords'], geo['Omega'], geo['t_geos'], geo['J'] if S else None, geo['g'], geo['dtau'], geo['Sigma'])
+    gen = torch.Generator(device='cpu').manual_seed(wseed)
+    flat = eng.flatten(network.MLP(4, width, do_skip=skip).init(1 + (wseed % 1000), 3 + 6 * deg))
+    flat = flat + 0.02 * torch.randn(flat.shape, generator=gen).to(flat)          # non-zero biases
+    eng.pack(flat)
+    tM0 = engine.frame_offsets(np.sort(rng.uniform(0, 0.8, B)), 0.0, geo['t_injection'], constants.GM_c3('hr'), dev)
+    dimg = (torch.rand((B, max(S, 1), geom.R), generator=gen) - 0.3).to(dev)
+    g1 = eng.render_bwd(geom, tM0, dimg).cpu().numpy().copy()
+    g2 = None
+    if eng.fits_tape(B, geom.P_eff):
+        img = eng.render_train(geom, tM0).cpu().numpy().copy()
+        g2 = eng.render_bwd_tape(geom, tM0, dimg).cpu().numpy().copy()
+        out['img%d' % i] = img
+    out['g%d' % i] = g1
+    if g2 is not None:
+        out['t%d' % i] = g2
+    out['cfg%d' % i] = np.array([width, S, deg, int(skip), H, W, G, B, geom.active_fraction])
+if what == 'save':
+    os.makedirs('gpurun_out', exist_ok=True)
+    np.savez('gpurun_out/fuzz_fused128_ref.npz', **out)
+    print('saved %d problems' % N)
+    sys.exit(0)
+ref = np.load('gpurun_out/fuzz_fused128_ref.npz')
+bad, worst = 0, 0.0
+for i in range(N):
+    for k in ('g', 't', 'img'):
+        key = '%s%d' % (k, i)
+        if key not in out:
+            continue
+        r, g = ref[key], out[key]
+        den = np.abs(r).max()
+        err = 0.0 if den == 0 and np.abs(g).max() == 0 else np.abs(g - r).max() / max(den, 1e-30)
+        worst = max(worst, err)
+        if not err < 2e-5:
+            bad += 1
+            print('FAIL problem %d %s cfg %s: max err %.3e of %.3e' % (i, k, out['cfg%d' % i], err, den))
+print('%d problems (width 97..128 x depth 4, bf16): %d failures, worst difference %.2e of the largest entry (fused vs generic backward; training-forward images included)' % (N, bad, worst))
+sys.exit(1 if bad else 0)
