@@ -13,6 +13,7 @@
 //                 One slab flush per workgroup at the end: no float atomics, deterministic.
 //   reduce_kernel sums the slabs of each layer's workgroups into the flat dparams (flax tree order).
 #include <utility>
+#include <type_traits>
 #include "fused_common.h"
 #include "bwd_common.h"
 
@@ -304,7 +305,8 @@ enum { MODE_FWD_TRAIN = 1, MODE_CHAIN = 2 };
 // spilled in its hot loop (12.8 ms vs 4.6 + 4.7 ms at config 2).
 // Weight-chunk stream of one tile: forward chunks 0..NCF-1 (MODE_FWD_TRAIN) or the transposed chunks of hidden
 // layers depth-1 .. 1 (MODE_CHAIN); the ring wraps to the next tile's first chunk.
-template <int W, class Pol, int DEG, int MODE>
+// RES: the whole chunk sequence resident in LDS (fused_common.h ResidentRing: no DMA, no per-chunk barrier), when it fits
+template <int W, class Pol, int DEG, int MODE, bool RES = false>
 __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
     using PK = Pack<W, Pol>;
     using BG = BwdGeom<W, Pol>;
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
     constexpr int sdbg = 0;                        // (a run-time MFMA-skip flag put every MFMA in its own basic block)
     using RG = DmaRing<CB, Pol::NWAVES>;
     constexpr int DIST = BG::RING_DIST_TAPED;
-    using RS = RingState<RG, CB, DIST, false, MT, BHN_CHAIN_STAMPS != 0>;
+    using RS = std::conditional_t<RES, ResidentRing<RG, CB, MT>, RingState<RG, CB, DIST, false, MT, BHN_CHAIN_STAMPS != 0>>;
     // stores guaranteed younger than chunk c+2 at the end of step c (RingState::step_end): every interval between
     // two DMA issues holds the >= ES stores of one pending-tile emission; with >= 16 k-steps the running step's
     // own emission (k-step 12) also follows its DMA issue (k-step 9).  The DMA pieces of the DIST-2 younger chunks
@@ -331,9 +333,13 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
     constexpr int YS0 = ES * (DIST - 2) + BHN_YS_EXTRA;                // steps whose own stores precede their DMA issue
     constexpr int YS_L1r = (KS >= 16) ? YS - ES : 0;                   // first steps of layer 1 when h_1 is not emitted
     constexpr int YS_L1 = YS_L1r > 0 ? YS_L1r : 0;
+    const int NCF = (MODE == MODE_CHAIN) ? 0 : PK::fwd_chunks(A.f.depth);
+    // delta chain: hidden layers depth-1 .. LEND produce gA_{l-1}; with TapeLayout::drop_ga0 it stops at gA_1 (LEND = 2)
+    const int LEND = (MODE == MODE_CHAIN && A.t.drop_ga0) ? 2 : 1;
+    const int NLB = (MODE == MODE_FWD_TRAIN) ? 0 : A.f.depth - LEND;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *ring = smem;
-    float *bias_lds = reinterpret_cast<float *>(smem + RS::NB * CB);  // depth x W + the 32 rows of the output tile, then one zero row
+    float *bias_lds = reinterpret_cast<float *>(smem + RS::lds_bytes(NCF + NLB * MT));  // depth x W + the 32 rows of the output tile, then one zero row
     const int nbias = a.depth * W + 32;                               // (the output layer's tile is read as one 32-row tile:
     float *zero_lds = bias_lds + nbias;                               //  a full W row for it put the f32 8x256 kernel over 160 KB)
     float *wout_lds = zero_lds + 32;
@@ -352,10 +358,6 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
     if (tid < 32) zero_lds[tid] = 0.f;
     for (int i = tid; i < W; i += Pol::NTHREADS) wout_lds[i] = reinterpret_cast<const float *>(a.packed + a.wout_off)[i];
 
-    const int NCF = (MODE == MODE_CHAIN) ? 0 : PK::fwd_chunks(a.depth);
-    // delta chain: hidden layers depth-1 .. LEND produce gA_{l-1}; with TapeLayout::drop_ga0 it stops at gA_1 (LEND = 2)
-    const int LEND = (MODE == MODE_CHAIN && A.t.drop_ga0) ? 2 : 1;
-    const int NLB = (MODE == MODE_FWD_TRAIN) ? 0 : a.depth - LEND;
     const bool have_ring = NCF + NLB * MT > 0;
     // first tile of the sequence starts with bias (forward) or zero (delta chain) accumulators
     const float *first_bias = (MODE == MODE_CHAIN) ? zero_lds : bias_lds;
@@ -507,6 +509,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
             // record what the delta chain needs, then the render epilogue of fused_fwd_kernel
             if (h == 0) e_g[pl] = e;
             if (a.images) RaySum<Pol::NWAVES>::run(a, seg_lds, b, p, inb, e, 0.f, false);      // (bhn_render_bwd: tape only)
+            if constexpr (RES) { if (a.images && !a.ray_direct) lds_barrier(); }                // (no ring barriers behind the combine)
         } else {
             float d = 0.f;
             if (h == 0 && inb && e != 0.f) {
@@ -1718,12 +1721,22 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
     const size_t lds_taped = (size_t)(BG::RING_DIST_TAPED + 1) * PK::CHUNK_BYTES + lds_fixed;
     size_t lds_dw = (size_t)BG::NBUF * BG::GROUP_BYTES + (t1.drop_h1 ? (size_t)2 * BG::MT * Pol::FRAG_BYTES + W * 4 : 0);
     if (t1.drop_ga && (size_t)BG::NBUF * BG::GROUP_BYTES_LAST2 > lds_dw) lds_dw = (size_t)BG::NBUF * BG::GROUP_BYTES_LAST2;
-    auto k_fwd = chain_kernel<W, Pol, 3, MODE_FWD_TRAIN>;
-    auto k_chn = chain_kernel<W, Pol, 3, MODE_CHAIN>;
+#ifndef BHN_RESIDENT
+#define BHN_RESIDENT 1           // 0: never keep the weight images resident in LDS (A/B builds)
+#endif
+    // small networks: the training forward / the delta chain keep their whole chunk sequence in LDS and run without the
+    // per-chunk barrier (ResidentRing), each when its own sequence fits
+    const size_t res_fwd = (size_t)PK::fwd_chunks(depth) * PK::CHUNK_BYTES + lds_fixed, res_chn = (size_t)PK::bwd_chunks(depth) * PK::CHUNK_BYTES + lds_fixed;
+    constexpr bool CAN_RES = BHN_RESIDENT != 0 && W <= 128 && BHN_CHAIN_STAMPS == 0 && !BHN_DROP_GA0;     // (width 256: no second instantiation)
+    const bool rf = CAN_RES && res_fwd <= 160 * 1024, rch = CAN_RES && res_chn <= 160 * 1024;
+    auto k_fwd = rf ? chain_kernel<W, Pol, 3, MODE_FWD_TRAIN, CAN_RES> : chain_kernel<W, Pol, 3, MODE_FWD_TRAIN, false>;
+    auto k_chn = rch ? chain_kernel<W, Pol, 3, MODE_CHAIN, CAN_RES> : chain_kernel<W, Pol, 3, MODE_CHAIN, false>;
+    const size_t lds_fwd = rf ? res_fwd : lds_taped, lds_chn = rch ? res_chn : lds_taped;
     auto kdw = dw_kernel<W, Pol>;
     static DeviceOnce once;                 // per template instantiation and device
     BHN_HIP(once.run(device, [&](int &) {
-        for (const void *k : {(const void *)k_fwd, (const void *)k_chn, (const void *)kdw}) {
+        for (const void *k : {(const void *)chain_kernel<W, Pol, 3, MODE_FWD_TRAIN, CAN_RES>, (const void *)chain_kernel<W, Pol, 3, MODE_FWD_TRAIN, false>,
+                              (const void *)chain_kernel<W, Pol, 3, MODE_CHAIN, CAN_RES>, (const void *)chain_kernel<W, Pol, 3, MODE_CHAIN, false>, (const void *)kdw}) {
             const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
         }
@@ -1752,7 +1765,7 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
         long long grid = ncu;
         if (grid > A.f.total_tiles) grid = A.f.total_tiles;
         if (what == RUN_FWD_TRAIN) {
-            hipLaunchKernelGGL(k_fwd, dim3((unsigned)grid), dim3(Pol::NTHREADS), lds_taped, st, A);
+            hipLaunchKernelGGL(k_fwd, dim3((unsigned)grid), dim3(Pol::NTHREADS), lds_fwd, st, A);
             BHN_HIP(hipGetLastError());
             continue;
         }
@@ -1763,7 +1776,7 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
         BHN_HIP(mark(0));
         if (f128) {                          // kernel slot 0 = the fused chain + dW kernel, slot 1 empty
             if (what == RUN_RECOMPUTE) {
-                hipLaunchKernelGGL(k_fwd, dim3((unsigned)grid), dim3(Pol::NTHREADS), lds_taped, st, A);
+                hipLaunchKernelGGL(k_fwd, dim3((unsigned)grid), dim3(Pol::NTHREADS), lds_fwd, st, A);
                 BHN_HIP(hipGetLastError());
             }
             long long g128 = A.t.NQ / 4;
@@ -1777,10 +1790,10 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
         }
         if (g_bwd_stages & 1) {
             if (what == RUN_RECOMPUTE) {     // forward again (tape only: A.f.images is null), then the chain
-                hipLaunchKernelGGL(k_fwd, dim3((unsigned)grid), dim3(Pol::NTHREADS), lds_taped, st, A);
+                hipLaunchKernelGGL(k_fwd, dim3((unsigned)grid), dim3(Pol::NTHREADS), lds_fwd, st, A);
                 BHN_HIP(hipGetLastError());
             }
-            hipLaunchKernelGGL(k_chn, dim3((unsigned)grid), dim3(Pol::NTHREADS), lds_taped, st, A);
+            hipLaunchKernelGGL(k_chn, dim3((unsigned)grid), dim3(Pol::NTHREADS), lds_chn, st, A);
         }
         BHN_HIP(hipGetLastError());
         BHN_HIP(mark(1));

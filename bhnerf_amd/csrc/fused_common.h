@@ -258,10 +258,10 @@ struct Pack {
     static_assert(2 * MT <= CH, "layer-0 chunk must hold all its fragments");
     // forward image: chunk 0 = layer 0 (frag m*2+ks), chunks 1+(l-1)*MT+m = hidden layer l tile m
     // (frag ks, enc block at KS,KS+1), last chunk = output layer (frag ks, row 0 real).
-    static DEVI constexpr int fwd_chunks(int depth) { return 1 + (depth - 1) * MT + 1; }
+    __host__ __device__ static constexpr int fwd_chunks(int depth) { return 1 + (depth - 1) * MT + 1; }
     // transposed image (delta chain through hidden layer l>=1): chunk (l-1)*MT+m, frag ks:
     //   element = kernel_l[32m+i][16ks+phi]
-    static DEVI constexpr int bwd_chunks(int depth) { return (depth - 1) * MT; }
+    __host__ __device__ static constexpr int bwd_chunks(int depth) { return (depth - 1) * MT; }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -674,6 +674,7 @@ struct RingState {
     // more resident chunk and one idle step per wave; 5 % slower in the render kernel.
     static constexpr int NB = DIST + (LAG ? 2 : 1);
     static_assert(DIST >= 2, "ring geometry");
+    __host__ __device__ static constexpr size_t lds_bytes(int) { return (size_t)NB * CB; }
     char *ring;
     // chunk sequence of one tile, consumed cyclically: NCA forward chunks (img_a, in order), then the transposed
     // chunks of the delta chain (img_b): hidden layers nlb .. 1, MT chunks each, stored layer-major ascending
@@ -746,6 +747,47 @@ struct RingState {
         for (int j = 0; j < DIST; ++j) RG::issue(DmaJob{true, next_src(), ring + j * CB, rs, wvu});
         RG::template wait_younger<RG::PPW * (DIST - 2)>();
         lds_barrier();
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// The same interface with the WHOLE chunk sequence resident in LDS (small networks: 4x128 bf16 is 14 chunks = 140 KB): copied
+// once at kernel start, no DMA, no counted waits and -- the point -- NO per-chunk workgroup barrier: the eight waves run
+// their tiles independently instead of in lockstep (at width 128 a chunk is 10 MFMAs per wave: the barrier cadence, the DMA
+// issue and the waits were a third of the kernel).  Each wave walks the chunks with its own cursor.
+// ---------------------------------------------------------------------------------------------
+template <class RG, int CB, int MT = 1>
+struct ResidentRing {
+    static constexpr int NB = 0;                 // (no ring buffers: lds_bytes(nc) is the footprint)
+    char *ring;
+    int NC, dbg, lag, o_cur, o_nxt, wvu;
+    long long *ts;
+    static DEVI int opaque(int v) { asm volatile("" : "+s"(v)); return v; }
+    __host__ __device__ static constexpr size_t lds_bytes(int nc) { return (size_t)nc * CB; }
+    DEVI const char *ch() const { return ring + opaque(o_cur); }
+    DEVI const char *chn() const { return ring + opaque(o_nxt); }
+    DEVI DmaJob job() { return DmaJob{false, 0u, nullptr, __amdgpu_buffer_rsrc_t(), wvu}; }
+    template <int STORES = 0>
+    DEVI void step_end() {
+        o_cur = o_nxt;
+        o_nxt = (o_nxt + CB == NC * CB) ? 0 : o_nxt + CB;
+    }
+    DEVI void idle_step() {}
+    // chunk j of the consumption order: forward chunks 0..nca-1 of img_a, then the transposed chunks of hidden layers
+    // nlb .. 1 (stored layer-major ascending in img_b), MT each -- RingState::next_src's order
+    DEVI void start(char *ring_, const char *a_, int nca, const char *b_, int nlb_, int dbg_, int) {
+        ring = ring_; NC = nca + nlb_ * MT; dbg = dbg_; lag = 0; ts = nullptr;
+        o_cur = 0; o_nxt = NC > 1 ? CB : 0;
+        wvu = opaque(__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)));
+        constexpr int VPC = CB / 16;             // 16-byte vectors per chunk
+        for (int v = threadIdx.x; v < NC * VPC; v += blockDim.x) {
+            const int j = v / VPC, r = v - j * VPC;
+            const char *src;
+            if (j < nca) src = a_ + (size_t)j * CB;
+            else { const int i = j - nca; src = b_ + (size_t)((nlb_ - 1 - i / MT) * MT + i % MT) * CB; }
+            reinterpret_cast<u32x4 *>(ring)[v] = reinterpret_cast<const u32x4 *>(src)[r];
+        }
+        __syncthreads();
     }
 };
 

@@ -1,5 +1,6 @@
 // Fused NeRF_Predictor forward (network.py:191-237) and fused image-plane prediction
 // (network.py:373-420): warp -> posenc -> skip-MLP -> sigmoid/masks [-> x w -> sum over the ray].
+#include <type_traits>
 #include "fused_common.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -140,7 +141,8 @@ extern "C" int bhn_pack_weights(const bhn_model *m, int32_t mode, const float *p
 #ifndef BHN_FWD_DIST
 #define BHN_FWD_DIST 4           // weight chunks in flight in the inference forward (6 measured 6 % slower here)
 #endif
-template <int W, class Pol, int DEG, bool RENDER, bool DBG = false>
+// RES: the whole weight image resident in LDS (ResidentRing: no DMA, no per-chunk barrier), when it fits
+template <int W, class Pol, int DEG, bool RENDER, bool DBG = false, bool RES = false>
 __global__ __launch_bounds__(Pol::NTHREADS) void fused_fwd_kernel(FusedArgs a) {
     const int dbg = DBG ? a.debug : 0;
     using PK = Pack<W, Pol>;
@@ -148,11 +150,10 @@ __global__ __launch_bounds__(Pol::NTHREADS) void fused_fwd_kernel(FusedArgs a) {
     constexpr int CB = PK::CHUNK_BYTES, MT = PK::MT, KS = PK::KS;
     using RG = DmaRing<CB, Pol::NWAVES>;
     constexpr int DIST = (Pol::ELEM_BYTES == 2) ? BHN_FWD_DIST : 3;                    // LDS-DMA weight ring: chunks in flight
-    using RS = RingState<RG, CB, DIST, Pol::PHASE_LAG, MT, DBG>;
-    constexpr int NB = RS::NB;
+    using RS = std::conditional_t<RES, ResidentRing<RG, CB, MT>, RingState<RG, CB, DIST, Pol::PHASE_LAG, MT, DBG>>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *ring = smem;                                              // NB x CB
-    float *bias_lds = reinterpret_cast<float *>(smem + NB * CB);     // (depth+1) x W
+    char *ring = smem;                                              // NB x CB (resident: all chunks)
+    float *bias_lds = reinterpret_cast<float *>(smem + RS::lds_bytes(PK::fwd_chunks(a.depth)));     // (depth+1) x W
     char *seg_lds = reinterpret_cast<char *>(bias_lds + (a.depth + 1) * W);      // RaySum scratch
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 31, h = lane >> 5;
@@ -218,6 +219,8 @@ __global__ __launch_bounds__(Pol::NTHREADS) void fused_fwd_kernel(FusedArgs a) {
         } else {
             // x J g^2 dtau Sigma and the sum over the ray: segment sums per wave, combined per workgroup tile (RaySum)
             RaySum<Pol::NWAVES>::run(a, seg_lds, b, p, inb, e, w0, true);
+            // resident weights: no ring barriers separate this tile's combine from the next tile's segment sums
+            if constexpr (RES) { if (!a.ray_direct) lds_barrier(); }
         }
     }
     if (!rs.lag) rs.idle_step();                        // every wave runs the same number of ring steps (barriers)
@@ -463,15 +466,22 @@ static int launch_fwd_wide(FusedArgs &a, hipStream_t st) {
 }
 #endif
 
-template <int W, class Pol, bool RENDER, bool DBG = false>
+#ifndef BHN_RESIDENT
+#define BHN_RESIDENT 1           // 0: never keep the weight image resident in LDS (A/B builds)
+#endif
+template <int W, class Pol, bool RENDER, bool DBG = false, bool RES = false>
 static int launch_fwd_w(FusedArgs &a, hipStream_t st) {
 #ifdef BHN_WIDE_FWD
     if constexpr (Pol::ELEM_BYTES == 2 && W == 256 && !DBG) return launch_fwd_wide<W, Pol, RENDER>(a, st);
 #endif
     using PK = Pack<W, Pol>;
-    const size_t lds = (size_t)((Pol::ELEM_BYTES == 2 ? BHN_FWD_DIST : 3) + (Pol::PHASE_LAG ? 2 : 1)) * PK::CHUNK_BYTES + (size_t)(a.depth + 1) * W * 4
-                       + RaySum<Pol::NWAVES>::bytes(a.Sx);
-    auto kern = fused_fwd_kernel<W, Pol, 3, RENDER, DBG>;
+    const size_t lds_fixed = (size_t)(a.depth + 1) * W * 4 + RaySum<Pol::NWAVES>::bytes(a.Sx);
+    if constexpr (!RES && !DBG && W <= 128 && BHN_RESIDENT != 0 && Pol::ELEM_BYTES == 2) {     // (f32, one wave per SIMD: measured 11 % slower resident)
+        // small networks: all chunks of the forward image resident in LDS, waves run without the per-chunk barrier
+        if ((size_t)PK::fwd_chunks(a.depth) * PK::CHUNK_BYTES + lds_fixed <= 160 * 1024) return launch_fwd_w<W, Pol, RENDER, DBG, true>(a, st);
+    }
+    const size_t lds = (RES ? (size_t)PK::fwd_chunks(a.depth) : (size_t)((Pol::ELEM_BYTES == 2 ? BHN_FWD_DIST : 3) + (Pol::PHASE_LAG ? 2 : 1))) * PK::CHUNK_BYTES + lds_fixed;
+    auto kern = fused_fwd_kernel<W, Pol, 3, RENDER, DBG, RES>;
     int dev = 0;
     BHN_HIP(hipGetDevice(&dev));
     BHN_CHECK_DEVICE(dev);

@@ -5,7 +5,7 @@ bounds of the test are statistical on this tiny problem (3 x 63 rays): a few per
 less than a factor of two; anything beyond that, and any f32 failure, is reported as HARD (exit code 1).  f32 draws with
 detected ReLU ties are adjudicated by the test itself (tests/test_gpu_backward.py::adjudicate_relu_ties) and print a
 "relu ties adjudicated" line.
-    python tools/fuzz_parity.py [N] [seed]"""
+    python tools/fuzz_parity.py [N] [seed]          (FUZZ_ONLY=i,j,...: run only these draws of the sequence)"""
 import os, sys, traceback
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,6 +15,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 dev = torch.device('cuda:0')
 bad = soft = 0
+ONLY = set(int(v) for v in os.environ.get('FUZZ_ONLY', '').split(',') if v)        # run only these draws (the RNG sequence is replayed for all)
 for i in range(N):
     width = int(rng.choice([int(rng.integers(1, 257)), 32, 64, 128, 256]))
     depth, S, deg = int(rng.integers(2, 9)), int(rng.integers(0, 4)), int(rng.integers(0, 5))
@@ -27,8 +28,12 @@ for i in range(N):
                                float(rng.choice([np.inf, rng.uniform(5.5, 14.0)])), float(rng.choice([np.inf, rng.uniform(1.0, 8.0)])))
     T.RANDOM_PROBLEM_SHAPE = (max(T.RANDOM_PROBLEM_SHAPE[0], 3), max(T.RANDOM_PROBLEM_SHAPE[1], 3)) + T.RANDOM_PROBLEM_SHAPE[2:]
     # (two rows / columns sit at alpha or beta = +-8: nothing inside the domain, all-zero images)
+    if ONLY and i not in ONLY:
+        continue
     try:
         T.test_random_problem_f32_and_bf16(dev, width, depth, S, deg)
+        if ONLY:
+            print('draw %d width %d depth %d S %d deg %d shape %s: passed' % (i, width, depth, S, deg, T.RANDOM_PROBLEM_SHAPE), flush=True)
     except Exception as e:                                   # noqa: BLE001 -- report and go on
         msg = str(e).split('\n')[0][:200]
         hard = True
@@ -41,6 +46,6 @@ for i in range(N):
             pass
         soft += not hard
         bad += hard
-        print('%s width %d depth %d S %d deg %d shape %s domain %s: %s' % ('HARD' if hard else 'soft', width, depth, S, deg, T.RANDOM_PROBLEM_SHAPE, tuple(round(v, 2) for v in T.RANDOM_PROBLEM_DOMAIN), msg), flush=True)
+        print('%s draw %d width %d depth %d S %d deg %d shape %s domain %s: %s' % ('HARD' if hard else 'soft', i, width, depth, S, deg, T.RANDOM_PROBLEM_SHAPE, tuple(round(v, 2) for v in T.RANDOM_PROBLEM_DOMAIN), msg), flush=True)
 print('%d of %d random configurations failed hard, %d exceeded a bf16 bound by less than 2x' % (bad, N, soft))
 sys.exit(1 if bad else 0)
