@@ -650,6 +650,18 @@ def main():
         width128 = {'workload': 'config-2 geometry (%dx%d rays x %d samples, %d frames/step, loss full), 4x128 MLP' % (H, W, G, batch),
                     'dtype': 'bf16', 'ms_per_step': round(1e3 * dt, 3), 'value': round(samples_step / dt, 1), 'unit': 'ray-samples/s',
                     'steps': n_w, 'tape_frame_group': grp_w, 'roofline': roof_w, 'loss': float(torch.as_tensor(opt_w.loss).float().mean())}
+        # the same steps with the step captured into a HIP graph (hparams['hip_graph']): same kernels, one launch
+        train_step.use_graph = True
+        try:
+            run_steps(opt_w, 3)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run_steps(opt_w, n_w)
+            torch.cuda.synchronize()
+            width128['ms_per_step_hip_graph'] = round(1e3 * (time.perf_counter() - t0) / n_w, 3)
+        finally:
+            train_step.use_graph = False
+            train_step._graphs.clear()
         del opt_w, pred_w, eng_w, geom_w
         torch.cuda.empty_cache()
       except Exception as exc:

@@ -598,15 +598,31 @@ __global__ __launch_bounds__(256) void dout128_kernel(BwdArgs A) {
 // feature of virtual position v (0..31) of a 32-feature tile: chunk (s, h) = v >> 3, element e = v & 7 of the canonical fragment
 __host__ __device__ inline int virt_feature(int v) { return 16 * ((v >> 4) & 1) + 4 * ((v >> 3) & 1) + (v & 3) + 8 * ((v >> 2) & 1); }
 
+// Stage 1 of the slab reduction: block (tile, part) adds the slabs [part * per, (part + 1) * per) of its tile in order and leaves
+// the partial sum in the first slab of its range (its own tile of its own range: no block reads what another one writes).
+// 65 x 8 blocks instead of 65: the sum over 256 slabs of 260 KB each is latency-bound per thread.
+__global__ __launch_bounds__(256) void reduce128_stage1(BwdArgs A, int nslabs, int per) {
+    const int tile = blockIdx.x, part = blockIdx.y, s0 = part * per, s1 = (s0 + per < nslabs) ? s0 + per : nslabs;
+    if (s0 >= s1) return;
+    float *base = A.f.slabs + (long long)tile * 1024 + threadIdx.x * 4;
+    f32x4 sum = *reinterpret_cast<const f32x4 *>(base + (long long)s0 * SLAB_FLOATS128);
+    for (int wg = s0 + 1; wg < s1; ++wg) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(base + (long long)wg * SLAB_FLOATS128);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sum[e] += v[e];
+    }
+    *reinterpret_cast<f32x4 *>(base + (long long)s0 * SLAB_FLOATS128) = sum;
+}
+
 // Sum the slabs of all workgroups (fixed order: bitwise reproducible) and write the flat gradient (flax tree order).
 // One block per slab tile; thread (g4, lane) owns the float4 at [g4][lane] of the tile: accumulator registers 4 g4 .. 4 g4 + 3 of
 // lane `lane`, i.e. rows (virtual output position) e + 8 g4 + 4 (lane >> 5), column (virtual input position) lane & 31.
 template <int DEPTH>
-__global__ __launch_bounds__(256) void reduce128_kernel(BwdArgs A, int nslabs) {
+__global__ __launch_bounds__(256) void reduce128_kernel(BwdArgs A, int nslabs, int step) {      // step: stride of the slabs that hold stage-1 sums
     const int tile = blockIdx.x, tid = threadIdx.x, g4 = tid >> 6, lane = tid & 63, hh = lane >> 5, col = lane & 31;
     const float *src = A.f.slabs + (long long)tile * 1024 + g4 * 256 + lane * 4;
     f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-    for (int wg = 0; wg < nslabs; ++wg) {
+    for (int wg = 0; wg < nslabs; wg += step) {
         const f32x4 v = *reinterpret_cast<const f32x4 *>(src + (long long)wg * SLAB_FLOATS128);
 #pragma unroll
         for (int e = 0; e < 4; ++e) sum[e] += v[e];
@@ -712,7 +728,10 @@ int bwd128_launch(const BwdArgs &A, int depth, int grid, hipStream_t st) {
 
 int reduce128_launch(const BwdArgs &A, int depth, int nslabs, hipStream_t st) {
     BHN_CHECK_ARG(depth == 4, "fused width-128 backward: depth %d", depth);
-    hipLaunchKernelGGL(reduce128_kernel<4>, dim3(SLAB_TILES), dim3(256), 0, st, A, nslabs);
+    const int parts = 8, per = (nslabs + parts - 1) / parts;
+    hipLaunchKernelGGL(reduce128_stage1, dim3(SLAB_TILES, parts), dim3(256), 0, st, A, nslabs, per);
+    BHN_HIP(hipGetLastError());
+    hipLaunchKernelGGL(reduce128_kernel<4>, dim3(SLAB_TILES), dim3(256), 0, st, A, nslabs, per);
     BHN_HIP(hipGetLastError());
     return BHN_OK;
 }
