@@ -436,35 +436,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         dnext = point_dout(Q);
         load_w(DEPTH - 1, wf);
         use_w(wf);
+        if (lane < 32) bout += dnext;
+        put_dout(dnext);
+        drain_and_barrier();                                   // the first quad's images landed, its dout visible
+        front(OFF_H + 0 * IMG, OFF_GA + 0 * IMG);              // top phase of the first quad: gA_{D-1} -> GA0, dW_out
+        drain_and_barrier();
     }
     for (; Q < nquads; Q += gridDim.x) {
         // the accumulators stay in the AGPRs, in place, across the back edge (hipcc otherwise shuffles them through VGPRs)
 #pragma unroll
         for (int l = 0; l < DEPTH - 1; ++l) asm volatile("" : "+a"(acc[l][0]), "+a"(acc[l][1]), "+a"(acc[l][2]), "+a"(acc[l][3]));
         asm volatile("" : "+a"(acc_e), "+a"(acc0));
-        const long long Qn = (Q + gridDim.x < nquads) ? Q + gridDim.x : Q;     // the last iteration re-loads its own quad (unused)
+        const bool has_next = Q + gridDim.x < nquads;
+        const long long Qn = has_next ? Q + gridDim.x : Q;     // the last iteration re-loads its own quad (with dout = 0: no contribution)
         if constexpr (BHN_B128_STAMPS != 0) {
             ts = (blockIdx.x == 0 && Q == blockIdx.x + 100ll * gridDim.x) ? reinterpret_cast<long long *>(a.slabs + 64 * 1024 + 256) + 64 * wv : nullptr;
             ts_i = 0;
             stamp();
         }
         const unsigned e_img = OFF_E + eb * ENC_IMG;
-        {
-            const float d = dnext;
-            if (lane < 32) bout += d;
-            put_dout(d);
-        }
-        // dout visible.  h_depth (H0) landed behind layer 1's barrier; the ten pieces issued under the layer-0 phase (h_{D-1},
-        // enc of this quad) stay in flight until the barrier behind the top phase
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        stamp();
-        if (!(BHN_B128_ABL & 64)) __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        stamp();
-        // ---- top: gA_{D-1} -> GA0, dW_out ----
-        if (!(BHN_B128_ABL & 32)) front(OFF_H + 0 * IMG, OFF_GA + 0 * IMG);
-        stamp();
-        drain_and_barrier();                                   // GA0 complete; h_{D-1} (H1) and enc landed; H0 free
+        // (the top phase of THIS quad -- gA_{D-1} -> GA0, dW_out -- ran at the end of the previous iteration, beside layer 0's dW)
         // Layers D-1 .. 1.  Buffers alternate: gA_l in GA[(D-1-l) & 1], h_l in H[(D-l) & 1]; the h image that the mask of
         // layer l+1 has just released takes h_{l-1} (or the next quad's h_D).
 #pragma unroll
@@ -492,14 +483,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int ln = (l - 1 >= 1) ? l - 1 : DEPTH - 1;  // next layer's weights (this layer's are dead behind the chain MFMAs)
             auto side_dw = [&](int k) {
                 if constexpr (!(BHN_B128_ABL & 16)) post_slice(c1, 1, h_img, ga_out, k);
+                if (k < 4) {                                  // (all sixteen issued in the first half: the last ones have four k-steps to land)
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi) wf[mi][k] = load_w1(ln, mi, k);
+                    for (int mi = 0; mi < 2; ++mi) { wf[mi][2 * k] = load_w1(ln, mi, 2 * k); wf[mi][2 * k + 1] = load_w1(ln, mi, 2 * k + 1); }
+                }
             };
             if (l == SKIPL) dw_phase(std::true_type{}, ga_in, h_img, e_img, acc[l - 1], acc_e, bsum[l - 1], side_dw);
             else dw_phase(std::false_type{}, ga_in, h_img, e_img, acc[l - 1], acc_e, bsum[l - 1], side_dw);
             stamp();
             use_w(wf);
-            if (l == 1) asm volatile("" : "+v"(dnext));        // (the compiler's wait for this load belongs here, at a drain point)
+            if (l == 1) {
+                asm volatile("" : "+v"(dnext));                // (the compiler's wait for this load belongs here, at a drain point)
+                const float d = has_next ? dnext : 0.f;        // the next quad's dout: DOUT was last read by this quad's top phase
+                if (lane < 32) bout += d;
+                put_dout(d);
+            }
             stamp();
             drain_and_barrier();                               // gA_{l-1} complete; the h image issued above has landed
         }
@@ -511,6 +509,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             stamp();
             dw0_phase(OFF_GA + gi0 * IMG, e_img, [&](int k) { dma_h_piece(rs_h, hfree, k); });
             stamp();
+            // ... and the NEXT quad's top phase beside it (its h_D landed behind layer 1's barrier; GA0 was last read by layer 1):
+            // one barrier and one drain fewer per iteration than a top phase of its own
+            if (!(BHN_B128_ABL & 32)) front(OFF_H + 0 * IMG, OFF_GA + 0 * IMG);
+            stamp();
+            drain_and_barrier();                               // GA0 complete; h_{D-1} (H1) and enc of the next quad landed
         }
         eb ^= 1;
     }

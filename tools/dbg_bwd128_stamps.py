@@ -12,10 +12,10 @@ geom = pred.geometry(geo['coords'], geo['Omega'], geo['t_geos'], None, geo['g'],
 eng.pack(eng.flatten(network.MLP(4, 128).init(1, 21)))
 tM0 = engine.frame_offsets(np.linspace(0, 1, B), 0.0, geo['t_injection'], constants.GM_c3('hr'), dev)
 dimg = torch.rand((B, 1, geom.R), device=dev) * 1e-3
-names = ['iter start', 'lgkm wait', 'barrier0', 'front', 'drain1', 'barrier1']
+names = ['iter start']
 for l in (3, 2, 1):
     names += ['L%d setup' % l, 'L%d chain pb0 (+dma)' % l, 'L%d chain pb1 (+post0)' % l, 'L%d dW (+post1, w loads)' % l, 'L%d use_w' % l, 'L%d drain' % l, 'L%d barrier' % l]
-names += ['L0 setup', 'L0 dW (+dma)']
+names += ['L0 setup', 'L0 dW (+dma)', 'top phase of the next quad', 'drain', 'barrier']
 for rep in range(3):
     eng.render_train(geom, tM0); eng.render_bwd_tape(geom, tM0, dimg); torch.cuda.synchronize()
 ws = eng._ws

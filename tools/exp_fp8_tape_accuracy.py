@@ -86,3 +86,26 @@ for l in range(depth + 1):
         tot[name][0] += float(d.norm() ** 2); tot[name][1] += float(exact.norm() ** 2)
     print('dW_%-7d %12.2e %14.2e %22.2e' % (l, *row))
 print('%-10s %12.2e %14.2e %22.2e' % ('all layers', *[np.sqrt(v[0] / v[1]) for v in tot.values()]))
+
+
+# ---- one scale per LAYER (what an unscaled 8-bit MFMA can accumulate without touching the accumulator between groups) -----------
+def layer_scaled(x, dt, fmax):
+    s = torch.exp2(torch.ceil(torch.log2(x.abs().amax().clamp_min(1e-300) / fmax)))
+    return rnd(x / s, dt) * s
+
+
+print('\none power-of-two scale per layer instead of per 32-point group:')
+tot2 = {k: [0.0, 0.0] for k in ('e4m3 / e4m3', 'e5m2 (gA) / e4m3 (h)', 'e5m2 / e5m2')}
+print('%-10s %14s %22s %14s   flushed gA (e4m3)' % ('layer', *tot2.keys()))
+for l in range(depth + 1):
+    exact = gA[l].T @ h[l]
+    row = []
+    for name, ga_q, h_q in (('e4m3 / e4m3', layer_scaled(gA[l], E4, 448.0), layer_scaled(h[l], E4, 448.0)),
+                            ('e5m2 (gA) / e4m3 (h)', layer_scaled(gA[l], E5, 57344.0), layer_scaled(h[l], E4, 448.0)),
+                            ('e5m2 / e5m2', layer_scaled(gA[l], E5, 57344.0), layer_scaled(h[l], E5, 57344.0))):
+        d = ga_q.T @ h_q - exact
+        row.append(float(d.norm() / exact.norm()))
+        tot2[name][0] += float(d.norm() ** 2); tot2[name][1] += float(exact.norm() ** 2)
+    q = layer_scaled(gA[l], E4, 448.0)
+    print('dW_%-7d %14.2e %22.2e %14.2e   %.3f of the nonzero entries' % (l, *row, float(((q == 0) & (gA[l] != 0)).sum()) / max(float((gA[l] != 0).sum()), 1)))
+print('%-10s %14.2e %22.2e %14.2e' % ('all layers', *[np.sqrt(v[0] / v[1]) for v in tot2.values()]))
