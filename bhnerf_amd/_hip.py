@@ -21,8 +21,10 @@ DEBUG_SIGNATURES = {        # include/bhnerf_hip_debug.h: only libbhnerf_hip_dbg
     'bhn_debug_read': (C.c_int, [C.c_void_p, C.c_size_t]),
 }
 
-BHN_F32, BHN_BF16 = 0, 1
-MODES = {'f32': BHN_F32, 'fp32': BHN_F32, 'float32': BHN_F32, 'bf16': BHN_BF16, 'bfloat16': BHN_BF16}
+BHN_F32, BHN_BF16, BHN_BF16_T8 = 0, 1, 2
+BHN_T8_CALIBRATE = 0x100
+MODES = {'f32': BHN_F32, 'fp32': BHN_F32, 'float32': BHN_F32, 'bf16': BHN_BF16, 'bfloat16': BHN_BF16,
+         'bf16_t8': BHN_BF16_T8}            # bf16 arithmetic, 8-bit (e4m3) backward tape: include/bhnerf_hip.h
 
 
 class HipError(RuntimeError):

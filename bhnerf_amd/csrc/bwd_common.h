@@ -50,6 +50,9 @@ struct BwdArgs {
     int F;
     int width_true;                            // the model's hidden width (flat parameter layout); W is the kernel width
     long long nparams;
+    // 8-bit tape (PolBF16T8): [0 .. 7] the power-of-two scale of gA_l this call stores with, [8 .. 15] the largest |gA_l| it saw
+    // (f32 bit patterns, atomicMax), at the head of the tape region of the workspace
+    float *t8;
 };
 
 

@@ -68,6 +68,8 @@ int bhn_mlp_shape(const bhn_model *m, MlpShape *s);   // validates, returns BHN_
 // relu' (.) bf16(dout) into a transposed weight image of layer depth-1 whose columns are pre-scaled by W_out
 // (bhn_pack_weights): the same product with the factor W_out[k] moved from the B operand to the A operand.
 __host__ __device__ static inline bool bhn_folds_wout(int mode, int depth) { return mode == BHN_BF16 && depth >= 3; }
+// BHN_BF16_T8 (+ BHN_T8_CALIBRATE) is BHN_BF16 for everything but the tape of the backward
+static inline int bhn_norm_mode(int mode) { return ((mode & 0xff) == BHN_BF16_T8 && !(mode & ~(0xff | BHN_T8_CALIBRATE))) ? BHN_BF16 : mode; }
 
 // Number of compute units of a device (cached); 0 for a device id outside [0, BHN_MAX_DEVICES) -- callers turn that into
 // BHN_EINVAL (BHN_CHECK_DEVICE), the same answer DeviceOnce::run gives for such an id.

@@ -46,6 +46,8 @@ template <int W, class Pol>
 struct BwdGeom {
     static constexpr int MT = W / 32;
     static constexpr int TILE_BYTES = 2 * Pol::FRAG_BYTES;          // 32 features x 32 points
+    // bytes of one h / gA tile ON THE TAPE: the 8-bit tape (Pol::TAPE8) halves these; the encoded-input tile stays bf16
+    static constexpr int TAPE_TILE = Pol::TAPE8 ? 1024 : TILE_BYTES;
     static constexpr int NTMAX = MT + 2;                            // h tiles + enc tile + ones tile
     static constexpr int SLAB_FLOATS = (MT + 1) * NTMAX * 1024;     // row MT: the output layer's row when it rides on job depth-1
     // wave grid of the dW kernel
@@ -60,7 +62,9 @@ struct BwdGeom {
     static constexpr int SWEEP = (Pol::NWAVES <= 4) ? NTMAX : 5;
     static constexpr int NPASS = (NPW_ALL + SWEEP - 1) / SWEEP;
     static constexpr int NPW = (NPW_ALL + NPASS - 1) / NPASS;
-    static constexpr int GROUP_BYTES = (2 * MT + 1) * TILE_BYTES;   // A tiles + h tiles + enc tile
+    // A tiles + h tiles + enc tile (8-bit tape: the largest group image is the layer-1 job's -- 8-bit A tiles, the recomputed
+    // bf16 h_1 tiles, the encoded inputs)
+    static constexpr int GROUP_BYTES = Pol::TAPE8 ? MT * TAPE_TILE + (MT + 1) * TILE_BYTES : (2 * MT + 1) * TILE_BYTES;
     static constexpr int GROUP_BYTES_LAST2 = GROUP_BYTES + 1024;               // + the KiB that starts with the f32 dout (dw_body2 LAST)
     // chain kernels: prefetch distance of the LDS-DMA weight ring (RING_DIST_TAPED+1 buffers of one chunk)
     static constexpr int RING_DIST_TAPED = (Pol::ELEM_BYTES == 2) ? BHN_TAPED_DIST : 3;
@@ -209,6 +213,46 @@ DEVI bf16x8 tr_frag(const char *tile, int s, int trl) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
+// ---- 8-bit tape (PolBF16T8): transposed read of a PAIR of e4m3 tape tiles (TapePost::store_tile8 images, tiles 2M and 2M+1
+// of a layer, 1 KiB each, consecutive in LDS) --------------------------------------------------------------------------------
+// ds_read_b64_tr_b16 moves 16-bit units; a unit of the 8-bit image is the byte pair (element 2u, element 2u+1) of one
+// point, so lane i of a 16-lane group receives, for 4 points per read, the two features j = 2 (i & 3) + {0, 1} of fragment
+// s = (i >> 2) & 1, lane half h = i >> 3 of ITS tile (groups 0 / 2: tile 2M, groups 1 / 3: tile 2M+1; groups 2, 3 = k half 1).
+// Two reads = 8 points, in the point order of the bf16 fragments (tr_frag: element j of k half kh = point
+// 16 s2 + 8 (j >> 2) + 4 kh + (j & 3)) -- the other operand may be a bf16 tile; the bytes are sorted per feature (2 v_perm per read pair and feature) and widened to bf16 by
+// v_cvt_scalef32_pk_bf16_fp8, which also multiplies by the layer's power-of-two scale: out come the fragments (feature on
+// the lane, 8 points of k-step s2 in the registers) of two VIRTUAL 32-row tiles -- `fa`: the even elements, `fb`: the odd
+// ones -- i.e. row n of virtual tile 2M + ab is feature t8_feature(2M + ab, n) of the layer.  The dW slabs are indexed by
+// virtual rows / columns; reduce_kernel undoes the permutation.
+struct Raw8 { u32x2 lo, hi; };
+DEVI int tr8_lane_off() {
+    const int lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15, tsel = g & 1, kh = g >> 1;
+    return 1024 * tsel + 128 * (kh ^ tsel) + 32 * (li >> 2) + 8 * (li & 3);          // (odd tiles swap their 4-point blocks); the second read: + 256
+}
+DEVI Raw8 tr8_read(const char *pair, int s2, int tr8) {
+    typedef s16x4 __attribute__((address_space(3))) * lds_v4;
+    Raw8 r;
+    r.lo = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(pair + 512 * s2 + tr8)));
+    r.hi = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(pair + 512 * s2 + 256 + tr8)));
+    return r;
+}
+DEVI void tr8_widen(const Raw8 &r, float scale, bf16x8 &fa, bf16x8 &fb) {
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    const unsigned a_lo = __builtin_amdgcn_perm(r.lo[1], r.lo[0], 0x06040200u), b_lo = __builtin_amdgcn_perm(r.lo[1], r.lo[0], 0x07050301u);
+    const unsigned a_hi = __builtin_amdgcn_perm(r.hi[1], r.hi[0], 0x06040200u), b_hi = __builtin_amdgcn_perm(r.hi[1], r.hi[0], 0x07050301u);
+    const b2 a0 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(a_lo, scale, false), a1 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(a_lo, scale, true);
+    const b2 a2 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(a_hi, scale, false), a3 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(a_hi, scale, true);
+    const b2 b0 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(b_lo, scale, false), b1 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(b_lo, scale, true);
+    const b2 b2_ = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(b_hi, scale, false), b3 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(b_hi, scale, true);
+    fa = (bf16x8){a0[0], a0[1], a1[0], a1[1], a2[0], a2[1], a3[0], a3[1]};
+    fb = (bf16x8){b0[0], b0[1], b1[0], b1[1], b2_[0], b2_[1], b3[0], b3[1]};
+}
+// feature of row (or column) n of virtual tile t (see above)
+__host__ __device__ static inline int t8_feature(int t, int n) {
+    const int i = n & 15, hh = i >> 3, s = (i >> 2) & 1, j = 2 * (i & 3) + (t & 1);
+    return 32 * ((t & ~1) + (n >> 4)) + 16 * s + 8 * (j >> 2) + 4 * hh + (j & 3);
+}
+
 // Post object of the training kernels (fused_common.h "Software-pipelined ring steps"): finishes the PENDING
 // output tile in the MFMA shadows of the running step --
 //   k-steps 0..7   RELU: relu + relu bits (forward) / !RELU: apply the recorded relu bits `mask` (delta chain),
@@ -226,24 +270,66 @@ struct TapePost {
     // even tile's half to the odd tile's step, which stores the word; `stash` (optional) is a second, LDS destination
     unsigned *mword, *stash;
     unsigned &macc;
-    bool hi, last;          // odd tile of the word / last tile of the layer (stores a half-filled word when MT is odd)
+    bool hi, last;          // odd tile of the word (8-bit tape: of the tile pair) / last tile of the layer (stores a half-filled word when MT is odd)
     int edbg;
     const TapeEmit<Pol> &em;
     typename Pol::frag id[2];
     f32x16 tr;
+    // 8-bit tape, delta chain: the power-of-two scale of the pending tile's layer (gA / t8_sc is what the tape holds) and the
+    // running largest |gA| of the layer (for the NEXT call's scale); the forward's h tiles have scale 1
+    float t8_sc;
+    unsigned &t8_amax;       // (two bf16 magnitudes: the packed maximum over the dwords of the recorded tiles; an f32 maximum over
+                             //  the accumulators in elems() made hipcc spill 70 registers in the delta chain)
     DEVI TapePost(const f32x16 &p, typename Pol::frag &a, typename Pol::frag &b, unsigned mask_in, const TapeEmit<Pol> &em_, char *dst_,
-                  unsigned *mword_, unsigned *stash_, unsigned &macc_, bool hi_, bool last_, int edbg_)
+                  unsigned *mword_, unsigned *stash_, unsigned &macc_, bool hi_, bool last_, int edbg_, float t8_sc_, unsigned &t8_amax_)
         : pend(p), d0(a), d1(b), mask(RELU ? 0u : Pol::mask_spread(mask_in)), dst(dst_), mword(mword_), stash(stash_),
-          macc(macc_), hi(hi_), last(last_), edbg(edbg_), em(em_) {}
+          macc(macc_), hi(hi_), last(last_), edbg(edbg_), em(em_), t8_sc(t8_sc_), t8_amax(t8_amax_) {}
     template <int R0, int N>
     DEVI void elems() {
         if constexpr (RELU) pack_elems<Pol, R0, N>(pend, d0, d1, mask);
         else {
 #pragma unroll
-            for (int r = R0; r < R0 + N; r += 2) Pol::mask_pair(r < 8 ? d0 : d1, (r & 7) >> 1, r >> 1, pend[r], pend[r + 1], mask);
+            for (int r = R0; r < R0 + N; r += 2) {
+                if constexpr (Pol::TAPE8) {
+                    // the tape holds gA / t8_sc as e4m3 (|.| <= 448; the conversion makes NaN of anything larger): the pair is
+                    // limited to +-448 t8_sc BEFORE it is rounded to bf16 -- a no-op unless the gradient grew by more than the
+                    // 16x head room since the call the scale was taken from (DESIGN.md, 8-bit tape)
+                    const float lim = 448.f * t8_sc;
+                    const float x = pend[r], y = pend[r + 1];
+                    Pol::mask_pair(r < 8 ? d0 : d1, (r & 7) >> 1, r >> 1, __builtin_amdgcn_fmed3f(x, -lim, lim), __builtin_amdgcn_fmed3f(y, -lim, lim), mask);
+                } else Pol::mask_pair(r < 8 ? d0 : d1, (r & 7) >> 1, r >> 1, pend[r], pend[r + 1], mask);
+            }
             if (R0 < 8) asm volatile("" : "+v"(d0));
             if (R0 + N > 8) asm volatile("" : "+v"(d1));
         }
+    }
+    // 8-bit tape: the tile as 16 e4m3 bytes per lane (its two bf16 B fragments through v_cvt_scalef32_pk_fp8_bf16: byte
+    // 2 i + e of fragment s = element 2 i + e, i.e. feature 16 s + phi16(h, 2 i + e)), ONE 16-byte store.  Tile image (1 KiB):
+    // point pt at byte 32 (pt ^ 4 par), par = tile & 1 -- lane half h at + 16 h, fragment s at + 8 s -- so that the
+    // transposed LDS reads of the dW kernel (tr8_pair: a 16-lane group gathers 4 points x 32 bytes = 128 contiguous bytes,
+    // the groups of an even and an odd tile in the same instruction) fall on disjoint bank halves.
+    DEVI void store_tile8() {
+        typedef short s16x2 __attribute__((ext_vector_type(2)));
+        typedef short i16x2 __attribute__((ext_vector_type(2)));
+        const u32x4 w0 = __builtin_bit_cast(u32x4, d0), w1 = __builtin_bit_cast(u32x4, d1);
+        u32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            unsigned lo = i < 2 ? w0[2 * i] : w1[2 * i - 4], hi2 = i < 2 ? w0[2 * i + 1] : w1[2 * i - 3];
+            if constexpr (RELU) {      // h >= 0: one signed packed min limits it to 448 (0x43e0)
+                lo = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(i16x2, lo), (i16x2){0x43e0, 0x43e0}));
+                hi2 = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(i16x2, hi2), (i16x2){0x43e0, 0x43e0}));
+            } else {                   // the largest magnitudes recorded so far (non-negative halves: the signed packed max)
+                const i16x2 m = __builtin_elementwise_max(__builtin_bit_cast(i16x2, lo & 0x7fff7fffu), __builtin_bit_cast(i16x2, hi2 & 0x7fff7fffu));
+                t8_amax = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, t8_amax), m));
+            }
+            s16x2 r = {0, 0};
+            r = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(r, __builtin_bit_cast(typename Pol::bf16x2, lo), t8_sc, false);
+            r = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(r, __builtin_bit_cast(typename Pol::bf16x2, hi2), t8_sc, true);
+            o[i] = __builtin_bit_cast(unsigned, r);
+        }
+        const int lane = threadIdx.x & 63, pt = lane & 31, hh = lane >> 5;
+        __builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(dst + ((32 * pt + 16 * hh) ^ (hi ? 128 : 0))));
     }
     DEVI void bits_and_transpose() {
         if constexpr (RELU) {
@@ -261,7 +347,8 @@ struct TapePost {
     }
     DEVI void store_tile() {
         if (edbg & 2) return;
-        if constexpr (Pol::ELEM_BYTES == 2) TapeEmit<Pol>::store_native(dst, d0, d1, edbg);
+        if constexpr (Pol::TAPE8) store_tile8();
+        else if constexpr (Pol::ELEM_BYTES == 2) TapeEmit<Pol>::store_native(dst, d0, d1, edbg);
         else TapeEmit<Pol>::store(dst, tr, edbg);
     }
     unsigned w = 0;                             // the pair rounded in the previous k-step (pack_pipe)
@@ -314,6 +401,8 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
     constexpr int CB = PK::CHUNK_BYTES, MT = PK::MT, KS = PK::KS;
     constexpr int MW = (MT + 1) / 2;                                   // mask words per layer per lane
     constexpr int TB = BG::TILE_BYTES;
+    constexpr int TT = BG::TAPE_TILE;                                  // an h / gA tile on the tape (8-bit tape: 1 KiB)
+    constexpr bool T8 = Pol::TAPE8;
     const FusedArgs &a = A.f;
     const int edbg = BHN_DBG(((A.debug >> 6) & 3) | (A.policy << 2));  // measurement aid for the tape emission (bits 2,3: store policy)
     constexpr int sdbg = 0;                        // (a run-time MFMA-skip flag put every MFMA in its own basic block)
@@ -325,7 +414,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
     // own emission (k-step 12) also follows its DMA issue (k-step 9).  The DMA pieces of the DIST-2 younger chunks
     // cancel out of the balance, so only this store count has to be a lower bound (relu-bit words, epilogue stores and
     // prefetch loads only add slack); the exceptions are the steps right after a layer-0 step without h_1 emission.
-    constexpr int ES = (Pol::ELEM_BYTES == 2) ? 2 : 4;                 // global stores of one tile emission
+    constexpr int ES = T8 ? 1 : (Pol::ELEM_BYTES == 2) ? 2 : 4;        // global stores of one tile emission
 #ifndef BHN_YS_EXTRA
 #define BHN_YS_EXTRA 0          // EXPERIMENT ONLY (-DBHN_YS_EXTRA=n): lets n more stores stay in flight than the ring proof allows
 #endif                          // (racy: wrong results possible) -- measures what the in-order vmcnt coupling of stores and weight DMA costs
@@ -345,9 +434,20 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
     float *wout_lds = zero_lds + 32;
     char *id_lds = reinterpret_cast<char *>(wout_lds + W);
     char *seg_lds = id_lds + (Pol::ELEM_BYTES == 2 ? 0 : 2 * Pol::FRAG_BYTES);   // RaySum scratch (bf16 has no identity table)
+    // 8-bit tape, delta chain (no RaySum there): 8 layer scales, then one |gA|max slot per layer and wave
+    float *t8_lds = reinterpret_cast<float *>(seg_lds);
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 31, h = lane >> 5;
     const int wvu = __builtin_amdgcn_readfirstlane(wv);           // the wave index as a scalar: tape addresses stay in SGPRs
+    auto t8_flush = [&](int l, unsigned packed) {          // packed: two bf16 magnitudes (TapePost::t8_amax)
+        float v = __builtin_fmaxf(__uint_as_float(packed << 16), __uint_as_float(packed & 0xffff0000u));
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v = __builtin_fmaxf(v, __shfl_xor(v, o, 64));
+        if (lane == 0) {
+            float *slot = t8_lds + 8 + l * Pol::NWAVES + wv;
+            *slot = __builtin_fmaxf(*slot, v);
+        }
+    };
     // scalars of the tape layout, pinned in registers (the compiler otherwise re-fetches kernel arguments inside the steps)
     long long h_lin = A.t.h_lin, ga_lin = A.t.ga_lin, lin_stride = A.t.lin_stride;
     asm volatile("" : "+s"(h_lin), "+s"(ga_lin), "+s"(lin_stride));
@@ -357,6 +457,13 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
         bias_lds[i] = reinterpret_cast<const float *>(a.packed + a.bias_off)[i];
     if (tid < 32) zero_lds[tid] = 0.f;
     for (int i = tid; i < W; i += Pol::NTHREADS) wout_lds[i] = reinterpret_cast<const float *>(a.packed + a.wout_off)[i];
+    if constexpr (T8 && MODE == MODE_CHAIN) {
+        if (tid < 8) {
+            const float v = A.t8[tid];
+            t8_lds[tid] = (v > 0.f && v < __builtin_inff()) ? v : 1.f;       // (a workspace that was never calibrated)
+        }
+        if (tid < a.depth * Pol::NWAVES) t8_lds[8 + tid] = 0.f;
+    }
 
     const bool have_ring = NCF + NLB * MT > 0;
     // first tile of the sequence starts with bias (forward) or zero (delta chain) accumulators
@@ -455,12 +562,13 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
                     }
                     if (dst) em.emit(dst + (long long)m * TB, d0, d1, edbg);
                 }
-            } l0{em, drop_h1 ? nullptr : A.tape + h_lin + lin_stride + qs * MT * TB, mask_g ? mask_g + lane : nullptr,
+            } l0{em, drop_h1 ? nullptr : A.tape + h_lin + lin_stride + qs * MT * TT, mask_g ? mask_g + lane : nullptr,
                  nullptr, 0u, edbg};
             f32x16 pend;
             layer0_step<W, Pol, RG, YS0>(rs, ap, enc, act, bias_lds, h, pend, l0);
             // ---- hidden layers 1..depth-1 and the output layer: the pending tile is (l-1, MT-1) at m = 0 ------
             int pl_layer = 0;                        // layer of the pending tile
+            unsigned t8_none = 0u;                   // (the forward's h tiles: scale 1, no maxima)
             unsigned macc = l0.macc;                 // relu bits of the even tile of the running mask word
 #pragma nounroll
             for (int l = 1; l <= a.depth; ++l) {
@@ -477,9 +585,9 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
                     frag &d1 = m == 0 ? act[KS - 1] : next[2 * (m > 0 ? m - 1 : 0) + 1];
                     const int widx = (pl_layer * MW + (pm >> 1)) * 64 + lane;
                     const bool no_h = drop_h1 && pl_layer == 0;     // layer 0's last tile: relu bits only
-                    TapePost<Pol, true> post(pend, d0, d1, 0u, em, A.tape + h_lin + (pl_layer + 1) * lin_stride + (qs * MT + pm) * TB,
+                    TapePost<Pol, true> post(pend, d0, d1, 0u, em, A.tape + h_lin + (pl_layer + 1) * lin_stride + (qs * MT + pm) * TT,
                                                  mask_g ? mask_g + widx : nullptr, nullptr,
-                                                 macc, pm & 1, pm == MT - 1, no_h ? (edbg | 2) : edbg);
+                                                 macc, pm & 1, pm == MT - 1, no_h ? (edbg | 2) : edbg, 1.f, t8_none);
                     // bias rows of the next tile: (l, m+1), or the first tile of the next sequence part
                     const float *bn = (out || (m == MT - 1 && l + 1 > a.depth)) ? nullptr : bl + 32 * (m + 1);
                     if (out) bn = bias_lds;                           // next tile, layer 0
@@ -534,7 +642,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
             unsigned last_mask = 0xffffu;            // relu bits still to be applied to the pending tile of gA_{depth-1}
             {
                 const bool keep_ga = !A.t.drop_ga;                    // else the dW kernel rebuilds gA_{depth-1}
-                char *gdst = A.tape + ga_lin + (a.depth - 1) * lin_stride + qs * MT * TB;
+                char *gdst = A.tape + ga_lin + (a.depth - 1) * lin_stride + qs * MT * TT;
                 if constexpr (Pol::ELEM_BYTES == 2) {
                     if (A.t.drop_ga) {
                         // W_out sits in the columns of this layer's transposed weight image (bhn_folds_wout): the B operand
@@ -592,6 +700,9 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
             unsigned pnd_mask = last_mask;           // its relu bits (0xffff: gA_{depth-1} is masked already)
             unsigned mq0 = cin.q0, mq1 = cin.q1, mcur = 0u;          // MODE_CHAIN: relu-bit words in flight from the tape
             unsigned no_acc = 0u;
+            float t8_sc = 1.f;
+            unsigned t8_amax = 0u;                    // 8-bit tape: scale of the pending tile's layer, |gA|max of that layer so far
+            if constexpr (T8) t8_sc = t8_lds[a.depth - 1];
 #pragma nounroll
             for (int l = a.depth - 1; l >= LEND; --l) {
 #pragma unroll
@@ -602,8 +713,8 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
                     frag &d0 = m == 0 ? dl[KS - 2] : next[2 * (m > 0 ? m - 1 : 0)];
                     frag &d1 = m == 0 ? dl[KS - 1] : next[2 * (m > 0 ? m - 1 : 0) + 1];
                     const bool no_ga = A.t.drop_ga && pnd_layer == a.depth - 1;     // gA_{depth-1}'s last tile: not recorded
-                    TapePost<Pol, false> post(pend, d0, d1, pnd_mask, em, A.tape + ga_lin + pnd_layer * lin_stride + (qs * MT + pm) * TB,
-                                                  nullptr, nullptr, no_acc, false, false, no_ga ? (edbg | 2) : edbg);
+                    TapePost<Pol, false> post(pend, d0, d1, pnd_mask, em, A.tape + ga_lin + pnd_layer * lin_stride + (qs * MT + pm) * TT,
+                                                  nullptr, nullptr, no_acc, T8 && (pm & 1), false, no_ga ? (edbg | 2) : edbg, t8_sc, t8_amax);
                     if (!(m & 1)) {                                  // word (l-1, m/2): use the oldest, fetch two ahead
                         mcur = mq0;
                         mq0 = mq1;
@@ -619,18 +730,36 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
                     pend = acc;
                     pnd_layer = l - 1;
                     pnd_mask = mcur >> ((m & 1) * 16);
+                    if constexpr (T8) {
+                        if (m == 0) {       // the last tile of gA_l has been posted: its layer's |.|max to the thread's slot, on to gA_{l-1}
+                            t8_flush(l, t8_amax);
+                            t8_amax = 0u;
+                            t8_sc = t8_lds[l - 1];
+                        }
+                    }
                 }
 #pragma unroll
                 for (int ks = 0; ks < KS - 2; ++ks) dl[ks] = next[ks];
             }
             if (a.depth > 1) {           // flush the last tile of gA_{LEND-1} (no further step to hide it behind)
                 TapePost<Pol, false> post(pend, dl[KS - 2], dl[KS - 1], pnd_mask, em,
-                                              A.tape + ga_lin + (LEND - 1) * lin_stride + (qs * MT + MT - 1) * TB, nullptr, nullptr, no_acc, false, false, edbg);
+                                              A.tape + ga_lin + (LEND - 1) * lin_stride + (qs * MT + MT - 1) * TT, nullptr, nullptr, no_acc, T8 && ((MT - 1) & 1), false, edbg,
+                                              t8_sc, t8_amax);
                 post.all();
+                if constexpr (T8) t8_flush(LEND - 1, t8_amax);
             }
         }   // MODE_CHAIN
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may land after the workgroup has released its LDS
+    if constexpr (T8 && MODE == MODE_CHAIN) {
+        // the workgroup's largest |gA_l| per recorded layer -> the state block (t8_update_kernel turns it into the next call's scale)
+        __syncthreads();
+        if (tid + 1 < a.depth) {
+            float v = 0.f;
+            for (int w = 0; w < Pol::NWAVES; ++w) v = __builtin_fmaxf(v, t8_lds[8 + tid * Pol::NWAVES + w]);
+            atomicMax(reinterpret_cast<unsigned *>(A.t8) + 8 + tid, __float_as_uint(v));
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -950,19 +1079,31 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
     static_assert(!LAST || JT == JT_HIDDEN || JT == JT_SKIP, "LAST: hidden / skip job");
     static_assert(!OUTENC || LAST, "OUTENC: a LAST job");
     static_assert(BG::NBUF == 4, "ring of four group buffers");
-    constexpr int MT = BG::MT, TB = BG::TILE_BYTES;
-    constexpr int OFF_H = MT * TB, OFF_E = 2 * MT * TB, OFF_D32 = BG::GROUP_BYTES;       // LDS group image [A][h][enc][f32 dout piece]
-    constexpr int GB = LAST ? BG::GROUP_BYTES_LAST2 : BG::GROUP_BYTES;
+    constexpr int MT = BG::MT, TB = BG::TILE_BYTES, TT = BG::TAPE_TILE;
+    constexpr bool T8 = Pol::TAPE8;                                    // 8-bit h / gA tape tiles (tr8_read / tr8_widen)
     constexpr bool has_h = JT != JT_FIRST, make_h = JT == JT_HIDDEN1, enc_extra = JT == JT_SKIP;
+    static_assert(!T8 || !OUTENC, "8-bit tape: even depths / no skip into the output layer");
+    // LDS group image [A][h][enc][f32 dout piece]; 8-bit tape: A and streamed h tiles are 1 KiB, a recomputed h_1 tile 2 KiB
+    constexpr int OFF_H = MT * TT, OFF_E = T8 ? OFF_H + (make_h ? MT * TB : MT * TT) : 2 * MT * TB, OFF_D32 = OFF_E + TB;
+    constexpr int GB = OFF_D32 + (LAST ? 1024 : 0);
+    static_assert(T8 || (OFF_D32 == BG::GROUP_BYTES && GB == (LAST ? BG::GROUP_BYTES_LAST2 : BG::GROUP_BYTES)), "group image");
+    static_assert(GB <= BG::GROUP_BYTES + 1024, "group image larger than the host's LDS budget");
     constexpr int nH = has_h ? MT : 0, nB = nH + ((JT == JT_FIRST || JT == JT_SKIP) ? 1 : 0);   // slab tile nB: the bias column
     constexpr int nBr = has_h ? MT : 1;                                // B tiles of the regular tile grid
     constexpr int WRR = BG::WRR, WCC = BG::WCC;
     constexpr int MPW = (MT + WRR - 1) / WRR, NPW = (nBr + WCC - 1) / WCC;
     static_assert(NPW <= 5, "one sweep");
+    constexpr bool B8 = T8 && has_h && !make_h;                       // the B tiles are 8-bit tape tiles too
+    static_assert(!T8 || MPW == 2, "8-bit tape: the A tiles come in pairs (width 256)");
+    static_assert(!B8 || NPW % 2 == 0, "8-bit tape: the B tiles come in pairs (width 256)");
     constexpr int ME = (MPW + WCC - 1) / WCC;                          // A tiles a wave pairs with the enc tile / the output row
     constexpr int NTOT = 2 * NPW;                                      // MFMA steps per group (k-step major)
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: wave-uniform branches
     const int trl = tr_lane_off();
+    const int tr8 = tr8_lane_off();
+    // 8-bit tape: what the A bytes are multiplied by on their way to bf16 (gA_l: the layer's scale; h_depth of the LAST job: 1)
+    float scaleA = 1.f;
+    if constexpr (T8 && !LAST) scaleA = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, A.t8[job])));
     const int nwg = A.wg_begin[job + 1] - A.wg_begin[job];
     const int kb = blockIdx.x - A.wg_begin[job];
     const long long q0 = uniform64(A.t.NQ * kb / nwg), q1 = uniform64(A.t.NQ * (kb + 1) / nwg);
@@ -1014,7 +1155,7 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
     if constexpr (LAST) {
 #pragma unroll
         for (int mi = 0; mi < MPW; ++mi) {
-            const int f = 32 * (wr * MPW + mi) + (lane & 31);
+            const int f = T8 ? t8_feature(wr * MPW + mi, lane & 31) : 32 * (wr * MPW + mi) + (lane & 31);
             wout_r[mi] = f < W ? reinterpret_cast<const float *>(A.f.packed + A.f.wout_off)[f] : 0.f;
         }
     }
@@ -1024,7 +1165,7 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
 #pragma unroll
     for (int ni = 0; ni < NPW; ++ni) {
         const int n = nbase + ni;
-        boff[ni] = has_h ? OFF_H + (n < nH ? n : 0) * TB : OFF_E;        // a column share that ends early repeats tile 0 (dropped at the flush)
+        boff[ni] = has_h ? OFF_H + (n < nH ? n : 0) * (B8 ? TT : TB) : OFF_E;        // a column share that ends early repeats tile 0 (dropped at the flush)
     }
     const bool bias_rows = wc == 0;                                    // this wave sums the bias column of its A tiles
     const bool out_bias_wave = LAST && wr == 0 && wc == 0;             // ... and this one the output layer's bias
@@ -1051,11 +1192,21 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
         if constexpr (make_h) return Pol::lds_frag(gp + boff[t % NPW], t / NPW, lane);     // written by make_h_write in fragment order
         else return tr_frag(gp + boff[t % NPW], t / NPW, trl);
     };
+    // 8-bit B tiles: raw read of pair u = (k-step u / (NPW/2), tiles 2 (u % (NPW/2)), +1 of the wave's share)
+    auto load_braw = [&](const char *gp, int u) -> Raw8 { return tr8_read(gp + boff[2 * (u % (NPW / 2))], u / (NPW / 2), tr8); };
     auto a_load = [&](const char *gp, AState &st) {
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll
-            for (int mi = 0; mi < MPW; ++mi) st.af[s2][mi] = tr_frag(gp + (wr * MPW + mi) * TB, s2, trl);
+            for (int mi = 0; mi < MPW; ++mi) {
+                if constexpr (T8) {
+                    // the raw pair read (4 dwords) rides in af[s2][0] until a_prep widens it into af[s2][0], af[s2][1]
+                    if (mi == 0) {
+                        const Raw8 raw = tr8_read(gp + (wr * MPW) * TT, s2, tr8);
+                        st.af[s2][0] = __builtin_bit_cast(frag, (u32x4){raw.lo[0], raw.lo[1], raw.hi[0], raw.hi[1]});
+                    }
+                } else st.af[s2][mi] = tr_frag(gp + (wr * MPW + mi) * TB, s2, trl);
+            }
             if constexpr (LAST) {
                 // dout of this lane's eight points of k-step s2: tape point order p = (j&3) + 8(j>>2) + 16 s2 + 4 (lane>>5)
                 const float *d32 = reinterpret_cast<const float *>(gp + OFF_D32) + 16 * s2 + 4 * (lane >> 5);
@@ -1069,6 +1220,14 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
     // the group behind the last one is loaded but must not be accumulated)
     auto a_prep = [&](AState &st, int k, bool live) {
         const int s2 = k / MPW, mi = k % MPW;
+        if constexpr (T8) {
+            if (mi == 0) {
+                const u32x4 rw = __builtin_bit_cast(u32x4, st.af[s2][0]);
+                Raw8 raw;
+                raw.lo = (u32x2){rw[0], rw[1]}; raw.hi = (u32x2){rw[2], rw[3]};
+                tr8_widen(raw, scaleA, st.af[s2][0], st.af[s2][1]);
+            }
+        }
         if constexpr (LAST) {
             typedef float f32x2 __attribute__((ext_vector_type(2)));
             typedef short i16x2 __attribute__((ext_vector_type(2)));
@@ -1112,6 +1271,43 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
     auto mma_phase = [&](const char *gp, const AState &cur, const frag (&bc)[2], const char *gnext, AState &nx, frag (&bn)[2],
                          bool live_next) {
         frag bq[3], benc;
+        if constexpr (B8) {
+            // 8-bit B tiles come in pairs (tiles 2k, 2k+1 of the wave's share, one k-step = MFMA steps 2u, 2u+1): the raw
+            // read of pair u+1 is in flight while pair u is widened and used
+            constexpr int NPAIR = NTOT / 2;
+            frag bcur[2] = {bc[0], bc[1]}, bnx[2];
+            Raw8 rnext, rawn;
+            if (NPAIR > 1) rnext = load_braw(gp, 1);
+#pragma unroll
+            for (int t = 0; t < NTOT; ++t) {
+                const int u = t >> 1, e = t & 1;
+                if (e == 0 && u + 1 < NPAIR) {
+                    tr8_widen(rnext, 1.f, bnx[0], bnx[1]);
+                    if (u + 2 < NPAIR) rnext = load_braw(gp, u + 2);
+                }
+                if (enc_extra && (t % NPW) == (NPW >= 2 ? NPW - 2 : 0)) benc = tr_frag(gp + OFF_E, t / NPW, trl);
+                if (t == 0) a_load(gnext, nx);
+                __builtin_amdgcn_sched_barrier(0);
+                const int s2 = t / NPW, ni = t % NPW;
+#pragma unroll
+                for (int mi = 0; mi < MPW; ++mi) acc[mi][ni] = Pol::mma(cur.af[s2][mi], bcur[e], acc[mi][ni]);
+                if constexpr (enc_extra) {
+                    if (ni == NPW - 1) {
+#pragma unroll
+                        for (int mi = 0; mi < MPW; ++mi)
+                            if ((mi % WCC) == wc) acc_e[mi / WCC] = Pol::mma(cur.af[s2][mi], benc, acc_e[mi / WCC]);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < NPREP; ++k)
+                    if (t == (T_PREP + k < NTOT ? T_PREP + k : NTOT - 1)) a_prep(nx, k, live_next);
+                if (t == (NTOT >= 2 ? NTOT - 2 : 0)) rawn = load_braw(gnext, 0);
+                if (t == NTOT - 1) tr8_widen(rawn, 1.f, bn[0], bn[1]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (e == 1) { bcur[0] = bnx[0]; bcur[1] = bnx[1]; }
+            }
+            return;
+        }
         if constexpr (make_h) {
             bq[0] = load_b(gp, 0);
             if (NTOT > 1) bq[1] = load_b(gp, 1);
@@ -1146,11 +1342,11 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
     };
 
     // ---- the stream: pieces (1 KiB = one wave-wide DMA) this job needs: [A tiles][h tiles][enc tile][f32 dout piece]
-    constexpr int PA = MT * TB / 1024, PH = (has_h && !make_h) ? MT * TB / 1024 : 0,
+    constexpr int PA = MT * TT / 1024, PH = (has_h && !make_h) ? MT * TT / 1024 : 0,
                   PE = (JT == JT_FIRST || JT == JT_SKIP || make_h || OUTENC) ? TB / 1024 : 0, PD = LAST ? 1 : 0;
     using Stream = TapeStream<Pol::NWAVES, PA, PH, PE, PD, OFF_H, OFF_E, OFF_D32>;
     constexpr int PPW = Stream::PPW;
-    const Stream stream(srcA, (long long)MT * TB, srcH, (long long)MT * TB, srcE, TB, srcD, A.t.dout_stride, wv);
+    const Stream stream(srcA, (long long)MT * TT, srcH, (long long)MT * TT, srcE, TB, srcD, A.t.dout_stride, wv);
     auto issue = [&](long long q, char *buf) {
         q = q < q1 ? q : q1 - 1;
         if (BHN_DBG(A.wrap)) q %= A.wrap;
@@ -1173,7 +1369,8 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
             a_load(smem, sa);
 #pragma unroll
             for (int k = 0; k < NPREP; ++k) a_prep(sa, k, true);
-            if constexpr (!make_h) { ba[0] = load_b(smem, 0); ba[1] = load_b(smem, NTOT > 1 ? 1 : 0); }
+            if constexpr (B8) tr8_widen(load_braw(smem, 0), 1.f, ba[0], ba[1]);
+            else if constexpr (!make_h) { ba[0] = load_b(smem, 0); ba[1] = load_b(smem, NTOT > 1 ? 1 : 0); }
         }
         auto body = [&](AState &cur, AState &nx, frag (&bc)[2], frag (&bn)[2], long long q, int it) {
             // group q+1 has landed for this wave (q+2 may still be in flight), then it is published to the workgroup
@@ -1215,7 +1412,10 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
             f32x4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = t[4 * g4 + e];
-            if constexpr (LAST) {
+            if constexpr (LAST && T8) {      // rows are virtual (t8_feature)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= wout_g[t8_feature(m, 8 * g4 + 4 * (lane >> 5) + e)];
+            } else if constexpr (LAST) {
                 const f32x4 w4 = *reinterpret_cast<const f32x4 *>(wout_g + 32 * m + 8 * g4 + 4 * (lane >> 5));
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] *= w4[e];
@@ -1445,7 +1645,10 @@ __global__ __launch_bounds__(Pol::NTHREADS) __attribute__((amdgpu_waves_per_eu(P
                 else dw_body2<W, Pol, JT_FIRST>(A, job, smem);
             } else dw_body2<W, Pol, JT_FIRST>(A, job, smem);
         } else if (job == depth - 1 && A.t.drop_ga) {
-            if ((A.f.skip_mask >> job) & 1) {
+            if constexpr (Pol::TAPE8) {           // (no skip into the output layer: checked by the host)
+                if ((A.f.skip_mask >> job) & 1) dw_body2<W, Pol, JT_SKIP, true>(A, job, smem);
+                else dw_body2<W, Pol, JT_HIDDEN, true>(A, job, smem);
+            } else if ((A.f.skip_mask >> job) & 1) {
                 if (out_skip) dw_body2<W, Pol, JT_SKIP, true, true>(A, job, smem);
                 else dw_body2<W, Pol, JT_SKIP, true>(A, job, smem);
             } else {
@@ -1517,7 +1720,12 @@ __global__ __launch_bounds__(256) void reduce_kernel(BwdArgs A) {
     // input feature of this column
     long long kin = -1;
     bool is_bias = false;
-    if (n < nH) { if (32 * n + col < WT) kin = 32 * n + col; }
+    // 8-bit tape: rows of every job and the columns that came from 8-bit h tiles (all but the recomputed h_1 of layer 1) are
+    // virtual (t8_feature); the output layer's row rides on job depth-1 with ITS row index in the column position
+    if (n < nH) {
+        const int c = (Pol::TAPE8 && !(l == 1 && A.t.drop_h1)) ? t8_feature(n, col) : 32 * n + col;
+        if (c < WT) kin = c;
+    }
     else if (n < nB) { const int fe = bhn_enc_slot_feature(col, A.f.deg); if (fe >= 0) kin = (has_h ? WT : 0) + fe; }
     else is_bias = col == 0;
     if (kin < 0 && !is_bias) return;
@@ -1525,10 +1733,33 @@ __global__ __launch_bounds__(256) void reduce_kernel(BwdArgs A) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int r = 4 * g4 + e, row = (r & 3) + 4 * hh + 8 * (r >> 2);
-        const int o = out ? 0 : 32 * mi + row;
+        const int o = out ? 0 : Pol::TAPE8 ? t8_feature(mi, row) : 32 * mi + row;
         if (out ? row != 0 : o >= WT) continue;
         A.dparams[is_bias ? A.bias_off[l] + o : A.kernel_off[l] + kin * outw + o] = sum[e];
     }
+}
+
+// 8-bit tape state (BwdArgs::t8).  t8_update: the scales of the NEXT call from the largest |gA_l| the delta chain just saw --
+// the power of two that puts 16 |gA_l|max at or below 448, e4m3's largest value: four binades of head room for growth from
+// one call to the next, thirteen and a half below the maximum before values flush to zero (tools/exp_fp8_tape_accuracy.py:
+// the dW error does not notice) -- and the maxima cleared.  t8_open: scales so large that nothing is limited (the
+// calibration pass of BHN_T8_CALIBRATE: only its maxima are used).
+__global__ void t8_update_kernel(float *st, int n) {
+    const int l = threadIdx.x;
+    if (l >= n) return;
+    unsigned *bits = reinterpret_cast<unsigned *>(st);
+    const float a = __uint_as_float(bits[8 + l]);
+    if (a > 0.f && a < __builtin_inff()) {
+        int e;
+        const float mant = frexpf(a * (16.f / 448.f), &e);            // a 16 / 448 = mant 2^e, mant in [0.5, 1)
+        if (mant == 0.5f) --e;
+        e = e < -100 ? -100 : e > 100 ? 100 : e;
+        st[l] = ldexpf(1.f, e);
+    } else if (!(st[l] > 0.f && st[l] < __builtin_inff())) st[l] = 1.f;
+    bits[8 + l] = 0u;
+}
+__global__ void t8_open_kernel(float *st) {
+    if (threadIdx.x < 8) { st[threadIdx.x] = 0x1p60f; reinterpret_cast<unsigned *>(st)[8 + threadIdx.x] = 0u; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1561,7 +1792,7 @@ static void tape_layout(int depth, bool layer1_takes_enc, long long NQ, TapeLayo
     t->NQ = NQ;
     t->drop_h1 = Pol::ELEM_BYTES == 2 && depth >= 2 && !layer1_takes_enc;
     long long off = 0;
-    const long long per_tensor = NQ * BG::MT * (long long)BG::TILE_BYTES;
+    const long long per_tensor = NQ * BG::MT * (long long)BG::TAPE_TILE;
     for (int l = 1; l <= depth; ++l) {
         if (l == 1 && t->drop_h1) { t->h_off[l] = -1; continue; }
         t->h_off[l] = off; off += per_tensor;
@@ -1603,6 +1834,9 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
     using BG = BwdGeom<W, Pol>;
     using PK = Pack<W, Pol>;
     BHN_CHECK_DEVICE(device);
+    const bool t8_cal = Pol::TAPE8 && (mode & BHN_T8_CALIBRATE);
+    mode = bhn_norm_mode(mode);
+    constexpr size_t t8_bytes = Pol::TAPE8 ? 256 : 0;                   // the 8-bit tape's state block, in front of the tape
     const int ncu = bhn_num_cus(device);
 #ifdef BHN_DEBUG
     static const int grid_override = dbg_env_int("BHN_DEBUG_DW_GRID", 0);
@@ -1629,7 +1863,7 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
         const long long tiles = (query_P + Pol::NWAVES * 32 - 1) / (Pol::NWAVES * 32) * query_B;
         TapeLayout t;
         layout(tiles * Pol::NWAVES, &t);
-        *query_bytes = slab_bytes + (size_t)t.total;
+        *query_bytes = slab_bytes + t8_bytes + (size_t)t.total;
         return BHN_OK;
     }
     BwdArgs A;
@@ -1643,16 +1877,16 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
     const long long groups_per_frame = (long long)A.f.tiles_per_frame * Pol::NWAVES;
     TapeLayout t1;
     layout(groups_per_frame, &t1);
-    if (workspace_bytes < slab_bytes + (size_t)t1.total) {
+    if (workspace_bytes < slab_bytes + t8_bytes + (size_t)t1.total) {
         bhn_set_error("render_bwd workspace too small: %zu bytes, need >= %zu (slabs %zu + one frame of tape %lld)",
-                      workspace_bytes, slab_bytes + (size_t)t1.total, slab_bytes, t1.total);
+                      workspace_bytes, slab_bytes + t8_bytes + (size_t)t1.total, slab_bytes, t1.total);
         return BHN_EWORKSPACE;
     }
     long long fpp = 1;
     while (fpp < A.f.B) {
         TapeLayout tn;
         layout(groups_per_frame * (fpp + 1), &tn);
-        if (slab_bytes + (size_t)tn.total > workspace_bytes) break;
+        if (slab_bytes + t8_bytes + (size_t)tn.total > workspace_bytes) break;
         ++fpp;
     }
     if (what != RUN_RECOMPUTE && fpp < A.f.B) {
@@ -1661,7 +1895,13 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
         return BHN_EWORKSPACE;
     }
     A.f.slabs = reinterpret_cast<float *>(workspace);
-    A.tape = reinterpret_cast<char *>(workspace) + slab_bytes;
+    A.tape = reinterpret_cast<char *>(workspace) + slab_bytes + t8_bytes;
+    A.t8 = Pol::TAPE8 ? reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + slab_bytes) : nullptr;
+    if constexpr (Pol::TAPE8) {
+        // what the 8-bit kernels are built for (everything the reference's own drivers use at this width)
+        BHN_CHECK_ARG(t1.drop_h1 && t1.drop_ga && !s.skip_in[depth] && s.width_true == W,
+                      "BHN_BF16_T8: depth >= 3, no skip into layer 1 or into the output layer, net_width == %d", W);
+    }
     A.f.slab_floats = BG::SLAB_FLOATS;
     A.f.dimages = dimages;
     A.f.images = images;
@@ -1793,6 +2033,16 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
                 hipLaunchKernelGGL(k_fwd, dim3((unsigned)grid), dim3(Pol::NTHREADS), lds_fwd, st, A);
                 BHN_HIP(hipGetLastError());
             }
+            if constexpr (Pol::TAPE8) {
+                if (t8_cal && pass == 0) {
+                    // calibration: the delta chain once with nothing limited (its tape output is overwritten below), its
+                    // |gA_l| maxima become this call's scales
+                    hipLaunchKernelGGL(t8_open_kernel, dim3(1), dim3(64), 0, st, A.t8);
+                    hipLaunchKernelGGL(k_chn, dim3((unsigned)grid), dim3(Pol::NTHREADS), lds_chn, st, A);
+                    hipLaunchKernelGGL(t8_update_kernel, dim3(1), dim3(64), 0, st, A.t8, depth);
+                    BHN_HIP(hipGetLastError());
+                }
+            }
             hipLaunchKernelGGL(k_chn, dim3((unsigned)grid), dim3(Pol::NTHREADS), lds_chn, st, A);
         }
         BHN_HIP(hipGetLastError());
@@ -1805,6 +2055,9 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
         const int rcr = reduce128_launch(A, depth, nslabs128, st);
         if (rcr != BHN_OK) return rcr;
     } else if (what != RUN_FWD_TRAIN && (g_bwd_stages & 4)) hipLaunchKernelGGL((reduce_kernel<W, Pol>), dim3((unsigned)ReduceGeom<W, Pol>::blocks(depth, (unsigned)A.f.skip_mask)), dim3(256), 0, st, A);
+    if constexpr (Pol::TAPE8) {
+        if (what != RUN_FWD_TRAIN) hipLaunchKernelGGL(t8_update_kernel, dim3(1), dim3(64), 0, st, A.t8, depth);      // the next call's scales
+    }
     BHN_HIP(hipGetLastError());
     if (events && n_events > 3 && events[3]) BHN_HIP(hipEventRecord((hipEvent_t)events[3], st));
     return BHN_OK;
@@ -1829,13 +2082,22 @@ static int bwd_entry(int what, const bhn_model *m, int32_t mode, const void *pac
                      const bhn_frames *fr, const float *dimages, float *images, float *dparams, void *workspace,
                      size_t workspace_bytes, void *stream, void *const *ev = nullptr, int nev = 0) {
     BHN_CHECK_ARG(m, "null model");
-    BHN_CHECK_ARG(mode == BHN_F32 || mode == BHN_BF16, "bad mode %d", mode);
+    const bool t8 = (mode & 0xff) == BHN_BF16_T8 && bhn_norm_mode(mode) == BHN_BF16;
+    BHN_CHECK_ARG(mode == BHN_F32 || mode == BHN_BF16 || t8, "bad mode %d", mode);
     int dev = 0;
     BHN_HIP(hipGetDevice(&dev));
     MlpShape shape;
     const int rcs = bhn_mlp_shape(m, &shape);
     if (rcs != BHN_OK) return rcs;
     const int kernel_width = shape.width;
+    if (t8) {
+        if (kernel_width != 256 || shape.depth < 3) {
+            bhn_set_error("BHN_BF16_T8 (8-bit tape) is built for net_width 256 and net_depth >= 3 (got %d x %d); use BHN_BF16", shape.depth, shape.width_true);
+            return BHN_EUNSUPPORTED;
+        }
+        return bwd_run<256, PolBF16T8>(what, m, mode, packed, geom, fr, dimages, images, dparams, workspace, workspace_bytes,
+                                       (hipStream_t)stream, nullptr, 0, 0, dev, ev, nev);
+    }
     return (mode == BHN_BF16)
                ? bwd_dispatch<PolBF16>(what, kernel_width, m, mode, packed, geom, fr, dimages, images, dparams, workspace,
                                        workspace_bytes, (hipStream_t)stream, nullptr, 0, 0, dev, ev, nev)
@@ -1847,6 +2109,10 @@ extern "C" size_t bhn_render_bwd_workspace_bytes(const bhn_model *m, int32_t mod
     MlpShape s;
     if (bhn_mlp_shape(m, &s) != BHN_OK || B <= 0 || P <= 0) return 0;
     size_t q = 0;
+    if ((mode & 0xff) == BHN_BF16_T8 && bhn_norm_mode(mode) == BHN_BF16) {
+        if (s.width != 256 || s.depth < 3) return 0;
+        return bwd_run<256, PolBF16T8>(RUN_QUERY, m, mode, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, &q, B, P, device) == BHN_OK ? q : 0;
+    }
     int rc = (mode == BHN_BF16)
                  ? bwd_dispatch<PolBF16>(RUN_QUERY, s.width, m, mode, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, &q, B, P, device)
                  : bwd_dispatch<PolF32>(RUN_QUERY, s.width, m, mode, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, &q, B, P, device);
@@ -1883,7 +2149,7 @@ extern "C" const char *bhn_render_bwd_tape_kernel_name(int32_t i);
 extern "C" const char *bhn_render_bwd_tape_kernel_name_for(const bhn_model *m, int32_t mode, int32_t i) {
     MlpShape s;
     if (!m || bhn_mlp_shape(m, &s) != BHN_OK) return nullptr;
-    if (bwd128_supported(mode, s.width, s.depth)) {
+    if (bwd128_supported(bhn_norm_mode(mode), s.width, s.depth)) {
         static const char *const names[BHN_BWD_TAPE_KERNELS] = {"bwd128_kernel", "-", "reduce128_kernel"};
         return (i >= 0 && i < BHN_BWD_TAPE_KERNELS) ? names[i] : nullptr;
     }

@@ -18,6 +18,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #define DEVI __device__ __forceinline__
@@ -34,6 +35,7 @@ struct PolBF16 {
     static constexpr int NTHREADS = NWAVES * 64;
     static constexpr int ELEM_BYTES = 2;
     static constexpr int FRAG_BYTES = 1024;     // 64 lanes x 8 bf16
+    static constexpr bool TAPE8 = false;        // (PolBF16T8: the h / gA tape tiles in 8 bits)
 #ifndef BHN_LDS_PF
 #define BHN_LDS_PF 4
 #endif
@@ -137,12 +139,20 @@ struct PolBF16 {
     static constexpr bool FAST_TRIG = true;
 };
 
+// bf16 arithmetic everywhere, but the backward's tape keeps the two operands of the weight-gradient GEMMs -- the layer inputs
+// h_l and the pre-activation gradients gA_l -- as OCP e4m3 bytes (BHN_BF16_T8; fused_bwd.hip "8-bit tape").  Forward, delta
+// chain and every accumulation are those of PolBF16.
+struct PolBF16T8 : PolBF16 {
+    static constexpr bool TAPE8 = true;
+};
+
 struct PolF32 {
     static constexpr int MODE = BHN_F32;
     static constexpr int NWAVES = 4;            // 1 wave per SIMD, 512 registers each
     static constexpr int NTHREADS = NWAVES * 64;
     static constexpr int ELEM_BYTES = 4;
     static constexpr int FRAG_BYTES = 2048;     // 2 halves x 64 lanes x 4 f32
+    static constexpr bool TAPE8 = false;
     static constexpr int LDS_PREFETCH = 2;
     static constexpr bool PHASE_LAG = false;    // one wave per SIMD
     using frag = f32x8;

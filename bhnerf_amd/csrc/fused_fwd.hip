@@ -26,6 +26,7 @@ static void packed_layout(const MlpShape &s, int mode, PackedLayout *L) {
 }
 
 extern "C" size_t bhn_packed_bytes(const bhn_model *m, int32_t mode) {
+    mode = bhn_norm_mode(mode);
     MlpShape s;
     if (bhn_mlp_shape(m, &s) != BHN_OK) return 0;
     PackedLayout L;
@@ -119,6 +120,7 @@ __global__ void pack_weights_kernel(PackArgs a) {
 }
 
 extern "C" int bhn_pack_weights(const bhn_model *m, int32_t mode, const float *params, void *packed, void *stream) {
+    mode = bhn_norm_mode(mode);
     BHN_CHECK_ARG(params && packed, "null pointer");
     BHN_CHECK_ARG(mode == BHN_F32 || mode == BHN_BF16, "bad mode %d", mode);
     PackArgs a;
@@ -543,6 +545,7 @@ extern "C" int bhn_predict_fwd(const bhn_model *m, int32_t mode, const void *pac
     FusedArgs a;
     MlpShape s;
     BHN_CHECK_ARG(emission, "null emission");
+    mode = bhn_norm_mode(mode);
     const int nw = (mode == BHN_BF16) ? PolBF16::NWAVES : PolF32::NWAVES;
     int rc = fused_fill_args(m, mode, packed, geom, fr, false, &a, &s, nw);
     if (rc != BHN_OK) return rc;
@@ -558,6 +561,7 @@ extern "C" int bhn_render_fwd(const bhn_model *m, int32_t mode, const void *pack
     FusedArgs a;
     MlpShape s;
     BHN_CHECK_ARG(images, "null images");
+    mode = bhn_norm_mode(mode);
     const int nw = (mode == BHN_BF16) ? PolBF16::NWAVES : PolF32::NWAVES;
     int rc = fused_fill_args(m, mode, packed, geom, fr, true, &a, &s, nw);
     if (rc != BHN_OK) return rc;

@@ -247,7 +247,19 @@ class FusedPredictor:
         if self._ws is None or self._ws.numel() < want:
             self._ws = None
             self._ws = torch.empty((want,), dtype=torch.uint8, device=self.device)
+            self._t8_calibrated = False        # (the 8-bit tape's scales live in the workspace)
         return self._ws
+
+    def recalibrate(self):
+        """8-bit tape mode: take the tape scales of the next backward call from that call itself (it runs its delta chain
+        twice) instead of from the call before it.  Done automatically on the first backward call on a new workspace."""
+        self._t8_calibrated = False
+
+    def _bwd_mode(self):
+        if self.mode != _hip.BHN_BF16_T8 or getattr(self, '_t8_calibrated', False):
+            return self.mode
+        self._t8_calibrated = True
+        return self.mode | _hip.BHN_T8_CALIBRATE
 
     @_on_device
     def render_bwd(self, geom, tM0, dimages, out=None):
@@ -257,7 +269,7 @@ class FusedPredictor:
             out = torch.empty((self.nparams,), dtype=torch.float32, device=self.device)
         ws = self.workspace(int(tM0.numel()), geom.P_eff)
         gs, fs = geom.c_struct_fused(), self._frames(tM0)
-        _hip.check(_hip.lib().bhn_render_bwd(C.byref(self.model), self.mode, _hip.ptr(self.packed), C.byref(gs),
+        _hip.check(_hip.lib().bhn_render_bwd(C.byref(self.model), self._bwd_mode(), _hip.ptr(self.packed), C.byref(gs),
                                              C.byref(fs), _hip.ptr(dimages), _hip.ptr(out), _hip.ptr(ws), ws.numel(),
                                              _hip.stream_ptr(self.device)))
         return out
@@ -305,7 +317,7 @@ class FusedPredictor:
             out = torch.empty((self.nparams,), dtype=torch.float32, device=self.device)
         ws = self.workspace(int(tM0.numel()), geom.P_eff)
         gs, fs = geom.c_struct_fused(), self._frames(tM0)
-        _hip.check(_hip.lib().bhn_render_bwd_tape(C.byref(self.model), self.mode, _hip.ptr(self.packed), C.byref(gs),
+        _hip.check(_hip.lib().bhn_render_bwd_tape(C.byref(self.model), self._bwd_mode(), _hip.ptr(self.packed), C.byref(gs),
                                                   C.byref(fs), _hip.ptr(dimages), _hip.ptr(out), _hip.ptr(ws), ws.numel(),
                                                   _hip.stream_ptr(self.device)))
         return out

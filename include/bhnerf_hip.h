@@ -37,7 +37,15 @@ extern "C" {
 #define BHN_ABI_VERSION 2
 
 enum { BHN_OK = 0, BHN_EINVAL = 1, BHN_EUNSUPPORTED = 2, BHN_EHIP = 3, BHN_EWORKSPACE = 4 };
-enum { BHN_F32 = 0, BHN_BF16 = 1 };
+enum { BHN_F32 = 0, BHN_BF16 = 1, BHN_BF16_T8 = 2 };
+/* BHN_BF16_T8 ("8-bit tape", width 256, depth >= 3 only; an opt-in training mode, NOT a parity mode): the arithmetic of
+ * BHN_BF16, but the backward's tape keeps the two operands of the weight-gradient GEMMs (layer inputs h_l, pre-activation
+ * gradients gA_l) as OCP e4m3 bytes -- half the tape traffic; the gradient differs from BHN_BF16's by ~2e-3 of its norm.
+ * gA_l is stored with one power-of-two scale per layer taken from the largest |gA_l| of the PREVIOUS backward call on the
+ * same workspace (kept in the workspace); OR BHN_T8_CALIBRATE into `mode` on the first backward call on a workspace (or
+ * whenever the gradient's magnitude may have jumped by more than 16x): that call runs the delta chain twice.  Every
+ * entry point that does not touch the tape treats BHN_BF16_T8 as BHN_BF16. */
+#define BHN_T8_CALIBRATE 0x100
 
 /* NeRF_Predictor hyper-parameters: network.py:147-157 (scale,rmin,rmax,z_width,posenc_deg,
  * net_depth,net_width,do_skip; activation=relu and out_channel=1 are fixed as in every driver). */
