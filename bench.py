@@ -25,7 +25,8 @@ measured in this run: they are read from the committed rocprofv3 counter passes 
 (PMC counters cannot be collected from inside the process) and are flagged `profiles_match_this_build: false` when the
 library they were collected on is not the one loaded here.  `fwd_images_per_s` is frames / time of
 `optimization.total_movie_loss` (the reference's test path, optimization.py:14-66) over the whole movie;
-`parity_mode` is the same step in the f32 (1e-5 parity) arithmetic; `cpu_baseline` is the oracle's PyTorch-CPU
+`parity_mode` is the same step in the f32 (1e-5 parity) arithmetic; `tape8_mode` the same step with the backward's tape in 8
+bits (BHN_BF16_T8: bf16 arithmetic, e4m3 dW operands -- an A/B beside the headline, never the headline); `cpu_baseline` is the oracle's PyTorch-CPU
 restatement timed on the host cores on a bounded sample BEFORE the GPU work starts (best of a thread-count sweep).
 """
 import argparse
@@ -71,6 +72,7 @@ def parse():
                     help='N > 1: run the all-reduce of step k under step k+1 (one-step-stale gradients; NOT the reference semantics, off by default)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity-mode', action='store_true', help='skip the f32 parity-mode block')
+    ap.add_argument('--no-tape8', action='store_true', help='skip the 8-bit-tape A/B block')
     ap.add_argument('--no-width128', action='store_true', help='skip the block with the same step on the reference-default 4x128 network')
     ap.add_argument('--no-tutorial-domain', action='store_true',
                     help='skip the masked-domain variant (profiling runs: keeps every launch of a kernel the same shape)')
@@ -333,7 +335,7 @@ def kernel_times(eng, geom, tM0, dimg, reps=5):
             a.record(); eng.render_train(geom, tM0[sl]); b.record()
             fs = eng._frames(tM0[sl])
             d = dimg[sl].contiguous()
-            _hip.check(lib.bhn_render_bwd_tape_timed(C.byref(eng.model), eng.mode, _hip.ptr(eng.packed), C.byref(gs), C.byref(fs),
+            _hip.check(lib.bhn_render_bwd_tape_timed(C.byref(eng.model), eng._bwd_mode(), _hip.ptr(eng.packed), C.byref(gs), C.byref(fs),
                                                      _hip.ptr(d), _hip.ptr(out), _hip.ptr(ws), ws.numel(),
                                                      _hip.stream_ptr(eng.device), sets[k].ev, nk + 1))
         torch.cuda.synchronize()
@@ -624,6 +626,39 @@ def main():
         del opt_p, pred_p, eng_p, geom_p
         torch.cuda.empty_cache()
 
+    # ---- A/B: the same step with the backward's tape in 8 bits (BHN_BF16_T8).  bf16
+    #      arithmetic, e4m3 dW operands: NOT the headline's precision -- reported beside it, never as `value` ----------
+    tape8 = None
+    if world == 1 and args.mode == 'bf16' and args.width == 256 and args.depth >= 3 and args.depth % 2 == 0 and not args.no_tape8 and not args.masked:
+      try:
+        pred_8 = network.NeRF_Predictor(*dom, net_depth=args.depth, net_width=args.width, mode='bf16_t8', device=dev)
+        opt_8 = optimization.Optimizer(hparams, pred_8, rt_args)
+        run_steps(opt_8, max(2, args.warmup))
+        torch.cuda.synchronize()
+        n_8 = max(2, min(args.steps, 50))
+        t0 = time.perf_counter()
+        run_steps(opt_8, n_8)
+        torch.cuda.synchronize()
+        dt8 = (time.perf_counter() - t0) / n_8
+        eng_8 = pred_8.engine()
+        geom_8 = pred_8.geometry(rt_args['coords'], rt_args['Omega'], rt_args['t_geos'], None, rt_args['g'], rt_args['dtau'], rt_args['Sigma'])
+        # the gradient of both modes on the SAME weights, frames and d(loss)/d(images)
+        eng.pack(opt.state.flat); eng_8.pack(opt.state.flat)
+        eng.render_train(geom, tM0); g16 = eng.render_bwd_tape(geom, tM0, dimg).clone()
+        eng_8.render_train(geom_8, tM0); g8 = eng_8.render_bwd_tape(geom_8, tM0, dimg).clone()
+        kms8, _ = kernel_times(eng_8, geom_8, tM0, dimg)
+        tf8 = f_train * samples_step / dt8 / 1e12
+        tape8 = {'dtype': 'bf16 arithmetic, e4m3 tape of the dW operands (BHN_BF16_T8)', 'ms_per_step': round(1e3 * dt8, 3),
+                 'value': round(samples_step / dt8, 1), 'unit': 'ray-samples/s', 'steps': n_8,
+                 'step_mfma_frac': round(tf8 / PEAK_TFLOPS['bf16'], 4), 'vs_bf16_step': round(1e3 * dt8 / ms_step, 4),
+                 'kernel_ms': {k: round(v, 3) for k, v in kms8.items()},
+                 'gradient_rel_l2_vs_bf16': float((g8 - g16).norm() / g16.norm()),
+                 'loss': float(torch.as_tensor(opt_8.loss).float().mean())}
+        del opt_8, pred_8, eng_8, geom_8
+        torch.cuda.empty_cache()
+      except Exception as exc:                       # a side block must never cost the headline line
+        tape8 = {'error': repr(exc)}
+
     # ---- the reference's DEFAULT network, 4x128 (network.py:19-20, every tutorial and fit script): the same config-2 geometry,
     #      frames and loss; bf16; its own kernel path (fused delta chain + dW) ----------
     width128 = None
@@ -744,6 +779,8 @@ def main():
             out['other_configs'] = {'error': repr(exc)}
     if parity:
         out['parity_mode'] = parity
+    if tape8:
+        out['tape8_mode'] = tape8
     if tutorial_domain:
         out['tutorial_domain'] = tutorial_domain
     if cpu:

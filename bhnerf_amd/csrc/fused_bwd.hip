@@ -2110,7 +2110,10 @@ extern "C" size_t bhn_render_bwd_workspace_bytes(const bhn_model *m, int32_t mod
     if (bhn_mlp_shape(m, &s) != BHN_OK || B <= 0 || P <= 0) return 0;
     size_t q = 0;
     if ((mode & 0xff) == BHN_BF16_T8 && bhn_norm_mode(mode) == BHN_BF16) {
-        if (s.width != 256 || s.depth < 3) return 0;
+        if (s.width != 256 || s.depth < 3) {
+            bhn_set_error("BHN_BF16_T8 (8-bit tape) is built for net_width 256 and net_depth >= 3 (got %d x %d); use BHN_BF16", s.depth, s.width_true);
+            return 0;
+        }
         return bwd_run<256, PolBF16T8>(RUN_QUERY, m, mode, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, &q, B, P, device) == BHN_OK ? q : 0;
     }
     int rc = (mode == BHN_BF16)

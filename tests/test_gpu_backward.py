@@ -312,9 +312,9 @@ def random_problem(width, depth, S, deg, nudge=0.0, drop_ties=False):
                 ties=ties, dropped=dropped, ties_left=ties_left)
 
 
-def random_problem_errors(prob, mode, dev):
+def random_problem_errors(prob, mode, dev, grad_out=None):
     """(image error / image maximum, gradient max error / largest entry, gradient relative L2) of the HIP path against the
-    float64 oracle on a random_problem()."""
+    float64 oracle on a random_problem(); `grad_out` (a list) receives the device gradient."""
     from bhnerf_amd import network, units
     g, S, img_ref, gref = prob['g'], prob['S'], prob['img_ref'], prob['gref']
     pred, rt = device_setup(g, mode, dev)
@@ -336,7 +336,73 @@ def random_problem_errors(prob, mode, dev):
         assert not img.any() and not gdev.any(), (mode, 'non-zero output for an empty domain')
         return 0.0, 0.0, 0.0
     ierr = np.abs(img - img_ref.numpy()).max() / img_ref.abs().max().item()
+    if grad_out is not None:
+        grad_out.append(gdev)
     return ierr, np.abs(gdev - gref).max() / np.abs(gref).max(), l2err(gdev, gref)
+
+
+@pytest.mark.parametrize('depth,S,deg', [(4, 0, 3), (4, 3, 1), (6, 1, 2), (8, 0, 3)])
+def test_tape8_mode_gradient(dev, depth, S, deg):
+    """BHN_BF16_T8 (include/bhnerf_hip.h: bf16 arithmetic, the backward's tape of h_l / gA_l as e4m3 bytes; width 256): same
+    images as the bf16 mode, a gradient inside the bf16 mode's bounds against the float64 oracle and close to the bf16 mode's own
+    gradient.  The rounding of the 8-bit operands is ~3 % per element and averages out over the points of the sum: 4e-2 of the
+    gradient's norm on this problem of a few thousand points in the domain; 2e-3 from 30 k points on
+    (test_tape8_mode_scales_follow_the_gradient, tools/dbg_t8.py; tools/exp_fp8_tape_accuracy.py predicts 2.4e-3)."""
+    prob = random_problem(256, depth, S, deg)
+    g16, g8 = [], []
+    i16, _, _ = random_problem_errors(prob, 'bf16', dev, g16)
+    i8, gerr, l2 = random_problem_errors(prob, 'bf16_t8', dev, g8)
+    assert i8 == i16                                           # the forward is the bf16 mode's
+    assert gerr < GTOL['bf16'] and l2 < L2TOL['bf16'], (gerr, l2)
+    assert l2err(g8[0], g16[0]) < 4e-2, l2err(g8[0], g16[0])
+
+
+def test_tape8_mode_scales_follow_the_gradient(dev):
+    """The 8-bit tape stores gA_l with one power-of-two scale per layer taken from the PREVIOUS backward call on the workspace
+    (the first call calibrates itself).  The scale has 16x head room: a gradient 8x larger than the last call's is exact to the
+    mode's accuracy at once; one 1000x larger is limited (finite, no NaN) in that call and accurate again in the next; one 60x
+    smaller is stored with six binades less range for one call."""
+    from bhnerf_amd import engine, network, synthetic, constants
+    geo = synthetic.synthetic_geodesics(16, 16, 64, seed=5)
+    out = {}
+    for mode in ('bf16', 'bf16_t8'):
+        pred = network.NeRF_Predictor(8.0, 0.0, np.inf, np.inf, net_depth=4, net_width=256, mode=mode, device=dev)
+        eng = pred.engine()
+        geom = pred.geometry(geo['coords'], geo['Omega'], geo['t_geos'], None, geo['g'], geo['dtau'], geo['Sigma'])
+        eng.pack(eng.flatten(network.MLP(4, 256).init(1, 21)))
+        tM0 = engine.frame_offsets(np.linspace(0, 0.8, 2), 0.0, geo['t_injection'], constants.GM_c3('hr'), dev)
+        gen = torch.Generator(device='cpu').manual_seed(7)
+        dimg = ((torch.rand((2, 1, geom.R), generator=gen) - 0.3) * 1e-3).to(dev)
+        res = []
+        for factor in (1.0, 8.0, 1000.0, 1000.0, 16.0, 16.0):
+            eng.render_train(geom, tM0)
+            res.append(eng.render_bwd_tape(geom, tM0, factor * dimg).cpu().numpy() / factor)
+        out[mode] = res
+    for i, (a, b) in enumerate(zip(out['bf16_t8'], out['bf16'])):
+        assert np.isfinite(a).all(), i
+        err = l2err(a, b)
+        if i == 2:
+            assert err > 5e-3, ('the 1000x call was expected to be limited', err)        # documents the behaviour: limited, not NaN
+        elif i == 4:
+            assert err < 2e-2, (i, err)       # a gradient 60x SMALLER than the last call's: six binades of range lost for one call
+        else:
+            assert err < 5e-3, (i, err)
+
+
+def test_tape8_mode_rejects_other_networks(dev):
+    """The 8-bit tape kernels exist for width 256, depth >= 3, no skip-concat into layer 1 or the output layer: anything else
+    is BHN_EUNSUPPORTED (loud), never a silent fallback.  Forward-only entry points treat the mode as bf16."""
+    from bhnerf_amd import engine, network, synthetic, constants, _hip
+    geo = synthetic.synthetic_geodesics(8, 8, 32, seed=5)
+    for width, depth in ((128, 4), (256, 2), (256, 5)):
+        pred = network.NeRF_Predictor(8.0, 0.0, np.inf, np.inf, net_depth=depth, net_width=width, mode='bf16_t8', device=dev)
+        eng = pred.engine()
+        geom = pred.geometry(geo['coords'], geo['Omega'], geo['t_geos'], None, geo['g'], geo['dtau'], geo['Sigma'])
+        eng.pack(eng.flatten(network.MLP(depth, width).init(1, 21)))
+        tM0 = engine.frame_offsets(np.linspace(0, 0.8, 2), 0.0, geo['t_injection'], constants.GM_c3('hr'), dev)
+        assert torch.isfinite(eng.render(geom, tM0)).all()
+        with pytest.raises(_hip.HipError):
+            eng.render_train(geom, tM0)
 
 
 @pytest.mark.parametrize('mode', ['f32', 'bf16'])

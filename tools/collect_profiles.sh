@@ -18,18 +18,18 @@ mkdir -p $O
 need() { [ -s "$1" ] || { echo "collect_profiles: missing or empty $1" >&2; exit 1; }; }
 python3 $R/bench.py > $O/${TAG}_bench_line.json 2> $O/bench.err
 need $O/${TAG}_bench_line.json
-rm -rf /tmp/kt; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o kt -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity-mode --no-tutorial-domain --no-other-configs --no-width128 > /tmp/kt.log 2>&1
+rm -rf /tmp/kt; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o kt -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity-mode --no-tape8 --no-tutorial-domain --no-other-configs --no-width128 > /tmp/kt.log 2>&1
 f=$(find /tmp/kt -name "*kernel_stats.csv" | head -1); need "$f"; cp "$f" $O/${TAG}_bench_kernel_stats.csv
 rm -rf /tmp/ktf; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ktf -o kt -- python3 $R/bench.py --mode f32 --steps 3 --warmup 1 --no-cpu-baseline --no-tutorial-domain --no-other-configs --no-width128 > /tmp/ktf.log 2>&1
 f=$(find /tmp/ktf -name "*kernel_stats.csv" | head -1); need "$f"; cp "$f" $O/${TAG}_f32_kernel_stats.csv
-rm -rf /tmp/ktw; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ktw -o kt -- python3 $R/bench.py --width 128 --steps 5 --warmup 2 --no-cpu-baseline --no-parity-mode --no-tutorial-domain --no-other-configs --no-width128 > /tmp/ktw.log 2>&1
+rm -rf /tmp/ktw; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ktw -o kt -- python3 $R/bench.py --width 128 --steps 5 --warmup 2 --no-cpu-baseline --no-parity-mode --no-tape8 --no-tutorial-domain --no-other-configs --no-width128 > /tmp/ktw.log 2>&1
 f=$(find /tmp/ktw -name "*kernel_stats.csv" | head -1); need "$f"; cp "$f" $O/${TAG}_w128_kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/pm_$c; rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pm_$c -o p -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity-mode --no-tutorial-domain --no-other-configs --no-width128 > /tmp/pm_$c.log 2>&1
+  rm -rf /tmp/pm_$c; rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pm_$c -o p -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity-mode --no-tape8 --no-tutorial-domain --no-other-configs --no-width128 > /tmp/pm_$c.log 2>&1
   f=$(find /tmp/pm_$c -name "*counter_collection.csv" | head -1); need "$f"; cp "$f" /tmp/pm_$c.csv
 done
 for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/pw_$c; rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pw_$c -o p -- python3 $R/bench.py --width 128 --steps 3 --warmup 1 --no-cpu-baseline --no-parity-mode --no-tutorial-domain --no-other-configs --no-width128 > /tmp/pw_$c.log 2>&1
+  rm -rf /tmp/pw_$c; rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pw_$c -o p -- python3 $R/bench.py --width 128 --steps 3 --warmup 1 --no-cpu-baseline --no-parity-mode --no-tape8 --no-tutorial-domain --no-other-configs --no-width128 > /tmp/pw_$c.log 2>&1
   f=$(find /tmp/pw_$c -name "*counter_collection.csv" | head -1); need "$f"; cp "$f" /tmp/pw_$c.csv
 done
 LIBMD5=$(md5sum $R/bhnerf_amd/csrc/libbhnerf_hip.so | cut -d" " -f1)
@@ -59,7 +59,7 @@ for c in ('FETCH_SIZE', 'WRITE_SIZE'):
 for n, d in out.items():
     d['hbm_bytes'] = int((2 * d.get('FETCH_SIZE_KiB', 0) + d.get('WRITE_SIZE_KiB', 0)) * 1024)
     d['ms_under_profiler'] = round(sum(ms[n]) / len(ms[n]), 4)
-print(json.dumps({'lib_md5': os.environ.get('LIBMD5'), 'note': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace) of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity-mode --no-tutorial-domain --no-other-configs --no-width128`; averages per launch in KiB as reported; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 with the gfx950 correction (FETCH_SIZE reports half of wide coalesced reads, MI355X_MICROARCH.md HBM section)', 'kernels': out}, indent=1))
+print(json.dumps({'lib_md5': os.environ.get('LIBMD5'), 'note': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace) of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity-mode --no-tape8 --no-tutorial-domain --no-other-configs --no-width128`; averages per launch in KiB as reported; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 with the gfx950 correction (FETCH_SIZE reports half of wide coalesced reads, MI355X_MICROARCH.md HBM section)', 'kernels': out}, indent=1))
 PY
 done
 need $O/${TAG}_pmc_traffic.json
@@ -104,7 +104,7 @@ need $O/${TAG}_ring_ceiling_microbench.txt
 : > $O/${TAG}_telemetry_bench.txt
 python3 $R/tools/smi_sample.py >> $O/${TAG}_telemetry_bench.txt & SMI=$!
 sleep 2; date +"# bench.py --steps 400 starts %s" >> $O/${TAG}_telemetry_bench.txt
-python3 $R/bench.py --steps 400 --warmup 5 --no-cpu-baseline --no-parity-mode --no-tutorial-domain --no-other-configs --no-width128 > /tmp/bench400.json 2> /tmp/bench400.err
+python3 $R/bench.py --steps 400 --warmup 5 --no-cpu-baseline --no-parity-mode --no-tape8 --no-tutorial-domain --no-other-configs --no-width128 > /tmp/bench400.json 2> /tmp/bench400.err
 date +"# bench.py ends %s" >> $O/${TAG}_telemetry_bench.txt; sleep 1; kill $SMI || true
 python3 -c "import json; d=json.load(open('/tmp/bench400.json')); print('# bench.py --steps 400: ms_per_step %.3f' % d['ms_per_step'])" >> $O/${TAG}_telemetry_bench.txt
 ls -la $O
