@@ -645,7 +645,7 @@ def main():
         # the gradient of both modes on the SAME weights, frames and d(loss)/d(images)
         eng.pack(opt.state.flat); eng_8.pack(opt.state.flat)
         eng.render_train(geom, tM0); g16 = eng.render_bwd_tape(geom, tM0, dimg).clone()
-        eng_8.render_train(geom_8, tM0); g8 = eng_8.render_bwd_tape(geom_8, tM0, dimg).clone()
+        eng_8.render_train(geom_8, tM0); g8 = eng_8.render_bwd_tape(geom_8, tM0, dimg).clone()      # (scales: last training step's ratios x this |dimg|max)
         kms8, _ = kernel_times(eng_8, geom_8, tM0, dimg)
         tf8 = f_train * samples_step / dt8 / 1e12
         tape8 = {'dtype': 'bf16 arithmetic, e4m3 tape of the dW operands (BHN_BF16_T8)', 'ms_per_step': round(1e3 * dt8, 3),

@@ -50,8 +50,9 @@ struct BwdArgs {
     int F;
     int width_true;                            // the model's hidden width (flat parameter layout); W is the kernel width
     long long nparams;
-    // 8-bit tape (PolBF16T8): [0 .. 7] the power-of-two scale of gA_l this call stores with, [8 .. 15] the largest |gA_l| it saw
-    // (f32 bit patterns, atomicMax), at the head of the tape region of the workspace
+    // 8-bit tape (PolBF16T8): the state block at the head of the tape region of the workspace (fused_bwd.hip, t8_prepare_kernel):
+    // [0 .. 7] the power-of-two scale of gA_l in this call, [8 .. 15] the largest |gA_l| it saw, [16 .. 23] their ratios to
+    // |dimages|max carried to the next call, [24] |dimages|max
     float *t8;
 };
 

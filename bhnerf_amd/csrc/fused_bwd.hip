@@ -702,7 +702,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
             unsigned no_acc = 0u;
             float t8_sc = 1.f;
             unsigned t8_amax = 0u;                    // 8-bit tape: scale of the pending tile's layer, |gA|max of that layer so far
-            if constexpr (T8) t8_sc = t8_lds[a.depth - 1];
+            if constexpr (T8) t8_sc = 0x1p60f;        // (gA_{depth-1} is not recorded -- TapeLayout::drop_ga -- and must not be limited either)
 #pragma nounroll
             for (int l = a.depth - 1; l >= LEND; --l) {
 #pragma unroll
@@ -1739,23 +1739,48 @@ __global__ __launch_bounds__(256) void reduce_kernel(BwdArgs A) {
     }
 }
 
-// 8-bit tape state (BwdArgs::t8).  t8_update: the scales of the NEXT call from the largest |gA_l| the delta chain just saw --
-// the power of two that puts 16 |gA_l|max at or below 448, e4m3's largest value: four binades of head room for growth from
-// one call to the next, thirteen and a half below the maximum before values flush to zero (tools/exp_fp8_tape_accuracy.py:
-// the dW error does not notice) -- and the maxima cleared.  t8_open: scales so large that nothing is limited (the
-// calibration pass of BHN_T8_CALIBRATE: only its maxima are used).
-__global__ void t8_update_kernel(float *st, int n) {
+// 8-bit tape state (BwdArgs::t8; floats): [0..7] the power-of-two scale gA_l is stored with in THIS call, [8..15] the largest
+// |gA_l| this call's delta chain saw (bit patterns, atomicMax), [16..23] ratio_l = |gA_l|max / |dimages|max of the previous
+// call, [24] |dimages|max of this call.  The delta chain is linear in d(loss)/d(images), so the ratios depend on the weights
+// and on WHERE the residuals are, not on how large they are: they move slowly from step to step, while the loss scale may
+// jump by orders of magnitude (a new batch, a restart, a caller's loss weights) -- that part is measured, not predicted.
+//   t8_prepare  (start of every backward call)  |dimages|max; scale_l = the power of two that puts 16 ratio_l |dimages|max
+//               at or below 448, e4m3's largest value: four binades of head room, thirteen and a half below the maximum
+//               before values flush to zero (tools/exp_fp8_tape_accuracy.py: the dW error does not notice)
+//   t8_update   (end of the call)  ratio_l from the maxima the chain just saw; maxima cleared
+//   t8_open     (BHN_T8_CALIBRATE: in front of a chain pass whose tape output is discarded)  scales so large that
+//               nothing is limited; only the maxima of that pass are used
+__global__ __launch_bounds__(1024) void t8_prepare_kernel(float *st, const float *dimages, long long n, int nl) {
+    __shared__ float red[16];
+    float m = 0.f;
+    for (long long i = threadIdx.x; i < n; i += 1024) m = __builtin_fmaxf(m, __builtin_fabsf(dimages[i]));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float d = 0.f;
+        for (int i = 0; i < 16; ++i) d = __builtin_fmaxf(d, red[i]);
+        if (!(d < __builtin_inff())) d = 0.f;                            // (inf / NaN in d(loss)/d(images): leave the scales alone)
+        st[24] = d;
+        for (int l = 0; l < nl; ++l) {
+            const float a = st[16 + l] * d;                               // expected largest |gA_l|
+            if (a > 0.f && a < __builtin_inff()) {
+                int e;
+                const float mant = frexpf(a * (16.f / 448.f), &e);        // a 16 / 448 = mant 2^e, mant in [0.5, 1)
+                if (mant == 0.5f) --e;
+                e = e < -100 ? -100 : e > 100 ? 100 : e;
+                st[l] = ldexpf(1.f, e);
+            } else if (!(st[l] > 0.f && st[l] < __builtin_inff())) st[l] = 1.f;
+        }
+    }
+}
+__global__ void t8_update_kernel(float *st, int nl) {
     const int l = threadIdx.x;
-    if (l >= n) return;
+    if (l >= nl) return;
     unsigned *bits = reinterpret_cast<unsigned *>(st);
-    const float a = __uint_as_float(bits[8 + l]);
-    if (a > 0.f && a < __builtin_inff()) {
-        int e;
-        const float mant = frexpf(a * (16.f / 448.f), &e);            // a 16 / 448 = mant 2^e, mant in [0.5, 1)
-        if (mant == 0.5f) --e;
-        e = e < -100 ? -100 : e > 100 ? 100 : e;
-        st[l] = ldexpf(1.f, e);
-    } else if (!(st[l] > 0.f && st[l] < __builtin_inff())) st[l] = 1.f;
+    const float a = __uint_as_float(bits[8 + l]), d = st[24];
+    if (a > 0.f && a < __builtin_inff() && d > 0.f) st[16 + l] = a / d;
     bits[8 + l] = 0u;
 }
 __global__ void t8_open_kernel(float *st) {
@@ -1986,6 +2011,12 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
     const int B_total = A.f.B;
     const double *tM0 = A.f.tM0;
     int nslabs128 = 0;
+    if constexpr (Pol::TAPE8) {
+        if (what != RUN_FWD_TRAIN) {         // this call's tape scales: the stored ratios times the size of THIS d(loss)/d(images)
+            hipLaunchKernelGGL(t8_prepare_kernel, dim3(1), dim3(1024), 0, st, A.t8, dimages, (long long)B_total * A.f.Sx * A.f.R, depth);
+            BHN_HIP(hipGetLastError());
+        }
+    }
     if (what == RUN_FWD_TRAIN)
         BHN_HIP(hipMemsetAsync(images, 0, sizeof(float) * (size_t)B_total * A.f.Sx * A.f.R, st));
     for (int b0 = 0, pass = 0; b0 < B_total; b0 += (int)fpp, ++pass) {
@@ -2035,11 +2066,12 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
             }
             if constexpr (Pol::TAPE8) {
                 if (t8_cal && pass == 0) {
-                    // calibration: the delta chain once with nothing limited (its tape output is overwritten below), its
-                    // |gA_l| maxima become this call's scales
+                    // calibration: the delta chain once with nothing limited (its tape output is overwritten below); the
+                    // ratios of its |gA_l| maxima to |dimages|max give this call's scales
                     hipLaunchKernelGGL(t8_open_kernel, dim3(1), dim3(64), 0, st, A.t8);
                     hipLaunchKernelGGL(k_chn, dim3((unsigned)grid), dim3(Pol::NTHREADS), lds_chn, st, A);
                     hipLaunchKernelGGL(t8_update_kernel, dim3(1), dim3(64), 0, st, A.t8, depth);
+                    hipLaunchKernelGGL(t8_prepare_kernel, dim3(1), dim3(1024), 0, st, A.t8, dimages, (long long)B_total * A.f.Sx * A.f.R, depth);
                     BHN_HIP(hipGetLastError());
                 }
             }
@@ -2056,7 +2088,7 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
         if (rcr != BHN_OK) return rcr;
     } else if (what != RUN_FWD_TRAIN && (g_bwd_stages & 4)) hipLaunchKernelGGL((reduce_kernel<W, Pol>), dim3((unsigned)ReduceGeom<W, Pol>::blocks(depth, (unsigned)A.f.skip_mask)), dim3(256), 0, st, A);
     if constexpr (Pol::TAPE8) {
-        if (what != RUN_FWD_TRAIN) hipLaunchKernelGGL(t8_update_kernel, dim3(1), dim3(64), 0, st, A.t8, depth);      // the next call's scales
+        if (what != RUN_FWD_TRAIN) hipLaunchKernelGGL(t8_update_kernel, dim3(1), dim3(64), 0, st, A.t8, depth);      // the next call's ratios
     }
     BHN_HIP(hipGetLastError());
     if (events && n_events > 3 && events[3]) BHN_HIP(hipEventRecord((hipEvent_t)events[3], st));

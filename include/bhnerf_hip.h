@@ -41,9 +41,10 @@ enum { BHN_F32 = 0, BHN_BF16 = 1, BHN_BF16_T8 = 2 };
 /* BHN_BF16_T8 ("8-bit tape", width 256, depth >= 3 only; an opt-in training mode, NOT a parity mode): the arithmetic of
  * BHN_BF16, but the backward's tape keeps the two operands of the weight-gradient GEMMs (layer inputs h_l, pre-activation
  * gradients gA_l) as OCP e4m3 bytes -- half the tape traffic; the gradient differs from BHN_BF16's by ~2e-3 of its norm.
- * gA_l is stored with one power-of-two scale per layer taken from the largest |gA_l| of the PREVIOUS backward call on the
- * same workspace (kept in the workspace); OR BHN_T8_CALIBRATE into `mode` on the first backward call on a workspace (or
- * whenever the gradient's magnitude may have jumped by more than 16x): that call runs the delta chain twice.  Every
+ * gA_l is stored with one power-of-two scale per layer: (largest |gA_l| / largest |dimages| of the PREVIOUS backward call on
+ * the same workspace, kept in the workspace) x (largest |dimages| of this call) x 16 head room.  OR BHN_T8_CALIBRATE into
+ * `mode` on the first backward call on a workspace (or after the weights were replaced wholesale): that call runs the delta
+ * chain twice to take the ratios from itself.  Every
  * entry point that does not touch the tape treats BHN_BF16_T8 as BHN_BF16. */
 #define BHN_T8_CALIBRATE 0x100
 

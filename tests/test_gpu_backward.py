@@ -358,10 +358,11 @@ def test_tape8_mode_gradient(dev, depth, S, deg):
 
 
 def test_tape8_mode_scales_follow_the_gradient(dev):
-    """The 8-bit tape stores gA_l with one power-of-two scale per layer taken from the PREVIOUS backward call on the workspace
-    (the first call calibrates itself).  The scale has 16x head room: a gradient 8x larger than the last call's is exact to the
-    mode's accuracy at once; one 1000x larger is limited (finite, no NaN) in that call and accurate again in the next; one 60x
-    smaller is stored with six binades less range for one call."""
+    """The 8-bit tape stores gA_l with one power-of-two scale per layer: the ratio |gA_l|max / |dimages|max of the PREVIOUS
+    backward call on the workspace (the first call calibrates itself) times |dimages|max of this call, with 16x head room.
+    Jumps of the loss scale in either direction are therefore exact at once; ratios that are off by more than the head room
+    (stale state, weights replaced wholesale without BHN_T8_CALIBRATE) make the tape values LIMITED -- finite, no NaN -- and
+    recover by up to 16x per call."""
     from bhnerf_amd import engine, network, synthetic, constants
     geo = synthetic.synthetic_geodesics(16, 16, 64, seed=5)
     out = {}
@@ -369,24 +370,32 @@ def test_tape8_mode_scales_follow_the_gradient(dev):
         pred = network.NeRF_Predictor(8.0, 0.0, np.inf, np.inf, net_depth=4, net_width=256, mode=mode, device=dev)
         eng = pred.engine()
         geom = pred.geometry(geo['coords'], geo['Omega'], geo['t_geos'], None, geo['g'], geo['dtau'], geo['Sigma'])
-        eng.pack(eng.flatten(network.MLP(4, 256).init(1, 21)))
+        flat = eng.flatten(network.MLP(4, 256).init(1, 21))
+        eng.pack(flat)
         tM0 = engine.frame_offsets(np.linspace(0, 0.8, 2), 0.0, geo['t_injection'], constants.GM_c3('hr'), dev)
         gen = torch.Generator(device='cpu').manual_seed(7)
         dimg = ((torch.rand((2, 1, geom.R), generator=gen) - 0.3) * 1e-3).to(dev)
+        one_frame = dimg.clone(); one_frame[1] = 0.0                       # the residuals somewhere else: the ratios move a little
         res = []
-        for factor in (1.0, 8.0, 1000.0, 1000.0, 16.0, 16.0):
+        for d, factor in ((dimg, 1.0), (dimg, 8.0), (dimg, 1e5), (dimg, 1e-4), (one_frame, 1.0), (dimg, 1.0)):
             eng.render_train(geom, tM0)
-            res.append(eng.render_bwd_tape(geom, tM0, factor * dimg).cpu().numpy() / factor)
+            res.append(eng.render_bwd_tape(geom, tM0, factor * d).cpu().numpy() / factor)
+        if mode == 'bf16_t8':
+            # stale state: the ratios 1000x too small (layout of the state block: fused_bwd.hip t8_prepare_kernel; it sits behind
+            # the dW slabs, one per compute unit).  The tape values are limited to the range, the maxima seen are those of the
+            # limited chain, so the ratios recover by at most the head room (16x) per call
+            ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+            off = ncu * 9 * 10 * 1024 * 4
+            st = eng._ws[off:off + 128].view(torch.float32)
+            st[16:24] *= 1e-3
+        for _ in range(4):
+            eng.render_train(geom, tM0)
+            res.append(eng.render_bwd_tape(geom, tM0, dimg).cpu().numpy())
         out[mode] = res
-    for i, (a, b) in enumerate(zip(out['bf16_t8'], out['bf16'])):
-        assert np.isfinite(a).all(), i
-        err = l2err(a, b)
-        if i == 2:
-            assert err > 5e-3, ('the 1000x call was expected to be limited', err)        # documents the behaviour: limited, not NaN
-        elif i == 4:
-            assert err < 2e-2, (i, err)       # a gradient 60x SMALLER than the last call's: six binades of range lost for one call
-        else:
-            assert err < 5e-3, (i, err)
+    errs = [l2err(a, b) for a, b in zip(out['bf16_t8'], out['bf16'])]
+    assert all(np.isfinite(a).all() for a in out['bf16_t8']), errs
+    assert max(errs[:6]) < 5e-3, errs
+    assert errs[6] > 5e-3 and errs[9] < 5e-3, errs      # limited right after the state went stale, accurate again three calls later
 
 
 def test_tape8_mode_rejects_other_networks(dev):
