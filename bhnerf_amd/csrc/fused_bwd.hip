@@ -1088,6 +1088,11 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
     constexpr int GB = OFF_D32 + (LAST ? 1024 : 0);
     static_assert(T8 || (OFF_D32 == BG::GROUP_BYTES && GB == (LAST ? BG::GROUP_BYTES_LAST2 : BG::GROUP_BYTES)), "group image");
     static_assert(GB <= BG::GROUP_BYTES + 1024, "group image larger than the host's LDS budget");
+#ifndef BHN_T8_NBUF
+#define BHN_T8_NBUF 4            // ring depth of the 8-bit tape's dW jobs (8 = the bf16 jobs' bytes in flight: measured no faster, the jobs are VALU-bound)
+#endif
+    constexpr int NB = (T8 && !make_h) ? BHN_T8_NBUF : 4;              // group buffers of the ring (a power of two)
+    static_assert((NB & (NB - 1)) == 0 && NB >= 4 && NB * GB <= 160 * 1024, "ring size");
     constexpr int nH = has_h ? MT : 0, nB = nH + ((JT == JT_FIRST || JT == JT_SKIP) ? 1 : 0);   // slab tile nB: the bias column
     constexpr int nBr = has_h ? MT : 1;                                // B tiles of the regular tile grid
     constexpr int WRR = BG::WRR, WCC = BG::WCC;
@@ -1115,7 +1120,7 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
     const int nbase = wc * NPW;
     const bool works = wr * MPW < MT && nbase < nBr;                   // this wave owns accumulator tiles
     // HIDDEN1: W_0 and b_0 behind the ring (see dw_body)
-    char *w0_lds = smem + BG::NBUF * GB;
+    char *w0_lds = smem + NB * GB;
     float *b0_lds = reinterpret_cast<float *>(w0_lds + 2 * MT * Pol::FRAG_BYTES);
     if constexpr (make_h) {
         const char *w0 = A.f.packed + A.f.fwd_off;
@@ -1358,10 +1363,9 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
     if (q0 < q1) {
         AState sa, sb;
         frag ba[2], bb[2];
-        issue(q0, smem);
-        issue(q0 + 1, smem + GB);
-        issue(q0 + 2, smem + 2 * GB);
-        if (!BHN_DBG(A.debug & 2)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+#pragma unroll
+        for (int j = 0; j < NB - 1; ++j) issue(q0 + j, smem + j * GB);
+        if (!BHN_DBG(A.debug & 2)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 2) * PPW) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if constexpr (make_h) make_h_write(smem, make_h_mma(make_h_read(smem)));     // published by the first loop barrier
@@ -1373,16 +1377,16 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
             else if constexpr (!make_h) { ba[0] = load_b(smem, 0); ba[1] = load_b(smem, NTOT > 1 ? 1 : 0); }
         }
         auto body = [&](AState &cur, AState &nx, frag (&bc)[2], frag (&bn)[2], long long q, int it) {
-            // group q+1 has landed for this wave (q+2 may still be in flight), then it is published to the workgroup
-            if (!BHN_DBG(A.debug & 2)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+            // group q+1 has landed for this wave (q+2 .. q+NB-2 may still be in flight), then it is published to the workgroup
+            if (!BHN_DBG(A.debug & 2)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 3) * PPW) : "memory");
             if constexpr (make_h) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's h-tile writes
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");      // the raw barrier is not a compiler fence
-            // every wave has finished group q-1: its buffer takes group q+3
-            if (!BHN_DBG(A.debug & 2)) issue(q + 3, smem + ((it + 3) & 3) * GB);
+            // every wave has finished group q-1: its buffer takes group q+NB-1
+            if (!BHN_DBG(A.debug & 2)) issue(q + NB - 1, smem + ((it + NB - 1) & (NB - 1)) * GB);
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const char *gp = smem + it * GB;
-            char *gnext = smem + ((it + 1) & 3) * GB;
+            char *gnext = smem + ((it + 1) & (NB - 1)) * GB;
             const bool live_next = q + 1 < q1;
             f32x16 hacc = {};
             if constexpr (make_h) hacc = make_h_mma(make_h_read(gnext));
@@ -1394,10 +1398,10 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
         int it = 0;
         for (long long q = q0; q < q1;) {
             body(sa, sb, ba, bb, q, it);
-            ++q; it = (it + 1) & 3;
+            ++q; it = (it + 1) & (NB - 1);
             if (q >= q1) break;
             body(sb, sa, bb, ba, q, it);
-            ++q; it = (it + 1) & 3;
+            ++q; it = (it + 1) & (NB - 1);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -1986,6 +1990,10 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
     const size_t lds_taped = (size_t)(BG::RING_DIST_TAPED + 1) * PK::CHUNK_BYTES + lds_fixed;
     size_t lds_dw = (size_t)BG::NBUF * BG::GROUP_BYTES + (t1.drop_h1 ? (size_t)2 * BG::MT * Pol::FRAG_BYTES + W * 4 : 0);
     if (t1.drop_ga && (size_t)BG::NBUF * BG::GROUP_BYTES_LAST2 > lds_dw) lds_dw = (size_t)BG::NBUF * BG::GROUP_BYTES_LAST2;
+    if constexpr (Pol::TAPE8) {          // the 8-bit jobs other than layer 1's run a deeper ring of smaller group images (dw_body2: NB)
+        const size_t deep = (size_t)BHN_T8_NBUF * (2 * BG::MT * BG::TAPE_TILE + BG::TILE_BYTES + 1024);
+        if (deep > lds_dw) lds_dw = deep;
+    }
 #ifndef BHN_RESIDENT
 #define BHN_RESIDENT 1           // 0: never keep the weight images resident in LDS (A/B builds)
 #endif
