@@ -138,8 +138,11 @@ def cpu_baseline(args, geo, GM_c3):
     default_threads = torch.get_num_threads()
     sweep, t_start = {}, time.perf_counter()
     for nthr in sorted({n for n in (8, 16, 32, 64, 128, ncores) if n <= ncores} or {ncores}):
-        if sweep and (time.perf_counter() - t_start > args.cpu_seconds or sweep[max(sweep)] > 1.05 * min(sweep.values())):
-            break                              # out of budget, or the last (larger) count was already slower than the best
+        tried = sorted(sweep)
+        if sweep and (time.perf_counter() - t_start > args.cpu_seconds or
+                      (len(tried) >= 3 and all(sweep[n] > 1.05 * min(sweep.values()) for n in tried[-2:]))):
+            break                              # out of budget, or the last TWO (larger) counts were slower than the best
+                                               # (one is not enough: the curve is not monotonic -- 16 threads slower than 8, 32 faster)
         torch.set_num_threads(nthr)
         ks, bs = ot.tree_to_lists(tree, torch.float32)
         tr = ot.CpuTrainer(ks, bs, geom, hp, num_iters=1000)
