@@ -192,7 +192,8 @@ class GraphedImageStep:
         self.GM = constants.GM_c3(t_units) if t_units is not None else 1.0
         self.t_start, self.t_inj = float(t_start), float(rt['t_injection'])
         args[np.arange(min(args.num_frames, network._world()[1]))]            # (makes the device-resident copies of the per-frame arrays)
-        self.full = [engine._hip.as_f32(a, dev) for a in args._dev[:3]]         # whole-movie target, sigma, offset
+        # whole-movie target, sigma, offset as ONE tensor: the batch is gathered by a single index_select
+        self.full = torch.stack([engine._hip.as_f32(a, dev) for a in args._dev[:3]])
         self.tshape = (B, geom.Sx, geom.R) if dtype == 'full' else (B, geom.Sx)
         # per-step inputs: a ring of pinned staging slots (the host runs ahead of the GPU: a slot is rewritten only after the
         # copies issued from it have executed), three device buffers the graph reads
@@ -221,7 +222,7 @@ class GraphedImageStep:
         from . import engine
         st, eng, geom = self.state, self.eng, self.geom
         eng.pack(st.flat)
-        tgt, sig, off = (a.index_select(0, self.d_idx).reshape(self.tshape) for a in self.full)
+        tgt, sig, off = (a.reshape(self.tshape) for a in self.full.index_select(1, self.d_idx))
         images = eng.render_train(geom, self.d_tM0, out=self.images)
         loss, dimg = engine.chi2_image(images, tgt, sig, off, self.scale, self.dtype)
         buf = st.grad_buffer()
@@ -398,6 +399,7 @@ class TemporalBatchedArgs(object):
         self.args = self.host_args + [self.t_values]
         self.default_t_units = units.hr
         self._dev = None
+        self._stack = None
         self._rng = _shared_rng(0)
 
     def sample(self, batchsize, replace=False):
@@ -410,8 +412,14 @@ class TemporalBatchedArgs(object):
             if self._dev is None:
                 dev = torch.device('cuda', torch.cuda.current_device())
                 self._dev = [torch.as_tensor(a, device=dev) for a in self.host_args]
+                # arguments of one shape and dtype (target / sigma / offset of an image-plane loss) are gathered by ONE kernel
+                same = len(self._dev) > 1 and len({(tuple(a.shape), a.dtype) for a in self._dev}) == 1
+                self._stack = torch.stack(self._dev) if same else None
             idx = torch.as_tensor(key, device=self._dev[0].device if self._dev else 'cuda')
-            out = [a.index_select(0, idx) for a in self._dev]
+            if self._stack is not None:
+                out = list(self._stack.index_select(1, idx))
+            else:
+                out = [a.index_select(0, idx) for a in self._dev]
         else:
             out = [a[key, ...] for a in self.host_args]
         out.append(self.t_values[key])
