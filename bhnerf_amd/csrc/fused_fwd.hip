@@ -275,36 +275,40 @@ DEVI void wide_step(const char *ch, const char *chn, APipe<Pol> &ap, const typen
     for (int i = 0; i < PF - 1; ++i) ap.f[i] = a[(NF + i) % PF];
 }
 
-template <int W, class Pol, int DEG, bool RENDER>
-__global__ __launch_bounds__(256) void fused_fwd_wide_kernel(FusedArgs a) {
+// NW = 8, RES (the product's forward of width <= 128 networks whose weight image fits LDS, launch_fwd_pair): eight waves
+// x 64 points over the RESIDENT weight image.  There the register argument above does not apply -- two activation sets of a
+// 128-wide layer are 128 registers, everything fits the 256 VGPRs of a wave at two waves per SIMD -- and the LDS argument
+// does: one 1-KiB A fragment per MFMA and wave is exactly the LDS bandwidth of a CU; feeding two MFMAs per
+// fragment halves it.
+template <int W, class Pol, int DEG, bool RENDER, int NW = 4, bool RES = false>
+__global__ __launch_bounds__(NW * 64) void fused_fwd_wide_kernel(FusedArgs a) {
     using PK = Pack<W, Pol>;
     using frag = typename Pol::frag;
     static_assert(Pol::ELEM_BYTES == 2, "bf16");
-    constexpr int CB = PK::CHUNK_BYTES, MT = PK::MT, KS = PK::KS, NW = 4, NF = KS + 2, PF = Pol::LDS_PREFETCH;
+    constexpr int CB = PK::CHUNK_BYTES, MT = PK::MT, KS = PK::KS, NF = KS + 2, PF = Pol::LDS_PREFETCH, VW = 2 * NW;
     using RG = DmaRing<CB, NW>;
     constexpr int DIST = BHN_FWD_DIST;
-    using RS = RingState<RG, CB, DIST, false, MT, false>;
-    constexpr int NB = RS::NB;
+    using RS = std::conditional_t<RES, ResidentRing<RG, CB, MT>, RingState<RG, CB, DIST, false, MT, false>>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *ring = smem;
-    float *bias_lds = reinterpret_cast<float *>(smem + NB * CB);
+    float *bias_lds = reinterpret_cast<float *>(smem + RS::lds_bytes(PK::fwd_chunks(a.depth)));
     char *seg_lds = reinterpret_cast<char *>(bias_lds + (a.depth + 1) * W);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 31, h = lane >> 5;
-    for (int i = tid; i < (a.depth + 1) * W; i += 256) bias_lds[i] = reinterpret_cast<const float *>(a.packed + a.bias_off)[i];
+    for (int i = tid; i < (a.depth + 1) * W; i += NW * 64) bias_lds[i] = reinterpret_cast<const float *>(a.packed + a.bias_off)[i];
     RS rs;
     rs.start(ring, a.packed + a.fwd_off, PK::fwd_chunks(a.depth), nullptr, 0, 0, 0);
     APipe<Pol> ap;
     ap.prime(rs.ch(), bias_lds);
-    // wave wv owns the 32-point groups 2 wv and 2 wv + 1 of the workgroup tile (virtual waves of an 8-wave tile)
-    PointIn nx0 = load_point<8>(a, blockIdx.x, 2 * wv, pl), nx1 = load_point<8>(a, blockIdx.x, 2 * wv + 1, pl);
+    // wave wv owns the 32-point groups 2 wv and 2 wv + 1 of the workgroup tile (virtual waves of a 2 NW-group tile)
+    PointIn nx0 = load_point<VW>(a, blockIdx.x, 2 * wv, pl), nx1 = load_point<VW>(a, blockIdx.x, 2 * wv + 1, pl);
     for (long long tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
         const PointIn in0 = nx0, in1 = nx1;
         frag enc0[2], enc1[2];
         bool live0, live1;
         point_prologue<Pol, DEG>(a, in0, enc0, live0);
         point_prologue<Pol, DEG>(a, in1, enc1, live1);
-        nx0 = load_point<8>(a, tile + gridDim.x, 2 * wv, pl);
-        nx1 = load_point<8>(a, tile + gridDim.x, 2 * wv + 1, pl);
+        nx0 = load_point<VW>(a, tile + gridDim.x, 2 * wv, pl);
+        nx1 = load_point<VW>(a, tile + gridDim.x, 2 * wv + 1, pl);
         float w00 = 0.f, w01 = 0.f;
         if (RENDER && h == 0 && in0.inb) w00 = a.w[in0.p];
         if (RENDER && h == 0 && in1.inb) w01 = a.w[in1.p];
@@ -384,12 +388,13 @@ __global__ __launch_bounds__(256) void fused_fwd_wide_kernel(FusedArgs a) {
             if (h == 0 && in0.inb) a.emission[(long long)in0.b * a.P + in0.p] = e0;
             if (h == 0 && in1.inb) a.emission[(long long)in1.b * a.P + in1.p] = e1;
         } else {
-            RaySum<8>::put(a, seg_lds, 2 * wv, in0.p, in0.inb, e0, w00, true, in0.b);
-            RaySum<8>::put(a, seg_lds, 2 * wv + 1, in1.p, in1.inb, e1, w01, true, in1.b);
+            RaySum<VW>::put(a, seg_lds, 2 * wv, in0.p, in0.inb, e0, w00, true, in0.b);
+            RaySum<VW>::put(a, seg_lds, 2 * wv + 1, in1.p, in1.inb, e1, w01, true, in1.b);
             if (!a.ray_direct) {
                 lds_barrier();
-                RaySum<8>::combine(a, seg_lds, 2 * wv, in0.b);
-                RaySum<8>::combine(a, seg_lds, 2 * wv + 1, in1.b);
+                RaySum<VW>::combine(a, seg_lds, 2 * wv, in0.b);
+                RaySum<VW>::combine(a, seg_lds, 2 * wv + 1, in1.b);
+                if constexpr (RES) lds_barrier();      // (no ring barriers between this tile's combine and the next tile's segment sums)
             }
         }
     }
@@ -503,6 +508,60 @@ static int launch_fwd_w(FusedArgs &a, hipStream_t st) {
     return BHN_OK;
 }
 
+// ---- 64 points per wave over a resident weight image (fused_fwd_wide_kernel<.., 8, true>): bf16 networks of width <= 128 whose
+//      forward image, biases and the ray-sum scratch of 16 point groups fit LDS.  A workgroup tile is 16 groups: the caller
+//      fills FusedArgs with nwaves = 16 (fwd_tile_groups). ----
+//      EXPERIMENT (-DBHN_FWD_PAIR=1; round 4, one box): 4x128 render 0.995 -> 0.914 ms, 8x64 0.767 -> 0.665, but 4x64 0.404 ->
+//      0.445 and 6x32 0.314 -> 0.357 (the small kernels are bound by their point prologue, not by LDS), and the images of
+//      `render` are no longer bit-identical to the training forward's (16-group instead of 8-group tiles: another summation
+//      order for rays that straddle a tile).  Not in the product build.
+#ifndef BHN_FWD_PAIR
+#define BHN_FWD_PAIR 0
+#endif
+static bool fwd_pair_ok(int mode, const MlpShape &s, int Sx) {
+    if (!BHN_FWD_PAIR || mode != BHN_BF16 || s.width > 128) return false;
+    const size_t chunk = (size_t)(s.width / 16 + 2) * PolBF16::FRAG_BYTES, chunks = 1 + (size_t)(s.depth - 1) * (s.width / 32) + 1;
+    return chunks * chunk + (size_t)(s.depth + 1) * s.width * 4 + RaySum<16>::bytes(Sx) <= 160 * 1024;
+}
+static int fwd_tile_groups(const bhn_model *m, int mode, const bhn_geom *geom) {
+    MlpShape s;
+    if (m && geom && bhn_mlp_shape(m, &s) == BHN_OK && fwd_pair_ok(mode, s, geom->S > 0 ? geom->S : 1)) return 16;
+    return (mode == BHN_BF16) ? PolBF16::NWAVES : PolF32::NWAVES;
+}
+#if BHN_FWD_PAIR
+template <int W, bool RENDER>
+static int launch_fwd_pair_w(FusedArgs &a, hipStream_t st) {
+    using PK = Pack<W, PolBF16>;
+    const size_t lds = (size_t)PK::fwd_chunks(a.depth) * PK::CHUNK_BYTES + (size_t)(a.depth + 1) * W * 4 + RaySum<16>::bytes(a.Sx);
+    auto kern = fused_fwd_wide_kernel<W, PolBF16, 3, RENDER, 8, true>;
+    int dev = 0;
+    BHN_HIP(hipGetDevice(&dev));
+    BHN_CHECK_DEVICE(dev);
+    static DeviceOnce once;
+    BHN_HIP(once.run(dev, [&](int &occ) {
+        occ = 1;
+        return hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }));
+    long long grid = (long long)bhn_num_cus(dev);
+    if (grid > a.total_tiles) grid = a.total_tiles;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, st, a);
+    BHN_HIP(hipGetLastError());
+    return BHN_OK;
+}
+template <bool RENDER>
+static int launch_fwd_pair(FusedArgs &a, int width, hipStream_t st) {
+    switch (width) {
+        case 32: return launch_fwd_pair_w<32, RENDER>(a, st);
+        case 64: return launch_fwd_pair_w<64, RENDER>(a, st);
+        case 128: return launch_fwd_pair_w<128, RENDER>(a, st);
+        default: bhn_set_error("internal: paired forward at width %d", width); return BHN_EINVAL;
+    }
+}
+#else
+template <bool RENDER>
+static int launch_fwd_pair(FusedArgs &, int, hipStream_t) { return BHN_EINVAL; }
+#endif
+
 template <class Pol, bool RENDER>
 static int launch_fwd(FusedArgs &a, int width, hipStream_t st) {
     switch (width) {
@@ -546,12 +605,13 @@ extern "C" int bhn_predict_fwd(const bhn_model *m, int32_t mode, const void *pac
     MlpShape s;
     BHN_CHECK_ARG(emission, "null emission");
     mode = bhn_norm_mode(mode);
-    const int nw = (mode == BHN_BF16) ? PolBF16::NWAVES : PolF32::NWAVES;
+    const int nw = fwd_tile_groups(m, mode, geom);
     int rc = fused_fill_args(m, mode, packed, geom, fr, false, &a, &s, nw);
     if (rc != BHN_OK) return rc;
     a.emission = emission;
     if (geom->groups)   // points of skipped groups are outside the domain: emission 0
         BHN_HIP(hipMemsetAsync(emission, 0, sizeof(float) * (size_t)a.B * a.P, (hipStream_t)stream));
+    if (nw == 16) return launch_fwd_pair<false>(a, s.width, (hipStream_t)stream);
     return mode == BHN_BF16 ? launch_fwd<PolBF16, false>(a, s.width, (hipStream_t)stream)
                             : launch_fwd<PolF32, false>(a, s.width, (hipStream_t)stream);
 }
@@ -562,7 +622,7 @@ extern "C" int bhn_render_fwd(const bhn_model *m, int32_t mode, const void *pack
     MlpShape s;
     BHN_CHECK_ARG(images, "null images");
     mode = bhn_norm_mode(mode);
-    const int nw = (mode == BHN_BF16) ? PolBF16::NWAVES : PolF32::NWAVES;
+    const int nw = fwd_tile_groups(m, mode, geom);
     int rc = fused_fill_args(m, mode, packed, geom, fr, true, &a, &s, nw);
     if (rc != BHN_OK) return rc;
     a.images = images;
@@ -576,6 +636,7 @@ extern "C" int bhn_render_fwd(const bhn_model *m, int32_t mode, const void *pack
         return launch_fwd_w<256, PolBF16, true, true>(a, (hipStream_t)stream);
     }
 #endif
+    if (nw == 16) return launch_fwd_pair<true>(a, s.width, (hipStream_t)stream);
     return mode == BHN_BF16 ? launch_fwd<PolBF16, true>(a, s.width, (hipStream_t)stream)
                             : launch_fwd<PolF32, true>(a, s.width, (hipStream_t)stream);
 }
