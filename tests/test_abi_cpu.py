@@ -95,6 +95,21 @@ def test_argument_validation_reports_errors(lib):
         _hip.check(lib.bhn_chi2_image(None, None, None, None, 1.0, 0, 1, 1, 1, None, None, None))
 
 
+def test_tape8_mode_is_bf16_outside_the_backward_and_rejects_other_networks(lib):
+    """BHN_BF16_T8 (include/bhnerf_hip.h): every entry point that does not touch the tape treats it as BHN_BF16 (same packed
+    image), with or without BHN_T8_CALIBRATE; the backward exists for width 256 / depth >= 3 only and says so."""
+    from bhnerf_amd import _hip
+    assert _hip.MODES['bf16_t8'] == _hip.BHN_BF16_T8 == 2 and _hip.BHN_T8_CALIBRATE == 0x100
+    m256 = _hip.make_model(4, 256, 3, True, 1.0, 0.0, 1.0, 1.0)
+    n16 = lib.bhn_packed_bytes(C.byref(m256), _hip.BHN_BF16)
+    assert n16 > 0 and lib.bhn_packed_bytes(C.byref(m256), _hip.BHN_BF16_T8) == n16
+    assert lib.bhn_packed_bytes(C.byref(m256), _hip.BHN_BF16_T8 | _hip.BHN_T8_CALIBRATE) == n16
+    for depth, width in ((4, 128), (2, 256)):
+        m = _hip.make_model(depth, width, 3, True, 1.0, 0.0, 1.0, 1.0)
+        assert lib.bhn_render_bwd_workspace_bytes(C.byref(m), _hip.BHN_BF16_T8, 8, 1 << 20, 0) == 0
+        assert b'BHN_BF16_T8' in lib.bhn_last_error()
+
+
 def test_device_path_fails_loudly_without_gpu():
     import torch
     from bhnerf_amd import _hip, kgeo, network
