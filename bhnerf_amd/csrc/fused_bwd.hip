@@ -236,16 +236,28 @@ DEVI Raw8 tr8_read(const char *pair, int s2, int tr8) {
     r.hi = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(pair + 512 * s2 + 256 + tr8)));
     return r;
 }
-DEVI void tr8_widen(const Raw8 &r, float scale, bf16x8 &fa, bf16x8 &fb) {
+// the two e4m3 fragments (8 points of one feature each: the operands of v_mfma_f32_32x32x16_fp8_fp8) of a raw pair read
+struct Pair8 { u32x2 a, b; };
+DEVI Pair8 tr8_sort(const Raw8 &r) {
+    Pair8 p;
+    p.a = (u32x2){__builtin_amdgcn_perm(r.lo[1], r.lo[0], 0x06040200u), __builtin_amdgcn_perm(r.hi[1], r.hi[0], 0x06040200u)};
+    p.b = (u32x2){__builtin_amdgcn_perm(r.lo[1], r.lo[0], 0x07050301u), __builtin_amdgcn_perm(r.hi[1], r.hi[0], 0x07050301u)};
+    return p;
+}
+// e4m3 fragment -> bf16 fragment, times a power-of-two scale (exact)
+DEVI bf16x8 widen8(const u32x2 &f, float scale) {
     typedef __bf16 b2 __attribute__((ext_vector_type(2)));
-    const unsigned a_lo = __builtin_amdgcn_perm(r.lo[1], r.lo[0], 0x06040200u), b_lo = __builtin_amdgcn_perm(r.lo[1], r.lo[0], 0x07050301u);
-    const unsigned a_hi = __builtin_amdgcn_perm(r.hi[1], r.hi[0], 0x06040200u), b_hi = __builtin_amdgcn_perm(r.hi[1], r.hi[0], 0x07050301u);
-    const b2 a0 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(a_lo, scale, false), a1 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(a_lo, scale, true);
-    const b2 a2 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(a_hi, scale, false), a3 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(a_hi, scale, true);
-    const b2 b0 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(b_lo, scale, false), b1 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(b_lo, scale, true);
-    const b2 b2_ = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(b_hi, scale, false), b3 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(b_hi, scale, true);
-    fa = (bf16x8){a0[0], a0[1], a1[0], a1[1], a2[0], a2[1], a3[0], a3[1]};
-    fb = (bf16x8){b0[0], b0[1], b1[0], b1[1], b2_[0], b2_[1], b3[0], b3[1]};
+    const b2 a0 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(f[0], scale, false), a1 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(f[0], scale, true);
+    const b2 a2 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(f[1], scale, false), a3 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(f[1], scale, true);
+    return (bf16x8){a0[0], a0[1], a1[0], a1[1], a2[0], a2[1], a3[0], a3[1]};
+}
+DEVI void tr8_widen(const Raw8 &r, float scale, bf16x8 &fa, bf16x8 &fb) {
+    const Pair8 p = tr8_sort(r);
+    fa = widen8(p.a, scale);
+    fb = widen8(p.b, scale);
+}
+DEVI f32x16 mma8(const u32x2 &a, const u32x2 &b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(__builtin_bit_cast(long, a), __builtin_bit_cast(long, b), c, 0, 0, 0);
 }
 // feature of row (or column) n of virtual tile t (see above)
 __host__ __device__ static inline int t8_feature(int t, int n) {
@@ -627,7 +639,10 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
             char *dgrp = A.tape + A.t.dout_off + q * A.t.dout_stride;
             if (A.t.drop_ga) {
                 // 32 f32 per group: the job of layer depth-1 rebuilds gA_{depth-1} and makes the output layer's row from them
-                if (h == 0 && !(edbg & 2)) __builtin_nontemporal_store(d, reinterpret_cast<float *>(dgrp) + pl);
+                // (8-bit tape: that job turns them into e4m3(dout / scale) -- which makes NaN of anything beyond 448 scale)
+                float dt = d;
+                if constexpr (T8) { const float lim = 448.f * t8_lds[a.depth - 1]; dt = __builtin_amdgcn_fmed3f(d, -lim, lim); }
+                if (h == 0 && !(edbg & 2)) __builtin_nontemporal_store(dt, reinterpret_cast<float *>(dgrp) + pl);
             } else {
                 // dout as a 32x32 (feature x point) tile whose feature 0 is dout: the A operand of dW_out
                 frag d0 = Pol::zero(), d1 = Pol::zero();
@@ -701,7 +716,9 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
             unsigned mq0 = cin.q0, mq1 = cin.q1, mcur = 0u;          // MODE_CHAIN: relu-bit words in flight from the tape
             unsigned no_acc = 0u;
             float t8_sc = 1.f;
-            unsigned t8_amax = 0u;                    // 8-bit tape: scale of the pending tile's layer, |gA|max of that layer so far
+            // (seeded with |dout|: the first flush below -- layer depth-1, whose gA is not recorded -- leaves the largest |dout|, the
+            //  scale of the e4m3(dout) the dW job of that layer forms)
+            unsigned t8_amax = T8 ? (unsigned)__builtin_bit_cast(unsigned short, (__bf16)__builtin_fabsf(dout)) : 0u;     // 8-bit tape: scale of the pending tile's layer, |gA|max of that layer so far
             if constexpr (T8) t8_sc = 0x1p60f;        // (gA_{depth-1} is not recorded -- TapeLayout::drop_ga -- and must not be limited either)
 #pragma nounroll
             for (int l = a.depth - 1; l >= LEND; --l) {
@@ -754,7 +771,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
     if constexpr (T8 && MODE == MODE_CHAIN) {
         // the workgroup's largest |gA_l| per recorded layer -> the state block (t8_update_kernel turns it into the next call's scale)
         __syncthreads();
-        if (tid + 1 < a.depth) {
+        if (tid < a.depth) {                  // (layer depth-1: the largest |dout|)
             float v = 0.f;
             for (int w = 0; w < Pol::NWAVES; ++w) v = __builtin_fmaxf(v, t8_lds[8 + tid * Pol::NWAVES + w]);
             atomicMax(reinterpret_cast<unsigned *>(A.t8) + 8 + tid, __float_as_uint(v));
@@ -1099,6 +1116,13 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
     constexpr int MPW = (MT + WRR - 1) / WRR, NPW = (nBr + WCC - 1) / WCC;
     static_assert(NPW <= 5, "one sweep");
     constexpr bool B8 = T8 && has_h && !make_h;                       // the B tiles are 8-bit tape tiles too
+#ifndef BHN_T8_F8MFMA
+#define BHN_T8_F8MFMA 1          // 0 (A/B builds): widen both operands to bf16 in front of every MFMA (the first version)
+#endif
+    // both operands 8-bit: the weight-gradient tiles are accumulated by v_mfma_f32_32x32x16_fp8_fp8 straight from the sorted
+    // bytes (gA / scale times h; the scale is applied at the flush); bf16 is made only where bf16 code needs it (bias sums,
+    // the encoded-input tile, the output layer's row)
+    constexpr bool F8 = B8 && BHN_T8_F8MFMA != 0;
     static_assert(!T8 || MPW == 2, "8-bit tape: the A tiles come in pairs (width 256)");
     static_assert(!B8 || NPW % 2 == 0, "8-bit tape: the B tiles come in pairs (width 256)");
     constexpr int ME = (MPW + WCC - 1) / WCC;                          // A tiles a wave pairs with the enc tile / the output row
@@ -1109,6 +1133,10 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
     // 8-bit tape: what the A bytes are multiplied by on their way to bf16 (gA_l: the layer's scale; h_depth of the LAST job: 1)
     float scaleA = 1.f;
     if constexpr (T8 && !LAST) scaleA = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, A.t8[job])));
+    if constexpr (F8 && LAST) {          // the scale of dout (= of gA_{depth-1} without its W_out factor): the A bytes are (h != 0) e4m3(dout / scaleA)
+        const float v = A.t8[job];
+        scaleA = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (v > 0.f && v < __builtin_inff()) ? v : 1.f)));
+    }
     const int nwg = A.wg_begin[job + 1] - A.wg_begin[job];
     const int kb = blockIdx.x - A.wg_begin[job];
     const long long q0 = uniform64(A.t.NQ * kb / nwg), q1 = uniform64(A.t.NQ * (kb + 1) / nwg);
@@ -1192,7 +1220,7 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
     }
 
     // ---- per-group A state: fragments of the wave's A tiles for both k-steps (+ LAST: the f32 dout of the lane's points)
-    struct AState { frag af[2][MPW]; f32x4 da[2], db[2]; frag ef[2]; };      // ef: encoded-input fragments (OUTENC, one wave)
+    struct AState { frag af[2][MPW]; f32x4 da[2], db[2]; frag ef[2]; u32x2 a8[2][MPW]; };      // ef: encoded-input fragments (OUTENC, one wave); a8: e4m3 fragments (F8)
     auto load_b = [&](const char *gp, int t) -> frag {
         if constexpr (make_h) return Pol::lds_frag(gp + boff[t % NPW], t / NPW, lane);     // written by make_h_write in fragment order
         else return tr_frag(gp + boff[t % NPW], t / NPW, trl);
@@ -1225,7 +1253,59 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
     // the group behind the last one is loaded but must not be accumulated)
     auto a_prep = [&](AState &st, int k, bool live) {
         const int s2 = k / MPW, mi = k % MPW;
-        if constexpr (T8) {
+        if constexpr (F8) {
+            if (mi == 0) {
+                const u32x4 rw = __builtin_bit_cast(u32x4, st.af[s2][0]);
+                Raw8 raw;
+                raw.lo = (u32x2){rw[0], rw[1]}; raw.hi = (u32x2){rw[2], rw[3]};
+                const Pair8 pr = tr8_sort(raw);
+                st.a8[s2][0] = pr.a; st.a8[s2][1] = pr.b;
+            }
+            if constexpr (!LAST) {
+                // bf16 copies only where bf16 code reads them: the bias sums (wave column 0) and the encoded-input MFMA
+                if (bias_rows || (enc_extra && (mi % WCC) == wc)) st.af[s2][mi] = widen8(st.a8[s2][mi], scaleA);
+            } else {
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                typedef short s16x2 __attribute__((ext_vector_type(2)));
+                const f32x4 da = st.da[s2], db = st.db[s2];
+                const u32x2 h8 = st.a8[s2][mi];                      // h_depth of the lane's feature, 8 points
+                const bool my_row = (mi % WCC) == wc;
+                // e4m3(dout / scaleA) of the lane's eight points (the chain limited dout to the range when it recorded it)
+                u32x2 d8;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const f32x4 d4 = i == 0 ? da : db;
+                    s16x2 r = {0, 0};
+                    r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, d4[0], d4[1], scaleA, false);
+                    r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, d4[2], d4[3], scaleA, true);
+                    d8[i] = __builtin_bit_cast(unsigned, r);
+                }
+                if (my_row) {        // the output layer's row: dW_out[f] += dout_p h_depth[p][f] (bf16 operands, v_dot2c)
+                    const frag hb = widen8(h8, 1.f);
+                    float o = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const f32x2 dd = {i < 2 ? da[2 * i] : db[2 * i - 4], i < 2 ? da[2 * i + 1] : db[2 * i - 3]};
+                        const typename Pol::bf16x2 dpk = {(__bf16)dd[0], (__bf16)dd[1]};
+                        const typename Pol::bf16x2 hp = {hb[2 * i], hb[2 * i + 1]};
+                        o = __builtin_amdgcn_fdot2_f32_bf16(hp, dpk, o, false);
+                    }
+                    if (live) orow[mi / WCC] += o;
+                }
+                // A bytes = (h != 0) ? e4m3(dout / scaleA) : 0.  h bytes are <= 0x7e: + 0x7f sets bit 7 of every nonzero byte, no carries
+                u32x2 g8;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const unsigned t = (h8[i] + 0x7f7f7f7fu) & 0x80808080u;
+                    g8[i] = d8[i] & (t | (t - (t >> 7)));
+                }
+                st.a8[s2][mi] = g8;
+                if (bias_rows || (enc_extra && (mi % WCC) == wc)) st.af[s2][mi] = widen8(g8, scaleA);      // (the bias of layer depth-1, summed below)
+                if (live && out_bias_wave && mi == 0) bout += (da[0] + da[1]) + (da[2] + da[3]) + (db[0] + db[1]) + (db[2] + db[3]);
+            }
+            if (live && bias_rows) bsum[mi] = Pol::sum8(st.af[s2][mi], bsum[mi]);
+            return;
+        } else if constexpr (T8) {
             if (mi == 0) {
                 const u32x4 rw = __builtin_bit_cast(u32x4, st.af[s2][0]);
                 Raw8 raw;
@@ -1276,6 +1356,48 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
     auto mma_phase = [&](const char *gp, const AState &cur, const frag (&bc)[2], const char *gnext, AState &nx, frag (&bn)[2],
                          bool live_next) {
         frag bq[3], benc;
+        if constexpr (F8) {
+            // e4m3 operands: pair u of the wave's B tiles arrives sorted in ONE register quad (bc[0] / bn[0]: fragments of tile 2k
+            // in dwords 0-1, of tile 2k+1 in dwords 2-3)
+            constexpr int NPAIR = NTOT / 2;
+            u32x4 bcur = __builtin_bit_cast(u32x4, bc[0]), bnx = bcur;
+            Raw8 rnext, rawn;
+            if (NPAIR > 1) rnext = load_braw(gp, 1);
+#pragma unroll
+            for (int t = 0; t < NTOT; ++t) {
+                const int u = t >> 1, e = t & 1;
+                if (e == 0 && u + 1 < NPAIR) {
+                    const Pair8 pr = tr8_sort(rnext);
+                    bnx = (u32x4){pr.a[0], pr.a[1], pr.b[0], pr.b[1]};
+                    if (u + 2 < NPAIR) rnext = load_braw(gp, u + 2);
+                }
+                if (enc_extra && (t % NPW) == (NPW >= 2 ? NPW - 2 : 0)) benc = tr_frag(gp + OFF_E, t / NPW, trl);
+                if (t == 0) a_load(gnext, nx);
+                __builtin_amdgcn_sched_barrier(0);
+                const int s2 = t / NPW, ni = t % NPW;
+                const u32x2 bnow = e == 0 ? (u32x2){bcur[0], bcur[1]} : (u32x2){bcur[2], bcur[3]};
+#pragma unroll
+                for (int mi = 0; mi < MPW; ++mi) acc[mi][ni] = mma8(cur.a8[s2][mi], bnow, acc[mi][ni]);
+                if constexpr (enc_extra) {
+                    if (ni == NPW - 1) {
+#pragma unroll
+                        for (int mi = 0; mi < MPW; ++mi)
+                            if ((mi % WCC) == wc) acc_e[mi / WCC] = Pol::mma(cur.af[s2][mi], benc, acc_e[mi / WCC]);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < NPREP; ++k)
+                    if (t == (T_PREP + k < NTOT ? T_PREP + k : NTOT - 1)) a_prep(nx, k, live_next);
+                if (t == (NTOT >= 2 ? NTOT - 2 : 0)) rawn = load_braw(gnext, 0);
+                if (t == NTOT - 1) {
+                    const Pair8 pr = tr8_sort(rawn);
+                    bn[0] = __builtin_bit_cast(frag, (u32x4){pr.a[0], pr.a[1], pr.b[0], pr.b[1]});
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (e == 1) bcur = bnx;
+            }
+            return;
+        }
         if constexpr (B8) {
             // 8-bit B tiles come in pairs (tiles 2k, 2k+1 of the wave's share, one k-step = MFMA steps 2u, 2u+1): the raw
             // read of pair u+1 is in flight while pair u is widened and used
@@ -1373,7 +1495,10 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
             a_load(smem, sa);
 #pragma unroll
             for (int k = 0; k < NPREP; ++k) a_prep(sa, k, true);
-            if constexpr (B8) tr8_widen(load_braw(smem, 0), 1.f, ba[0], ba[1]);
+            if constexpr (F8) {
+                const Pair8 pr = tr8_sort(load_braw(smem, 0));
+                ba[0] = __builtin_bit_cast(frag, (u32x4){pr.a[0], pr.a[1], pr.b[0], pr.b[1]});
+            } else if constexpr (B8) tr8_widen(load_braw(smem, 0), 1.f, ba[0], ba[1]);
             else if constexpr (!make_h) { ba[0] = load_b(smem, 0); ba[1] = load_b(smem, NTOT > 1 ? 1 : 0); }
         }
         auto body = [&](AState &cur, AState &nx, frag (&bc)[2], frag (&bn)[2], long long q, int it) {
@@ -1409,16 +1534,21 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
     // LAST: row i of A tile m carries the factor W_out[32 m + i] (a_prep); accumulator register r of a lane holds row
     // (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     const float *wout_g = reinterpret_cast<const float *>(A.f.packed + A.f.wout_off);
-    auto flush_tile = [&](int m, int n, const f32x16 &t) {
+    auto flush_tile = [&](int m, int n, const f32x16 &t, bool enc_tile = false) {
         float *tp = slab + (long long)(m * BG::NTMAX + n) * 1024;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             f32x4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = t[4 * g4 + e];
-            if constexpr (LAST && T8) {      // rows are virtual (t8_feature)
+            if constexpr (LAST && T8) {      // rows are virtual (t8_feature); F8: the tile was accumulated on dout / scaleA
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] *= wout_g[t8_feature(m, 8 * g4 + 4 * (lane >> 5) + e)];
+                for (int e = 0; e < 4; ++e) v[e] *= (F8 && n < nBr && !enc_tile ? scaleA : 1.f) * wout_g[t8_feature(m, 8 * g4 + 4 * (lane >> 5) + e)];
+            } else if constexpr (F8) {       // accumulated on gA / scaleA (the encoded-input tile: on the widened copy, true scale)
+                if (!enc_tile) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= scaleA;
+                }
             } else if constexpr (LAST) {
                 const f32x4 w4 = *reinterpret_cast<const f32x4 *>(wout_g + 32 * m + 8 * g4 + 4 * (lane >> 5));
 #pragma unroll
@@ -1451,7 +1581,7 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
             const int n = nbase + ni;
             if (m < MT && n < nBr) flush_tile(m, n, acc[mi][ni]);
         }
-        if (enc_extra && (mi % WCC) == wc && m < MT) flush_tile(m, nH, acc_e[mi / WCC]);
+        if (enc_extra && (mi % WCC) == wc && m < MT) flush_tile(m, nH, acc_e[mi / WCC], true);
         flush_column0(m, nB, LAST ? bsum[mi] * wout_r[mi] : bsum[mi], bias_rows && m < MT);
         if constexpr (LAST) {
             // the output layer's row: slab row MT, tile m, row 0, column f = lane & 31 (where reduce_kernel reads dW_out[32 m + f])
