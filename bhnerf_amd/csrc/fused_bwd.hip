@@ -1116,6 +1116,9 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
     constexpr int MPW = (MT + WRR - 1) / WRR, NPW = (nBr + WCC - 1) / WCC;
     static_assert(NPW <= 5, "one sweep");
     constexpr bool B8 = T8 && has_h && !make_h;                       // the B tiles are 8-bit tape tiles too
+#ifndef BHN_T8_ABL
+#define BHN_T8_ABL 0             // measurement builds (results wrong): 1 no e4m3 MFMAs, 2 no A preparation, 4 no B sorting in the e4m3 jobs, 8 the tape stream only (no MFMA phase in any 8-bit job)
+#endif
 #ifndef BHN_T8_F8MFMA
 #define BHN_T8_F8MFMA 1          // 0 (A/B builds): widen both operands to bf16 in front of every MFMA (the first version)
 #endif
@@ -1254,6 +1257,9 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
     auto a_prep = [&](AState &st, int k, bool live) {
         const int s2 = k / MPW, mi = k % MPW;
         if constexpr (F8) {
+#if (BHN_T8_ABL & 2)
+            return;
+#endif
             if (mi == 0) {
                 const u32x4 rw = __builtin_bit_cast(u32x4, st.af[s2][0]);
                 Raw8 raw;
@@ -1367,7 +1373,11 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
             for (int t = 0; t < NTOT; ++t) {
                 const int u = t >> 1, e = t & 1;
                 if (e == 0 && u + 1 < NPAIR) {
+#if (BHN_T8_ABL & 4)
+                    const Pair8 pr = {rnext.lo, rnext.hi};
+#else
                     const Pair8 pr = tr8_sort(rnext);
+#endif
                     bnx = (u32x4){pr.a[0], pr.a[1], pr.b[0], pr.b[1]};
                     if (u + 2 < NPAIR) rnext = load_braw(gp, u + 2);
                 }
@@ -1377,7 +1387,13 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
                 const int s2 = t / NPW, ni = t % NPW;
                 const u32x2 bnow = e == 0 ? (u32x2){bcur[0], bcur[1]} : (u32x2){bcur[2], bcur[3]};
 #pragma unroll
-                for (int mi = 0; mi < MPW; ++mi) acc[mi][ni] = mma8(cur.a8[s2][mi], bnow, acc[mi][ni]);
+                for (int mi = 0; mi < MPW; ++mi) {
+#if (BHN_T8_ABL & 1)
+                    asm volatile("" :: "v"(cur.a8[s2][mi]), "v"(bnow));
+#else
+                    acc[mi][ni] = mma8(cur.a8[s2][mi], bnow, acc[mi][ni]);
+#endif
+                }
                 if constexpr (enc_extra) {
                     if (ni == NPW - 1) {
 #pragma unroll
@@ -1515,7 +1531,7 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
             const bool live_next = q + 1 < q1;
             f32x16 hacc = {};
             if constexpr (make_h) hacc = make_h_mma(make_h_read(gnext));
-            if (!BHN_DBG(A.debug & 1) && works) mma_phase(gp, cur, bc, gnext, nx, bn, live_next);
+            if (!BHN_DBG(A.debug & 1) && works && !(T8 && (BHN_T8_ABL & 8))) mma_phase(gp, cur, bc, gnext, nx, bn, live_next);
             if constexpr (make_h) {
                 if (live_next) make_h_write(gnext, hacc);
             }
@@ -1768,6 +1784,9 @@ __global__ __launch_bounds__(Pol::NTHREADS) __attribute__((amdgpu_waves_per_eu(P
     int job = 0;
     while (job < depth && (int)blockIdx.x >= A.wg_begin[job + 1]) ++job;
     if (BHN_DBG(A.debug >> 2) && (A.debug >> 2) - 1 != job) return;
+#ifdef BHN_T8_ONLY_JOB          // measurement builds: only this job of the 8-bit tape's dW kernel runs (the release build has no run-time switches)
+    if (Pol::TAPE8 && job != BHN_T8_ONLY_JOB) return;
+#endif
     if constexpr (Pol::ELEM_BYTES == 2) {           // bf16: software-pipelined bodies; the output layer rides on job depth-1
         const bool out_skip = (A.f.skip_mask >> depth) & 1;             // odd depths with do_skip
         if (job == depth) {                                               // (depth < 3 only)
@@ -2085,7 +2104,8 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
                                                                   // same MFMA work + the recompute: not byte-bound any more
             work[l] = (double)(mtA + nB) + 0.5;
             if (l == 0 && t1.drop_ga0) work[l] = job0r_w * BG::MT / 8.0 + 0.5;     // rebuilds gA_0: 20 MFMAs per group and wave, 16 conflicted LDS reads
-            if (l == depth - 1 && t1.drop_ga) work[l] += jobl_w * BG::MT / 8.0;    // + the rebuild of gA and the output row
+            // + the rebuild of gA and the output row (8-bit tape: the byte masks of that job are its long pole; 12 measured 2-3 % faster than 8)
+            if (l == depth - 1 && t1.drop_ga) work[l] += (Pol::TAPE8 ? 12 : jobl_w) * BG::MT / 8.0;
             if constexpr (Pol::ELEM_BYTES == 4) {
                 // f32: the jobs are MFMA-bound (a 32x32x2 MFMA is 64 cycles; one 32x32 tile product over a 32-point
                 // group = 16 of them = 0.55 us at the observed 1.87 GHz) unless they stream more than ~34 GB/s per
