@@ -274,3 +274,29 @@ def test_hip_graph_step_is_bitwise_equal_to_the_eager_step(dev, problem, case):
     for a, b in zip(runs[False], runs[True]):
         assert torch.equal(a, b)
     assert not torch.equal(runs[True][0], init)                      # (the steps did move the parameters)
+
+
+def test_hip_graph_step_with_the_8bit_tape(dev, problem):
+    """mode='bf16_t8' under hparams['hip_graph']: the tape-scale kernels (t8_prepare / t8_update, fused_bwd.hip) are part of the
+    captured backward and keep their state in the workspace, so a replayed step follows the eager one.  Not bitwise: the
+    warm-up steps of the capture leave other scale ratios behind than the eager run's history (powers of two that almost
+    always coincide).  Compared on the LOSS curve of seven Adam steps: Adam turns every gradient entry into a step of size lr,
+    so parameters with near-zero gradients move with the sign of the rounding noise in any reduced-precision mode."""
+    from bhnerf_amd import network, optimization, units
+    p = problem
+    tgt, dom, rt = p['movie'][:, 0], (8.0, 1.0, 8.0, 4.0), dict(p['rt'], J=1.0)
+    runs = {}
+    for mode, graph in (('bf16', False), ('bf16_t8', False), ('bf16_t8', True)):
+        pred = network.NeRF_Predictor(*dom, net_depth=4, net_width=256, mode=mode, device=dev)
+        step = optimization.TrainStep.image(p['t_frames'] * units.hr, tgt, sigma=float(np.abs(tgt).mean()) * 0.1, dtype='full')
+        opt = optimization.Optimizer({'num_iters': 7, 'lr_init': 2e-3, 'lr_final': 2e-4, 'seed': 1, 'hip_graph': graph}, pred, rt)
+        losses = []
+        opt.run(2, step, rt, log_fns=[optimization.LogFn(lambda o: losses.append(float(torch.as_tensor(o.loss).reshape(-1)[0])))])
+        assert opt.state.step == 7 and bool(step._graphs) == graph
+        assert torch.isfinite(opt.state.flat).all()
+        runs[(mode, graph)] = np.array(losses)
+    ref = runs[('bf16', False)]
+    assert len(ref) >= 3 and ref[-1] < ref[0]
+    for k in (('bf16_t8', False), ('bf16_t8', True)):
+        assert np.abs(runs[k] - ref).max() < 0.03 * ref.max(), (k, runs[k], ref)
+    assert np.abs(runs[('bf16_t8', True)] - runs[('bf16_t8', False)]).max() < 0.01 * ref.max()
