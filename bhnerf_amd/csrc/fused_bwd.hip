@@ -1894,19 +1894,22 @@ __global__ __launch_bounds__(256) void reduce_kernel(BwdArgs A) {
 
 // 8-bit tape state (BwdArgs::t8; floats): [0..7] the power-of-two scale gA_l is stored with in THIS call, [8..15] the largest
 // |gA_l| this call's delta chain saw (bit patterns, atomicMax), [16..23] ratio_l = |gA_l|max / |dimages|max of the previous
-// call, [24] |dimages|max of this call.  The delta chain is linear in d(loss)/d(images), so the ratios depend on the weights
+// call, [24] |dimages|max of this call ([25]: its partial maxima in flight).  The delta chain is linear in d(loss)/d(images), so the ratios depend on the weights
 // and on WHERE the residuals are, not on how large they are: they move slowly from step to step, while the loss scale may
 // jump by orders of magnitude (a new batch, a restart, a caller's loss weights) -- that part is measured, not predicted.
-//   t8_prepare  (start of every backward call)  |dimages|max; scale_l = the power of two that puts 16 ratio_l |dimages|max
+//   t8_dmax + t8_prepare  (start of every backward call)  |dimages|max; scale_l = the power of two that puts 16 ratio_l |dimages|max
 //               at or below 448, e4m3's largest value: four binades of head room, thirteen and a half below the maximum
 //               before values flush to zero (tools/exp_fp8_tape_accuracy.py: the dW error does not notice)
 //   t8_update   (end of the call)  ratio_l from the maxima the chain just saw; maxima cleared
 //   t8_open     (BHN_T8_CALIBRATE: in front of a chain pass whose tape output is discarded)  scales so large that
 //               nothing is limited; only the maxima of that pass are used
-__global__ __launch_bounds__(1024) void t8_prepare_kernel(float *st, const float *dimages, long long n, int nl) {
+// |dimages|max in two kernels: partial maxima of up to 64 blocks meet in st[25] (atomicMax on the bit patterns of non-negative
+// floats; zero between calls: t8_prepare resets it), one thread then turns it into the scales.  (One block over all of
+// dimages took 26 us at config 2 and would take 0.3 ms at config 3's 1.5 M pixels.)
+__global__ __launch_bounds__(1024) void t8_dmax_kernel(float *st, const float *dimages, long long n) {
     __shared__ float red[16];
     float m = 0.f;
-    for (long long i = threadIdx.x; i < n; i += 1024) m = __builtin_fmaxf(m, __builtin_fabsf(dimages[i]));
+    for (long long i = blockIdx.x * 1024ll + threadIdx.x; i < n; i += (long long)gridDim.x * 1024) m = __builtin_fmaxf(m, __builtin_fabsf(dimages[i]));
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o, 64));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
@@ -1914,18 +1917,28 @@ __global__ __launch_bounds__(1024) void t8_prepare_kernel(float *st, const float
     if (threadIdx.x == 0) {
         float d = 0.f;
         for (int i = 0; i < 16; ++i) d = __builtin_fmaxf(d, red[i]);
-        if (!(d < __builtin_inff())) d = 0.f;                            // (inf / NaN in d(loss)/d(images): leave the scales alone)
+        if (!(d < __builtin_inff())) d = __builtin_inff();             // (inf / NaN in d(loss)/d(images): t8_prepare leaves the scales alone)
+        atomicMax(reinterpret_cast<unsigned *>(st) + 25, __float_as_uint(d));
+    }
+}
+__global__ void t8_prepare_kernel(float *st, int nl, int fresh) {
+    if (threadIdx.x != 0) return;
+    float d = st[24];
+    if (fresh) {                                                        // this call's |dimages|max: from t8_dmax_kernel
+        d = st[25];
+        st[25] = 0.f;
+        if (!(d < __builtin_inff())) d = 0.f;
         st[24] = d;
-        for (int l = 0; l < nl; ++l) {
-            const float a = st[16 + l] * d;                               // expected largest |gA_l|
-            if (a > 0.f && a < __builtin_inff()) {
-                int e;
-                const float mant = frexpf(a * (16.f / 448.f), &e);        // a 16 / 448 = mant 2^e, mant in [0.5, 1)
-                if (mant == 0.5f) --e;
-                e = e < -100 ? -100 : e > 100 ? 100 : e;
-                st[l] = ldexpf(1.f, e);
-            } else if (!(st[l] > 0.f && st[l] < __builtin_inff())) st[l] = 1.f;
-        }
+    }
+    for (int l = 0; l < nl; ++l) {
+        const float a = st[16 + l] * d;                                   // expected largest |gA_l|
+        if (a > 0.f && a < __builtin_inff()) {
+            int e;
+            const float mant = frexpf(a * (16.f / 448.f), &e);            // a 16 / 448 = mant 2^e, mant in [0.5, 1)
+            if (mant == 0.5f) --e;
+            e = e < -100 ? -100 : e > 100 ? 100 : e;
+            st[l] = ldexpf(1.f, e);
+        } else if (!(st[l] > 0.f && st[l] < __builtin_inff())) st[l] = 1.f;
     }
 }
 __global__ void t8_update_kernel(float *st, int nl) {
@@ -2171,7 +2184,10 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
     int nslabs128 = 0;
     if constexpr (Pol::TAPE8) {
         if (what != RUN_FWD_TRAIN) {         // this call's tape scales: the stored ratios times the size of THIS d(loss)/d(images)
-            hipLaunchKernelGGL(t8_prepare_kernel, dim3(1), dim3(1024), 0, st, A.t8, dimages, (long long)B_total * A.f.Sx * A.f.R, depth);
+            const long long npx = (long long)B_total * A.f.Sx * A.f.R;
+            if (t8_cal) BHN_HIP(hipMemsetAsync(A.t8 + 25, 0, 4, st));        // (a workspace that has never been used)
+            hipLaunchKernelGGL(t8_dmax_kernel, dim3((unsigned)(npx >= 65536 ? 64 : (npx + 1023) / 1024)), dim3(1024), 0, st, A.t8, dimages, npx);
+            hipLaunchKernelGGL(t8_prepare_kernel, dim3(1), dim3(64), 0, st, A.t8, depth, 1);
             BHN_HIP(hipGetLastError());
         }
     }
@@ -2229,7 +2245,7 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
                     hipLaunchKernelGGL(t8_open_kernel, dim3(1), dim3(64), 0, st, A.t8);
                     hipLaunchKernelGGL(k_chn, dim3((unsigned)grid), dim3(Pol::NTHREADS), lds_chn, st, A);
                     hipLaunchKernelGGL(t8_update_kernel, dim3(1), dim3(64), 0, st, A.t8, depth);
-                    hipLaunchKernelGGL(t8_prepare_kernel, dim3(1), dim3(1024), 0, st, A.t8, dimages, (long long)B_total * A.f.Sx * A.f.R, depth);
+                    hipLaunchKernelGGL(t8_prepare_kernel, dim3(1), dim3(64), 0, st, A.t8, depth, 0);
                     BHN_HIP(hipGetLastError());
                 }
             }
