@@ -16,18 +16,21 @@ Inputs are synthetic geodesic arrays resident in HBM before the time
 "all-active" variant (rmin=0, rmax=inf, z_width=inf, nothing pre-injection) is used so that every
 ray-sample goes through the full MLP (evaluated points == total points).
 
-Prints ONE JSON line on rank 0.  `roofline` refers to the MLP kernel with the largest share of the step on SURVEY 8(d)'s
-ALGORITHMIC-FLOP basis (bound: mfma -- the fused MLP is a dense contraction; the tape bytes the design chose to move are
-reported beside it as `tape_stream`, never as the roofline), every kernel timed live with HIP events on the launch stream
-(`bhn_render_bwd_tape_timed` records the caller's events between the kernels of the backward);
-`roofline.step_mfma_frac` is the whole step on the same basis.  Keys ending in `_from_profiles` (and `traffic`) are NOT
-measured in this run: they are read from the committed rocprofv3 counter passes `profiles/<roofline.profiles_tag>_*`
-(PMC counters cannot be collected from inside the process) and are flagged `profiles_match_this_build: false` when the
-library they were collected on is not the one loaded here.  `fwd_images_per_s` is frames / time of
-`optimization.total_movie_loss` (the reference's test path, optimization.py:14-66) over the whole movie;
-`parity_mode` is the same step in the f32 (1e-5 parity) arithmetic; `tape8_mode` the same step with the backward's tape in 8
-bits (BHN_BF16_T8: bf16 arithmetic, e4m3 dW operands -- an A/B beside the headline, never the headline); `cpu_baseline` is the oracle's PyTorch-CPU
-restatement timed on the host cores on a bounded sample BEFORE the GPU work starts (best of a thread-count sweep).
+Prints ONE JSON line on rank 0.  `roofline` refers to the MLP kernel with the largest share of the step.  SURVEY 8(d) puts the
+fused MLP, forward and backward, on the MFMA roofline: `roofline.bound` is "mfma", `achieved` = ALGORITHMIC flops per launch
+(SURVEY 8(d)'s per-point figure x the points one launch evaluates) / that kernel's average launch duration, `frac` =
+achieved / the dense bf16 (or f32) MFMA peak.  The tape bytes this design chose to move are NOT algorithmic work: they are
+reported beside it as `roofline.tape_stream` (GB/s of tape, its fraction of 8 TB/s, bytes per point) and never as `frac`.
+Every kernel is timed live with HIP events on the launch stream (`bhn_render_bwd_tape_timed` records the caller's events
+between the kernels of the backward); `roofline.step_mfma_frac` is the whole step on the same basis.  Keys ending in
+`_from_profiles` (and `traffic`) are NOT measured in this run: they are read from the committed rocprofv3 counter passes
+`profiles/<roofline.profiles_tag>_*` (PMC counters cannot be collected from inside the process) and are flagged
+`profiles_match_this_build: false` when the library they were collected on is not the one loaded here.
+`fwd_images_per_s` is frames / time of `optimization.total_movie_loss` (the reference's test path, optimization.py:14-66)
+over the whole movie; `parity_mode` is the same step in the f32 (1e-5 parity) arithmetic; `tape8_mode` the same step with the
+backward's tape in 8 bits (BHN_BF16_T8: bf16 arithmetic, e4m3 dW operands -- an A/B beside the headline, never the headline);
+`cpu_baseline` is the oracle's PyTorch-CPU restatement timed on the host cores on a bounded sample BEFORE the GPU work starts
+(best of a thread-count sweep).
 """
 import argparse
 import ctypes as C
@@ -42,9 +45,11 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
+from kernel_names import short_name, FWD_NAME, CHAIN_NAME, FUSED_NAME, INFER_NAME      # (kernel names as rocprofv3 prints them)
 
 PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}      # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
-PROFILE_TAG = 'r4'                                  # profiles/<tag>_pmc_traffic.json etc. (tools/collect_profiles.sh)
+PROFILE_TAG = 'r5'                                  # profiles/<tag>_pmc_traffic.json etc. (tools/collect_profiles.sh)
 
 
 def mlp_flops(depth, width, F=21):
@@ -286,6 +291,8 @@ def strong_scaling_share(dev, mode='bf16'):
                     res['gpu_ms_per_graph_replay'] = round(e0.elapsed_time(e1) / n, 4)
                     gm = g[0].geom
                     res['active_fraction'] = round(gm.active_fraction, 4)
+                    res['process_group'] = GraphedBackend() if g[0].dist else None
+                    res['collective_in_graph'] = bool(g[0].collective_in_graph)    # RCCL all-reduce + Adam captured inside the graph
             del opt, pred, step
             torch.cuda.empty_cache()
         if 'gpu_ms_per_graph_replay' in res:
@@ -294,6 +301,11 @@ def strong_scaling_share(dev, mode='bf16'):
         res['ray_samples_per_s_hip_graph'] = round(c['H'] * c['W'] * c['G'] / (res['wall_ms_per_step_hip_graph'] * 1e-3), 1)
         out[name] = res
     return out
+
+
+def GraphedBackend():
+    import torch.distributed as dist
+    return dist.get_backend() if dist.is_initialized() else None
 
 
 class HipEvents:
@@ -338,9 +350,11 @@ def kernel_times(eng, geom, tM0, dimg, reps=5):
             a.record(); eng.render_train(geom, tM0[sl]); b.record()
             fs = eng._frames(tM0[sl])
             d = dimg[sl].contiguous()
-            _hip.check(lib.bhn_render_bwd_tape_timed(C.byref(eng.model), eng._bwd_mode(), _hip.ptr(eng.packed), C.byref(gs), C.byref(fs),
+            bmode = eng._bwd_mode()
+            _hip.check(lib.bhn_render_bwd_tape_timed(C.byref(eng.model), bmode, _hip.ptr(eng.packed), C.byref(gs), C.byref(fs),
                                                      _hip.ptr(d), _hip.ptr(out), _hip.ptr(ws), ws.numel(),
                                                      _hip.stream_ptr(eng.device), sets[k].ev, nk + 1))
+            eng._bwd_done(bmode)
         torch.cuda.synchronize()
     for k in range(reps * len(slices)):
         a, b = fwd_ev[k]
@@ -349,9 +363,6 @@ def kernel_times(eng, geom, tM0, dimg, reps=5):
             acc[n] += sets[k].elapsed(i, i + 1) / reps
     acc.pop('-', None)                              # (an empty kernel slot of the fused width-128 backward)
     return acc, group
-
-
-FWD_NAME, CHAIN_NAME, FUSED_NAME = 'chain_kernel<MODE_FWD_TRAIN>', 'chain_kernel<MODE_CHAIN>', 'bwd128_kernel'
 
 
 def tape_bytes_per_point(depth, width, mode, fused):
@@ -394,7 +405,7 @@ def roofline_block(eng, geom, tM0, dimg, depth, width, mode, frames_per_gpu, std
         torch.cuda.synchronize()
         return float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
-    kern_ms['fused_fwd_kernel (inference)'] = timed(lambda: eng.render(geom, tM0))
+    kern_ms[INFER_NAME] = timed(lambda: eng.render(geom, tM0))
     pts = frames_per_gpu * geom.P * geom.visited_fraction     # points that go through the MLP
     f_fwd, f_chain, f_dw, f_train = mlp_flops(depth, width)
     alg = {FWD_NAME: f_fwd, FUSED_NAME: f_chain + f_dw} if fused else {FWD_NAME: f_fwd, CHAIN_NAME: f_chain, 'dw_kernel': f_dw}
@@ -406,59 +417,66 @@ def roofline_block(eng, geom, tM0, dimg, depth, width, mode, frames_per_gpu, std
         gb = bpp[k] * pts / (kern_ms[k] * 1e-3) / 1e9
         per[k] = {'ms': round(kern_ms[k], 4), 'mfma_tflops': round(tf, 1), 'mfma_frac': round(tf / peak, 4),
                   'tape_GB_per_s': round(gb, 1), 'hbm_frac': round(gb / 8000.0, 4), 'tape_bytes_per_point': round(bpp[k], 1),
-                  'bound': 'hbm' if gb / 8000.0 > tf / peak else 'mfma'}
+                  'closer_to': 'hbm (tape stream)' if gb / 8000.0 > tf / peak else 'mfma'}
     dom_k = max(alg, key=lambda k: kern_ms[k])
     d = per[dom_k]
     # what the committed counter passes say about this workload (NOT measured in this run; see the module docstring)
     lib_md5 = file_md5(_hip_lib_path())
+    sfx = '_w128' if (width == 128 and not std) else ''      # the width-128 passes of tools/collect_profiles.sh
+    use = std or sfx == '_w128'
     prof = {'pmc': {}, 'sq': {}, 'stats': {}, 'match': None}
+    traffic_file = 'profiles/%s_pmc_traffic%s.json' % (PROFILE_TAG, sfx)
     try:
-        j = json.load(open(os.path.join(ROOT, 'profiles', PROFILE_TAG + '_pmc_traffic.json')))
-        prof['pmc'] = j['kernels'] if std else {}
+        j = json.load(open(os.path.join(ROOT, traffic_file)))
+        prof['pmc'] = j['kernels'] if use else {}
         prof['match'] = (j.get('lib_md5') == lib_md5) if j.get('lib_md5') else None
     except Exception:
         pass
     try:
-        prof['sq'] = json.load(open(os.path.join(ROOT, 'profiles', PROFILE_TAG + '_sq_summary.json')))['kernels'] if std else {}
+        prof['sq'] = json.load(open(os.path.join(ROOT, 'profiles', PROFILE_TAG + sfx + '_sq_summary.json')))['kernels'] if use else {}
     except Exception:
         pass
     try:                                             # rocprofv3 --kernel-trace --stats averages of the same workload
         import csv
-        tagn = {', 1>': FWD_NAME, ', 2>': CHAIN_NAME, 'dw_kernel': 'dw_kernel', 'bwd128_kernel': FUSED_NAME}
-        for r in csv.DictReader(open(os.path.join(ROOT, 'profiles', PROFILE_TAG + '_bench_kernel_stats.csv'))):
-            for t, n in tagn.items():
-                if t in r['Name'] and std:
-                    prof['stats'][n] = float(r['AverageNs']) * 1e-6
+        stats_file = os.path.join(ROOT, 'profiles', PROFILE_TAG + ('_w128' if sfx else '_bench') + '_kernel_stats.csv')
+        for r in csv.DictReader(open(stats_file)):
+            n = short_name(r['Name'])                 # template arguments by position (tools/kernel_names.py)
+            if n and use:
+                prof['stats'][n] = float(r['AverageNs']) * 1e-6
     except Exception:
         pass
-    if d['bound'] == 'hbm':
-        roofline = {'bound': 'hbm', 'kernel': dom_k, 'achieved': d['tape_GB_per_s'], 'peak': 8000.0, 'unit': 'GB/s', 'frac': d['hbm_frac'],
-                    'algorithmic_bytes_per_point': d['tape_bytes_per_point'], 'mfma_frac_of_this_kernel': d['mfma_frac']}
-    else:
-        roofline = {'bound': 'mfma', 'kernel': dom_k, 'achieved': d['mfma_tflops'], 'peak': peak, 'unit': 'TFLOP/s', 'frac': d['mfma_frac'],
-                    'algorithmic_flop_per_point': alg[dom_k], 'hbm_frac_of_this_kernel': d['hbm_frac']}
+    # the fused MLP is on the MFMA roofline, on ALGORITHMIC flops; the tape bytes are design overhead, shown beside it
+    roofline = {'bound': 'mfma', 'kernel': dom_k, 'achieved': d['mfma_tflops'], 'peak': peak, 'unit': 'TFLOP/s', 'frac': d['mfma_frac'],
+                'algorithmic_flop_per_point': alg[dom_k],
+                'tape_stream': {'GB_per_s': d['tape_GB_per_s'], 'frac_of_8TBps': d['hbm_frac'], 'tape_bytes_per_point': d['tape_bytes_per_point'],
+                                'note': 'bytes of tape this kernel moves through HBM per evaluated point (DESIGN.md 3): the design\'s own traffic, not algorithmic work'}}
     roofline.update({'points_per_launch': int(pts),
                      'traffic': prof['pmc'].get(dom_k, {}).get('hbm_bytes'),
-                     'traffic_source': 'profiles/%s_pmc_traffic.json (rocprofv3 --pmc passes, not measured in this run)' % PROFILE_TAG,
+                     'traffic_source': '%s (rocprofv3 --pmc passes, not measured in this run)' % traffic_file,
                      'profiles_tag': PROFILE_TAG, 'profiles_match_this_build': prof['match']})
     if dom_k in prof['stats']:                       # the same fraction on the rocprofv3 average duration of the committed profile
         ms_p = prof['stats'][dom_k]
-        roofline['frac_from_profiles'] = round((d['hbm_frac'] if d['bound'] == 'hbm' else d['mfma_frac']) * kern_ms[dom_k] / ms_p, 4)
+        roofline['frac_from_profiles'] = round(d['mfma_frac'] * kern_ms[dom_k] / ms_p, 4)
         roofline['kernel_ms_from_profiles'] = round(ms_p, 4)
     roofline['kernels'] = per
     roofline['kernel_ms'] = {k: round(v, 4) for k, v in kern_ms.items()}
     roofline['kernel_ms_sum'] = round(sum(v for k, v in kern_ms.items() if 'inference' not in k), 4)
     roofline['kernel_ms_note'] = 'each kernel timed separately from the step loop (HIP events around / between the launches)'
-    if prof['sq']:    # matrix-pipe busy fraction of SIMD cycles from the committed SQ counter passes
-        tag = {', 1>': FWD_NAME, ', 2>': CHAIN_NAME, 'dw_kernel': 'dw_kernel', 'bwd128_kernel': FUSED_NAME, 'fused_fwd_kernel': 'fused_fwd_kernel (inference)'}
-        busy = {n: v['mfma_busy_frac'] for k, v in prof['sq'].items() for t, n in tag.items() if t in k}
-        roofline['mfma_busy_frac_from_profiles'] = busy
+    if prof['pmc']:
         tk = [k for k in alg]
-        pms = {n: v.get('ms') for k, v in prof['sq'].items() for t, n in tag.items() if t in k}
+        if all(k in prof['pmc'] and 'hbm_bytes' in prof['pmc'][k] for k in tk):
+            roofline['step_mlp_traffic_from_profiles'] = int(sum(prof['pmc'][k]['hbm_bytes'] for k in tk))
+    if prof['sq']:    # matrix-pipe busy fraction of SIMD cycles from the committed SQ counter passes (keys: short kernel names)
+        busy = {k: v['mfma_busy_frac'] for k, v in prof['sq'].items() if 'mfma_busy_frac' in v}
+        roofline['mfma_busy_frac_from_profiles'] = busy
+        conf = {k: v['lds_bank_conflict_frac'] for k, v in prof['sq'].items() if 'lds_bank_conflict_frac' in v}
+        roofline['lds_bank_conflict_frac_from_profiles'] = conf
+        tk = [k for k in alg]
+        pms = {k: v.get('ms') for k, v in prof['sq'].items()}
         if all(k in busy and pms.get(k) for k in tk):
             roofline['step_mfma_busy_frac_from_profiles'] = round(sum(busy[k] * pms[k] for k in tk) / sum(pms[k] for k in tk), 3)
-    inf_tf = f_fwd * pts / (kern_ms['fused_fwd_kernel (inference)'] * 1e-3) / 1e12
-    roofline['inference_forward'] = {'ms': round(kern_ms['fused_fwd_kernel (inference)'], 4), 'mfma_tflops': round(inf_tf, 1), 'mfma_frac': round(inf_tf / peak, 4)}
+    inf_tf = f_fwd * pts / (kern_ms[INFER_NAME] * 1e-3) / 1e12
+    roofline['inference_forward'] = {'ms': round(kern_ms[INFER_NAME], 4), 'mfma_tflops': round(inf_tf, 1), 'mfma_frac': round(inf_tf / peak, 4)}
     roofline['_std'] = std
     roofline['_alg'] = alg
     return roofline, kern_ms, group
@@ -598,7 +616,7 @@ def main():
         fwd_path = {'value': round(nt / dt_f, 1), 'unit': 'images/s', 'frames': nt, 'batch': args.frames_per_gpu,
                     'ms_per_movie': round(1e3 * dt_f, 3), 'movie_loss': movie_loss,
                     'path': 'optimization.total_movie_loss -> TrainStep(update_state=False) -> pack, fused render, chi^2 per batch',
-                    'kernel_only_images_per_s': round(args.frames_per_gpu / (kern_ms['fused_fwd_kernel (inference)'] * 1e-3), 1)}
+                    'kernel_only_images_per_s': round(args.frames_per_gpu / (kern_ms[INFER_NAME] * 1e-3), 1)}
       except Exception as exc:                       # a side block must never cost the headline line
         fwd_path = {'error': repr(exc)}
 

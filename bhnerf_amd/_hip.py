@@ -21,6 +21,7 @@ DEBUG_SIGNATURES = {        # include/bhnerf_hip_debug.h: only libbhnerf_hip_dbg
     'bhn_debug_read': (C.c_int, [C.c_void_p, C.c_size_t]),
 }
 
+ABI_VERSION = 3              # BHN_ABI_VERSION of include/bhnerf_hip.h this binding was written against
 BHN_F32, BHN_BF16, BHN_BF16_T8 = 0, 1, 2
 BHN_T8_CALIBRATE = 0x100
 MODES = {'f32': BHN_F32, 'fp32': BHN_F32, 'float32': BHN_F32, 'bf16': BHN_BF16, 'bfloat16': BHN_BF16,
@@ -110,6 +111,14 @@ def lib():
             handle = C.CDLL(LIB_PATH)
         except OSError as exc:
             raise HipError('cannot load %s: %s' % (LIB_PATH, exc))
+        try:
+            handle.bhn_version.restype = C.c_int
+            have = int(handle.bhn_version())
+        except AttributeError:
+            have = -1
+        if have != ABI_VERSION:      # a stale build would fail later, at a symbol lookup or as "bad mode"
+            raise HipError('%s implements ABI version %d, this package binds version %d: rebuild it (make -C bhnerf_amd/csrc)'
+                           % (LIB_PATH, have, ABI_VERSION))
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)
             fn.restype, fn.argtypes = res, args

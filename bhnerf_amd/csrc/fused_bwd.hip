@@ -2185,7 +2185,9 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
     if constexpr (Pol::TAPE8) {
         if (what != RUN_FWD_TRAIN) {         // this call's tape scales: the stored ratios times the size of THIS d(loss)/d(images)
             const long long npx = (long long)B_total * A.f.Sx * A.f.R;
-            if (t8_cal) BHN_HIP(hipMemsetAsync(A.t8 + 25, 0, 4, st));        // (a workspace that has never been used)
+            // a calibrating call starts from a clean state block: the workspace may never have been used, and t8_update keeps
+            // a layer's OLD ratio when the chain saw only zeros there -- all-zero ratios fall back to scale 1 (t8_prepare)
+            if (t8_cal) BHN_HIP(hipMemsetAsync(A.t8, 0, t8_bytes, st));
             hipLaunchKernelGGL(t8_dmax_kernel, dim3((unsigned)(npx >= 65536 ? 64 : (npx + 1023) / 1024)), dim3(1024), 0, st, A.t8, dimages, npx);
             hipLaunchKernelGGL(t8_prepare_kernel, dim3(1), dim3(64), 0, st, A.t8, depth, 1);
             BHN_HIP(hipGetLastError());

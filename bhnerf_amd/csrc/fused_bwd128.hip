@@ -161,8 +161,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             dma_piece(rs, (unsigned)(pb * TB + 1024 * half), lds0 + OFF_E + eb * ENC_IMG + 1024 * e, voffE);
         }
     };
-    // dout of point pl of group 4 Q + wv: dout128_kernel has turned the tape's e into dout = dE e (1 - e) in place
-    const float *dout_g = reinterpret_cast<const float *>(A.tape + A.t.e_off);
+    // dout of point pl of group 4 Q + wv: dout128_kernel has made dout = dE e (1 - e) from the tape's e (a region of its own: the
+    // recorded tape stays as the forward left it, a second backward call on it gives the same gradient)
+    const float *dout_g = reinterpret_cast<const float *>(A.tape + A.t.dout_off);
     auto point_dout = [&](long long Q) -> float { return dout_g[(4 * Q + wv) * 32 + pl]; };
     auto put_dout = [&](float d) {
         if (lane < 32) {
@@ -577,11 +578,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 }
 
-// dout = dE e (1 - e) per point, in place over the e the forward recorded (sigmoid'(out - 10) = e (1 - e); dE = sum_s dimg w)
+// dout = dE e (1 - e) per point from the e the forward recorded (sigmoid'(out - 10) = e (1 - e); dE = sum_s dimg w) -> the tape's
+// dout region
 __global__ __launch_bounds__(256) void dout128_kernel(BwdArgs A) {
     const FusedArgs &a = A.f;
     const long long n = A.t.NQ * 32;
-    float *eg = reinterpret_cast<float *>(A.tape + A.t.e_off);
+    const float *eg = reinterpret_cast<const float *>(A.tape + A.t.e_off);
+    float *dg = reinterpret_cast<float *>(A.tape + A.t.dout_off);
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const long long q = i >> 5;
         int b; long long p; bool inb;
@@ -594,7 +597,7 @@ __global__ __launch_bounds__(256) void dout128_kernel(BwdArgs A) {
             for (int s = 0; s < a.Sx; ++s) dE += a.dimages[((long long)b * a.Sx + s) * a.R + ray] * a.w[(long long)s * a.P + p];
             d = dE * e * (1.f - e);
         }
-        eg[i] = d;
+        dg[i] = d;
     }
 }
 
@@ -705,7 +708,9 @@ void bwd128_tape_layout(int depth, long long NQ, TapeLayout *t) {
     t->h_lin = -2 * per_tensor;                                  // h_off[l] = h_lin + l * lin_stride, l >= 2
     t->enc_off = off; off += NQ * (long long)TB;
     t->e_off = off; off += NQ * 128;
-    t->mask_off = -1; t->dout_off = -1; t->encp_off = -1;
+    t->dout_off = off; off += NQ * 128;                         // f32 dout per point (dout128_kernel), beside the recorded e
+    t->dout_stride = 128;
+    t->mask_off = -1; t->encp_off = -1;
     t->total = (long long)(((size_t)off + 1024 + 255) / 256 * 256);
 }
 

@@ -33,6 +33,11 @@ struct PolBF16 {
     static constexpr int MODE = BHN_BF16;
     static constexpr int NWAVES = 8;            // 2 waves per SIMD, <=256 VGPRs each
     static constexpr int NTHREADS = NWAVES * 64;
+    static constexpr int WPE = 2;               // waves per SIMD the kernels are built for (register budget 512 / WPE)
+#ifndef BHN_FWD_DIST
+#define BHN_FWD_DIST 4           // weight chunks in flight in the inference forward (6 measured 6 % slower here)
+#endif
+    static constexpr int FWD_DIST = BHN_FWD_DIST;
     static constexpr int ELEM_BYTES = 2;
     static constexpr int FRAG_BYTES = 1024;     // 64 lanes x 8 bf16
     static constexpr bool TAPE8 = false;        // (PolBF16T8: the h / gA tape tiles in 8 bits)
@@ -146,10 +151,24 @@ struct PolBF16T8 : PolBF16 {
     static constexpr bool TAPE8 = true;
 };
 
+// PolBF16 on HALF-size workgroups: 4 waves (one per SIMD, 256 registers each), TWO workgroups per CU, each with its own weight
+// ring.  The two waves of a SIMD then belong to different workgroups: no barrier couples them, their per-tile prologues and
+// epilogues drift apart and the wave that wins the issue arbitration no longer waits for the one that loses it.
+struct PolBF16H : PolBF16 {
+    static constexpr int NWAVES = 4;
+    static constexpr int NTHREADS = NWAVES * 64;
+#ifndef BHN_FWD_DIST_H
+#define BHN_FWD_DIST_H 3
+#endif
+    static constexpr int FWD_DIST = BHN_FWD_DIST_H;      // (DIST + 1) chunks per workgroup: two workgroups must fit 160 KB
+};
+
 struct PolF32 {
     static constexpr int MODE = BHN_F32;
     static constexpr int NWAVES = 4;            // 1 wave per SIMD, 512 registers each
     static constexpr int NTHREADS = NWAVES * 64;
+    static constexpr int WPE = 1;
+    static constexpr int FWD_DIST = 3;
     static constexpr int ELEM_BYTES = 4;
     static constexpr int FRAG_BYTES = 2048;     // 2 halves x 64 lanes x 4 f32
     static constexpr bool TAPE8 = false;

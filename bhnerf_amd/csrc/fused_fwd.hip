@@ -140,18 +140,15 @@ extern "C" int bhn_pack_weights(const bhn_model *m, int32_t mode, const float *p
 // ---------------------------------------------------------------------------------------------
 // DBG: measurement build (bit 128: per-wave time stamps [compute done, barrier passed] of the ring steps of one tile); (tools/dbg_fwd_ablate.py): a.debug bits knock out one cost at a time -- 1 hidden/output MFMAs,
 // 2 relu+pack, 4 weight DMA + its waits, 8 barriers, 16 posenc trig, 32 epilogue.  Results are then meaningless.
-#ifndef BHN_FWD_DIST
-#define BHN_FWD_DIST 4           // weight chunks in flight in the inference forward (6 measured 6 % slower here)
-#endif
 // RES: the whole weight image resident in LDS (ResidentRing: no DMA, no per-chunk barrier), when it fits
 template <int W, class Pol, int DEG, bool RENDER, bool DBG = false, bool RES = false>
-__global__ __launch_bounds__(Pol::NTHREADS) void fused_fwd_kernel(FusedArgs a) {
+__global__ __launch_bounds__(Pol::NTHREADS) __attribute__((amdgpu_waves_per_eu(Pol::WPE, Pol::WPE))) void fused_fwd_kernel(FusedArgs a) {
     const int dbg = DBG ? a.debug : 0;
     using PK = Pack<W, Pol>;
     using frag = typename Pol::frag;
     constexpr int CB = PK::CHUNK_BYTES, MT = PK::MT, KS = PK::KS;
     using RG = DmaRing<CB, Pol::NWAVES>;
-    constexpr int DIST = (Pol::ELEM_BYTES == 2) ? BHN_FWD_DIST : 3;                    // LDS-DMA weight ring: chunks in flight
+    constexpr int DIST = Pol::FWD_DIST;                                                // LDS-DMA weight ring: chunks in flight
     using RS = std::conditional_t<RES, ResidentRing<RG, CB, MT>, RingState<RG, CB, DIST, Pol::PHASE_LAG, MT, DBG>>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *ring = smem;                                              // NB x CB (resident: all chunks)
@@ -487,7 +484,7 @@ static int launch_fwd_w(FusedArgs &a, hipStream_t st) {
         // small networks: all chunks of the forward image resident in LDS, waves run without the per-chunk barrier
         if ((size_t)PK::fwd_chunks(a.depth) * PK::CHUNK_BYTES + lds_fixed <= 160 * 1024) return launch_fwd_w<W, Pol, RENDER, DBG, true>(a, st);
     }
-    const size_t lds = (RES ? (size_t)PK::fwd_chunks(a.depth) : (size_t)((Pol::ELEM_BYTES == 2 ? BHN_FWD_DIST : 3) + (Pol::PHASE_LAG ? 2 : 1))) * PK::CHUNK_BYTES + lds_fixed;
+    const size_t lds = (RES ? (size_t)PK::fwd_chunks(a.depth) : (size_t)(Pol::FWD_DIST + (Pol::PHASE_LAG ? 2 : 1))) * PK::CHUNK_BYTES + lds_fixed;
     auto kern = fused_fwd_kernel<W, Pol, 3, RENDER, DBG, RES>;
     int dev = 0;
     BHN_HIP(hipGetDevice(&dev));
@@ -523,9 +520,13 @@ static bool fwd_pair_ok(int mode, const MlpShape &s, int Sx) {
     const size_t chunk = (size_t)(s.width / 16 + 2) * PolBF16::FRAG_BYTES, chunks = 1 + (size_t)(s.depth - 1) * (s.width / 32) + 1;
     return chunks * chunk + (size_t)(s.depth + 1) * s.width * 4 + RaySum<16>::bytes(Sx) <= 160 * 1024;
 }
+#ifndef BHN_FWD_HALF
+#define BHN_FWD_HALF 0           // 1: bf16 width-256 forward on half-size workgroups, two per CU (PolBF16H)
+#endif
 static int fwd_tile_groups(const bhn_model *m, int mode, const bhn_geom *geom) {
     MlpShape s;
     if (m && geom && bhn_mlp_shape(m, &s) == BHN_OK && fwd_pair_ok(mode, s, geom->S > 0 ? geom->S : 1)) return 16;
+    if (BHN_FWD_HALF && mode == BHN_BF16 && m && bhn_mlp_shape(m, &s) == BHN_OK && s.width == 256) return PolBF16H::NWAVES;
     return (mode == BHN_BF16) ? PolBF16::NWAVES : PolF32::NWAVES;
 }
 #if BHN_FWD_PAIR
@@ -568,7 +569,9 @@ static int launch_fwd(FusedArgs &a, int width, hipStream_t st) {
         case 32: return launch_fwd_w<32, Pol, RENDER>(a, st);
         case 64: return launch_fwd_w<64, Pol, RENDER>(a, st);
         case 128: return launch_fwd_w<128, Pol, RENDER>(a, st);
-        case 256: return launch_fwd_w<256, Pol, RENDER>(a, st);
+        case 256:
+            if constexpr (BHN_FWD_HALF != 0 && Pol::ELEM_BYTES == 2) return launch_fwd_w<256, PolBF16H, RENDER>(a, st);
+            else return launch_fwd_w<256, Pol, RENDER>(a, st);
         default:
             bhn_set_error("net_width %d: fused kernels are built for 32, 64, 128, 256", width);
             return BHN_EUNSUPPORTED;

@@ -258,8 +258,12 @@ class FusedPredictor:
     def _bwd_mode(self):
         if self.mode != _hip.BHN_BF16_T8 or getattr(self, '_t8_calibrated', False):
             return self.mode
-        self._t8_calibrated = True
         return self.mode | _hip.BHN_T8_CALIBRATE
+
+    def _bwd_done(self, mode):
+        """After a backward call has been ENQUEUED without error: a calibrating call need not be repeated."""
+        if mode & _hip.BHN_T8_CALIBRATE:
+            self._t8_calibrated = True
 
     @_on_device
     def render_bwd(self, geom, tM0, dimages, out=None):
@@ -269,9 +273,11 @@ class FusedPredictor:
             out = torch.empty((self.nparams,), dtype=torch.float32, device=self.device)
         ws = self.workspace(int(tM0.numel()), geom.P_eff)
         gs, fs = geom.c_struct_fused(), self._frames(tM0)
-        _hip.check(_hip.lib().bhn_render_bwd(C.byref(self.model), self._bwd_mode(), _hip.ptr(self.packed), C.byref(gs),
+        mode = self._bwd_mode()
+        _hip.check(_hip.lib().bhn_render_bwd(C.byref(self.model), mode, _hip.ptr(self.packed), C.byref(gs),
                                              C.byref(fs), _hip.ptr(dimages), _hip.ptr(out), _hip.ptr(ws), ws.numel(),
                                              _hip.stream_ptr(self.device)))
+        self._bwd_done(mode)
         return out
 
 
@@ -317,9 +323,11 @@ class FusedPredictor:
             out = torch.empty((self.nparams,), dtype=torch.float32, device=self.device)
         ws = self.workspace(int(tM0.numel()), geom.P_eff)
         gs, fs = geom.c_struct_fused(), self._frames(tM0)
-        _hip.check(_hip.lib().bhn_render_bwd_tape(C.byref(self.model), self._bwd_mode(), _hip.ptr(self.packed), C.byref(gs),
+        mode = self._bwd_mode()
+        _hip.check(_hip.lib().bhn_render_bwd_tape(C.byref(self.model), mode, _hip.ptr(self.packed), C.byref(gs),
                                                   C.byref(fs), _hip.ptr(dimages), _hip.ptr(out), _hip.ptr(ws), ws.numel(),
                                                   _hip.stream_ptr(self.device)))
+        self._bwd_done(mode)
         return out
 
 

@@ -276,6 +276,7 @@ class NeRF_Predictor:
 
     def clear_geometry_cache(self):
         self._geoms.clear()
+        self._graph_epoch = getattr(self, '_graph_epoch', 0) + 1      # captured training steps (optimization.GraphedImageStep) are dropped too
 
     # -- reference API -----------------------------------------------------------------------------
     def init_params(self, raytracing_args=None, seed=1):

@@ -166,22 +166,32 @@ def _shared_rng(stream):
 
 
 class GraphedImageStep:
-    """One `gradient_step_image` (pack -> training forward -> chi^2 -> fused backward -> Adam) for a fixed ray set and batch
-    size, captured ONCE into a HIP graph and replayed per step.  Everything that changes from step to step lives in device
-    buffers the graph reads: the frame indices (the batch of target / sigma / offset is gathered inside the graph), the frame
-    time offsets tM0, and Adam's learning rate and bias corrections (bhn_adam_step_dev).  Per step the host fills one pinned
-    staging buffer, issues three small asynchronous copies and one graph launch -- instead of ~25 Python-level launches --
+    """One `gradient_step_image` (pack -> training forward -> chi^2 -> fused backward -> [all-reduce] -> Adam) for a fixed ray
+    set and batch size, captured ONCE into a HIP graph and replayed per step.  Everything that changes from step to step lives
+    in device buffers the graph reads: the frame indices (the batch of target / sigma / offset is gathered inside the graph),
+    the frame time offsets tM0, and Adam's learning rate and bias corrections (bhn_adam_step_dev).  Per step the host fills one
+    pinned staging buffer, issues ONE small asynchronous copy and one graph launch -- instead of ~25 Python-level launches --
     which is what a GPU needs when its share of a step is a single small frame (the reference's b = 8 on 8 devices,
-    optimization.py:289-291).  With a process group the graph ends at the gradient; the all-reduce and Adam follow eagerly.
-    The arithmetic is the un-captured step's, kernel for kernel: parameters are bitwise equal (tests/test_gpu_api.py)."""
+    optimization.py:289-291).  With an RCCL process group the all-reduce and Adam are captured too (`collective_in_graph`);
+    when the backend cannot be captured (gloo) the graph ends at the gradient and the exchange + Adam follow eagerly.
+    The arithmetic is the un-captured step's, kernel for kernel: parameters are bitwise equal (tests/test_gpu_api.py).
+
+    A HIP graph bakes raw device addresses in.  The step therefore keeps a reference to everything it captured (ray-tracing
+    dict, geometry, workspace, parameters, Adam moments, gradient buffer) and `stale()` compares them with what an eager step
+    would use NOW -- a re-allocated workspace (another ray set or batch size needed a larger one), a replaced parameter or
+    gradient tensor, an edited ray set (new geometry fingerprint), a cleared geometry cache -- before every replay; a stale
+    graph is dropped and captured again.  `loss` is returned as a copy; `images` is a VIEW of the graph's output buffer, which
+    the next step on this ray set overwrites (the reference's training loop discards it: optimization.py:132)."""
 
     def __init__(self, state, args, dtype, scale, rt, n_local):
         from . import engine, _hip
         pred = state.predictor
         eng = pred.engine()
         self.state, self.eng, self.args, self.dtype, self.scale = state, eng, args, dtype, float(scale)
+        self.rt, self.pred = rt, pred                                          # (kept alive: the cache key holds their ids)
+        self.epoch = getattr(pred, '_graph_epoch', 0)
         dev = eng.device
-        self.geom = geom = pred.geometry(rt['coords'], rt['Omega'], rt['t_geos'], network._stokes_or_none(rt['J']), rt['g'], rt['dtau'], rt['Sigma'])
+        self.geom = geom = self._geometry()
         B = self.B = int(n_local)
         if not eng.fits_tape(B, geom.P_eff):
             raise ValueError('the tape of %d frames does not fit the workspace: no graph for this step' % B)
@@ -192,8 +202,11 @@ class GraphedImageStep:
         self.GM = constants.GM_c3(t_units) if t_units is not None else 1.0
         self.t_start, self.t_inj = float(t_start), float(rt['t_injection'])
         args[np.arange(min(args.num_frames, network._world()[1]))]            # (makes the device-resident copies of the per-frame arrays)
-        # whole-movie target, sigma, offset as ONE tensor: the batch is gathered by a single index_select
-        self.full = torch.stack([engine._hip.as_f32(a, dev) for a in args._dev[:3]])
+        # whole-movie target, sigma, offset as ONE tensor (the batch is gathered by a single index_select): the stack
+        # TemporalBatchedArgs keeps for its own gathers -- no third device copy of the movie
+        if args._stack is None or args._stack.shape[0] != 3 or args._stack.dtype != torch.float32:
+            raise ValueError('target / sigma / offset of one shape and dtype expected: no graph for this step')
+        self.full = args._stack
         self.tshape = (B, geom.Sx, geom.R) if dtype == 'full' else (B, geom.Sx)
         # per-step inputs: a ring of pinned staging slots (the host runs ahead of the GPU: a slot is rewritten only after the
         # copies issued from it have executed), three device buffers the graph reads
@@ -214,9 +227,46 @@ class GraphedImageStep:
         self.d_hyp.fill_(1.0)
         self.images = torch.empty((B, geom.Sx, geom.R), dtype=torch.float32, device=dev)
         self.n = eng.nparams
-        self.with_adam = not network._dist_on()                               # (a process group: exchange + Adam stay outside the graph)
+        # a process group: the all-reduce is captured when the backend runs on the stream (RCCL); else exchange + Adam stay eager
+        self.dist = network._dist_on()
+        self.collective_in_graph = self.dist and self._backend() == 'nccl' and os.environ.get('BHNERF_GRAPH_COLLECTIVE', '1') == '1'
+        self.with_adam = (not self.dist) or self.collective_in_graph
         self.graph = None
-        self.loss = None
+        self.loss = self.lossv = None
+        self.captured = None
+
+    @staticmethod
+    def _backend():
+        import torch.distributed as dist
+        try:
+            return dist.get_backend()
+        except Exception:
+            return None
+
+    def _geometry(self):
+        rt = self.rt
+        return self.pred.geometry(rt['coords'], rt['Omega'], rt['t_geos'], network._stokes_or_none(rt['J']), rt['g'], rt['dtau'], rt['Sigma'])
+
+    def matches(self, state, rt):
+        """This entry was built for exactly these objects (the cache key is their id(): ids are only unique among LIVE
+        objects, and this entry keeps its own alive)."""
+        return state is self.state and rt is self.rt
+
+    def stale(self):
+        """True when an eager step would no longer use what this graph captured (see the class docstring)."""
+        st, eng = self.state, self.eng
+        if self.pred.engine() is not eng or getattr(self.pred, '_graph_epoch', 0) != self.epoch:
+            return True
+        if self._geometry() is not self.geom:                  # edited ray set / evicted and rebuilt geometry
+            return True
+        rt = self.rt
+        t_start = rt['t_start_obs']
+        if float(getattr(t_start, 'value', t_start)) != self.t_start or float(rt['t_injection']) != self.t_inj:
+            return True
+        if self.captured is None:
+            return False
+        ws, flat, m, v, grad = self.captured
+        return not (eng._ws is ws and st.flat is flat and st.m is m and st.v is v and st.grad_buffer() is grad)
 
     def _body(self):
         from . import engine
@@ -227,9 +277,14 @@ class GraphedImageStep:
         loss, dimg = engine.chi2_image(images, tgt, sig, off, self.scale, self.dtype)
         buf = st.grad_buffer()
         eng.render_bwd_tape(geom, self.d_tM0, dimg, out=buf[:self.n])
-        if self.with_adam:
+        lossv = loss
+        if self.collective_in_graph:
+            rank, world = network._world()
+            lossv = network.dp_allreduce(buf, self.n, loss, rank, world)            # (the reference's pmean, network.py:620)
+            engine.adam_step_dev(st.flat, buf[:self.n], st.m, st.v, self.d_hyp, grad_scale=1.0 / world)
+        elif self.with_adam:
             engine.adam_step_dev(st.flat, buf[:self.n], st.m, st.v, self.d_hyp, grad_scale=1.0)
-        return loss, buf
+        return loss, lossv, buf
 
     def _stage(self, key):
         from . import engine
@@ -245,32 +300,50 @@ class GraphedImageStep:
         self.d_buf.copy_(sl['buf'], non_blocking=True)
         sl['done'].record()
 
+    def _capture(self):
+        st = self.state
+        # two eager steps' worth of kernels on a side stream first (lazy allocations, kernel attributes, the communicator's
+        # first collective), on a COPY of the optimiser state; then the capture
+        keep = [t.clone() for t in (st.flat, st.m, st.v)]
+        s = torch.cuda.Stream(device=self.eng.device)
+        s.wait_stream(torch.cuda.current_stream(self.eng.device))
+        with torch.cuda.stream(s):
+            self._body()
+        torch.cuda.current_stream(self.eng.device).wait_stream(s)
+        for t, k in zip((st.flat, st.m, st.v), keep):
+            t.copy_(k)
+        graph = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(graph):
+                self.loss, self.lossv, self.buf = self._body()
+        except Exception:
+            if not self.collective_in_graph:
+                raise
+            # the collective refused capture: keep the exchange and Adam outside the graph
+            self.collective_in_graph, self.with_adam = False, False
+            torch.cuda.synchronize(self.eng.device)
+            for t, k in zip((st.flat, st.m, st.v), keep):
+                t.copy_(k)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self.loss, self.lossv, self.buf = self._body()
+        for t, k in zip((st.flat, st.m, st.v), keep):                          # (capture does not execute, but stay safe)
+            t.copy_(k)
+        self.graph = graph
+        self.captured = (self.eng._ws, st.flat, st.m, st.v, self.buf)
+
     def __call__(self, key):
         """key: this rank's frame indices of the step (length B).  Returns (loss vector, state, images (1, B, [S], H, W))."""
         st, geom = self.state, self.geom
         assert len(key) == self.B
         self._stage(key)
         if self.graph is None:
-            # two eager steps' worth of kernels on a side stream first (lazy allocations, kernel attributes), on a COPY of
-            # the optimiser state; then the capture
-            keep = [t.clone() for t in (st.flat, st.m, st.v)]
-            s = torch.cuda.Stream(device=self.eng.device)
-            s.wait_stream(torch.cuda.current_stream(self.eng.device))
-            with torch.cuda.stream(s):
-                self._body()
-            torch.cuda.current_stream(self.eng.device).wait_stream(s)
-            for t, k in zip((st.flat, st.m, st.v), keep):
-                t.copy_(k)
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self.loss, self.buf = self._body()
-            for t, k in zip((st.flat, st.m, st.v), keep):                          # (capture does not execute, but stay safe)
-                t.copy_(k)
+            self._capture()
         self.graph.replay()
         rank, world = network._world()
         if self.with_adam:
             st.step += 1
-            loss_vec = self.loss
+            loss_vec = self.lossv.clone()
         else:
             loss_vec = network._exchange_and_apply(st, self.buf, self.n, self.loss, rank, world)
         out = self.images.reshape((1, self.B) + ((geom.S,) if geom.S else ()) + geom.spatial)
@@ -299,16 +372,36 @@ class TrainStep(object):
         self.use_graph = os.environ.get('BHNERF_HIP_GRAPH') == '1'
         self._graphs = {}
 
+    MAX_GRAPHS = 16          # > the sub-pixel ray sets of a run (scripts use up to 10); each entry owns a HIP graph + staging
+
+    def clear_graphs(self):
+        """Drop every captured step (they are rebuilt on demand)."""
+        self._graphs.clear()
+
     def _graphed(self, state, rt, indices):
         key = shard(np.atleast_1d(np.asarray(indices)))
         gkey = (id(rt), len(key), id(state))
         g = self._graphs.get(gkey)
+        if g is not None and g is not False and (not g.matches(state, rt) or g.stale()):
+            # another object at a recycled id, or the step would no longer run on what was captured (re-allocated workspace,
+            # replaced state tensors, edited ray set, cleared geometry cache): never replay it
+            del self._graphs[gkey]
+            g = None
         if g is None:
             try:
                 g = GraphedImageStep(state, self.args[0], str(self.dtype[0]), float(self.scale[0]), rt, len(key))
             except ValueError:
-                g = False                                  # (tape does not fit: this step stays eager)
-            self._graphs[gkey] = g
+                g = False                                  # (tape does not fit / arguments of mixed shapes: this step stays eager)
+            self._graphs[gkey] = g if g else False
+            if g is False:
+                self._nograph_refs = getattr(self, '_nograph_refs', {})
+                self._nograph_refs[gkey] = (rt, state)     # (keeps the ids of a "no graph" entry from being recycled)
+            while len(self._graphs) > self.MAX_GRAPHS:
+                old = next(iter(self._graphs))
+                self._graphs.pop(old)
+                getattr(self, '_nograph_refs', {}).pop(old, None)
+        else:
+            self._graphs[gkey] = self._graphs.pop(gkey)    # LRU order
         return g(key) if g else None
 
     def __call__(self, state, raytracing_args, indices, update_state=True):

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define BHN_ABI_VERSION 2
+#define BHN_ABI_VERSION 3      /* 3: BHN_BF16_T8 / BHN_T8_CALIBRATE, bhn_adam_hyper, bhn_adam_step_dev, bhn_render_bwd_tape_kernel_name_for */
 
 enum { BHN_OK = 0, BHN_EINVAL = 1, BHN_EUNSUPPORTED = 2, BHN_EHIP = 3, BHN_EWORKSPACE = 4 };
 enum { BHN_F32 = 0, BHN_BF16 = 1, BHN_BF16_T8 = 2 };
@@ -146,7 +146,9 @@ int bhn_render_bwd(const bhn_model *m, int32_t mode, const void *packed, const b
  * bhn_render_fwd_train renders `images` AND records layer inputs, ReLU bits and emission on the tape in
  * `workspace`; bhn_render_bwd_tape then runs only the delta chain + weight-gradient GEMMs from that
  * tape.  Both calls must see the same model/geometry/frames and a workspace of at least
- * bhn_render_bwd_workspace_bytes(B,P) bytes (BHN_EWORKSPACE otherwise: use the pair above). */
+ * bhn_render_bwd_workspace_bytes(B,P) bytes (BHN_EWORKSPACE otherwise: use the pair above).
+ * bhn_render_bwd_tape only READS what the forward recorded (its own intermediates go to regions of their own), so it may
+ * be called any number of times on one recorded tape, with the same or with other `dimages`. */
 int bhn_render_fwd_train(const bhn_model *m, int32_t mode, const void *packed, const bhn_geom *geom,
                          const bhn_frames *fr, float *images, void *workspace, size_t workspace_bytes,
                          void *stream);

@@ -300,3 +300,78 @@ def test_hip_graph_step_with_the_8bit_tape(dev, problem):
     for k in (('bf16_t8', False), ('bf16_t8', True)):
         assert np.abs(runs[k] - ref).max() < 0.03 * ref.max(), (k, runs[k], ref)
     assert np.abs(runs[('bf16_t8', True)] - runs[('bf16_t8', False)]).max() < 0.01 * ref.max()
+
+
+def test_hip_graph_is_never_replayed_on_stale_addresses_or_geometry(dev, problem):
+    """A HIP graph bakes device addresses in: the captured step must be dropped and captured again when (a) a
+    second ray set with MORE points makes the engine re-allocate its workspace, (b) a ray-tracing dict is edited in place
+    (new geometry), (c) a new dict is allocated where a dead one lived (recycled id()), (d) the geometry cache is cleared.
+    Every scenario is run eagerly and through the graph path: parameters, Adam moments and losses bitwise equal."""
+    import gc
+    from bhnerf_amd import network, optimization, synthetic, units
+    p = problem
+    tgt = p['movie'].sum(axis=(-1, -2))
+    dom = (8.0, 0.0, np.inf, np.inf)
+
+    def make_rt(H, seed, J=True):
+        geo = synthetic.synthetic_geodesics(H, H, 32, fov_M=16.0, seed=seed, S=3)
+        return network.raytracing_args(dict(x=geo['coords'][0], y=geo['coords'][1], z=geo['coords'][2], dtau=geo['dtau'], Sigma=geo['Sigma'],
+                                            t=geo['t_geos'], g=geo['g']), geo['Omega'], geo['t_injection'], 0.0 * units.hr, J=geo['J'])
+
+    def run(graph):
+        pred = network.NeRF_Predictor(*dom, net_depth=4, net_width=128, mode='bf16', device=dev)
+        step = optimization.TrainStep.image(p['t_frames'] * units.hr, tgt, sigma=float(np.abs(tgt).mean()) * 0.1, dtype='lc')
+        step.use_graph = graph
+        rt_small, rt_big = make_rt(12, 3), make_rt(20, 4)
+        opt = optimization.Optimizer({'num_iters': 50, 'lr_init': 2e-3, 'lr_final': 2e-4, 'seed': 1}, pred, rt_small)
+        st, losses, events = opt.state, [], []
+
+        def do(rt, idx):
+            nonlocal st
+            loss, st, _ = step(st, rt, np.asarray(idx))
+            losses.append(loss.reshape(-1)[0].clone())
+
+        do(rt_small, [0, 1]); do(rt_small, [2, 3])
+        ws0 = pred.engine()._ws
+        do(rt_big, [1, 4])                                   # (a) larger tape: the workspace is re-allocated
+        events.append(pred.engine()._ws is not ws0)
+        do(rt_small, [0, 5]); do(rt_small, [3, 2])           # ... the small set's graph was captured on the old workspace
+        rt_small['g'] *= 1.5                                 # (b) in-place edit: new geometry
+        do(rt_small, [0, 1])
+        for k in range(4):                                   # (c) dicts that die and are re-born, possibly at the same id()
+            rt_tmp = make_rt(12, 10 + k)
+            do(rt_tmp, [k, k + 1])
+            del rt_tmp
+            gc.collect()
+        pred.clear_geometry_cache()                          # (d)
+        do(rt_big, [2, 3])
+        return st.flat.clone(), st.m.clone(), st.v.clone(), torch.stack(losses), events, step
+
+    eager, graphed = run(False), run(True)
+    assert eager[4] == [True] and graphed[4] == [True]       # the scenario really re-allocated the workspace
+    assert any(graphed[5]._graphs.values())
+    for a, b in zip(eager[:4], graphed[:4]):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('width', [128, 256])
+def test_recorded_tape_can_be_replayed(dev, problem, width):
+    """bhn_render_bwd_tape only reads what the training forward recorded (the fused width-128 backward used to turn
+    the tape's emission into dout in place): a second call on the same tape returns the same gradient bit for bit, and a
+    call with other dimages in between does not disturb it."""
+    from bhnerf_amd import constants, engine, network
+    geo = problem['geo']
+    pred = network.NeRF_Predictor(8.0, 0.0, np.inf, np.inf, net_depth=4, net_width=width, mode='bf16', device=dev)
+    eng = pred.engine()
+    geom = pred.geometry(geo['coords'], geo['Omega'], geo['t_geos'], geo['J'], geo['g'], geo['dtau'], geo['Sigma'])
+    eng.pack(eng.flatten(network.MLP(4, width).init(1, 21)))
+    tM0 = engine.frame_offsets(problem['t_frames'][:4], 0.0, geo['t_injection'], constants.GM_c3('hr'), dev)
+    gen = torch.Generator(device=dev).manual_seed(0)
+    d1 = torch.randn((4, geom.Sx, geom.R), device=dev, generator=gen)
+    d2 = torch.randn((4, geom.Sx, geom.R), device=dev, generator=gen)
+    eng.render_train(geom, tM0)
+    g1 = eng.render_bwd_tape(geom, tM0, d1).clone()
+    g2 = eng.render_bwd_tape(geom, tM0, d2).clone()
+    g1b = eng.render_bwd_tape(geom, tM0, d1).clone()
+    assert float(g1.abs().max()) > 0 and not torch.equal(g1, g2)
+    assert torch.equal(g1, g1b)

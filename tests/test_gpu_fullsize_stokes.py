@@ -180,3 +180,62 @@ def test_config3_render_with_reference_pinned_J(dev):
         for s in range(3):
             err = np.abs(got[:, s] - ref[:, s]).max() / np.abs(ref[:, s]).max()
             assert err <= tol, (mode, s, err)
+
+
+@pytest.mark.parametrize('name', ['config5', 'config3'])
+def test_polarised_lightcurve_gradient_against_oracle_on_a_ray_subset(dev, name, capsys):
+    """the gradient of the 'lc' chi-square of the three Stokes light curves at the shapes of configs 3 and 5
+    (S = 3, point-compacted recovery domain, 8 frames) against torch.autograd on the float64 oracle, the loss restricted to
+    256 rays of the full geometry (rays are independent; the light curve of a subset is the subset's own sum).  Config 5 is
+    the reference-default 4x128 network: in bf16 its gradient comes out of bwd128_kernel (fused delta chain + dW), held
+    here to the ORACLE and not to the library's other backward route.  Tolerances: f32 2e-5, bf16 3e-2 relative L2
+    (observed values are printed)."""
+    from oracle import oracle_torch as ot
+    from bhnerf_amd import network, units
+    p = make_problem(name, dev)
+    c, geo = p['c'], p['geo']
+    G, HW = c['G'], c['H'] * c['W']
+    # 256 rays drawn among those that cross the recovery domain (most rays of the 40 M field of view miss |z| <= 4, r <= 20)
+    r2 = (geo['coords'] ** 2).sum(0).reshape(HW, G)
+    inside = ((r2 >= c['rmin'] ** 2) & (r2 <= c['rmax'] ** 2) & (np.abs(geo['coords'][2].reshape(HW, G)) <= c['z_width'])).sum(1)
+    cand = np.nonzero(inside >= 4)[0]
+    rays = np.sort(np.random.default_rng(41).choice(cand, size=256, replace=False))
+    sub = lambda v: np.ascontiguousarray(v.reshape((-1, G))[rays].reshape(16, 16, G))
+    g = dict(coords=np.stack([sub(geo['coords'][i]) for i in range(3)]), Omega=sub(geo['Omega']), t_geos=sub(geo['t_geos']),
+             g=sub(geo['g']), dtau=sub(geo['dtau']), Sigma=sub(geo['Sigma']), J=np.stack([sub(geo['J'][s]) for s in range(3)]))
+    t64 = lambda x: torch.tensor(np.asarray(x, dtype=np.float64))
+    ks, bs = ot.tree_to_lists(p['tree'], torch.float64)
+    geom_t = dict(coords=t64(g['coords']), Omega=t64(g['Omega']), t_geos=t64(g['t_geos']), g=t64(g['g']), dtau=t64(g['dtau']),
+                  Sigma=t64(g['Sigma']), J=t64(g['J']), t_start_obs=0.0, t_injection=float(geo['t_injection']))
+    hp = dict(GM_c3=p['GM_c3'], scale=c['rmax'], rmin=c['rmin'], rmax=c['rmax'], z_width=c['z_width'], posenc_deg=3, net_depth=4)
+    tr = ot.CpuTrainer(ks, bs, geom_t, hp)
+    with torch.no_grad():
+        lc0 = tr.forward(t64(p['t_frames'])).sum(dim=(-1, -2)).numpy()                    # (B, 3) light curves of the subset
+    assert np.abs(lc0[:, 0]).max() > 0
+    rng = np.random.default_rng(42)
+    target = lc0 * rng.uniform(0.7, 1.3, lc0.shape)
+    sigma = np.abs(lc0).mean(axis=0, keepdims=True) * rng.uniform(0.05, 0.2, lc0.shape) + 1e-30
+    offset = np.zeros_like(lc0)
+    loss_ref, _, grads_ref = tr.loss_and_grad(t64(p['t_frames']), t64(target), t64(sigma), t64(offset), 1.0, 'lc')
+    n = len(tr.k)
+    gref = np.concatenate([np.concatenate([grads_ref[i].numpy().ravel(), grads_ref[n + i].numpy().ravel()]) for i in range(n)])
+    assert np.linalg.norm(gref) > 0
+    for mode, l2tol in (('f32', 2e-5), ('bf16', 3e-2)):
+        pred = network.NeRF_Predictor(c['rmax'], c['rmin'], c['rmax'], c['z_width'], net_depth=4, net_width=c['width'], mode=mode, device=dev)
+        gm = pred.geometry(g['coords'], g['Omega'], g['t_geos'], g['J'], g['g'], g['dtau'], g['Sigma'])
+        assert gm.compact is not None and gm.S == 3                                       # the point-compacted layout, three Stokes planes
+        params = pred.engine().flatten(p['tree']).requires_grad_(True)
+        tree = network.ParamTree()
+        tree.flat = params
+        loss, _ = network.loss_fn_image(tree, pred.apply, target, sigma, offset, p['t_frames'], g['coords'], g['Omega'], g['J'],
+                                        g['g'], g['dtau'], g['Sigma'], 0.0, g['t_geos'], float(geo['t_injection']), 1.0, units.hr, 'lc')
+        loss.backward()
+        gdev = params.grad.cpu().numpy().astype(np.float64)
+        lerr = abs(loss.item() - loss_ref.item()) / abs(loss_ref.item())
+        err = float(np.linalg.norm(gdev - gref) / np.linalg.norm(gref))
+        emax = float(np.abs(gdev - gref).max() / np.abs(gref).max())
+        with capsys.disabled():
+            print('\n[%s %s] lc gradient vs f64 oracle on 256 rays: rel L2 %.3e, max-norm %.3e, loss rel err %.3e (active fraction %.3f)'
+                  % (name, mode, err, emax, lerr, gm.active_fraction))
+        assert lerr <= (1e-5 if mode == 'f32' else 3e-2)
+        assert err < l2tol, (mode, err)

@@ -11,7 +11,7 @@
 #   <tag>_telemetry_bench.txt     board power / SMI clock during 400 training steps of bench.py (tools/smi_sample.py)
 # The files land in gpurun_out/profiles/ (merged back by gpurun); copy them to profiles/ and commit.
 set -euo pipefail
-TAG=${1:-r4}
+TAG=${1:-r5}
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/profiles
@@ -38,6 +38,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 LIBMD5=$(md5sum $R/bhnerf_amd/csrc/libbhnerf_hip.so | cut -d" " -f1)
 export LIBMD5
+export REPO_ROOT=$R
 for W in 256 128; do
 export PMC_W=$W
 python3 - > $O/${TAG}_pmc_traffic$( [ $W = 128 ] && echo _w128 ).json <<'PY'
@@ -45,12 +46,9 @@ import csv, json, collections, os
 PFX = '/tmp/pm_' if os.environ.get('PMC_W') == '256' else '/tmp/pw_'
 out = collections.OrderedDict()
 ms = collections.defaultdict(list)
-def short(k):
-    if 'chain_kernel' in k: return 'chain_kernel<MODE_FWD_TRAIN>' if ', 1>' in k else 'chain_kernel<MODE_CHAIN>' if ', 2>' in k else None
-    for n in ('bwd128_kernel', 'dout128_kernel', 'reduce128_kernel', 'dw_kernel', 'reduce_kernel', 'rt_kernel', 'adam_kernel', 'chi2_image_kernel', 'pack_weights_kernel', 'eht_vis_kernel', 'eht_bwd_kernel'):
-        if n in k: return n
-    if 'fused_fwd_kernel' in k: return 'fused_fwd_kernel (inference)'
-    return None
+import sys
+sys.path.insert(0, os.environ['REPO_ROOT'] + '/tools')
+from kernel_names import short_name as short, expected_kernels
 for c in ('FETCH_SIZE', 'WRITE_SIZE'):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(PFX + '%s.csv' % c)):
@@ -63,12 +61,18 @@ for c in ('FETCH_SIZE', 'WRITE_SIZE'):
 for n, d in out.items():
     d['hbm_bytes'] = int((2 * d.get('FETCH_SIZE_KiB', 0) + d.get('WRITE_SIZE_KiB', 0)) * 1024)
     d['ms_under_profiler'] = round(sum(ms[n]) / len(ms[n]), 4)
+missing = [k for k in expected_kernels(int(os.environ['PMC_W'])) if k not in out or 'FETCH_SIZE_KiB' not in out[k] or 'WRITE_SIZE_KiB' not in out[k]]
+if missing:          # (round 4: a renamed template argument dropped both chain kernels from this file without a word)
+    sys.exit('collect_profiles: kernels missing from the traffic passes: %s (names seen: %s)' % (missing, sorted(out)))
+step = [k for k in expected_kernels(int(os.environ['PMC_W'])) if 'inference' not in k]
+out['step_mlp_kernels_sum'] = {'kernels': step, 'hbm_bytes': sum(out[k]['hbm_bytes'] for k in step)}
 print(json.dumps({'lib_md5': os.environ.get('LIBMD5'), 'note': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace) of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity-mode --no-tape8 --no-tutorial-domain --no-other-configs --no-width128`; averages per launch in KiB as reported; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 with the gfx950 correction (FETCH_SIZE reports half of wide coalesced reads, MI355X_MICROARCH.md HBM section)', 'kernels': out}, indent=1))
 PY
 done
 need $O/${TAG}_pmc_traffic.json
 need $O/${TAG}_pmc_traffic_w128.json
 for W in 256 128; do
+export PMC_W=$W
 SFX=$( [ $W = 128 ] && echo _w128 || true )
 bash $R/tools/pmc_collect.sh bf16 $W > /tmp/sq.log 2>&1
 ls $R/gpurun_out/pmc/pass*.txt > /dev/null
@@ -95,6 +99,11 @@ for k, c in d.items():
                   'cu_cycles_per_cu': round(cu / 256), 'ms': c.get('duration_ms')}
     except KeyError:
         pass
+sys.path.insert(0, os.environ['REPO_ROOT'] + '/tools')
+from kernel_names import expected_kernels
+missing = [k for k in expected_kernels(int(os.environ['PMC_W'])) if k not in out]
+if missing:
+    sys.exit('collect_profiles: kernels missing from the SQ counter passes: %s (names seen: %s)' % (missing, sorted(d)))
 print(json.dumps({'lib_md5': os.environ.get('LIBMD5'), 'note': 'from sq_counters.txt (rocprofv3 --pmc SQ_* passes of tools/pmc_run.py, one launch each): mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES) = fraction of SIMD cycles with the matrix pipe busy', 'kernels': out}, indent=1))
 PY
 done

@@ -16,13 +16,15 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_
   rocprofv3 --pmc $grp --kernel-trace --output-format csv -d /tmp/pmc_$i -o p -- python3 $R/tools/pmc_run.py $MODE $WIDTH > /tmp/pmc_$i.log 2>&1
   grep -i -E "error|traceback|exception" /tmp/pmc_$i.log | head -5; ls -R /tmp/pmc_$i | head -8; f=$(find /tmp/pmc_$i -name "*counter_collection.csv" | head -1)
   echo "pass $i: $f"
-  [ -n "$f" ] && python3 - "$f" > $R/gpurun_out/pmc/pass$i.txt <<'PY'
+  [ -n "$f" ] && python3 - "$f" $R > $R/gpurun_out/pmc/pass$i.txt <<'PY'
 import csv, sys, collections
+sys.path.insert(0, sys.argv[2] + '/tools')
+from kernel_names import short_name, FWD_NAME, CHAIN_NAME, FUSED_NAME, INFER_NAME
 rows = list(csv.DictReader(open(sys.argv[1])))
 agg = collections.OrderedDict()
 for r in rows:
-    k = r['Kernel_Name'][:60]
-    if not any(s in k for s in ('chain_kernel', 'dw_kernel', 'fused_fwd_kernel', 'bwd128_kernel', 'fwd128')): continue
+    k = short_name(r['Kernel_Name'])                 # (template arguments matched by position: tools/kernel_names.py)
+    if k not in (FWD_NAME, CHAIN_NAME, FUSED_NAME, INFER_NAME, 'dw_kernel'): continue
     d = agg.setdefault(k, collections.OrderedDict())
     d.setdefault(r['Counter_Name'], []).append(float(r['Counter_Value']))
     d.setdefault('duration_ms', []).append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) * 1e-6)
