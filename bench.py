@@ -190,8 +190,8 @@ def other_configs(dev, mode):
     B = 8
     out = {}
 
-    def time_steps(step, opt, rt, n_warm=2, n=3):
-        idx = np.arange(B)
+    def time_steps(step, opt, rt, n_warm=2, n=3, nb=B):
+        idx = np.arange(nb)
         for _ in range(n_warm):
             opt.loss, opt.state, _ = step(opt.state, rt, idx)
         torch.cuda.synchronize()
@@ -212,13 +212,33 @@ def other_configs(dev, mode):
         target = np.random.default_rng(5).uniform(0.5, 1.5, (B, 3)).astype(np.float32)
         step = optimization.TrainStep.image(t_frames * units.hr, target, sigma=0.1, dtype='lc')
         opt = optimization.Optimizer({'num_iters': 100, 'lr_init': 1e-4, 'lr_final': 1e-6}, pred, rt)
-        dt = time_steps(step, opt, rt)
+        small = c['H'] <= 64
+        dt = time_steps(step, opt, rt, n=20 if small else 3)
         gm = pred.geometry(rt['coords'], rt['Omega'], rt['t_geos'], rt['J'], rt['g'], rt['dtau'], rt['Sigma'])
         n = B * c['H'] * c['W'] * c['G']
         out[name] = {'workload': '%dx%d rays x %d samples, Stokes I/Q/U, loss lc, 4x%d MLP, %d frames/step' % (c['H'], c['W'], c['G'], c['width'], B),
                      'dtype': mode, 'ms_per_step': round(1e3 * dt, 3), 'value': round(n / dt, 1), 'unit': 'ray-samples/s',
                      'active_fraction': round(gm.active_fraction, 4), 'visited_fraction': round(gm.visited_fraction, 4),
                      'tape_frame_group': (B if pred.engine().fits_tape(B, gm.P_eff) else pred.engine().tape_group(B, gm.P_eff))}
+        # the same steps captured into a HIP graph (hparams['hip_graph']): eager and graph side by side
+        step.use_graph = True
+        try:
+            dtg = time_steps(step, opt, rt, n_warm=3, n=20 if small else 3)
+            if any(step._graphs.values()):
+                out[name]['ms_per_step_hip_graph'] = round(1e3 * dtg, 3)
+            if small:       # the reference's own batch size (scripts/Fit_ALMA_LP_Apr11_SgrA_Flare.yaml:46: batchsize 6)
+                step.use_graph = False
+                dt6 = time_steps(step, opt, rt, n=20, nb=6)
+                step.use_graph = True
+                dt6g = time_steps(step, opt, rt, n_warm=3, n=20, nb=6)
+                out[name + '_batch6'] = {'workload': out[name]['workload'].replace('%d frames/step' % B, '6 frames/step'), 'dtype': mode,
+                                         'ms_per_step': round(1e3 * dt6, 3), 'ms_per_step_hip_graph': round(1e3 * dt6g, 3),
+                                         'value': round(6 * c['H'] * c['W'] * c['G'] / dt6, 1), 'unit': 'ray-samples/s'}
+        except Exception as exc:
+            out[name]['hip_graph_error'] = repr(exc)
+        finally:
+            step.use_graph = False
+            step.clear_graphs()
         del opt, pred, gm, rt
         torch.cuda.empty_cache()
     # config 4: EHT2017 (u, v) tracks from the reference's station file (fixture g11: data, made by tests/golden/make_eht2017.py)

@@ -75,6 +75,16 @@ static inline int bhn_norm_mode(int mode) { return ((mode & 0xff) == BHN_BF16_T8
 // BHN_EINVAL (BHN_CHECK_DEVICE), the same answer DeviceOnce::run gives for such an id.
 int bhn_num_cus(int device);
 
+// Grid of a persistent kernel over `units` equal work items on at most `max_grid` workgroups: the smallest grid with the same
+// number of rounds as max_grid (365 items on 256 CUs take two rounds either way: 183 workgroups then do what 256 would, with
+// fewer weight preludes and fewer per-workgroup gradient slabs to flush and reduce).
+static inline long long bhn_balanced_grid(long long units, long long max_grid) {
+    if (units <= 0 || max_grid <= 0) return 1;
+    if (units <= max_grid) return units;
+    const long long rounds = (units + max_grid - 1) / max_grid;
+    return (units + rounds - 1) / rounds;
+}
+
 // Per-device one-time setup of a kernel (hipFuncSetAttribute applies to the device that is current when it is
 // called; a process may drive several devices, from several threads): run `f` once per device, remember its result.
 // Only SUCCESS is remembered: a transient failure (e.g. an earlier sticky asynchronous error on that device) is returned

@@ -38,6 +38,9 @@
 #else
 #define BHN_DBG(x) 0
 #endif
+#ifndef BHN_EXP_NO_GA0
+#define BHN_EXP_NO_GA0 0         // 1 (MEASUREMENT build, gradient of layer 0 wrong): gA_0 neither recorded nor streamed -- the upper bound of a
+#endif                           // delta chain that accumulates dW_0 itself (round 5)
 #ifndef BHN_TAPED_DIST
 #define BHN_TAPED_DIST 7         // weight chunks in flight in the training-forward / delta-chain kernels (bf16; 4 measured 2 % slower)
 #endif
@@ -418,7 +421,11 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
     const FusedArgs &a = A.f;
     const int edbg = BHN_DBG(((A.debug >> 6) & 3) | (A.policy << 2));  // measurement aid for the tape emission (bits 2,3: store policy)
     constexpr int sdbg = 0;                        // (a run-time MFMA-skip flag put every MFMA in its own basic block)
-    using RG = DmaRing<CB, Pol::NWAVES>;
+    // the delta chain's transposed image never uses the two encoded-input fragments of a chunk: its ring copies (and its steps
+    // stream) only the KS hidden fragments
+    // (KS >= 8: the A-fragment prefetch of a step runs LDS_PREFETCH - 1 fragments into the NEXT chunk, which must have that many)
+    constexpr int NFR = (MODE == MODE_CHAIN && KS >= 8) ? KS : KS + 2;
+    using RG = DmaRing<RES ? CB : NFR * Pol::FRAG_BYTES, Pol::NWAVES>;
     constexpr int DIST = BG::RING_DIST_TAPED;
     using RS = std::conditional_t<RES, ResidentRing<RG, CB, MT>, RingState<RG, CB, DIST, false, MT, BHN_CHAIN_STAMPS != 0>>;
     // stores guaranteed younger than chunk c+2 at the end of step c (RingState::step_end): every interval between
@@ -729,7 +736,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
                     const int pm = m == 0 ? MT - 1 : m - 1;
                     frag &d0 = m == 0 ? dl[KS - 2] : next[2 * (m > 0 ? m - 1 : 0)];
                     frag &d1 = m == 0 ? dl[KS - 1] : next[2 * (m > 0 ? m - 1 : 0) + 1];
-                    const bool no_ga = A.t.drop_ga && pnd_layer == a.depth - 1;     // gA_{depth-1}'s last tile: not recorded
+                    const bool no_ga = (A.t.drop_ga && pnd_layer == a.depth - 1) || (BHN_EXP_NO_GA0 && pnd_layer == 0);     // gA_{depth-1}'s last tile: not recorded
                     TapePost<Pol, false> post(pend, d0, d1, pnd_mask, em, A.tape + ga_lin + pnd_layer * lin_stride + (qs * MT + pm) * TT,
                                                   nullptr, nullptr, no_acc, T8 && (pm & 1), false, no_ga ? (edbg | 2) : edbg, t8_sc, t8_amax);
                     if (!(m & 1)) {                                  // word (l-1, m/2): use the oldest, fetch two ahead
@@ -737,11 +744,12 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
                         mq0 = mq1;
                         mq1 = chain_word(mask_g, (a.depth - 1 - l) * MW + (m >> 1) + 2);
                     }
-                    const f32x16 acc = ring_step<W, Pol, RG>(ch, chn, ap, dl, enc, false,
+                    const f32x16 acc = ring_step<W, Pol, RG, TapePost<Pol, false>, NFR>(ch, chn, ap, dl, enc, false,
                                                              (l == LEND && m == MT - 1) ? first_bias : zero_lds, post, dj, sdbg);
                     // without the gA_{depth-1} emissions the intervals around this layer's first DMA issue hold one
                     // emission less: the step ends whose window reaches back to it count one less (small widths: none)
-                    if (A.t.drop_ga && l == a.depth - 1 && m <= 4) rs.template step_end<YS_L1>();
+                    if (BHN_EXP_NO_GA0 && l == LEND && m >= 1) rs.template step_end<0>();
+                    else if (A.t.drop_ga && l == a.depth - 1 && m <= 4) rs.template step_end<YS_L1>();
                     else if (A.t.drop_ga && l == a.depth - 1) rs.template step_end<(KS >= 16 ? YS : 0)>();
                     else rs.template step_end<YS>();
                     pend = acc;
@@ -760,7 +768,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
             }
             if (a.depth > 1) {           // flush the last tile of gA_{LEND-1} (no further step to hide it behind)
                 TapePost<Pol, false> post(pend, dl[KS - 2], dl[KS - 1], pnd_mask, em,
-                                              A.tape + ga_lin + (LEND - 1) * lin_stride + (qs * MT + MT - 1) * TT, nullptr, nullptr, no_acc, T8 && ((MT - 1) & 1), false, edbg,
+                                              A.tape + ga_lin + (LEND - 1) * lin_stride + (qs * MT + MT - 1) * TT, nullptr, nullptr, no_acc, T8 && ((MT - 1) & 1), false, BHN_EXP_NO_GA0 ? (edbg | 2) : edbg,
                                               t8_sc, t8_amax);
                 post.all();
                 if constexpr (T8) t8_flush(LEND - 1, t8_amax);
@@ -1784,6 +1792,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) __attribute__((amdgpu_waves_per_eu(P
     int job = 0;
     while (job < depth && (int)blockIdx.x >= A.wg_begin[job + 1]) ++job;
     if (BHN_DBG(A.debug >> 2) && (A.debug >> 2) - 1 != job) return;
+    if (BHN_EXP_NO_GA0 && job == 0) return;
 #ifdef BHN_T8_ONLY_JOB          // measurement builds: only this job of the 8-bit tape's dW kernel runs (the release build has no run-time switches)
     if (Pol::TAPE8 && job != BHN_T8_ONLY_JOB) return;
 #endif
@@ -2130,6 +2139,7 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
                 work[l] = (tp > 0.075 * kib ? tp : 0.075 * kib) + 0.1;
             }
             if (l > last_job) work[l] = 0;
+            if (BHN_EXP_NO_GA0 && l == 0) work[l] = 0.01;
             tot += work[l];
         }
         int used = 0;
@@ -2209,8 +2219,7 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
         A.wrap = dbg_env_int("BHN_DEBUG_WRAP", 0);
         A.policy = dbg_env_int("BHN_DEBUG_POLICY", 0);
 #endif
-        long long grid = ncu;
-        if (grid > A.f.total_tiles) grid = A.f.total_tiles;
+        const long long grid = bhn_balanced_grid(A.f.total_tiles, ncu);
         if (what == RUN_FWD_TRAIN) {
             hipLaunchKernelGGL(k_fwd, dim3((unsigned)grid), dim3(Pol::NTHREADS), lds_fwd, st, A);
             BHN_HIP(hipGetLastError());
@@ -2226,8 +2235,8 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
                 hipLaunchKernelGGL(k_fwd, dim3((unsigned)grid), dim3(Pol::NTHREADS), lds_fwd, st, A);
                 BHN_HIP(hipGetLastError());
             }
-            long long g128 = A.t.NQ / 4;
-            if (g128 > ncu) g128 = ncu;
+            // (later passes ACCUMULATE onto the slabs of the first: never more workgroups than the first pass had)
+            const long long g128 = bhn_balanced_grid(A.t.NQ / 4, (pass > 0 && nslabs128 > 0 && nslabs128 < ncu) ? nslabs128 : ncu);
             if ((int)g128 > nslabs128) nslabs128 = (int)g128;
             const int rc128 = bwd128_launch(A, depth, (int)g128, st);
             if (rc128 != BHN_OK) return rc128;

@@ -569,12 +569,15 @@ DEVI void prio_flip(int t, int wvu) {
 // One output tile of a hidden / output / delta-chain layer: acc = ap.bias + sum_ks A[ks] . src[ks] (+ the enc
 // block when with_enc), A streamed from the ring chunk `ch`; reads the head of the next chunk `chn` and the bias
 // rows `bias_next` of the next tile before returning (both consumed after the barrier).
-template <int W, class Pol, class RG, class Post>
+// NFR: fragments of a chunk the step streams -- KS + 2 (hidden fragments + the encoded-input block), or KS for chunk
+// sequences that never use the encoded-input block (the transposed image of the delta chain: `with_enc` must be false)
+template <int W, class Pol, class RG, class Post, int NFR = W / 16 + 2>
 DEVI f32x16 ring_step(const char *ch, const char *chn, APipe<Pol> &ap, const typename Pol::frag (&src)[W / 16],
                       const typename Pol::frag (&enc)[2], bool with_enc, const float *bias_next, Post &post, DmaJob dma,
                       int dbg = 0) {
     const int lane = threadIdx.x & 63;
-    constexpr int KS = W / 16, NF = KS + 2, PF = Pol::LDS_PREFETCH;
+    constexpr int KS = W / 16, NF = NFR, PF = Pol::LDS_PREFETCH;
+    static_assert(NF == KS + 2 || (NF == KS && KS >= PF - 1), "chunk fragments (the prefetch reaches PF - 1 fragments into the next chunk)");
     typename Pol::frag a[PF];
 #pragma unroll
     for (int i = 0; i < PF - 1; ++i) a[i] = ap.f[i];
@@ -696,14 +699,20 @@ DEVI void lds_barrier() {
 // are resident or in flight; step_end() waits for this wave's pieces of chunk c+2 (NOT c+1: the A-fragment
 // prefetch of the next step reads chunk c+2 before that step's barrier) and synchronises the workgroup.
 // ---------------------------------------------------------------------------------------------
+// CB: bytes between consecutive chunks of the packed image (the source stride).  RG copies RG::NPIECE KiB of each chunk and
+// the ring buffers are RG::NPIECE KiB apart -- normally the whole chunk; the delta chain leaves out the two encoded-input
+// fragments its transposed image never uses (16 instead of 18 pieces at width 256: two instead of three DMA issues per wave
+// and step).
 template <class RG, int CB, int DIST, bool LAG, int MT = 1, bool STAMPS = false>
 struct RingState {
+    static constexpr int CBL = RG::NPIECE * 1024;          // bytes copied per chunk = stride of the ring buffers in LDS
+    static_assert(CBL <= CB, "the ring copies at most a whole chunk");
     // LAG (measured, not used): the second wave of every SIMD (waves NWAVES/2..) consumes the ring ONE STEP BEHIND
     // the first, so that the two waves of a SIMD are never in their per-tile VALU phases at the same time.  Costs one
     // more resident chunk and one idle step per wave; 5 % slower in the render kernel.
     static constexpr int NB = DIST + (LAG ? 2 : 1);
     static_assert(DIST >= 2, "ring geometry");
-    __host__ __device__ static constexpr size_t lds_bytes(int) { return (size_t)NB * CB; }
+    __host__ __device__ static constexpr size_t lds_bytes(int) { return (size_t)NB * CBL; }
     char *ring;
     // chunk sequence of one tile, consumed cyclically: NCA forward chunks (img_a, in order), then the transposed
     // chunks of the delta chain (img_b): hidden layers nlb .. 1, MT chunks each, stored layer-major ascending
@@ -722,8 +731,8 @@ struct RingState {
     // and rotated at the step end (3 SALU) instead of being derived from `cur` each time (three wrap()s and multiplies:
     // ~25 of the 140-190 instructions of a ring step, round-2 ISA census).
     int o_cur, o_nxt, o_prv, wvu;
-    DEVI const char *ch() const { return ring + opaque(LAG ? wrap(cur - lag) * CB : o_cur); }
-    DEVI const char *chn() const { return ring + opaque(LAG ? wrap(cur - lag + 1) * CB : o_nxt); }
+    DEVI const char *ch() const { return ring + opaque(LAG ? wrap(cur - lag) * CBL : o_cur); }
+    DEVI const char *chn() const { return ring + opaque(LAG ? wrap(cur - lag + 1) * CBL : o_nxt); }
     DEVI unsigned next_src() {
         unsigned src;
         if (issue_c < NCA) src = (unsigned)issue_c * CB;
@@ -736,7 +745,7 @@ struct RingState {
     }
     DEVI DmaJob job() {
         if (dbg & 4) return DmaJob{false, 0u, nullptr, rs, wvu};
-        return DmaJob{true, next_src(), ring + (LAG ? wrap(cur - 2) * CB : o_prv), rs, wvu};
+        return DmaJob{true, next_src(), ring + (LAG ? wrap(cur - 2) * CBL : o_prv), rs, wvu};
     }
     // STORES: global stores this wave is GUARANTEED to have issued after the DMA pieces of chunk c+2 (issued in the
     // middle of step c-2) other than the two younger chunks: vmcnt retires in order and counts stores, so they may
@@ -756,7 +765,7 @@ struct RingState {
         else {
             o_prv = o_cur;
             o_cur = o_nxt;
-            o_nxt = (o_nxt == (NB - 1) * CB) ? 0 : o_nxt + CB;
+            o_nxt = (o_nxt == (NB - 1) * CBL) ? 0 : o_nxt + CBL;
         }
     }
     DEVI void idle_step() {      // a step in which this wave consumes nothing (lagging waves: first; the others: last)
@@ -769,11 +778,11 @@ struct RingState {
         off_b = b_ ? (unsigned)(b_ - a_) : 0u;                  // (the transposed image follows the forward image)
         rs = RG::resource(a_);
         dbg = dbg_; cur = 0; issue_c = 0; lag = LAG ? lag_ : 0; ts = nullptr;
-        o_cur = 0; o_nxt = CB; o_prv = (NB - 1) * CB;
+        o_cur = 0; o_nxt = CBL; o_prv = (NB - 1) * CBL;
         wvu = opaque(__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)));
         if constexpr (BHN_PRIO_MODE == 1) { if (wvu >= 4) __builtin_amdgcn_s_setprio(1); }
 #pragma unroll
-        for (int j = 0; j < DIST; ++j) RG::issue(DmaJob{true, next_src(), ring + j * CB, rs, wvu});
+        for (int j = 0; j < DIST; ++j) RG::issue(DmaJob{true, next_src(), ring + j * CBL, rs, wvu});
         RG::template wait_younger<RG::PPW * (DIST - 2)>();
         lds_barrier();
     }

@@ -498,8 +498,7 @@ static int launch_fwd_w(FusedArgs &a, hipStream_t st) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, kern, Pol::NTHREADS, lds) == hipSuccess && o > 0) occ = o;
         return hipSuccess;
     }));
-    long long grid = (long long)bhn_num_cus(dev) * once.value[dev];
-    if (grid > a.total_tiles) grid = a.total_tiles;
+    const long long grid = bhn_balanced_grid(a.total_tiles, (long long)bhn_num_cus(dev) * once.value[dev]);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(Pol::NTHREADS), lds, st, a);
     BHN_HIP(hipGetLastError());
     return BHN_OK;

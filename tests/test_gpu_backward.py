@@ -436,15 +436,20 @@ def test_taped_training_path_equals_recompute_path(dev, golden, tag, mode):
     assert torch.equal(grad, grad_ref)
 
 
-@pytest.mark.parametrize('depth', [2, 3, 5])
-def test_networks_without_skip_connection(dev, depth):
+@pytest.mark.parametrize('depth,width,B,do_skip', [(2, 64, 2, False), (3, 64, 2, False), (5, 64, 2, False),
+                                                   (4, 128, 2, False),      # the fused width-128 backward with the skip tile discarded
+                                                   (4, 128, 6, True),       # ... and at the reference's own batch size 6
+                                                   (4, 128, 6, False)])     #     (scripts/Fit_ALMA_LP_Apr11_SgrA_Flare.yaml:46)
+def test_networks_without_skip_connection_and_batch_of_six(dev, depth, width, B, do_skip):
     """do_skip=False with depths outside the reference's 4/6/8 (two hidden layers: the layer-1 weight-gradient job
-    that recomputes h_1 is also the last hidden layer): images and gradient vs the oracle.  (Depth 1 is rejected.)"""
+    that recomputes h_1 is also the last hidden layer) and at width 128 / depth 4, where the gradient comes out of
+    bwd128_kernel<4, 3> with the skip layer's encoded-input tile discarded by reduce128_kernel;
+    frame batches of 6, the reference's own batch size: images and gradient vs the f64 oracle.  (Depth 1 is rejected.)"""
     from bhnerf_amd import network, units, _hip
     with pytest.raises(_hip.HipError):
         network.NeRF_Predictor(8.0, net_depth=1, net_width=64, do_skip=False, device=dev).engine()
-    rng = np.random.default_rng(100 + depth)
-    H, Wd, G, B, width = 6, 5, 40, 2, 64
+    rng = np.random.default_rng(100 + depth + width + B)
+    H, Wd, G = 6, 5, 40
     alpha, beta = np.meshgrid(np.linspace(-7, 7, H), np.linspace(-7, 7, Wd), indexing='ij')
     s = np.linspace(-9.0, 9.0, G)
     coords = np.stack([alpha[..., None] * np.ones(G), beta[..., None] * 0.5 + s * 0.8, -beta[..., None] * 0.8 + s * 0.5])
@@ -452,8 +457,8 @@ def test_networks_without_skip_connection(dev, depth):
     f32r = lambda v: np.asarray(v, dtype=np.float32).astype(np.float64)
     geo = {k: f32r(v) for k, v in dict(coords=coords, Omega=1.0 / (r ** 1.5 + 0.1), t_geos=-(1000.0 - (s + 9.0)) * np.ones_like(r),
                                         g=rng.uniform(0.6, 1.4, r.shape), Sigma=r ** 2, dtau=(s[1] - s[0]) / r ** 2).items()}
-    t_frames = np.array([0.1, 0.7]); t_inj = -(1000.0 - 3.0)
-    tree = onp.he_uniform_params(rng, depth, width, 21, do_skip=False, dtype=np.float32)
+    t_frames = np.linspace(0.1, 0.7, B); t_inj = -(1000.0 - 3.0)
+    tree = onp.he_uniform_params(rng, depth, width, 21, do_skip=do_skip, dtype=np.float32)
     for i in range(depth + 1):
         d = tree['MLP_0']['Dense_%d' % i]
         d['kernel'] = d['kernel'].astype(np.float64); d['bias'] = f32r(rng.uniform(-0.1, 0.1, d['bias'].shape))
@@ -462,7 +467,7 @@ def test_networks_without_skip_connection(dev, depth):
     ks, bs = ot.tree_to_lists(tree, torch.float64)
     geom_t = dict(coords=t64(geo['coords']), Omega=t64(geo['Omega']), t_geos=t64(geo['t_geos']), g=t64(geo['g']), dtau=t64(geo['dtau']),
                   Sigma=t64(geo['Sigma']), J=None, t_start_obs=0.0, t_injection=t_inj)
-    hp = dict(GM_c3=onp.GM_C3_SGRA_HR, scale=8.0, rmin=2.0, rmax=8.0, z_width=4.0, posenc_deg=3, net_depth=depth, do_skip=False)
+    hp = dict(GM_c3=onp.GM_C3_SGRA_HR, scale=8.0, rmin=2.0, rmax=8.0, z_width=4.0, posenc_deg=3, net_depth=depth, do_skip=do_skip)
     tr = ot.CpuTrainer(ks, bs, geom_t, hp)
     target = rng.uniform(0, 1e-2, (B, H, Wd)); sigma = rng.uniform(0.5, 2.0, (B, H, Wd)); offset = np.zeros((B, H, Wd))
     loss_ref, img_ref, grads_ref = tr.loss_and_grad(t64(t_frames), t64(target), t64(sigma), t64(offset), 1.0, 'full')
@@ -471,7 +476,7 @@ def test_networks_without_skip_connection(dev, depth):
     assert np.abs(gref).max() > 0
     f = lambda k: np.ascontiguousarray(geo[k].astype(np.float32))
     for mode in ('f32', 'bf16'):
-        pred = network.NeRF_Predictor(8.0, 2.0, 8.0, 4.0, net_depth=depth, net_width=width, do_skip=False, mode=mode, device=dev)
+        pred = network.NeRF_Predictor(8.0, 2.0, 8.0, 4.0, net_depth=depth, net_width=width, do_skip=do_skip, mode=mode, device=dev)
         params = pred.engine().flatten(tree).requires_grad_(True)
         ptree = network.ParamTree(); ptree.flat = params
         loss, [images] = network.loss_fn_image(ptree, pred.apply, target, sigma, offset, t_frames, f('coords'), f('Omega'), 1.0, f('g'),

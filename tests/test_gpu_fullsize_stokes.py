@@ -213,8 +213,14 @@ def test_polarised_lightcurve_gradient_against_oracle_on_a_ray_subset(dev, name,
         lc0 = tr.forward(t64(p['t_frames'])).sum(dim=(-1, -2)).numpy()                    # (B, 3) light curves of the subset
     assert np.abs(lc0[:, 0]).max() > 0
     rng = np.random.default_rng(42)
-    target = lc0 * rng.uniform(0.7, 1.3, lc0.shape)
-    sigma = np.abs(lc0).mean(axis=0, keepdims=True) * rng.uniform(0.05, 0.2, lc0.shape) + 1e-30
+    # A well-conditioned chi-square: residuals of at least 40 % of the light curve and ONE noise level (a fraction of the Stokes I
+    # light curve) for all three Stokes parameters, as an instrument has.  (The Q and U light curves are sums of signed pixels
+    # that cancel to a few per cent of I at these inclinations; with sigma_Q ~ |lc_Q| and a residual that is a small difference
+    # of large numbers, the float32 rounding of the SUM over pixels is amplified by lc_I / lc_Q / residual fraction: a first
+    # version of this test measured 8e-4 (config 5) and 6e-5 (config 3) in the f32 mode that way -- the arithmetic of an f32
+    # light curve, which the f32 reference shares, not of the kernels.)
+    target = lc0 * rng.uniform(0.3, 0.6, lc0.shape)
+    sigma = np.abs(lc0[:, :1]).mean() * rng.uniform(0.05, 0.2, lc0.shape)
     offset = np.zeros_like(lc0)
     loss_ref, _, grads_ref = tr.loss_and_grad(t64(p['t_frames']), t64(target), t64(sigma), t64(offset), 1.0, 'lc')
     n = len(tr.k)
