@@ -26,6 +26,11 @@ struct TapeLayout {
     // tile at depth 4) and the dW job of layer 0 rebuilds gA_0 = (h_1 != 0) (.) W_1 gA_1 from the gA_1 tiles it streams
     // instead (the same bytes), with its rows of W_1 in registers (dw_body_first_r)
     int drop_ga0;
+    // bf16, width 256, depth >= 3 (round 5): gA_0 is not on the tape and NOBODY streams it: the delta chain itself accumulates
+    // dW_0 = gA_0^T [enc | 1] -- every wave stages its finished gA_0 tile in LDS, wave m adds tile m of all eight waves to the
+    // ONE accumulator tile it owns (fused_bwd.hip "dW_0 inside the delta chain") -- and flushes it to BwdArgs::slab0; the dW
+    // kernel has no layer-0 job.  The encoded-input tile on the tape carries 1 in slot 31 (the bias column), as for fused128.
+    int ga0_chain;
     long long dout_stride;                     // bytes per group of the dout region: tile (+ 32 f32 when drop_ga)
     // width-128 bf16 networks of depth <= 4 (fused_bwd128.hip): the tape holds only what the FORWARD knows -- h_1 .. h_depth,
     // the encoded inputs (slot 31 set to 1: the bias column of the fused dW GEMMs) and e; no relu bits (the fused
@@ -54,6 +59,11 @@ struct BwdArgs {
     // [0 .. 7] the power-of-two scale of gA_l in this call, [8 .. 15] the largest |gA_l| it saw, [16 .. 23] their ratios to
     // |dimages|max carried to the next call, [24] |dimages|max
     float *t8;
+    // TapeLayout::ga0_chain: dW_0 slabs of the delta chain's workgroups, [workgroup][tile m][1024] in the dW slab tile layout,
+    // and how many workgroups wrote them (the reduce kernel sums them in workgroup order)
+    float *slab0;
+    int n_chain_wg;
+    int chain_step;                            // stride of the dW_0 slabs that hold the stage-1 sums (chain_slab_stage1)
 };
 
 

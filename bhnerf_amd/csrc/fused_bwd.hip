@@ -38,9 +38,15 @@
 #else
 #define BHN_DBG(x) 0
 #endif
-#ifndef BHN_EXP_NO_GA0
-#define BHN_EXP_NO_GA0 0         // 1 (MEASUREMENT build, gradient of layer 0 wrong): gA_0 neither recorded nor streamed -- the upper bound of a
-#endif                           // delta chain that accumulates dW_0 itself (round 5)
+#ifndef BHN_GA0_CHAIN
+#define BHN_GA0_CHAIN 1          // bf16, width 256, depth >= 3: the delta chain accumulates dW_0 itself (TapeLayout::ga0_chain); 0: A/B builds
+#endif
+#ifndef BHN_GA0C_ABL
+#define BHN_GA0C_ABL 0           // measurement builds (dW_0 wrong): 1 no consumer (no extra MFMAs / staged-tile reads), 2 no staging writes, 4 no encoded-input DMA
+#endif
+#ifndef BHN_GA0C_DIST
+#define BHN_GA0C_DIST 4          // weight chunks in flight in that delta chain (its LDS also holds 64 KB of staging images)
+#endif
 #ifndef BHN_TAPED_DIST
 #define BHN_TAPED_DIST 7         // weight chunks in flight in the training-forward / delta-chain kernels (bf16; 4 measured 2 % slower)
 #endif
@@ -275,8 +281,42 @@ __host__ __device__ static inline int t8_feature(int t, int n) {
 //   k-step  6, 8   identity fragments from LDS; relu bits -> tape word, two
 //                  transposing MFMAs
 //   k-step 12      bf16 convert + two 1 KiB non-temporal stores to the tape (after the step's DMA issue at k-step 9)
-template <class Pol, bool RELU>
+// Delta chain with TapeLayout::ga0_chain: the wave that OWNS dW_0's accumulator tile m adds the staged gA_0 tile m of every wave of
+// the workgroup to it -- sixteen MFMAs (source wave p >> 1, k half p & 1), operands by transposed reads of the LDS staging
+// images (point on the K index, exactly as the dW kernel reads its tape tiles), two pairs of fragments in flight.  A block of
+// its own between the wave's ring step and the step's barrier: interleaved with the ring step's MFMAs (a second copy of every
+// step body) it cost the consumer the same ~1000 cycles and every OTHER step ~150 more (profiles/r5_chain_stamps.txt).
+struct Ga0Consumer {
+    const char *ga, *enc;        // staged gA_0 tiles / encoded-input tiles of the eight source waves (2 KiB apart)
+    int trl;                     // tr_lane_off()
+#ifndef BHN_GA0C_PF
+#define BHN_GA0C_PF 3            // fragment pairs in flight in the consumer block (8 registers each)
+#endif
+    DEVI void run(f32x16 &acc, int npairs) const {
+        constexpr int PF = BHN_GA0C_PF;
+        bf16x8 a[PF], b[PF];
+#pragma unroll
+        for (int p = 0; p < PF - 1; ++p) {
+            a[p] = tr_frag(ga + (p >> 1) * 2048, p & 1, trl);
+            b[p] = tr_frag(enc + (p >> 1) * 2048, p & 1, trl);
+        }
+#pragma unroll
+        for (int p = 0; p < npairs; ++p) {
+            const int q = p + PF - 1;
+            if (q < npairs) {
+                a[q % PF] = tr_frag(ga + (q >> 1) * 2048, q & 1, trl);
+                b[q % PF] = tr_frag(enc + (q >> 1) * 2048, q & 1, trl);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[p % PF], b[p % PF], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+};
+template <class Pol, bool RELU, bool STAGE = false>
 struct TapePost {
+    char *stage = nullptr;       // STAGE: the finished tile also goes to this LDS image (staging image of a gA_0 tile, or the sink)
+    int stage_off = 0;           // TapeEmit::native_off(0) of the lane
     const f32x16 &pend;
     typename Pol::frag &d0, &d1;
     unsigned mask;
@@ -361,6 +401,16 @@ struct TapePost {
         }
     }
     DEVI void store_tile() {
+        if constexpr (STAGE) {
+            // GA0C kernels: a finished gA_0 tile goes to its LDS staging image instead of the tape: two ds_write_b128 in the tape's slot
+            // layout (TapeEmit::native_off).  (Writing EVERY tile to LDS -- the others to a sink -- to save this wave-uniform branch
+            // measured 4 % slower on the kernel: profiles/r5_ab_ga0_chain.txt.)
+            if (stage) {
+                *reinterpret_cast<typename Pol::frag *>(stage + stage_off) = d0;
+                *reinterpret_cast<typename Pol::frag *>(stage + stage_off + 128) = d1;
+                return;
+            }
+        }
         if (edbg & 2) return;
         if constexpr (Pol::TAPE8) store_tile8();
         else if constexpr (Pol::ELEM_BYTES == 2) TapeEmit<Pol>::store_native(dst, d0, d1, edbg);
@@ -389,6 +439,7 @@ struct TapePost {
         bits_and_transpose();
         store_tile();
     }
+    DEVI void finish() {}
 };
 
 #ifdef BHN_DEBUG
@@ -408,8 +459,10 @@ enum { MODE_FWD_TRAIN = 1, MODE_CHAIN = 2 };
 // Weight-chunk stream of one tile: forward chunks 0..NCF-1 (MODE_FWD_TRAIN) or the transposed chunks of hidden
 // layers depth-1 .. 1 (MODE_CHAIN); the ring wraps to the next tile's first chunk.
 // RES: the whole chunk sequence resident in LDS (fused_common.h ResidentRing: no DMA, no per-chunk barrier), when it fits
-template <int W, class Pol, int DEG, int MODE, bool RES = false>
+template <int W, class Pol, int DEG, int MODE, bool RES = false, bool GA0C = false>
 __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
+    static_assert(!GA0C || (MODE == MODE_CHAIN && !RES && Pol::ELEM_BYTES == 2 && W / 32 == Pol::NWAVES),
+                  "dW_0 inside the delta chain: bf16, one gA_0 tile per wave, the barrier-stepped ring");
     using PK = Pack<W, Pol>;
     using BG = BwdGeom<W, Pol>;
     using frag = typename Pol::frag;
@@ -425,8 +478,8 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
     // stream) only the KS hidden fragments
     // (KS >= 8: the A-fragment prefetch of a step runs LDS_PREFETCH - 1 fragments into the NEXT chunk, which must have that many)
     constexpr int NFR = (MODE == MODE_CHAIN && KS >= 8) ? KS : KS + 2;
-    using RG = DmaRing<RES ? CB : NFR * Pol::FRAG_BYTES, Pol::NWAVES>;
-    constexpr int DIST = BG::RING_DIST_TAPED;
+    using RG = DmaRing<RES ? CB : NFR * Pol::FRAG_BYTES, Pol::NWAVES, GA0C>;     // (GA0C: transposed LDS reads in the kernel -> asm DMA)
+    constexpr int DIST = GA0C ? BHN_GA0C_DIST : BG::RING_DIST_TAPED;
     using RS = std::conditional_t<RES, ResidentRing<RG, CB, MT>, RingState<RG, CB, DIST, false, MT, BHN_CHAIN_STAMPS != 0>>;
     // stores guaranteed younger than chunk c+2 at the end of step c (RingState::step_end): every interval between
     // two DMA issues holds the >= ES stores of one pending-tile emission; with >= 16 k-steps the running step's
@@ -455,6 +508,12 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
     char *seg_lds = id_lds + (Pol::ELEM_BYTES == 2 ? 0 : 2 * Pol::FRAG_BYTES);   // RaySum scratch (bf16 has no identity table)
     // 8-bit tape, delta chain (no RaySum there): 8 layer scales, then one |gA|max slot per layer and wave
     float *t8_lds = reinterpret_cast<float *>(seg_lds);
+    // GA0C: staging images behind the fixed part (host: lds_fixed) -- the encoded-input tiles of the workgroup's eight groups
+    // (two tile parities) and the finished gA_0 tiles of the running / the previous step, all in the tape's slot layout
+    constexpr int STG = Pol::NWAVES * TB;                              // one image: a 2-KiB tile per wave
+    char *encS = seg_lds + RaySum<Pol::NWAVES>::bytes(A.f.Sx);
+    char *gaS = encS + 2 * STG;
+    const int stage_off = TapeEmit<Pol>::native_off(0);
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 31, h = lane >> 5;
     const int wvu = __builtin_amdgcn_readfirstlane(wv);           // the wave index as a scalar: tape addresses stay in SGPRs
@@ -533,6 +592,17 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
     // costs 12 registers the 4x256 kernel does not have)
     ChainIn cnxt;
     if constexpr (MODE == MODE_CHAIN) cnxt = load_chain(blockIdx.x);
+    // GA0C: dW_0 accumulator tiles (rows = an output tile of layer 0, columns = encoded-input slots, column 31 = bias).  The OLDER wave
+    // of every SIMD (waves 0 .. NWAVES/2 - 1) owns two -- tiles w and w + NWAVES/2 -- and the younger none: the older wave wins
+    // the issue arbitration and reaches every barrier ~500 cycles before its partner (ring-step stamps), so the
+    // consumer block runs in time the wave would otherwise spend waiting
+    constexpr int NCW = Pol::NWAVES / 2;             // consumer waves
+    f32x16 cacc0 = {}, cacc1 = {};
+    Ga0Consumer cons;
+    cons.trl = tr_lane_off(); cons.ga = cons.enc = nullptr;
+    int tpar = 0;                                    // parity of the tile: which encS image it uses
+    bool have_prev = false;                          // the previous tile's gA_0 tiles MT-2, MT-1 are staged and not yet consumed
+    bool has_next = false;                           // this workgroup has another tile after the running one (its inputs are being prefetched)
     for (long long tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
         PointIn in;
         if constexpr (MODE != MODE_CHAIN) in = load_point<Pol::NWAVES>(a, tile, wv, pl);
@@ -551,9 +621,9 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
         if constexpr (MODE != MODE_CHAIN) {
             point_prologue<Pol, DEG>(a, in, enc, live);
             // the encoded inputs are the B operand of dW_0 and of the skip layer
-            if (A.t.fused128) {
+            if (A.t.fused128 || A.t.ga0_chain) {
                 // slot 31 (k-step 1, lane half 1, element 7; an unused slot: zero weight rows) carries 1 on the tape: against
-                // it the fused dW GEMMs of fused_bwd128.hip produce the bias gradients
+                // it the fused dW GEMMs of fused_bwd128.hip (and the delta chain's own dW_0, ga0_chain) produce the bias gradients
                 frag e1 = enc[1];
                 if (h) Pol::set(e1, 7, 1.f);
                 em.emit(A.tape + A.t.enc_off + q * TB, enc[0], e1, edbg);
@@ -629,6 +699,15 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
         } else {
             cnxt = load_chain(tile + gridDim.x);
             e = cin.e;
+            has_next = tile + gridDim.x < a.total_tiles;
+            if constexpr (GA0C) {                    // this group's encoded-input tile (tape, slot 31 = 1) -> encS[tpar][wave]
+                const char *esrc = A.tape + A.t.enc_off + q * TB;
+                char *edst = encS + tpar * STG + wvu * TB;
+                if (!(BHN_GA0C_ABL & 4)) {
+                    dma_1k_asm<1>(esrc, edst);
+                    dma_1k_asm<1>(esrc + 1024, edst + 1024);
+                }
+            }
         }
         // ---- e ; dE, dout -----------------------------------------------------------------------
         float dout = 0.f;
@@ -736,19 +815,57 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
                     const int pm = m == 0 ? MT - 1 : m - 1;
                     frag &d0 = m == 0 ? dl[KS - 2] : next[2 * (m > 0 ? m - 1 : 0)];
                     frag &d1 = m == 0 ? dl[KS - 1] : next[2 * (m > 0 ? m - 1 : 0) + 1];
-                    const bool no_ga = (A.t.drop_ga && pnd_layer == a.depth - 1) || (BHN_EXP_NO_GA0 && pnd_layer == 0);     // gA_{depth-1}'s last tile: not recorded
-                    TapePost<Pol, false> post(pend, d0, d1, pnd_mask, em, A.tape + ga_lin + pnd_layer * lin_stride + (qs * MT + pm) * TT,
-                                                  nullptr, nullptr, no_acc, T8 && (pm & 1), false, no_ga ? (edbg | 2) : edbg, t8_sc, t8_amax);
+                    const bool no_ga = (A.t.drop_ga && pnd_layer == a.depth - 1) || (GA0C && pnd_layer == 0);     // gA_{depth-1}'s last tile: not recorded; GA0C: gA_0 is staged
+                    // GA0C: a finished gA_0 tile goes to the LDS staging image gaS[tile & 1] instead of the tape
+                    const bool staged = GA0C && pnd_layer == 0 && !(BHN_GA0C_ABL & 2);
+                    char *stage = staged ? gaS + (pm & 1) * STG + wvu * TB : nullptr;
                     if (!(m & 1)) {                                  // word (l-1, m/2): use the oldest, fetch two ahead
                         mcur = mq0;
                         mq0 = mq1;
                         mq1 = chain_word(mask_g, (a.depth - 1 - l) * MW + (m >> 1) + 2);
                     }
-                    const f32x16 acc = ring_step<W, Pol, RG, TapePost<Pol, false>, NFR>(ch, chn, ap, dl, enc, false,
-                                                             (l == LEND && m == MT - 1) ? first_bias : zero_lds, post, dj, sdbg);
+                    // GA0C: the consumer of this step is wave (m - 2) mod MT: in layer 1 it adds the gA_0 tile m - 2 (staged in step
+                    // m - 1, published by that step's barrier) of all waves to its accumulator; in the first two steps of the NEXT
+                    // tile waves MT-2, MT-1 do the same for the previous tile's last two gA_0 tiles
+                    bool cons_on = false;
+                    const int ctile = (m + MT - 2) % MT;             // the gA_0 tile consumed in step m (of layer 1; m <= 1: of the next tile's first layer)
+                    if constexpr (GA0C) {
+                        if (!(BHN_GA0C_ABL & 1) && wvu == ctile % NCW) {
+                            if (l == 1 && m >= 2) { cons_on = true; cons.ga = gaS + (m & 1) * STG; cons.enc = encS + tpar * STG; }
+                            else if (l == a.depth - 1 && m <= 1 && have_prev) { cons_on = true; cons.ga = gaS + m * STG; cons.enc = encS + (tpar ^ 1) * STG; }
+                        }
+                    }
+                    const float *bias_nx = (l == LEND && m == MT - 1) ? first_bias : zero_lds;
+                    char *tdst = A.tape + ga_lin + pnd_layer * lin_stride + (qs * MT + pm) * TT;
+                    TapePost<Pol, false, GA0C> post(pend, d0, d1, pnd_mask, em, tdst, nullptr, nullptr, no_acc, T8 && (pm & 1), false,
+                                                    no_ga ? (edbg | 2) : edbg, t8_sc, t8_amax);
+                    post.stage = stage; post.stage_off = stage_off;
+                    const f32x16 acc = ring_step<W, Pol, RG, TapePost<Pol, false, GA0C>, NFR, GA0C>(ch, chn, ap, dl, enc, false, bias_nx, post, dj, sdbg);
+                    if constexpr (GA0C) {
+                        if (cons_on) { if (ctile / NCW) cons.run(cacc1, 2 * MT); else cons.run(cacc0, 2 * MT); }      // (m is unrolled: folded)
+                    }
                     // without the gA_{depth-1} emissions the intervals around this layer's first DMA issue hold one
                     // emission less: the step ends whose window reaches back to it count one less (small widths: none)
-                    if (BHN_EXP_NO_GA0 && l == LEND && m >= 1) rs.template step_end<0>();
+                    if constexpr (GA0C) {
+                        // tile emissions (ES stores each) among this step and the DIST - 2 before it: none in the steps whose pending tile
+                        // is a gA_0 tile (layer 1, m >= 1) or gA_{depth-1}'s (first step of a tile)
+                        static_assert(!GA0C || BHN_GA0C_DIST == 4, "the store counts below are written for a window of three steps");
+                        // The first two steps of a tile also have the tile top's operations inside their window -- two encoded-input DMA
+                        // pieces, the dout store, this step's relu-bit word, and with a next tile its prefetch (MW + 2 relu-bit words, e):
+                        // counting them keeps the HBM latency of that prefetch out of the step end (every count is a lower bound)
+                        constexpr int TOP = 4, TOPN = TOP + MW + 3;
+                        if (l == a.depth - 1) {
+                            if (m == 0) { if (has_next) rs.template step_end<TOPN>(); else rs.template step_end<TOP>(); }
+                            else if (m == 1) { if (has_next) rs.template step_end<ES + TOPN>(); else rs.template step_end<ES + TOP>(); }
+                            else if (m == 2) rs.template step_end<2 * ES>();
+                            else rs.template step_end<3 * ES>();
+                        } else if (l == 1) {
+                            if (m == 0) rs.template step_end<3 * ES>();
+                            else if (m == 1) rs.template step_end<2 * ES>();
+                            else if (m == 2) rs.template step_end<ES>();
+                            else rs.template step_end<0>();
+                        } else rs.template step_end<3 * ES>();
+                    }
                     else if (A.t.drop_ga && l == a.depth - 1 && m <= 4) rs.template step_end<YS_L1>();
                     else if (A.t.drop_ga && l == a.depth - 1) rs.template step_end<(KS >= 16 ? YS : 0)>();
                     else rs.template step_end<YS>();
@@ -767,13 +884,45 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
                 for (int ks = 0; ks < KS - 2; ++ks) dl[ks] = next[ks];
             }
             if (a.depth > 1) {           // flush the last tile of gA_{LEND-1} (no further step to hide it behind)
-                TapePost<Pol, false> post(pend, dl[KS - 2], dl[KS - 1], pnd_mask, em,
-                                              A.tape + ga_lin + (LEND - 1) * lin_stride + (qs * MT + MT - 1) * TT, nullptr, nullptr, no_acc, T8 && ((MT - 1) & 1), false, BHN_EXP_NO_GA0 ? (edbg | 2) : edbg,
+                TapePost<Pol, false, GA0C> post(pend, dl[KS - 2], dl[KS - 1], pnd_mask, em,
+                                              A.tape + ga_lin + (LEND - 1) * lin_stride + (qs * MT + MT - 1) * TT, nullptr, nullptr, no_acc, T8 && ((MT - 1) & 1), false, GA0C ? (edbg | 2) : edbg,
                                               t8_sc, t8_amax);
+                if constexpr (GA0C) { post.stage = gaS + ((MT - 1) & 1) * STG + wvu * TB; post.stage_off = stage_off; }     // consumed in the second step of the next tile
                 post.all();
                 if constexpr (T8) t8_flush(LEND - 1, t8_amax);
             }
+            if constexpr (GA0C) { tpar ^= 1; have_prev = true; }
         }   // MODE_CHAIN
+    }
+    if constexpr (GA0C) {
+        // the last tile's gA_0 tiles MT-2, MT-1 have no next tile to be consumed in: one barrier (publishes tile MT-1's staging),
+        // then waves MT-2, MT-1 add them; every wave flushes its accumulator tile to the workgroup's dW_0 slab
+        if (have_prev) {
+            lds_barrier();
+            if (wvu == (MT - 2) % NCW || wvu == (MT - 1) % NCW) {       // tiles MT-2, MT-1: the second tile of their owners
+                cons.ga = gaS + (wvu & 1) * STG; cons.enc = encS + (tpar ^ 1) * STG;
+                cons.run(cacc1, 2 * MT);
+            }
+        }
+        if (wvu < NCW) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                float *tp = A.slab0 + ((long long)blockIdx.x * MT + wvu + k * NCW) * 1024;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e4 = 0; e4 < 4; ++e4) v[e4] = k ? cacc1[4 * g4 + e4] : cacc0[4 * g4 + e4];
+                    f32x4 *dst = reinterpret_cast<f32x4 *>(tp + g4 * 256 + lane * 4);
+                    if (A.accumulate) {
+                        const f32x4 old = *dst;
+#pragma unroll
+                        for (int e4 = 0; e4 < 4; ++e4) v[e4] += old[e4];
+                    }
+                    *dst = v;
+                }
+            }
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may land after the workgroup has released its LDS
     if constexpr (T8 && MODE == MODE_CHAIN) {
@@ -1792,7 +1941,6 @@ __global__ __launch_bounds__(Pol::NTHREADS) __attribute__((amdgpu_waves_per_eu(P
     int job = 0;
     while (job < depth && (int)blockIdx.x >= A.wg_begin[job + 1]) ++job;
     if (BHN_DBG(A.debug >> 2) && (A.debug >> 2) - 1 != job) return;
-    if (BHN_EXP_NO_GA0 && job == 0) return;
 #ifdef BHN_T8_ONLY_JOB          // measurement builds: only this job of the 8-bit tape's dW kernel runs (the release build has no run-time switches)
     if (Pol::TAPE8 && job != BHN_T8_ONLY_JOB) return;
 #endif
@@ -1851,6 +1999,22 @@ struct ReduceGeom {
     }
 };
 
+// Stage 1 of the reduction of the delta chain's dW_0 slabs (TapeLayout::ga0_chain): block (tile, part) adds the slabs
+// [part * per, (part + 1) * per) of its tile in order and leaves the sum in the first slab of its range (no block reads what
+// another one writes); reduce_kernel then adds the `parts` partial sums.  A serial sum over 256 slabs in 8 blocks is latency-bound.
+__global__ __launch_bounds__(256) void chain_slab_stage1(BwdArgs A, int mt, int per) {
+    const int tile = blockIdx.x, s0 = blockIdx.y * per, s1 = (s0 + per < A.n_chain_wg) ? s0 + per : A.n_chain_wg;
+    if (s0 >= s1) return;
+    float *base = A.slab0 + (long long)tile * 1024 + threadIdx.x * 4;
+    f32x4 sum = *reinterpret_cast<const f32x4 *>(base + (long long)s0 * mt * 1024);
+    for (int wg = s0 + 1; wg < s1; ++wg) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(base + (long long)wg * mt * 1024);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sum[e] += v[e];
+    }
+    *reinterpret_cast<f32x4 *>(base + (long long)s0 * mt * 1024) = sum;
+}
+
 template <int W, class Pol>
 __global__ __launch_bounds__(256) void reduce_kernel(BwdArgs A) {
     using BG = BwdGeom<W, Pol>;
@@ -1874,6 +2038,17 @@ __global__ __launch_bounds__(256) void reduce_kernel(BwdArgs A) {
     const int tid = threadIdx.x, g4 = tid >> 6, lane = tid & 63, hh = lane >> 5, col = lane & 31;
     const float *src = A.f.slabs + (long long)(mrow * BG::NTMAX + n) * 1024 + g4 * 256 + lane * 4;
     f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    const bool from_chain = l == 0 && A.t.ga0_chain;                // dW_0 slabs of the delta chain's workgroups: [wg][tile mi][1024],
+    if (from_chain) {                                                // encoded-input tile with the bias in column 31
+        if (n != 0) return;
+        // (the slabs that hold the stage-1 sums of chain_slab_stage1: every A.chain_step-th)
+        const float *s0 = A.slab0 + (long long)mi * 1024 + g4 * 256 + lane * 4;
+        for (int wg = 0; wg < A.n_chain_wg; wg += A.chain_step) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(s0 + (long long)wg * MT * 1024);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sum[e] += v[e];
+        }
+    } else
     for (int wg = A.wg_begin[jl]; wg < A.wg_begin[jl + 1]; ++wg) {
         const f32x4 v = *reinterpret_cast<const f32x4 *>(src + (long long)wg * BG::SLAB_FLOATS);
 #pragma unroll
@@ -1888,14 +2063,18 @@ __global__ __launch_bounds__(256) void reduce_kernel(BwdArgs A) {
         const int c = (Pol::TAPE8 && !(l == 1 && A.t.drop_h1)) ? t8_feature(n, col) : 32 * n + col;
         if (c < WT) kin = c;
     }
-    else if (n < nB) { const int fe = bhn_enc_slot_feature(col, A.f.deg); if (fe >= 0) kin = (has_h ? WT : 0) + fe; }
+    else if (n < nB) {
+        const int fe = bhn_enc_slot_feature(col, A.f.deg);
+        if (fe >= 0) kin = (has_h ? WT : 0) + fe;
+        else if (from_chain && col == 31) is_bias = true;           // slot 31 of the recorded inputs is 1
+    }
     else is_bias = col == 0;
     if (kin < 0 && !is_bias) return;
     const int outw = out ? 1 : WT;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int r = 4 * g4 + e, row = (r & 3) + 4 * hh + 8 * (r >> 2);
-        const int o = out ? 0 : Pol::TAPE8 ? t8_feature(mi, row) : 32 * mi + row;
+        const int o = out ? 0 : (Pol::TAPE8 && !from_chain) ? t8_feature(mi, row) : 32 * mi + row;      // (the chain's dW_0 tiles: bf16 staging, natural rows)
         if (out ? row != 0 : o >= WT) continue;
         A.dparams[is_bias ? A.bias_off[l] + o : A.kernel_off[l] + kin * outw + o] = sum[e];
     }
@@ -1985,6 +2164,15 @@ extern "C" int bhn_debug_set_bwd_stages(int32_t mask) {
 }
 #endif
 
+// the delta chain accumulates dW_0 itself (TapeLayout::ga0_chain): bf16, one gA_0 tile per wave (width 256),
+// depth >= 3 (the chain then starts from the folded W_out image: bhn_folds_wout)
+template <int W, class Pol>
+static constexpr bool ga0_chain_ok(int depth) {
+    // (not the 8-bit tape mode: its delta chain has 16 registers less to spare and spills with the consumer's state)
+    return BHN_GA0_CHAIN != 0 && BHN_DROP_GA0 == 0 && Pol::ELEM_BYTES == 2 && !Pol::TAPE8 &&
+           W / 32 == Pol::NWAVES && depth >= 3;
+}
+
 template <int W, class Pol>
 static void tape_layout(int depth, bool layer1_takes_enc, long long NQ, TapeLayout *t) {
     using BG = BwdGeom<W, Pol>;
@@ -2000,15 +2188,16 @@ static void tape_layout(int depth, bool layer1_takes_enc, long long NQ, TapeLayo
     if (t->drop_h1) { t->encp_off = off; off += NQ * (long long)BG::TILE_BYTES; }
     t->drop_ga = bhn_folds_wout(Pol::MODE, depth);
     t->drop_ga0 = BHN_DROP_GA0 && t->drop_ga && t->drop_h1 && BG::MT == Pol::NWAVES;     // (one feature tile of gA_0 per wave)
+    t->ga0_chain = ga0_chain_ok<W, Pol>(depth) && t->drop_ga;
     for (int l = 0; l < depth; ++l) {
-        if ((l == depth - 1 && t->drop_ga) || (l == 0 && t->drop_ga0)) { t->ga_off[l] = -1; continue; }
+        if ((l == depth - 1 && t->drop_ga) || (l == 0 && (t->drop_ga0 || t->ga0_chain))) { t->ga_off[l] = -1; continue; }
         t->ga_off[l] = off; off += per_tensor;
     }
     t->lin_stride = per_tensor;
     {
         const int lmin = t->drop_h1 ? 2 : 1;
         t->h_lin = (lmin <= depth ? t->h_off[lmin] : 0) - lmin * per_tensor;
-        t->ga_lin = t->drop_ga0 ? t->ga_off[1] - per_tensor : t->ga_off[0];
+        t->ga_lin = (t->drop_ga0 || t->ga0_chain) ? t->ga_off[1] - per_tensor : t->ga_off[0];
     }
     t->enc_off = off; off += NQ * (long long)BG::TILE_BYTES;
     t->dout_stride = t->drop_ga ? 128 : BG::TILE_BYTES;         // 32 f32 dout per group, or dout as an A tile (row 0 = dout)
@@ -2054,7 +2243,10 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
     // width 128, bf16, depth 4 (the reference's default network): delta chain and weight gradients fused in one kernel, the
     // gradient accumulated on chip, a tape of h_l / enc / e only (fused_bwd128.hip)
     const bool f128 = bwd128_supported(Pol::MODE, W, s.depth);
-    const size_t slab_bytes = align_up(f128 ? bwd128_slab_bytes(ncu) : (size_t)grid_dw * BG::SLAB_FLOATS * 4, 256);
+    // (ga0_chain: + one dW_0 slab of MT tiles per delta-chain workgroup, behind the dW kernel's slabs)
+    const bool ga0c = !f128 && ga0_chain_ok<W, Pol>(s.depth) && bhn_folds_wout(Pol::MODE, s.depth);
+    const size_t slab_dw_bytes = align_up(f128 ? bwd128_slab_bytes(ncu) : (size_t)grid_dw * BG::SLAB_FLOATS * 4, 256);
+    const size_t slab_bytes = slab_dw_bytes + (ga0c ? align_up((size_t)ncu * BG::MT * 4096, 256) : 0);
     auto layout = [&](long long NQ, TapeLayout *t) {
         if (f128) bwd128_tape_layout(s.depth, NQ, t);
         else tape_layout<W, Pol>(s.depth, s.depth >= 2 && s.skip_in[1], NQ, t);
@@ -2095,6 +2287,7 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
         return BHN_EWORKSPACE;
     }
     A.f.slabs = reinterpret_cast<float *>(workspace);
+    A.slab0 = ga0c ? reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + slab_dw_bytes) : nullptr;
     A.tape = reinterpret_cast<char *>(workspace) + slab_bytes + t8_bytes;
     A.t8 = Pol::TAPE8 ? reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + slab_bytes) : nullptr;
     if constexpr (Pol::TAPE8) {
@@ -2139,7 +2332,7 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
                 work[l] = (tp > 0.075 * kib ? tp : 0.075 * kib) + 0.1;
             }
             if (l > last_job) work[l] = 0;
-            if (BHN_EXP_NO_GA0 && l == 0) work[l] = 0.01;
+            if (t1.ga0_chain && l == 0) work[l] = 0;               // dW_0 comes out of the delta chain: no layer-0 job
             tot += work[l];
         }
         int used = 0;
@@ -2149,7 +2342,7 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
             if (n < 1) n = 1;
             if (l == last_job) n = grid_dw - used;
             if (n < 1) n = 1;
-            if (l > last_job) n = 0;
+            if (l > last_job || (t1.ga0_chain && l == 0)) n = 0;
             used += n;
             A.wg_begin[l + 1] = used;
         }
@@ -2176,19 +2369,24 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
     constexpr bool CAN_RES = BHN_RESIDENT != 0 && W <= 128 && BHN_CHAIN_STAMPS == 0 && !BHN_DROP_GA0;     // (width 256: no second instantiation)
     const bool rf = CAN_RES && res_fwd <= 160 * 1024, rch = CAN_RES && res_chn <= 160 * 1024;
     auto k_fwd = rf ? chain_kernel<W, Pol, 3, MODE_FWD_TRAIN, CAN_RES> : chain_kernel<W, Pol, 3, MODE_FWD_TRAIN, false>;
+    constexpr bool CAN_GA0C = ga0_chain_ok<W, Pol>(3);                // (compile-time part of the condition: which widths instantiate it)
     auto k_chn = rch ? chain_kernel<W, Pol, 3, MODE_CHAIN, CAN_RES> : chain_kernel<W, Pol, 3, MODE_CHAIN, false>;
-    const size_t lds_fwd = rf ? res_fwd : lds_taped, lds_chn = rch ? res_chn : lds_taped;
+    if (ga0c) k_chn = chain_kernel<W, Pol, 3, MODE_CHAIN, false, CAN_GA0C>;
+    // ga0_chain: a ring of BHN_GA0C_DIST + 1 buffers of the KS fragments the chain streams, the fixed part, 4 staging images of one tile per wave
+    const size_t lds_ga0c = (size_t)(BHN_GA0C_DIST + 1) * PK::KS * Pol::FRAG_BYTES + lds_fixed + (size_t)4 * Pol::NWAVES * BG::TILE_BYTES;
+    const size_t lds_fwd = rf ? res_fwd : lds_taped, lds_chn = ga0c ? lds_ga0c : rch ? res_chn : lds_taped;
     auto kdw = dw_kernel<W, Pol>;
     static DeviceOnce once;                 // per template instantiation and device
     BHN_HIP(once.run(device, [&](int &) {
         for (const void *k : {(const void *)chain_kernel<W, Pol, 3, MODE_FWD_TRAIN, CAN_RES>, (const void *)chain_kernel<W, Pol, 3, MODE_FWD_TRAIN, false>,
-                              (const void *)chain_kernel<W, Pol, 3, MODE_CHAIN, CAN_RES>, (const void *)chain_kernel<W, Pol, 3, MODE_CHAIN, false>, (const void *)kdw}) {
+                              (const void *)chain_kernel<W, Pol, 3, MODE_CHAIN, CAN_RES>, (const void *)chain_kernel<W, Pol, 3, MODE_CHAIN, false>,
+                              (const void *)chain_kernel<W, Pol, 3, MODE_CHAIN, false, CAN_GA0C>, (const void *)kdw}) {
             const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
         }
         return hipSuccess;
     }));
-    BHN_CHECK_ARG(lds_taped <= 160 * 1024 && lds_dw <= 160 * 1024, "LDS budget exceeded (chain %zu, dw %zu)", lds_taped, lds_dw);
+    BHN_CHECK_ARG(lds_taped <= 160 * 1024 && lds_dw <= 160 * 1024 && lds_chn <= 160 * 1024, "LDS budget exceeded (chain %zu / %zu, dw %zu)", lds_taped, lds_chn, lds_dw);
     const int B_total = A.f.B;
     const double *tM0 = A.f.tM0;
     int nslabs128 = 0;
@@ -2219,7 +2417,9 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
         A.wrap = dbg_env_int("BHN_DEBUG_WRAP", 0);
         A.policy = dbg_env_int("BHN_DEBUG_POLICY", 0);
 #endif
-        const long long grid = bhn_balanced_grid(A.f.total_tiles, ncu);
+        // (ga0_chain: later passes ACCUMULATE onto the dW_0 slabs of the first: never more workgroups than the first pass had)
+        const long long grid = bhn_balanced_grid(A.f.total_tiles, (pass > 0 && A.n_chain_wg > 0 && A.n_chain_wg < ncu) ? A.n_chain_wg : ncu);
+        if (pass == 0) A.n_chain_wg = (int)grid;
         if (what == RUN_FWD_TRAIN) {
             hipLaunchKernelGGL(k_fwd, dim3((unsigned)grid), dim3(Pol::NTHREADS), lds_fwd, st, A);
             BHN_HIP(hipGetLastError());
@@ -2271,7 +2471,15 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
     if (what != RUN_FWD_TRAIN && f128) {
         const int rcr = reduce128_launch(A, depth, nslabs128, st);
         if (rcr != BHN_OK) return rcr;
-    } else if (what != RUN_FWD_TRAIN && (g_bwd_stages & 4)) hipLaunchKernelGGL((reduce_kernel<W, Pol>), dim3((unsigned)ReduceGeom<W, Pol>::blocks(depth, (unsigned)A.f.skip_mask)), dim3(256), 0, st, A);
+    } else if (what != RUN_FWD_TRAIN && (g_bwd_stages & 4)) {
+        A.chain_step = 1;
+        if (ga0c && A.n_chain_wg > 16) {
+            const int parts = 16;
+            A.chain_step = (A.n_chain_wg + parts - 1) / parts;
+            hipLaunchKernelGGL(chain_slab_stage1, dim3(BG::MT, parts), dim3(256), 0, st, A, BG::MT, A.chain_step);
+        }
+        hipLaunchKernelGGL((reduce_kernel<W, Pol>), dim3((unsigned)ReduceGeom<W, Pol>::blocks(depth, (unsigned)A.f.skip_mask)), dim3(256), 0, st, A);
+    }
     if constexpr (Pol::TAPE8) {
         if (what != RUN_FWD_TRAIN) hipLaunchKernelGGL(t8_update_kernel, dim3(1), dim3(64), 0, st, A.t8, depth);      // the next call's ratios
     }

@@ -518,7 +518,9 @@ struct DmaJob {
     char *dst;
     __amdgpu_buffer_rsrc_t rs;
     int wvu;                                    // the issuing wave's index, held in an SGPR by the ring (hipcc otherwise
-};                                              // re-derives it from threadIdx with v_readfirstlane + shifts in every step)
+                                                // re-derives it from threadIdx with v_readfirstlane + shifts in every step)
+    u32x4 rsa;                                  // the same resource as four dwords (DmaRing<.., ASM = true>)
+};
 
 // Work folded into the MFMA shadows of a ring step ("Post" objects): at(t) is called right after MFMA t of the
 // step (t is a constant after unrolling) when the layer has >= 16 k-steps, all() before the first MFMA otherwise.
@@ -546,6 +548,7 @@ struct PackPost {
         }
     }
     DEVI void all() { pack_elems<Pol, 0, 16>(pend, d0, d1, mask); }
+    DEVI void finish() {}                       // (behind the last k-step of the ring step)
 };
 
 // EXPERIMENT (-DBHN_PRIO_MODE=n, round 3): issue priority of the two waves of a SIMD inside a ring step.  With equal
@@ -571,7 +574,9 @@ DEVI void prio_flip(int t, int wvu) {
 // rows `bias_next` of the next tile before returning (both consumed after the barrier).
 // NFR: fragments of a chunk the step streams -- KS + 2 (hidden fragments + the encoded-input block), or KS for chunk
 // sequences that never use the encoded-input block (the transposed image of the delta chain: `with_enc` must be false)
-template <int W, class Pol, class RG, class Post, int NFR = W / 16 + 2>
+// ZB: every tile of the sequence starts from a ZERO accumulator (the delta chain): no bias rows are read and ap.bias -- sixteen
+// registers that would hold zeros across the step boundary -- is not used
+template <int W, class Pol, class RG, class Post, int NFR = W / 16 + 2, bool ZB = false>
 DEVI f32x16 ring_step(const char *ch, const char *chn, APipe<Pol> &ap, const typename Pol::frag (&src)[W / 16],
                       const typename Pol::frag (&enc)[2], bool with_enc, const float *bias_next, Post &post, DmaJob dma,
                       int dbg = 0) {
@@ -581,7 +586,8 @@ DEVI f32x16 ring_step(const char *ch, const char *chn, APipe<Pol> &ap, const typ
     typename Pol::frag a[PF];
 #pragma unroll
     for (int i = 0; i < PF - 1; ++i) a[i] = ap.f[i];
-    f32x16 acc = ap.bias;
+    f32x16 acc;
+    if constexpr (ZB) { const f32x16 z = {}; acc = z; } else acc = ap.bias;
     const bool do_post = !(dbg & 2), do_mma = !(dbg & 1);
     if (do_post && KS < 16) post.all();
     __builtin_amdgcn_sched_barrier(0);
@@ -592,7 +598,7 @@ DEVI f32x16 ring_step(const char *ch, const char *chn, APipe<Pol> &ap, const typ
         if (do_mma) acc = Pol::mma(a[t % PF], src[t], acc);
         if (do_post && KS >= 16) post.at(t);
         if (t == (KS >= 16 ? 9 : 0) && dma.on) RG::issue(dma);
-        if (t == (KS >= 16 ? 13 : 0)) ap.bias = bias_acc(bias_next, 0, lane >> 5);   // next tile's bias, before the barrier
+        if constexpr (!ZB) { if (t == (KS >= 16 ? 13 : 0)) ap.bias = bias_acc(bias_next, 0, lane >> 5); }   // next tile's bias, before the barrier
         __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
@@ -601,6 +607,7 @@ DEVI f32x16 ring_step(const char *ch, const char *chn, APipe<Pol> &ap, const typ
         if (with_enc && do_mma) acc = Pol::mma(a[t % PF], enc[t - KS], acc);
         __builtin_amdgcn_sched_barrier(0);
     }
+    if (do_post) post.finish();
 #pragma unroll
     for (int i = 0; i < PF - 1; ++i) ap.f[i] = a[(NF + i) % PF];
     return acc;
@@ -653,8 +660,11 @@ DEVI void dma_1k_asm(const char *src, char *dst) {
 }
 #pragma clang diagnostic pop
 
-template <int CHUNK_BYTES, int NWAVES>
+// ASM: the pieces are issued from inline asm (dma_1k_asm's reason: kernels that also read LDS with ds_read_b64_tr_b16 -- the
+// builtin carries no memory operand and hipcc's waitcnt pass then drains EVERY LDS-DMA it knows about in front of each such read)
+template <int CHUNK_BYTES, int NWAVES, bool ASM_ = false>
 struct DmaRing {
+    static constexpr bool ASM = ASM_;
     static constexpr int NPIECE = CHUNK_BYTES / 1024;
     static constexpr int PPW = (NPIECE + NWAVES - 1) / NWAVES;
     static_assert(CHUNK_BYTES % 1024 == 0, "chunks are whole KiB");
@@ -665,17 +675,30 @@ struct DmaRing {
         void *us = reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo);
         return __builtin_amdgcn_make_buffer_rsrc(us, 0, 0x7fffffff, 0x00020000);
     }
+    static DEVI u32x4 resource_raw(const char *base) {
+        const unsigned long long u = reinterpret_cast<unsigned long long>(base);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+        return u32x4{lo, hi & 0xffffu, 0x7fffffffu, 0x00020000u};
+    }
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"      // (only: "inline asm clobber list contains reserved registers: M0")
     static DEVI void issue(const DmaJob &j) {
         const int wvu = j.wvu;
         const int voff = (int)(threadIdx.x & 63) * 16;
+        [[maybe_unused]] const unsigned m_base = ASM ? __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<unsigned long long>(j.dst)) : 0u;
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
             int piece = wvu + NWAVES * i;
             piece = piece < NPIECE ? piece : NPIECE - 1;        // tail waves re-issue the last piece (equal vmcnt for all waves)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(j.rs, (__attribute__((address_space(3))) void *)(j.dst + piece * 1024), 16, voff,
-                                                     (int)(j.soff + piece * 1024), 0, 0);
+            if constexpr (ASM) {
+                const unsigned m = m_base + (unsigned)piece * 1024u, so = j.soff + (unsigned)piece * 1024u;
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(m), "v"(voff), "s"(j.rsa), "s"(so) : "memory", "m0");
+            } else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(j.rs, (__attribute__((address_space(3))) void *)(j.dst + piece * 1024), 16, voff,
+                                                         (int)(j.soff + piece * 1024), 0, 0);
         }
     }
+#pragma clang diagnostic pop
     // vmcnt retires in issue order and counts loads, stores and LDS-DMA alike: a chunk has landed once at
     // most the operations issued AFTER its last piece are pending.  A smaller count than the true one is
     // always safe (it only waits longer).
@@ -719,6 +742,7 @@ struct RingState {
     const char *img_a;
     unsigned off_b;         // byte offset of the transposed image from img_a (both live in the packed-weight buffer)
     __amdgpu_buffer_rsrc_t rs;
+    u32x4 rsa;
     int NC, NCA, nlb, cur, issue_c, dbg, lag;
     long long *ts;          // STAMPS (measurement builds): per-step time stamps (compute done, barrier passed)
     static DEVI int wrap(int i) { return i < 0 ? i + NB : (i >= NB ? i - NB : i); }
@@ -744,8 +768,8 @@ struct RingState {
         return src;
     }
     DEVI DmaJob job() {
-        if (dbg & 4) return DmaJob{false, 0u, nullptr, rs, wvu};
-        return DmaJob{true, next_src(), ring + (LAG ? wrap(cur - 2) * CBL : o_prv), rs, wvu};
+        if (dbg & 4) return DmaJob{false, 0u, nullptr, rs, wvu, rsa};
+        return DmaJob{true, next_src(), ring + (LAG ? wrap(cur - 2) * CBL : o_prv), rs, wvu, rsa};
     }
     // STORES: global stores this wave is GUARANTEED to have issued after the DMA pieces of chunk c+2 (issued in the
     // middle of step c-2) other than the two younger chunks: vmcnt retires in order and counts stores, so they may
@@ -777,12 +801,13 @@ struct RingState {
         ring = ring_; img_a = a_; NCA = nca; nlb = nlb_; NC = nca + nlb_ * MT;
         off_b = b_ ? (unsigned)(b_ - a_) : 0u;                  // (the transposed image follows the forward image)
         rs = RG::resource(a_);
+        rsa = RG::resource_raw(a_);
         dbg = dbg_; cur = 0; issue_c = 0; lag = LAG ? lag_ : 0; ts = nullptr;
         o_cur = 0; o_nxt = CBL; o_prv = (NB - 1) * CBL;
         wvu = opaque(__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)));
         if constexpr (BHN_PRIO_MODE == 1) { if (wvu >= 4) __builtin_amdgcn_s_setprio(1); }
 #pragma unroll
-        for (int j = 0; j < DIST; ++j) RG::issue(DmaJob{true, next_src(), ring + j * CBL, rs, wvu});
+        for (int j = 0; j < DIST; ++j) RG::issue(DmaJob{true, next_src(), ring + j * CBL, rs, wvu, rsa});
         RG::template wait_younger<RG::PPW * (DIST - 2)>();
         lds_barrier();
     }
@@ -804,7 +829,7 @@ struct ResidentRing {
     __host__ __device__ static constexpr size_t lds_bytes(int nc) { return (size_t)nc * CB; }
     DEVI const char *ch() const { return ring + opaque(o_cur); }
     DEVI const char *chn() const { return ring + opaque(o_nxt); }
-    DEVI DmaJob job() { return DmaJob{false, 0u, nullptr, __amdgpu_buffer_rsrc_t(), wvu}; }
+    DEVI DmaJob job() { return DmaJob{false, 0u, nullptr, __amdgpu_buffer_rsrc_t(), wvu, u32x4{0u, 0u, 0u, 0u}}; }
     template <int STORES = 0>
     DEVI void step_end() {
         o_cur = o_nxt;

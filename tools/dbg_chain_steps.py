@@ -2,8 +2,8 @@
 at config 2: ticks spent computing and ticks waiting (DMA wait + barrier) per step.  bhn_debug_set_bwd_stages bit 12.
 Needs the library built with the stamps compiled in:  make -C bhnerf_amd/csrc CXXFLAGS="... -DBHN_CHAIN_STAMPS=1"."""
 import sys, ctypes as C, numpy as np, torch
-sys.path.insert(0, '/root/repo')
-import os; os.environ.setdefault('BHNERF_HIP_LIB', '/root/repo/bhnerf_amd/csrc/libbhnerf_hip_dbg.so')   # debug build: make -C bhnerf_amd/csrc debug
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
+import os; os.environ.setdefault('BHNERF_HIP_LIB', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'bhnerf_amd/csrc/libbhnerf_hip_dbg.so'))   # debug build: make -C bhnerf_amd/csrc debug
 from bhnerf_amd import _hip, engine, network, synthetic, constants
 dev = torch.device('cuda:0')
 lib = _hip.lib()
