@@ -158,6 +158,53 @@ def as_f32(x, device):
     return torch.as_tensor(np.ascontiguousarray(np.asarray(x, dtype=np.float32)), device=device)
 
 
+class _PinnedRing:
+    """Small host -> device copies that do not stall the host: a copy from PAGEABLE memory is synchronous on ROCm (the call
+    returns only after the stream has reached it, i.e. after every kernel launched before it: one such copy per training step
+    -- the frame offsets, the frame indices -- made the host wait for the GPU at every step and then pay the launch latency of
+    the next step's ~25 kernels in the open: 0.1-0.5 ms per step).  A ring of pinned staging slots; a slot is re-used only
+    after the copy issued from it has executed."""
+
+    def __init__(self, device, slots=32, nbytes=4096):
+        self.device, self.nbytes = device, nbytes
+        self.slots = [dict(buf=torch.zeros(nbytes, dtype=torch.uint8).pin_memory(), done=None) for _ in range(slots)]
+        for sl in self.slots:
+            sl['np'] = sl['buf'].numpy()
+        self.i = 0
+
+    def to_device(self, arr):
+        arr = np.ascontiguousarray(arr)
+        n = arr.nbytes
+        if n == 0 or n > self.nbytes:
+            return torch.as_tensor(arr, device=self.device)
+        sl = self.slots[self.i]
+        self.i = (self.i + 1) % len(self.slots)
+        if sl['done'] is not None:
+            sl['done'].synchronize()                 # (waits only when the GPU is a whole ring behind the host)
+        else:
+            sl['done'] = torch.cuda.Event()
+        sl['np'][:n] = arr.reshape(-1).view(np.uint8)
+        out = torch.empty(arr.shape, dtype=torch.from_numpy(arr[:0].reshape(-1)).dtype, device=self.device)
+        out.view(torch.uint8).reshape(-1).copy_(sl['buf'][:n], non_blocking=True)
+        sl['done'].record(torch.cuda.current_stream(self.device))
+        return out
+
+
+_rings = {}
+
+
+def h2d_small(arr, device):
+    """Device tensor with the contents (shape, dtype) of a small NumPy array, through the device's pinned staging ring."""
+    device = torch.device(device)
+    if device.type != 'cuda':
+        return torch.as_tensor(np.ascontiguousarray(arr), device=device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    ring = _rings.get(key)
+    if ring is None:
+        ring = _rings[key] = _PinnedRing(torch.device('cuda', key[1]))
+    return ring.to_device(arr)
+
+
 def make_model(net_depth, net_width, posenc_deg, do_skip, scale, rmin, rmax, z_width):
     big = 3.0e38
     clip = lambda v: float(min(max(v, -big), big))

@@ -146,7 +146,7 @@ def frame_offsets(t_frames, t_start_obs, t_injection, GM_c3, device):
     """tM0[b] = (t_frames[b]-t_start_obs)/GM_c3 - t_injection in float64 (emission.py:200-201)."""
     t = np.atleast_1d(np.asarray(t_frames, dtype=np.float64))
     tM0 = (t - float(t_start_obs)) / float(GM_c3) - float(t_injection)
-    return torch.as_tensor(tM0, dtype=torch.float64, device=device)
+    return _hip.h2d_small(np.asarray(tM0, dtype=np.float64), device)      # (pinned staging: no host stall, _hip._PinnedRing)
 
 
 class FusedPredictor:

@@ -508,7 +508,8 @@ class TemporalBatchedArgs(object):
                 # arguments of one shape and dtype (target / sigma / offset of an image-plane loss) are gathered by ONE kernel
                 same = len(self._dev) > 1 and len({(tuple(a.shape), a.dtype) for a in self._dev}) == 1
                 self._stack = torch.stack(self._dev) if same else None
-            idx = torch.as_tensor(key, device=self._dev[0].device if self._dev else 'cuda')
+            from . import _hip
+            idx = _hip.h2d_small(np.asarray(key, dtype=np.int64), self._dev[0].device if self._dev else 'cuda')
             if self._stack is not None:
                 out = list(self._stack.index_select(1, idx))
             else:
