@@ -12,7 +12,11 @@
 // iteration takes 128 points (four 32-point tape groups).  Activations live in LDS as [point][feature] images whose 256-byte
 // rows are stored in 16-byte chunks with the XOR swizzle that makes BOTH access patterns conflict-free
 // (cdna_hip_programming.md T10, "one image for row reads and transposed reads", form (b)):
-//     off(row, ch) = 256 row + 16 (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)))
+//     off(row, ch) = 256 row + 16 (ch ^ swz(row)),   swz(row) = ((row & 3) << 2) | (((row >> 2) & 3) ^ (row & 2))
+// (round 5: the `^ (row & 2)` -- without it the ds_write_b128 of the chain's output tiles, 8 consecutive rows per lane group, hit
+//  every bank twice: SQ_LDS_BANK_CONFLICT 21 % of the LDS-active cycles, profiles/r4_w128_sq_counters.txt; the three conditions --
+//  writes: swz & 7 distinct over 8 aligned rows; row reads: swz a bijection on 16 rows; transposed reads: swz >> 2 distinct over
+//  4 aligned rows -- are checked by tests/test_host_logic_cpu.py)
 //   * row reads  (ds_read_b128): lane (point, half) takes chunk 2 ks + half = the B fragment of k-step ks of a product that
 //     sums over FEATURES (the delta chain  gA_{l-1} = relu' (.) W_l gA_l);
 //   * transposed reads (ds_read_b64_tr_b16): lane = feature, 8 points in the registers = the A / B fragments of a product
@@ -109,18 +113,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // row access of point block 2j + pi: 256 (32 pb + n) + 16 ((half ^ swz) & 15); chunk pair C (even) is reached by ^ 16 C
     unsigned rowb[2];
     {
-        const int swz = ((pl & 3) << 2) | ((pl >> 2) & 3);
+        const int swz = ((pl & 3) << 2) | (((pl >> 2) & 3) ^ (pl & 2));
 #pragma unroll
         for (int pi = 0; pi < 2; ++pi) rowb[pi] = 256u * (32 * (2 * wj + pi) + pl) + 16u * ((hh ^ swz) & 15);
     }
     // transposed read of feature tile T: first / second 4-point block of the lane's 8 points of a 16-point k-step
     const int tg = lane >> 4, tcg = tg & 1, tkh = tg >> 1, tq = (lane & 15) >> 2, tp = lane & 3;
     auto tr_first = [&](int T) -> unsigned {
-        const int lc = 2 * tcg + (tp >> 1), swa = (tq << 2) | (2 * tkh);
+        const int lc = 2 * tcg + (tp >> 1), swa = (tq << 2) | ((2 * tkh) ^ (tq & 2));          // swz(row 8 tkh + tq)
         return 256u * (8 * tkh + tq) + 16u * (((4 * T) ^ lc ^ swa) & 15) + 8u * (tp & 1);
     };
     auto tr_second = [&](int T) -> unsigned {
-        const int lc = 2 * tcg + (tp >> 1), swb = (tq << 2) | (2 * tkh) | 1;
+        const int lc = 2 * tcg + (tp >> 1), swb = (tq << 2) | ((2 * tkh + 1) ^ (tq & 2));      // swz(row 8 tkh + tq + 4)
         return 256u * (8 * tkh + tq + 4) + 16u * (((4 * T) ^ lc ^ swb) & 15) + 8u * (tp & 1);
     };
     // this wave's tiles: chain / dW rows m0 = 2i, m1 = 2i + 1; dW columns n0 = 2j, n1 = 2j + 1; enc tile with m_e = 2i + j;
@@ -132,7 +136,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const unsigned trE = 64u * (8 * tkh + tq) + 32u * tcg + 8u * tp;      // encoded-input image: 64-byte rows, no swizzle
 
     // LDS-DMA lane offsets on the GLOBAL side (tape tiles are in the producer's slot layout, TapeEmit::native_off)
-    const unsigned voffH = 2048u * ((((lane & 15) >> 2) ^ (lane >> 4)) & 3) + 64u * (((lane & 3) ^ wv) & 3) + 16u * (lane >> 4);
+    // (LDS lane i of piece k lands on row 4 k + (i >> 4), chunk position i & 15, i.e. feature chunk (i & 15) ^ swz(row) with
+    //  row & 3 = i >> 4, (row >> 2) & 3 = wv: tile = chunk >> 2, fragment (s, h) = chunk & 3)
+    const unsigned voffH = 2048u * ((((lane & 15) >> 2) ^ (lane >> 4)) & 3) + 64u * (((lane & 3) ^ wv ^ ((lane >> 4) & 2)) & 3) + 16u * (lane >> 4);
     const unsigned voffE = 16u * ((lane >> 2) & 3) + 64u * (lane & 3) + 256u * (lane >> 4);
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<unsigned long long>(smem));
 

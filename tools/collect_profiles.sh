@@ -3,7 +3,7 @@
 #   <tag>_bench_line.json         the bench line of `python3 bench.py`
 #   <tag>_bench_kernel_stats.csv  rocprofv3 --kernel-trace --stats of the same command (per-kernel averages)
 #   <tag>_f32_kernel_stats.csv    the same for `bench.py --mode f32` (the parity mode)
-#   <tag>_t8_kernel_stats.csv     the same for tools/dbg_t8.py time: the bf16 and the 8-bit-tape kernels side by side
+#   <tag>_t8_kernel_stats.csv     the same for tools/debug/dbg_t8.py time: the bf16 and the 8-bit-tape kernels side by side
 #   <tag>_pmc_traffic.json        HBM traffic per launch (FETCH_SIZE / WRITE_SIZE, separate --pmc passes, gfx950 x2 on FETCH_SIZE)
 #   <tag>_sq_counters.txt / <tag>_sq_summary.json   SQ counter passes of tools/pmc_run.py (MFMA busy, waits, LDS conflicts)
 #   <tag>_ring_ceiling_microbench.txt + <tag>_telemetry_ceiling.txt   tools/step_bench.hip `ceiling`: the library's ring step
@@ -26,7 +26,7 @@ f=$(find /tmp/ktf -name "*kernel_stats.csv" | head -1); need "$f"; cp "$f" $O/${
 rm -rf /tmp/ktw; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ktw -o kt -- python3 $R/bench.py --width 128 --steps 5 --warmup 2 --no-cpu-baseline --no-parity-mode --no-tape8 --no-tutorial-domain --no-other-configs --no-width128 > /tmp/ktw.log 2>&1
 f=$(find /tmp/ktw -name "*kernel_stats.csv" | head -1); need "$f"; cp "$f" $O/${TAG}_w128_kernel_stats.csv
 # bf16 against the 8-bit tape mode (BHN_BF16_T8), kernel by kernel, at config 2's shape
-rm -rf /tmp/kt8; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt8 -o kt -- python3 $R/tools/dbg_t8.py time > $O/${TAG}_t8_times.txt 2>&1
+rm -rf /tmp/kt8; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt8 -o kt -- python3 $R/tools/debug/dbg_t8.py time > $O/${TAG}_t8_times.txt 2>&1
 f=$(find /tmp/kt8 -name "*kernel_stats.csv" | head -1); need "$f"; cp "$f" $O/${TAG}_t8_kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pm_$c; rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pm_$c -o p -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity-mode --no-tape8 --no-tutorial-domain --no-other-configs --no-width128 > /tmp/pm_$c.log 2>&1

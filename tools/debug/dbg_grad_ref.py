@@ -3,7 +3,7 @@ build against a dump (`check`, file tools/_grad_ref.npz) -- used when the tape l
 separate logic errors (large differences) from summation-order changes (~1e-6)."""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from bhnerf_amd import engine, network, synthetic, constants
 
 dev = torch.device('cuda:0')

@@ -2,7 +2,7 @@
 with and without a concurrent copy stream hammering HBM; every gradient must equal the first bit for bit."""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from bhnerf_amd import engine, network, synthetic, constants
 dev = torch.device('cuda:0')
 big = torch.empty(2 * 2**30 // 4, device=dev); big2 = torch.empty_like(big)

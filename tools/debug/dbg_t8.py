@@ -4,7 +4,7 @@ second call (scales from the first); then the kernel times of both modes at BASE
     python tools/dbg_t8.py [check|time|all]"""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from bhnerf_amd import engine, network, synthetic, constants
 
 dev = torch.device('cuda:0')

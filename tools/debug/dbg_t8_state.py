@@ -2,7 +2,7 @@
 with differently scaled d(loss)/d(images), and the per-layer error of each call against the bf16 mode."""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from bhnerf_amd import engine, network, synthetic, constants
 dev = torch.device('cuda:0')
 geo = synthetic.synthetic_geodesics(16, 16, 64, seed=5)

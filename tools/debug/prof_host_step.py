@@ -3,7 +3,7 @@
     python tools/prof_host_step.py [frames_per_step]"""
 import cProfile, pstats, sys, os, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from bhnerf_amd import network, optimization, synthetic, units
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 dev = torch.device('cuda:0')
