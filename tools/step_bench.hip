@@ -314,6 +314,7 @@ struct TapeLikePost {
             __builtin_nontemporal_store(d1, reinterpret_cast<typename Pol::frag *>(dst + 1024 + lane * 16));
         }
     }
+    DEVI void finish() {}
     DEVI void all() {}
 };
 
