@@ -397,10 +397,11 @@ def tape_bytes_per_point(depth, width, mode, fused):
     skip_layer = depth // 2 + 1 if depth >= 4 else None  # the layer that consumes concat[h, enc] (do_skip)
     rides = mode == 'bf16' and depth >= 3                # gA_{depth-1} and the dout tile are not on the tape
     drop_h1 = mode == 'bf16' and depth >= 2 and skip_layer != 1
+    ga0c = mode == 'bf16' and width == 256 and depth >= 3    # the delta chain accumulates dW_0 itself: gA_0 never leaves the chip
     bits = depth * ((mt + 1) // 2) * 8                   # relu-bit words: 4 B per lane and pair of tiles, per 32 points
     fwd = (depth - (1 if drop_h1 else 0)) * row + (2 if drop_h1 else 1) * 32 * elem + bits + 4
-    chain = (depth - (1 if rides else 0)) * row + bits + 4 + (4 if rides else 32 * elem)
-    tiles = (mt + 1) + (0 if rides else 1 + mt)          # dW reads per 32-point group and layer job: layer 0, output layer
+    chain = (depth - (1 if rides else 0) - (1 if ga0c else 0)) * row + bits + 4 + (4 if rides else 32 * elem) + (32 * elem if ga0c else 0)
+    tiles = (0 if ga0c else mt + 1) + (0 if rides else 1 + mt)      # dW reads per 32-point group and layer job: layer 0, output layer
     for l in range(1, depth):
         recomputed = l == 1 and drop_h1
         tiles += mt + (1 if recomputed else mt) + (1 if l == skip_layer else 0)
