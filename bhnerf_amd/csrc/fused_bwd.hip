@@ -558,17 +558,30 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
 
     // inputs of the next tile are fetched one tile ahead (geometry for the forward modes; for MODE_CHAIN the
     // recorded emission and dE = sum_s dimg * w, which only need the point index)
-    // ... and the first relu-bit words: layer depth-1 (all of it, for gA_{depth-1}) and the first two words of the
-    // chain sequence (layers depth-2 .. 0, MW words each); the rest is fetched two words (four steps) ahead
-    struct ChainIn { int b; long long p; bool inb; float e, dE; unsigned mtop[MW], q0, q1; };
-    const int chain_words = (a.depth - 1) * MW;
-    auto chain_word = [&](const unsigned *mg, int j) -> unsigned {   // word j of the chain sequence of tape group mg
-        if (j >= chain_words) return 0u;
-        return __builtin_nontemporal_load(mg + ((a.depth - 2 - j / MW) * MW + j % MW) * 64 + lane);
+    // ... and the relu-bit words of layer depth-1 (all of it, for gA_{depth-1}).  The words of the chain sequence (layers depth-2 .. 0,
+    // MW words each) come through a FIFO of whole LAYERS, filled at least MWL - 1 layers (>= 4 ring steps; 8 at width 256) ahead of
+    // their use -- see `layer_words` below.
+    struct ChainIn { int b; long long p; bool inb; float e, dE; unsigned mtop[MW]; };
+    // Relu-bit words of the layer at position `pos` of the chain sequence that starts at layer 0 of tile `tile0` and runs on into the
+    // workgroup's next tiles (NL = depth - 1 layers per tile).  WHY whole layers far ahead (round 5): vmcnt retires in issue order, so
+    // the wait in front of the first use of a loaded word also waits for every tape store issued BEFORE the load -- and under 3-4 TB/s
+    // of tape writes a store takes ~5 ring steps to retire.  With the words fetched two words (four steps) ahead every second step of
+    // the delta chain stalled for 500-1500 cycles (ring-step stamps: 50.4 k ticks per tile against 39.1 k with the stores switched
+    // off, the training forward -- no loads in its loop -- 49.3 k against 45.8 k; profiles/r5_chain_stamps.txt).
+    constexpr int MWL = MT >= 4 ? 2 : (MT == 2 ? 3 : 5);              // layers in the FIFO
+    const int NL = a.depth - ((MODE == MODE_CHAIN && A.t.drop_ga0) ? 2 : 1);      // chain layers per tile (= depth - LEND)
+    auto layer_words = [&](long long tile0, int pos, unsigned (&w)[MW]) {
+        long long t = tile0;
+        int j = pos;
+        while (j >= NL && NL > 0) { j -= NL; t += gridDim.x; }
+        const bool on = NL > 0 && t < a.total_tiles;
+        const unsigned *mg = reinterpret_cast<const unsigned *>(A.tape + A.t.mask_off) + (t * Pol::NWAVES + wvu) * (long long)(a.depth * MW * 64);
+#pragma unroll
+        for (int i = 0; i < MW; ++i) w[i] = on ? __builtin_nontemporal_load(mg + ((a.depth - 2 - j) * MW + i) * 64 + lane) : 0u;
     };
     auto load_chain = [&](long long tile) {
         ChainIn c;
-        c.b = 0; c.p = 0; c.inb = false; c.e = 0.f; c.dE = 0.f; c.q0 = c.q1 = 0u;
+        c.b = 0; c.p = 0; c.inb = false; c.e = 0.f; c.dE = 0.f;
 #pragma unroll
         for (int i = 0; i < MW; ++i) c.mtop[i] = 0u;
         if (tile < a.total_tiles) {
@@ -576,8 +589,6 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
                                  (tile * Pol::NWAVES + wvu) * (long long)(a.depth * MW * 64);
 #pragma unroll
             for (int i = 0; i < MW; ++i) c.mtop[i] = __builtin_nontemporal_load(mg + ((a.depth - 1) * MW + i) * 64 + lane);
-            c.q0 = chain_word(mg, 0);
-            c.q1 = chain_word(mg, 1);
             tile_point<Pol::NWAVES>(a, tile, wv, pl, c.b, c.p, c.inb);
             if (h == 0) c.e = (reinterpret_cast<const float *>(A.tape + A.t.e_off) + (tile * Pol::NWAVES + wvu) * 32)[pl];
             if (h == 0 && c.inb) {
@@ -591,7 +602,12 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
     // (the forward modes load their geometry at the tile start: a one-tile-ahead prefetch measured no faster and
     // costs 12 registers the 4x256 kernel does not have)
     ChainIn cnxt;
-    if constexpr (MODE == MODE_CHAIN) cnxt = load_chain(blockIdx.x);
+    unsigned mwf[MWL][MW];                           // relu-bit words: mwf[0] = the running chain layer's, mwf[k] = k layers ahead
+    if constexpr (MODE == MODE_CHAIN) {
+        cnxt = load_chain(blockIdx.x);
+#pragma unroll
+        for (int k = 0; k < MWL; ++k) layer_words(blockIdx.x, k, mwf[k]);
+    }
     // GA0C: dW_0 accumulator tiles (rows = an output tile of layer 0, columns = encoded-input slots, column 31 = bias).  The OLDER wave
     // of every SIMD (waves 0 .. NWAVES/2 - 1) owns two -- tiles w and w + NWAVES/2 -- and the younger none: the older wave wins
     // the issue arbitration and reaches every barrier ~500 cycles before its partner (ring-step stamps), so the
@@ -799,7 +815,6 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
             // ---- delta chain through hidden layers depth-1 .. 1: step (l, m) makes tile m of gA_{l-1} -------
             int pnd_layer = a.depth - 1;             // layer of the pending gA tile
             unsigned pnd_mask = last_mask;           // its relu bits (0xffff: gA_{depth-1} is masked already)
-            unsigned mq0 = cin.q0, mq1 = cin.q1, mcur = 0u;          // MODE_CHAIN: relu-bit words in flight from the tape
             unsigned no_acc = 0u;
             float t8_sc = 1.f;
             // (seeded with |dout|: the first flush below -- layer depth-1, whose gA is not recorded -- leaves the largest |dout|, the
@@ -819,11 +834,6 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
                     // GA0C: a finished gA_0 tile goes to the LDS staging image gaS[tile & 1] instead of the tape
                     const bool staged = GA0C && pnd_layer == 0 && !(BHN_GA0C_ABL & 2);
                     char *stage = staged ? gaS + (pm & 1) * STG + wvu * TB : nullptr;
-                    if (!(m & 1)) {                                  // word (l-1, m/2): use the oldest, fetch two ahead
-                        mcur = mq0;
-                        mq0 = mq1;
-                        mq1 = chain_word(mask_g, (a.depth - 1 - l) * MW + (m >> 1) + 2);
-                    }
                     // GA0C: the consumer of this step is wave (m - 2) mod MT: in layer 1 it adds the gA_0 tile m - 2 (staged in step
                     // m - 1, published by that step's barrier) of all waves to its accumulator; in the first two steps of the NEXT
                     // tile waves MT-2, MT-1 do the same for the previous tile's last two gA_0 tiles
@@ -851,9 +861,10 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
                         // is a gA_0 tile (layer 1, m >= 1) or gA_{depth-1}'s (first step of a tile)
                         static_assert(!GA0C || BHN_GA0C_DIST == 4, "the store counts below are written for a window of three steps");
                         // The first two steps of a tile also have the tile top's operations inside their window -- two encoded-input DMA
-                        // pieces, the dout store, this step's relu-bit word, and with a next tile its prefetch (MW + 2 relu-bit words, e):
-                        // counting them keeps the HBM latency of that prefetch out of the step end (every count is a lower bound)
-                        constexpr int TOP = 4, TOPN = TOP + MW + 3;
+                        // pieces, the dout store, and with a next tile the MW relu-bit words fetched at the end of the previous tile's last
+                        // layer and the next tile's prefetch (MW relu-bit words, e): counting them keeps the HBM latency of those loads out
+                        // of the step end (every count is a lower bound)
+                        constexpr int TOP = 3, TOPN = TOP + 2 * MW + 1;
                         if (l == a.depth - 1) {
                             if (m == 0) { if (has_next) rs.template step_end<TOPN>(); else rs.template step_end<TOP>(); }
                             else if (m == 1) { if (has_next) rs.template step_end<ES + TOPN>(); else rs.template step_end<ES + TOP>(); }
@@ -871,7 +882,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
                     else rs.template step_end<YS>();
                     pend = acc;
                     pnd_layer = l - 1;
-                    pnd_mask = mcur >> ((m & 1) * 16);
+                    pnd_mask = mwf[0][m >> 1] >> ((m & 1) * 16);       // word (l-1, m/2) of the FIFO's head layer
                     if constexpr (T8) {
                         if (m == 0) {       // the last tile of gA_l has been posted: its layer's |.|max to the thread's slot, on to gA_{l-1}
                             t8_flush(l, t8_amax);
@@ -882,6 +893,12 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
                 }
 #pragma unroll
                 for (int ks = 0; ks < KS - 2; ++ks) dl[ks] = next[ks];
+                // the FIFO of relu-bit words moves on by one layer; its tail takes the layer MWL positions ahead of the one just finished
+#pragma unroll
+                for (int k = 0; k + 1 < MWL; ++k)
+#pragma unroll
+                    for (int i = 0; i < MW; ++i) mwf[k][i] = mwf[k + 1][i];
+                layer_words(tile, (a.depth - 1 - l) + MWL, mwf[MWL - 1]);
             }
             if (a.depth > 1) {           // flush the last tile of gA_{LEND-1} (no further step to hide it behind)
                 TapePost<Pol, false, GA0C> post(pend, dl[KS - 2], dl[KS - 1], pnd_mask, em,
