@@ -475,9 +475,11 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
     const int edbg = BHN_DBG(((A.debug >> 6) & 3) | (A.policy << 2));  // measurement aid for the tape emission (bits 2,3: store policy)
     constexpr int sdbg = 0;                        // (a run-time MFMA-skip flag put every MFMA in its own basic block)
     // the delta chain's transposed image never uses the two encoded-input fragments of a chunk: its ring copies (and its steps
-    // stream) only the KS hidden fragments
+    // stream) only the KS hidden fragments; the training forward (bf16) keeps them in a resident block of their own (EncBlock)
     // (KS >= 8: the A-fragment prefetch of a step runs LDS_PREFETCH - 1 fragments into the NEXT chunk, which must have that many)
-    constexpr int NFR = (MODE == MODE_CHAIN && KS >= 8) ? KS : KS + 2;
+    using EB = EncBlock<W, Pol>;
+    constexpr bool ENCR = MODE != MODE_CHAIN && EB::ON && !RES;
+    constexpr int NFR = ((MODE == MODE_CHAIN && KS >= 8) || ENCR) ? KS : KS + 2;
     using RG = DmaRing<RES ? CB : NFR * Pol::FRAG_BYTES, Pol::NWAVES, GA0C>;     // (GA0C: transposed LDS reads in the kernel -> asm DMA)
     constexpr int DIST = GA0C ? BHN_GA0C_DIST : BG::RING_DIST_TAPED;
     using RS = std::conditional_t<RES, ResidentRing<RG, CB, MT>, RingState<RG, CB, DIST, false, MT, BHN_CHAIN_STAMPS != 0>>;
@@ -513,6 +515,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
     constexpr int STG = Pol::NWAVES * TB;                              // one image: a 2-KiB tile per wave
     char *encS = seg_lds + RaySum<Pol::NWAVES>::bytes(A.f.Sx);
     char *gaS = encS + 2 * STG;
+    char *encblk = encS;                                               // training forward (ENCR): the resident encoded-input weight block
     const int stage_off = TapeEmit<Pol>::native_off(0);
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 31, h = lane >> 5;
@@ -535,6 +538,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
         bias_lds[i] = reinterpret_cast<const float *>(a.packed + a.bias_off)[i];
     if (tid < 32) zero_lds[tid] = 0.f;
     for (int i = tid; i < W; i += Pol::NTHREADS) wout_lds[i] = reinterpret_cast<const float *>(a.packed + a.wout_off)[i];
+    if constexpr (ENCR) EB::fill(encblk, a.packed + a.fwd_off, a.depth, a.skip_mask);
     if constexpr (T8 && MODE == MODE_CHAIN) {
         if (tid < 8) {
             const float v = A.t8[tid];
@@ -670,7 +674,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
             } l0{em, drop_h1 ? nullptr : A.tape + h_lin + lin_stride + qs * MT * TT, mask_g ? mask_g + lane : nullptr,
                  nullptr, 0u, edbg};
             f32x16 pend;
-            layer0_step<W, Pol, RG, YS0>(rs, ap, enc, act, bias_lds, h, pend, l0);
+            layer0_step<W, Pol, RG, YS0, RS, Tile0, NFR>(rs, ap, enc, act, bias_lds, h, pend, l0);
             // ---- hidden layers 1..depth-1 and the output layer: the pending tile is (l-1, MT-1) at m = 0 ------
             int pl_layer = 0;                        // layer of the pending tile
             unsigned t8_none = 0u;                   // (the forward's h tiles: scale 1, no maxima)
@@ -696,7 +700,8 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
                     // bias rows of the next tile: (l, m+1), or the first tile of the next sequence part
                     const float *bn = (out || (m == MT - 1 && l + 1 > a.depth)) ? nullptr : bl + 32 * (m + 1);
                     if (out) bn = bias_lds;                           // next tile, layer 0
-                    const f32x16 acc = ring_step<W, Pol, RG>(ch, chn, ap, act, enc, sk, bn, post, dj, sdbg);
+                    const f32x16 acc = ring_step<W, Pol, RG, TapePost<Pol, true>, NFR>(ch, chn, ap, act, enc, sk, bn, post, dj, sdbg,
+                                                                                       encblk + 2 * (out ? MT : m) * Pol::FRAG_BYTES);
                     // without the h_1 emission the interval after this layer's first DMA issue holds no store: the
                     // three step ends that count it allow one emission less in flight (small widths: none)
                     if (drop_h1 && l == 1 && m <= 2) rs.template step_end<YS_L1>();
@@ -2371,6 +2376,8 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
     // ring + bias rows + zero row + output weights + identity fragments
     const size_t lds_fixed = ((size_t)depth * W + 32) * 4 + 128 + W * 4 + (Pol::ELEM_BYTES == 2 ? 0 : 2 * Pol::FRAG_BYTES) + RaySum<Pol::NWAVES>::bytes(A.f.Sx);
     const size_t lds_taped = (size_t)(BG::RING_DIST_TAPED + 1) * PK::CHUNK_BYTES + lds_fixed;
+    // training forward with the resident encoded-input block (EncBlock): ring buffers of the KS hidden fragments + the block
+    const size_t lds_fwd_encr = (size_t)(BG::RING_DIST_TAPED + 1) * PK::KS * Pol::FRAG_BYTES + lds_fixed + EncBlock<W, Pol>::BYTES;
     size_t lds_dw = (size_t)BG::NBUF * BG::GROUP_BYTES + (t1.drop_h1 ? (size_t)2 * BG::MT * Pol::FRAG_BYTES + W * 4 : 0);
     if (t1.drop_ga && (size_t)BG::NBUF * BG::GROUP_BYTES_LAST2 > lds_dw) lds_dw = (size_t)BG::NBUF * BG::GROUP_BYTES_LAST2;
     if constexpr (Pol::TAPE8) {          // the 8-bit jobs other than layer 1's run a deeper ring of smaller group images (dw_body2: NB)
@@ -2391,7 +2398,7 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
     if (ga0c) k_chn = chain_kernel<W, Pol, 3, MODE_CHAIN, false, CAN_GA0C>;
     // ga0_chain: a ring of BHN_GA0C_DIST + 1 buffers of the KS fragments the chain streams, the fixed part, 4 staging images of one tile per wave
     const size_t lds_ga0c = (size_t)(BHN_GA0C_DIST + 1) * PK::KS * Pol::FRAG_BYTES + lds_fixed + (size_t)4 * Pol::NWAVES * BG::TILE_BYTES;
-    const size_t lds_fwd = rf ? res_fwd : lds_taped, lds_chn = ga0c ? lds_ga0c : rch ? res_chn : lds_taped;
+    const size_t lds_fwd = rf ? res_fwd : (EncBlock<W, Pol>::ON ? lds_fwd_encr : lds_taped), lds_chn = ga0c ? lds_ga0c : rch ? res_chn : lds_taped;
     auto kdw = dw_kernel<W, Pol>;
     static DeviceOnce once;                 // per template instantiation and device
     BHN_HIP(once.run(device, [&](int &) {

@@ -577,12 +577,18 @@ DEVI void prio_flip(int t, int wvu) {
 // ZB: every tile of the sequence starts from a ZERO accumulator (the delta chain): no bias rows are read and ap.bias -- sixteen
 // registers that would hold zeros across the step boundary -- is not used
 template <int W, class Pol, class RG, class Post, int NFR = W / 16 + 2, bool ZB = false>
+// `encw` (NFR == KS with an encoded-input block, i.e. the forward kernels whose ring copies only the hidden fragments of a chunk):
+// the tile's two encoded-input weight fragments in the RESIDENT block the kernel filled at its start (EncBlock below)
 DEVI f32x16 ring_step(const char *ch, const char *chn, APipe<Pol> &ap, const typename Pol::frag (&src)[W / 16],
                       const typename Pol::frag (&enc)[2], bool with_enc, const float *bias_next, Post &post, DmaJob dma,
-                      int dbg = 0) {
+                      int dbg = 0, const char *encw = nullptr) {
     const int lane = threadIdx.x & 63;
     constexpr int KS = W / 16, NF = NFR, PF = Pol::LDS_PREFETCH;
     static_assert(NF == KS + 2 || (NF == KS && KS >= PF - 1), "chunk fragments (the prefetch reaches PF - 1 fragments into the next chunk)");
+    typename Pol::frag ew0 = Pol::zero(), ew1 = Pol::zero();
+    if constexpr (NF == KS) {
+        if (with_enc) { ew0 = Pol::lds_frag(encw, 0, lane); ew1 = Pol::lds_frag(encw, 1, lane); }     // (read here: landed long before the last k-step)
+    }
     typename Pol::frag a[PF];
 #pragma unroll
     for (int i = 0; i < PF - 1; ++i) a[i] = ap.f[i];
@@ -607,11 +613,39 @@ DEVI f32x16 ring_step(const char *ch, const char *chn, APipe<Pol> &ap, const typ
         if (with_enc && do_mma) acc = Pol::mma(a[t % PF], enc[t - KS], acc);
         __builtin_amdgcn_sched_barrier(0);
     }
+    if constexpr (NF == KS) {
+        if (with_enc && do_mma) { acc = Pol::mma(ew0, enc[0], acc); acc = Pol::mma(ew1, enc[1], acc); }
+    }
     if (do_post) post.finish();
 #pragma unroll
     for (int i = 0; i < PF - 1; ++i) ap.f[i] = a[(NF + i) % PF];
     return acc;
 }
+
+// Resident block of encoded-input weight fragments (forward kernels, bf16, KS >= 8, weight ring -- not the resident image): a chunk
+// of the packed forward image is KS hidden fragments + the 2-fragment encoded-input block, which only the ONE hidden layer with a
+// skip input (network.py:59-61: at most one per depth 2..8) and, at odd depths, the output layer use.  The ring copies the KS
+// hidden fragments only (two instead of three DMA issues per wave and step, 11 % fewer L2 -> LDS bytes; the delta chain got 2 %
+// from the same cut); the 2 x (MT + 1) encoded-input fragments are copied ONCE per workgroup into this block:
+// fragments 2 m, 2 m + 1 = tile m of the hidden skip layer, 2 MT, 2 MT + 1 = the output layer.
+template <int W, class Pol>
+struct EncBlock {
+    static constexpr int KS = W / 16, MT = W / 32, CB = (KS + 2) * Pol::FRAG_BYTES;
+    static constexpr int BYTES = 2 * (MT + 1) * Pol::FRAG_BYTES;
+    static constexpr bool ON = Pol::ELEM_BYTES == 2 && KS >= 8;
+    static DEVI void fill(char *blk, const char *fwd_image, int depth, int skip_mask) {      // all threads, before the first barrier
+        int ls = 0;
+        for (int l = 1; l < depth; ++l) if ((skip_mask >> l) & 1) { ls = l; break; }
+        constexpr int VPT = 2 * Pol::FRAG_BYTES / 16;                                          // 16-byte vectors per tile
+        for (int v = threadIdx.x; v < (MT + 1) * VPT; v += blockDim.x) {
+            const int m = v / VPT, r = v - m * VPT;
+            const int chunk = m < MT ? 1 + (ls - 1) * MT + m : 1 + (depth - 1) * MT;           // (ls == 0: never read)
+            u32x4 val = {0u, 0u, 0u, 0u};
+            if (m == MT || ls > 0) val = reinterpret_cast<const u32x4 *>(fwd_image + (size_t)chunk * CB + KS * Pol::FRAG_BYTES)[r];
+            reinterpret_cast<u32x4 *>(blk)[v] = val;
+        }
+    }
+};
 
 // ---------------------------------------------------------------------------------------------
 // LDS-DMA weight ring: chunk c+2 is copied global -> LDS (buffer_load_dwordx4 ... lds, no registers)
@@ -865,11 +899,11 @@ struct PackTile0 {
     }
 };
 
-template <int W, class Pol, class RG, int STORES, class RS, class L0>
+template <int W, class Pol, class RG, int STORES, class RS, class L0, int NFR = W / 16 + 2>
 DEVI void layer0_step(RS &rs, APipe<Pol> &ap, const typename Pol::frag (&enc)[2], typename Pol::frag (&act)[W / 16],
                       const float *bias_lds, int h, f32x16 &pend, L0 &l0) {
     const int lane = threadIdx.x & 63;
-    constexpr int KS = W / 16, MT = W / 32, NF = KS + 2, PF = Pol::LDS_PREFETCH;   // every chunk is a stream of KS+2 fragments;
+    constexpr int KS = W / 16, MT = W / 32, NF = NFR, PF = Pol::LDS_PREFETCH;      // every chunk is a stream of NFR (KS + 2, or KS) fragments;
     const char *ch = rs.ch(), *chn = rs.chn();                                     // layer 0 uses the first KS of them
     const DmaJob dj = rs.job();
     typename Pol::frag a[PF];
@@ -904,16 +938,17 @@ DEVI void layer0_step(RS &rs, APipe<Pol> &ap, const typename Pol::frag (&enc)[2]
 // hidden layer l: src -> dst.  On entry `pend` is the last tile of the previous layer (destination src[KS-2],
 // src[KS-1]); on exit it is this layer's last tile (destination dst[KS-2], dst[KS-1]).  bl = this layer's bias
 // rows; the rows of the next layer (or of the output layer) follow them at bl + W.
-template <int W, class Pol, class RG, class RS>
+template <int W, class Pol, class RG, class RS, int NFR = W / 16 + 2>
 DEVI void hidden_layer(RS &rs, APipe<Pol> &ap, typename Pol::frag (&src)[W / 16], typename Pol::frag (&dst)[W / 16],
-                       const typename Pol::frag (&enc)[2], bool sk, const float *bl, f32x16 &pend) {
+                       const typename Pol::frag (&enc)[2], bool sk, const float *bl, f32x16 &pend, const char *encblk = nullptr) {
     constexpr int KS = W / 16, MT = W / 32;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const char *ch = rs.ch(), *chn = rs.chn();
         const DmaJob dj = rs.job();
         PackPost<Pol> post(pend, m == 0 ? src[KS - 2] : dst[2 * (m > 0 ? m - 1 : 0)], m == 0 ? src[KS - 1] : dst[2 * (m > 0 ? m - 1 : 0) + 1]);
-        const f32x16 acc = ring_step<W, Pol, RG>(ch, chn, ap, src, enc, sk, bl + 32 * (m + 1), post, dj, rs.dbg);
+        const f32x16 acc = ring_step<W, Pol, RG, PackPost<Pol>, NFR>(ch, chn, ap, src, enc, sk, bl + 32 * (m + 1), post, dj, rs.dbg,
+                                                                     encblk + 2 * m * Pol::FRAG_BYTES);
         rs.step_end();
         pend = acc;
     }

@@ -147,17 +147,22 @@ __global__ __launch_bounds__(Pol::NTHREADS) __attribute__((amdgpu_waves_per_eu(P
     using PK = Pack<W, Pol>;
     using frag = typename Pol::frag;
     constexpr int CB = PK::CHUNK_BYTES, MT = PK::MT, KS = PK::KS;
-    using RG = DmaRing<CB, Pol::NWAVES>;
+    using EB = EncBlock<W, Pol>;
+    constexpr bool ENCR = EB::ON && !RES;                           // the ring copies the hidden fragments only; encoded-input block resident (EncBlock)
+    constexpr int NFR = ENCR ? KS : KS + 2;
+    using RG = DmaRing<ENCR ? KS * Pol::FRAG_BYTES : CB, Pol::NWAVES>;
     constexpr int DIST = Pol::FWD_DIST;                                                // LDS-DMA weight ring: chunks in flight
     using RS = std::conditional_t<RES, ResidentRing<RG, CB, MT>, RingState<RG, CB, DIST, Pol::PHASE_LAG, MT, DBG>>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *ring = smem;                                              // NB x CB (resident: all chunks)
+    char *ring = smem;                                              // NB x (bytes copied per chunk) (resident: all chunks)
     float *bias_lds = reinterpret_cast<float *>(smem + RS::lds_bytes(PK::fwd_chunks(a.depth)));     // (depth+1) x W
     char *seg_lds = reinterpret_cast<char *>(bias_lds + (a.depth + 1) * W);      // RaySum scratch
+    char *encblk = seg_lds + RaySum<Pol::NWAVES>::bytes(a.Sx);                   // EncBlock (ENCR)
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 31, h = lane >> 5;
     for (int i = tid; i < (a.depth + 1) * W; i += Pol::NTHREADS)
         bias_lds[i] = reinterpret_cast<const float *>(a.packed + a.bias_off)[i];
+    if constexpr (ENCR) EB::fill(encblk, a.packed + a.fwd_off, a.depth, a.skip_mask);
 
     // weight ring (LDS-DMA), software-pipelined steps: fused_common.h "Software-pipelined ring steps"
     RS rs;
@@ -188,7 +193,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) __attribute__((amdgpu_waves_per_eu(P
         }
         f32x16 pend;
         PackTile0<Pol> l0;
-        layer0_step<W, Pol, RG, 0>(rs, ap, enc, act, bias_lds, h, pend, l0);
+        layer0_step<W, Pol, RG, 0, RS, PackTile0<Pol>, NFR>(rs, ap, enc, act, bias_lds, h, pend, l0);
         // ---- hidden layers 1..depth-1, ping-pong act <-> next (no register copies) -------------
         float outv;
         {
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) __attribute__((amdgpu_waves_per_eu(P
             // every step then paid ~1000 cycles of instruction fetch); the price is 56 v_mov per layer
 #pragma nounroll
             for (int l = 1; l < a.depth; ++l) {
-                hidden_layer<W, Pol, RG>(rs, ap, act, next, enc, (a.skip_mask >> l) & 1, bias_lds + l * W, pend);
+                hidden_layer<W, Pol, RG, RS, NFR>(rs, ap, act, next, enc, (a.skip_mask >> l) & 1, bias_lds + l * W, pend, encblk);
 #pragma unroll
                 for (int ks = 0; ks < KS - 2; ++ks) act[ks] = next[ks];      // the pending tile lands in act[KS-2], act[KS-1]
             }
@@ -204,7 +209,8 @@ __global__ __launch_bounds__(Pol::NTHREADS) __attribute__((amdgpu_waves_per_eu(P
             const char *ch = rs.ch(), *chn = rs.chn();
             const DmaJob dj = rs.job();
             PackPost<Pol> post(pend, act[KS - 2], act[KS - 1]);
-            const f32x16 acc = ring_step<W, Pol, RG>(ch, chn, ap, act, enc, (a.skip_mask >> a.depth) & 1, bias_lds /* next tile, layer 0 */, post, dj, dbg);
+            const f32x16 acc = ring_step<W, Pol, RG, PackPost<Pol>, NFR>(ch, chn, ap, act, enc, (a.skip_mask >> a.depth) & 1, bias_lds /* next tile, layer 0 */, post, dj, dbg,
+                                                                         encblk + 2 * MT * Pol::FRAG_BYTES);
             outv = acc[0];
             rs.step_end();
         }
@@ -484,7 +490,10 @@ static int launch_fwd_w(FusedArgs &a, hipStream_t st) {
         // small networks: all chunks of the forward image resident in LDS, waves run without the per-chunk barrier
         if ((size_t)PK::fwd_chunks(a.depth) * PK::CHUNK_BYTES + lds_fixed <= 160 * 1024) return launch_fwd_w<W, Pol, RENDER, DBG, true>(a, st);
     }
-    const size_t lds = (RES ? (size_t)PK::fwd_chunks(a.depth) : (size_t)(Pol::FWD_DIST + (Pol::PHASE_LAG ? 2 : 1))) * PK::CHUNK_BYTES + lds_fixed;
+    constexpr bool ENCR = EncBlock<W, Pol>::ON && !RES;             // (the kernel's own condition)
+    const size_t lds = RES ? (size_t)PK::fwd_chunks(a.depth) * PK::CHUNK_BYTES + lds_fixed
+                           : (size_t)(Pol::FWD_DIST + (Pol::PHASE_LAG ? 2 : 1)) * (ENCR ? (size_t)PK::KS * Pol::FRAG_BYTES : (size_t)PK::CHUNK_BYTES) + lds_fixed +
+                             (ENCR ? (size_t)EncBlock<W, Pol>::BYTES : 0);
     auto kern = fused_fwd_kernel<W, Pol, 3, RENDER, DBG, RES>;
     int dev = 0;
     BHN_HIP(hipGetDevice(&dev));
