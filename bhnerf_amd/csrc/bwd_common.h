@@ -22,10 +22,6 @@ struct TapeLayout {
     // tile, and also makes dW_out from the same h_depth tiles (no separate output-layer job): -1 KB per point of
     // tape traffic (chain write + dW read of gA_{depth-1}, second dW read of h_depth)
     int drop_ga;
-    // bf16, width 256, depth >= 3: gA_0 is not on the tape: the delta chain stops at gA_1 (16 instead of 24 ring steps per
-    // tile at depth 4) and the dW job of layer 0 rebuilds gA_0 = (h_1 != 0) (.) W_1 gA_1 from the gA_1 tiles it streams
-    // instead (the same bytes), with its rows of W_1 in registers (dw_body_first_r)
-    int drop_ga0;
     // bf16, width 256, depth >= 3 (round 5): gA_0 is not on the tape and NOBODY streams it: the delta chain itself accumulates
     // dW_0 = gA_0^T [enc | 1] -- every wave stages its finished gA_0 tile in LDS, wave m adds tile m of all eight waves to the
     // ONE accumulator tile it owns (fused_bwd.hip "dW_0 inside the delta chain") -- and flushes it to BwdArgs::slab0; the dW

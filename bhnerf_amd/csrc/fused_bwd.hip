@@ -23,12 +23,6 @@
 #ifndef BHN_JOB1_W
 #define BHN_JOB1_W 13          // weight of the layer-1 dW job in B tiles at width 256 (measured optimum; scaled with the width)
 #endif
-#ifndef BHN_DROP_GA0
-#define BHN_DROP_GA0 0          // 1 (EXPERIMENT, measured slower: DESIGN.md 5): gA_0 not on the tape, rebuilt by the layer-0 dW job
-#endif
-#ifndef BHN_JOB0R_W
-#define BHN_JOB0R_W 24          // weight (in tiles at width 256) of the layer-0 dW job when it rebuilds gA_0 (measured optimum)
-#endif
 #ifndef BHN_JOBL_W
 #define BHN_JOBL_W 8            // extra weight (in tiles at width 256, scaled with the width) of the layer depth-1 dW job when it rebuilds gA_{depth-1} and carries the output row
 #endif
@@ -497,8 +491,8 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
     constexpr int YS_L1r = (KS >= 16) ? YS - ES : 0;                   // first steps of layer 1 when h_1 is not emitted
     constexpr int YS_L1 = YS_L1r > 0 ? YS_L1r : 0;
     const int NCF = (MODE == MODE_CHAIN) ? 0 : PK::fwd_chunks(A.f.depth);
-    // delta chain: hidden layers depth-1 .. LEND produce gA_{l-1}; with TapeLayout::drop_ga0 it stops at gA_1 (LEND = 2)
-    const int LEND = (MODE == MODE_CHAIN && A.t.drop_ga0) ? 2 : 1;
+    // delta chain: hidden layers depth-1 .. LEND = 1 produce gA_{l-1}
+    constexpr int LEND = 1;
     const int NLB = (MODE == MODE_FWD_TRAIN) ? 0 : A.f.depth - LEND;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *ring = smem;
@@ -573,7 +567,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
     // the delta chain stalled for 500-1500 cycles (ring-step stamps: 50.4 k ticks per tile against 39.1 k with the stores switched
     // off, the training forward -- no loads in its loop -- 49.3 k against 45.8 k; profiles/r5_chain_stamps.txt).
     constexpr int MWL = MT >= 4 ? 2 : (MT == 2 ? 3 : 5);              // layers in the FIFO
-    const int NL = a.depth - ((MODE == MODE_CHAIN && A.t.drop_ga0) ? 2 : 1);      // chain layers per tile (= depth - LEND)
+    const int NL = a.depth - LEND;                                     // chain layers per tile
     auto layer_words = [&](long long tile0, int pos, unsigned (&w)[MW]) {
         long long t = tile0;
         int j = pos;
@@ -1806,156 +1800,6 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// dW job of layer 0 that REBUILDS gA_0 (TapeLayout::drop_ga0; bf16, one 32-feature tile per wave: MT == NWAVES).
-// The delta chain stops at gA_1; this job streams the gA_1 tiles (the bytes the plain layer-0 job spends on gA_0) and the
-// encoded inputs, and wave w makes feature tile w of
-//     gA_0 = (h_1 != 0) (.) (gA_1 W_1^T),     h_1 = relu(enc W_0 + b_0)
-// with the POINT on the MFMA row (the orientation of the h_1 recompute of layer 1's job): A = tape tiles read as plain
-// fragments (point-on-lane images ARE A fragments), B = the wave's 16 fragments of W_1 -- chunk (layer 1, tile w) of the
-// transposed weight image, whose A fragments are B fragments of the transpose -- held in registers for the whole job.
-// The accumulator then has the feature on the lane and the points in the registers in the order the transposed tape reads
-// deliver (tr_frag): masked and rounded it is the A operand of dW_0 = gA_0^T enc without leaving the registers.
-// Same products, the same k order and the same rounding as the chain's own layer-1 step: gA_0 is bit-identical to what
-// the chain recorded.  20 MFMAs per group and wave instead of 2.
-// ---------------------------------------------------------------------------------------------
-template <int W, class Pol>
-DEVI void dw_body_first_r(const BwdArgs &A, char *smem) {
-    using BG = BwdGeom<W, Pol>;
-    using PK = Pack<W, Pol>;
-    using frag = typename Pol::frag;
-    static_assert(Pol::ELEM_BYTES == 2, "bf16");
-    constexpr int MT = BG::MT, TB = BG::TILE_BYTES, KS = PK::KS;
-    static_assert(MT == Pol::NWAVES, "one feature tile per wave");
-    constexpr int OFF_E = MT * TB, OFF_P = OFF_E + TB, GB = OFF_P + TB;          // LDS group image [gA_1 tiles][enc][enc, fragment form]
-    constexpr int NBUF = 4;
-    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int trl = tr_lane_off();
-    const int nwg = A.wg_begin[1] - A.wg_begin[0];
-    const int kb = blockIdx.x - A.wg_begin[0];
-    const long long q0 = uniform64(A.t.NQ * kb / nwg), q1 = uniform64(A.t.NQ * (kb + 1) / nwg);
-    // W_0 (layer-0 chunk of the forward image) and b_0 behind the ring, as in the layer-1 job
-    char *w0_lds = smem + NBUF * GB;
-    float *b0_lds = reinterpret_cast<float *>(w0_lds + 2 * MT * Pol::FRAG_BYTES);
-    {
-        const char *w0 = A.f.packed + A.f.fwd_off;
-        for (int i = tid; i < 2 * MT * Pol::FRAG_BYTES / 16; i += Pol::NTHREADS)
-            reinterpret_cast<u32x4 *>(w0_lds)[i] = reinterpret_cast<const u32x4 *>(w0)[i];
-        for (int i = tid; i < W; i += Pol::NTHREADS) b0_lds[i] = reinterpret_cast<const float *>(A.f.packed + A.f.bias_off)[i];
-    }
-    // this wave's fragments of W_1: chunk (layer 1, tile wv) of the transposed image, fragments 0 .. KS-1
-    frag w1[KS];
-    {
-        const char *c = A.f.packed + A.f.bwd_off + (size_t)wv * PK::CHUNK_BYTES;
-#pragma unroll
-        for (int sfr = 0; sfr < KS; ++sfr) w1[sfr] = *reinterpret_cast<const frag *>(c + sfr * Pol::FRAG_BYTES + lane * 16);
-    }
-    using Stream = TapeStream<Pol::NWAVES, MT * TB / 1024, 0, TB / 1024, TB / 1024, 0, OFF_E, OFF_P>;
-    constexpr int PPW = Stream::PPW;
-    // The gA_1 pieces are un-swizzled on their way into LDS: the tape's slot layout (made for the transposed reads of the
-    // other jobs) makes plain fragment reads 4-way bank-conflicted -- the four 4-point rows a 16-lane read group touches
-    // fall on the same banks.  DMA lane i fetches global slot (p & 3) + 4 (c & 1) + 8 (c >> 1) + 16 (p >> 2) of its 1-KiB
-    // piece (p = i & 15: point within the piece, c = i >> 4 = 2 s + h) and writes LDS slot i = p + 16 c: a fragment read
-    // then takes 16 consecutive slots per read group.  Free: only the lanes' global offsets are permuted.
-    const int dl_p = lane & 15, dl_c = lane >> 4;
-    const Stream stream(A.tape + A.t.ga_off[1], (long long)MT * TB, nullptr, 0, A.tape + A.t.enc_off, TB, A.tape + A.t.encp_off, TB, wv,
-                        16 * ((dl_p & 3) + 4 * (dl_c & 1) + 8 * (dl_c >> 1) + 16 * (dl_p >> 2)));
-    auto issue = [&](long long q, char *buf) {
-        q = q < q1 ? q : q1 - 1;
-        if (BHN_DBG(A.wrap)) q %= A.wrap;
-        stream.template issue<1>(q, buf);
-    };
-    // fragment s of a (un-swizzled) tile: lane (pt, h) reads slot (pt & 15) + 16 (2 s + h) of piece pt >> 4
-    const int nat = ((lane & 31) >> 4) * 1024 + 16 * (lane & 15) + 256 * (lane >> 5);
-    __syncthreads();
-    const frag w00 = Pol::lds_frag(w0_lds, 2 * wv, lane), w01 = Pol::lds_frag(w0_lds, 2 * wv + 1, lane);
-    const float b0 = b0_lds[32 * wv + (lane & 31)];
-    f32x16 acc0;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc0[r] = 0.f;
-    float bsum = 0.f;
-    if (q0 < q1) {
-#pragma unroll
-        for (int j = 0; j < NBUF - 1; ++j) issue(q0 + j, smem + j * GB);
-        int it = 0;
-        for (long long q = q0; q < q1; ++q) {
-            if (!BHN_DBG(A.debug & 2)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * PPW) : "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (!BHN_DBG(A.debug & 2)) issue(q + NBUF - 1, smem + ((it + NBUF - 1) & (NBUF - 1)) * GB);
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const char *gp = smem + it * GB;
-            if (!BHN_DBG(A.debug & 1)) {
-                // h_1 tile wv: D[point][feature] = enc W_0 + b_0 (two MFMAs, as the layer-1 job makes it)
-                f32x16 hacc;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) hacc[r] = b0;
-                hacc = Pol::mma(Pol::lds_frag(gp + OFF_P, 0, lane), w00, hacc);
-                hacc = Pol::mma(Pol::lds_frag(gp + OFF_P, 1, lane), w01, hacc);
-                // gA_1 W_1^T, tile wv: K = the 256 features of layer 1, fragment s = half (s & 1) of tape tile s >> 1
-                f32x16 dacc;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) dacc[r] = 0.f;
-                constexpr int PFD = 6;                                      // tape fragments in flight (the reads are bank-conflicted: long latency)
-                frag af[PFD];
-#pragma unroll
-                for (int i = 0; i < PFD - 1; ++i) af[i] = *reinterpret_cast<const frag *>(gp + (i >> 1) * TB + (i & 1) * 512 + nat);
-                const frag eb0 = tr_frag(gp + OFF_E, 0, trl), eb1 = tr_frag(gp + OFF_E, 1, trl);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int sfr = 0; sfr < KS; ++sfr) {
-                    constexpr int dummy = 0; (void)dummy;
-                    const int nx = sfr + PFD - 1;
-                    if (nx < KS) af[nx % PFD] = *reinterpret_cast<const frag *>(gp + (nx >> 1) * TB + (nx & 1) * 512 + nat);
-                    dacc = Pol::mma(af[sfr % PFD], w1[sfr], dacc);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                // gA_0 = (bf16(h_1) != 0) (.) bf16(dacc): the A fragments of dW_0 (fragment s = registers 8 s .. 8 s + 7)
-                frag ga[2];
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    typedef short i16x2 __attribute__((ext_vector_type(2)));
-                    const unsigned hb = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, Pol::pack_a(hacc[r], hacc[r + 1])), (i16x2){0, 0}));
-                    const i16x2 on = (i16x2){0, 0} - __builtin_bit_cast(i16x2, Pol::nonzero_halves(hb));      // 0xffff where h_1 != 0
-                    Pol::put_dword(ga[r >> 3], (r & 7) >> 1, Pol::pack_a(dacc[r], dacc[r + 1]) & __builtin_bit_cast(unsigned, on));
-                }
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    bsum = Pol::sum8(ga[s2], bsum);
-                    acc0 = Pol::mma(ga[s2], s2 ? eb1 : eb0, acc0);
-                }
-            }
-            it = (it + 1) & (NBUF - 1);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    // flush: slab tile (m = wv, n = 0) and the bias column (tile (wv, 1), column 0), the layout of the plain layer-0 job
-    float *slab = A.f.slabs + (long long)blockIdx.x * BG::SLAB_FLOATS;
-    {
-        float *tp = slab + (long long)(wv * BG::NTMAX + 0) * 1024;
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            f32x4 v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = acc0[4 * g4 + e];
-            f32x4 *dst = reinterpret_cast<f32x4 *>(tp + g4 * 256 + lane * 4);
-            if (A.accumulate) {
-                const f32x4 old = *dst;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += old[e];
-            }
-            *dst = v;
-        }
-        float v = bsum + __shfl_xor(bsum, 32, 64);
-        if (lane < 32) {
-            const int hh = (lane >> 2) & 1, r = (lane & 3) + 4 * (lane >> 3);
-            float *dst = slab + (long long)(wv * BG::NTMAX + 1) * 1024 + (r >> 2) * 256 + (32 * hh) * 4 + (r & 3);
-            if (A.accumulate) v += *dst;
-            *dst = v;
-        }
-    }
-}
-
 template <int W, class Pol>
 __global__ __launch_bounds__(Pol::NTHREADS) __attribute__((amdgpu_waves_per_eu(Pol::NWAVES == 4 ? 1 : (W <= 128 ? 4 : 2)))) void dw_kernel(BwdArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];       // NBUF x GROUP_BYTES
@@ -1971,12 +1815,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) __attribute__((amdgpu_waves_per_eu(P
         if (job == depth) {                                               // (depth < 3 only)
             if (out_skip) dw_body<W, Pol, JT_OUTSKIP>(A, job, smem);
             else dw_body<W, Pol, JT_OUT>(A, job, smem);
-        } else if (job == 0) {
-            if constexpr (BHN_DROP_GA0 != 0 && BwdGeom<W, Pol>::MT == Pol::NWAVES) {     // (experiment builds only)
-                if (A.t.drop_ga0) dw_body_first_r<W, Pol>(A, smem);
-                else dw_body2<W, Pol, JT_FIRST>(A, job, smem);
-            } else dw_body2<W, Pol, JT_FIRST>(A, job, smem);
-        } else if (job == depth - 1 && A.t.drop_ga) {
+        } else if (job == 0) dw_body2<W, Pol, JT_FIRST>(A, job, smem); else if (job == depth - 1 && A.t.drop_ga) {
             if constexpr (Pol::TAPE8) {           // (no skip into the output layer: checked by the host)
                 if ((A.f.skip_mask >> job) & 1) dw_body2<W, Pol, JT_SKIP, true>(A, job, smem);
                 else dw_body2<W, Pol, JT_HIDDEN, true>(A, job, smem);
@@ -2191,7 +2030,7 @@ extern "C" int bhn_debug_set_bwd_stages(int32_t mask) {
 template <int W, class Pol>
 static constexpr bool ga0_chain_ok(int depth) {
     // (not the 8-bit tape mode: its delta chain has 16 registers less to spare and spills with the consumer's state)
-    return BHN_GA0_CHAIN != 0 && BHN_DROP_GA0 == 0 && Pol::ELEM_BYTES == 2 && !Pol::TAPE8 &&
+    return BHN_GA0_CHAIN != 0 && Pol::ELEM_BYTES == 2 && !Pol::TAPE8 &&
            W / 32 == Pol::NWAVES && depth >= 3;
 }
 
@@ -2209,17 +2048,16 @@ static void tape_layout(int depth, bool layer1_takes_enc, long long NQ, TapeLayo
     }
     if (t->drop_h1) { t->encp_off = off; off += NQ * (long long)BG::TILE_BYTES; }
     t->drop_ga = bhn_folds_wout(Pol::MODE, depth);
-    t->drop_ga0 = BHN_DROP_GA0 && t->drop_ga && t->drop_h1 && BG::MT == Pol::NWAVES;     // (one feature tile of gA_0 per wave)
     t->ga0_chain = ga0_chain_ok<W, Pol>(depth) && t->drop_ga;
     for (int l = 0; l < depth; ++l) {
-        if ((l == depth - 1 && t->drop_ga) || (l == 0 && (t->drop_ga0 || t->ga0_chain))) { t->ga_off[l] = -1; continue; }
+        if ((l == depth - 1 && t->drop_ga) || (l == 0 && t->ga0_chain)) { t->ga_off[l] = -1; continue; }
         t->ga_off[l] = off; off += per_tensor;
     }
     t->lin_stride = per_tensor;
     {
         const int lmin = t->drop_h1 ? 2 : 1;
         t->h_lin = (lmin <= depth ? t->h_off[lmin] : 0) - lmin * per_tensor;
-        t->ga_lin = (t->drop_ga0 || t->ga0_chain) ? t->ga_off[1] - per_tensor : t->ga_off[0];
+        t->ga_lin = t->ga0_chain ? t->ga_off[1] - per_tensor : t->ga_off[0];
     }
     t->enc_off = off; off += NQ * (long long)BG::TILE_BYTES;
     t->dout_stride = t->drop_ga ? 128 : BG::TILE_BYTES;         // 32 f32 dout per group, or dout as an A tile (row 0 = dout)
@@ -2252,9 +2090,8 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
 #ifdef BHN_DEBUG
     static const int grid_override = dbg_env_int("BHN_DEBUG_DW_GRID", 0);
     static const int job1_w = dbg_env_int("BHN_DEBUG_JOB1_W", BHN_JOB1_W), jobl_w = dbg_env_int("BHN_DEBUG_JOBL_W", BHN_JOBL_W);
-    static const int job0r_w = dbg_env_int("BHN_DEBUG_JOB0R_W", BHN_JOB0R_W);
 #else
-    constexpr int grid_override = 0, job1_w = BHN_JOB1_W, jobl_w = BHN_JOBL_W, job0r_w = BHN_JOB0R_W;
+    constexpr int grid_override = 0, job1_w = BHN_JOB1_W, jobl_w = BHN_JOBL_W;
 #endif
     const int grid_dw = grid_override > 0 ? grid_override : ncu;        // one dW workgroup per CU
     MlpShape s;
@@ -2340,7 +2177,6 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
             if (l == 1 && t1.drop_h1) nB = job1_w * BG::MT / 8;   // reads only the encoded inputs instead of h_1 but has the
                                                                   // same MFMA work + the recompute: not byte-bound any more
             work[l] = (double)(mtA + nB) + 0.5;
-            if (l == 0 && t1.drop_ga0) work[l] = job0r_w * BG::MT / 8.0 + 0.5;     // rebuilds gA_0: 20 MFMAs per group and wave, 16 conflicted LDS reads
             // + the rebuild of gA and the output row (8-bit tape: the byte masks of that job are its long pole; 12 measured 2-3 % faster than 8)
             if (l == depth - 1 && t1.drop_ga) work[l] += (Pol::TAPE8 ? 12 : jobl_w) * BG::MT / 8.0;
             if constexpr (Pol::ELEM_BYTES == 4) {
@@ -2390,7 +2226,7 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
     // small networks: the training forward / the delta chain keep their whole chunk sequence in LDS and run without the
     // per-chunk barrier (ResidentRing), each when its own sequence fits
     const size_t res_fwd = (size_t)PK::fwd_chunks(depth) * PK::CHUNK_BYTES + lds_fixed, res_chn = (size_t)PK::bwd_chunks(depth) * PK::CHUNK_BYTES + lds_fixed;
-    constexpr bool CAN_RES = BHN_RESIDENT != 0 && W <= 128 && BHN_CHAIN_STAMPS == 0 && !BHN_DROP_GA0;     // (width 256: no second instantiation)
+    constexpr bool CAN_RES = BHN_RESIDENT != 0 && W <= 128 && BHN_CHAIN_STAMPS == 0;     // (width 256: no second instantiation)
     const bool rf = CAN_RES && res_fwd <= 160 * 1024, rch = CAN_RES && res_chn <= 160 * 1024;
     auto k_fwd = rf ? chain_kernel<W, Pol, 3, MODE_FWD_TRAIN, CAN_RES> : chain_kernel<W, Pol, 3, MODE_FWD_TRAIN, false>;
     constexpr bool CAN_GA0C = ga0_chain_ok<W, Pol>(3);                // (compile-time part of the condition: which widths instantiate it)
