@@ -876,14 +876,19 @@ struct ResidentRing {
         ring = ring_; NC = nca + nlb_ * MT; dbg = dbg_; lag = 0; ts = nullptr;
         o_cur = 0; o_nxt = NC > 1 ? CB : 0;
         wvu = opaque(__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)));
-        constexpr int VPC = CB / 16;             // 16-byte vectors per chunk
-        for (int v = threadIdx.x; v < NC * VPC; v += blockDim.x) {
-            const int j = v / VPC, r = v - j * VPC;
+        // the whole sequence by LDS-DMA, every piece in flight at once (round 5: through registers -- 12 dependent load / store
+        // rounds of 512 threads for a 100-KB image -- the copy took ~10 us per workgroup, a third of the training forward of a
+        // config-5-sized problem, where a workgroup has only five or six tiles to spread it over)
+        constexpr int PPC = CB / 1024;           // 1-KiB pieces per chunk
+        const int nw = (int)(blockDim.x >> 6);
+        for (int pc = wvu; pc < NC * PPC; pc += nw) {
+            const int j = pc / PPC, r = pc - j * PPC;
             const char *src;
             if (j < nca) src = a_ + (size_t)j * CB;
             else { const int i = j - nca; src = b_ + (size_t)((nlb_ - 1 - i / MT) * MT + i % MT) * CB; }
-            reinterpret_cast<u32x4 *>(ring)[v] = reinterpret_cast<const u32x4 *>(src)[r];
+            dma_1k<false>(src + r * 1024, ring + (size_t)pc * 1024);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 };

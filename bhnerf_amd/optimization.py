@@ -422,6 +422,8 @@ class TrainStep(object):
             for k in range(self.num_losses):
                 loss, state, images = fns[k](state, self.t_units, self.dtype[k], *self.args[k][indices], *rt.values(),
                                              float(self.scale[k]))
+                if len(ray_sets) == 1 and self.num_losses == 1:
+                    return loss, state, images          # (x / 1 + 0.0 is x: four element-wise launches per step that compute nothing)
                 loss_acc = loss_acc + loss / len(ray_sets)
                 images_acc = images_acc + images / len(ray_sets)
         return loss_acc, state, images_acc
