@@ -54,7 +54,8 @@ struct MlpShape {
     int width;                  // KERNEL width: the model's width padded to 32, 64, 128 or 256 (zero weights for the padding units)
     int width_true;             // the model's hidden width (network.py:154): what the flat parameter layout uses
     int F;                      // encoded input features 3 + 6*deg (network.py:118-122)
-    int deg;                    // posenc degree (0..BHN_DEG_MAX)
+    int deg;                    // posenc degree (0..BHN_DEG_MAX; general path: .. BHN_GEN_DEG_MAX)
+    int general;                // 1: a shape outside the fused kernels (posenc_deg > 4 or net_width > 256) -> general_mlp.hip
     int skip_in[BHN_MAX_LAYERS];   // 1 if layer l takes concat[h, enc] as input (network.py:59-61)
     int in_dim[BHN_MAX_LAYERS];    // true fan-in of layer l (l = depth is the output layer)
     int64_t kernel_off[BHN_MAX_LAYERS], bias_off[BHN_MAX_LAYERS];
@@ -62,6 +63,17 @@ struct MlpShape {
 };
 
 int bhn_mlp_shape(const bhn_model *m, MlpShape *s);   // validates, returns BHN_* code
+
+// general_mlp.hip: the f32 layer-by-layer path of the shapes the fused kernels are not built for (MlpShape::general)
+#define BHN_GEN_DEG_MAX 10     // 3 + 6 deg <= 63 encoded features
+#define BHN_GEN_WIDTH_MAX 512
+size_t gen_packed_bytes(const MlpShape &s);
+int gen_pack_weights(const MlpShape &s, const float *params, void *packed, hipStream_t st);
+int gen_forward(bool render, const bhn_model *m, int32_t mode, const void *packed, const bhn_geom *geom, const bhn_frames *fr,
+                float *out, hipStream_t st);
+size_t gen_bwd_workspace_bytes(const MlpShape &s, int32_t B, int64_t P);
+int gen_backward(const bhn_model *m, int32_t mode, const void *packed, const bhn_geom *geom, const bhn_frames *fr,
+                 const float *dimages, float *dparams, void *workspace, size_t workspace_bytes, hipStream_t st);
 
 // bf16 networks with >= 3 hidden layers: the backward never materialises gA_{depth-1} = W_out (.) dout (.) relu' --
 // the dW job of layer depth-1 rebuilds it from h_depth and dout (TapeLayout::drop_ga), and the delta chain feeds

@@ -2375,6 +2375,17 @@ static int bwd_entry(int what, const bhn_model *m, int32_t mode, const void *pac
     const int rcs = bhn_mlp_shape(m, &shape);
     if (rcs != BHN_OK) return rcs;
     const int kernel_width = shape.width;
+    if (shape.general) {
+        // shapes outside the fused kernels (general_mlp.hip, f32 in both modes): the training forward is the plain render, the
+        // backward recomputes what it needs
+        if (t8) { bhn_set_error("BHN_BF16_T8 (8-bit tape) is built for net_width 256, posenc_deg <= 4; use BHN_BF16"); return BHN_EUNSUPPORTED; }
+        BHN_CHECK_ARG(!ev, "per-kernel events are not available for posenc_deg > 4 / net_width > 256");
+        if (what == RUN_FWD_TRAIN) {
+            BHN_CHECK_ARG(images, "null pointer");
+            return gen_forward(true, m, mode, packed, geom, fr, images, (hipStream_t)stream);
+        }
+        return gen_backward(m, mode, packed, geom, fr, dimages, dparams, workspace, workspace_bytes, (hipStream_t)stream);
+    }
     if (t8) {
         if (kernel_width != 256 || shape.depth < 3) {
             bhn_set_error("BHN_BF16_T8 (8-bit tape) is built for net_width 256 and net_depth >= 3 (got %d x %d); use BHN_BF16", shape.depth, shape.width_true);
@@ -2394,8 +2405,9 @@ extern "C" size_t bhn_render_bwd_workspace_bytes(const bhn_model *m, int32_t mod
     MlpShape s;
     if (bhn_mlp_shape(m, &s) != BHN_OK || B <= 0 || P <= 0) return 0;
     size_t q = 0;
+    if (s.general && (mode & 0xff) != BHN_BF16_T8) return gen_bwd_workspace_bytes(s, B, P);
     if ((mode & 0xff) == BHN_BF16_T8 && bhn_norm_mode(mode) == BHN_BF16) {
-        if (s.width != 256 || s.depth < 3) {
+        if (s.general || s.width != 256 || s.depth < 3) {
             bhn_set_error("BHN_BF16_T8 (8-bit tape) is built for net_width 256 and net_depth >= 3 (got %d x %d); use BHN_BF16", s.depth, s.width_true);
             return 0;
         }
@@ -2437,6 +2449,10 @@ extern "C" const char *bhn_render_bwd_tape_kernel_name(int32_t i);
 extern "C" const char *bhn_render_bwd_tape_kernel_name_for(const bhn_model *m, int32_t mode, int32_t i) {
     MlpShape s;
     if (!m || bhn_mlp_shape(m, &s) != BHN_OK) return nullptr;
+    if (s.general) {
+        static const char *const names[BHN_BWD_TAPE_KERNELS] = {"gen_mlp_kernel<GEN_CHAIN>", "gen_dw_kernel", "gen_reduce_kernel"};
+        return (i >= 0 && i < BHN_BWD_TAPE_KERNELS) ? names[i] : nullptr;
+    }
     if (bwd128_supported(bhn_norm_mode(mode), s.width, s.depth)) {
         static const char *const names[BHN_BWD_TAPE_KERNELS] = {"bwd128_kernel", "-", "reduce128_kernel"};
         return (i >= 0 && i < BHN_BWD_TAPE_KERNELS) ? names[i] : nullptr;

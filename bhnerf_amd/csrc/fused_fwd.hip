@@ -29,6 +29,7 @@ extern "C" size_t bhn_packed_bytes(const bhn_model *m, int32_t mode) {
     mode = bhn_norm_mode(mode);
     MlpShape s;
     if (bhn_mlp_shape(m, &s) != BHN_OK) return 0;
+    if (s.general) return gen_packed_bytes(s);
     PackedLayout L;
     packed_layout(s, mode, &L);
     return L.total;
@@ -126,6 +127,7 @@ extern "C" int bhn_pack_weights(const bhn_model *m, int32_t mode, const float *p
     PackArgs a;
     int rc = bhn_mlp_shape(m, &a.s);
     if (rc != BHN_OK) return rc;
+    if (a.s.general) return gen_pack_weights(a.s, params, packed, (hipStream_t)stream);
     packed_layout(a.s, mode, &a.L);
     a.mode = mode;
     a.params = params;
@@ -616,6 +618,7 @@ extern "C" int bhn_predict_fwd(const bhn_model *m, int32_t mode, const void *pac
     MlpShape s;
     BHN_CHECK_ARG(emission, "null emission");
     mode = bhn_norm_mode(mode);
+    if (m && bhn_mlp_shape(m, &s) == BHN_OK && s.general) return gen_forward(false, m, mode, packed, geom, fr, emission, (hipStream_t)stream);
     const int nw = fwd_tile_groups(m, mode, geom);
     int rc = fused_fill_args(m, mode, packed, geom, fr, false, &a, &s, nw);
     if (rc != BHN_OK) return rc;
@@ -633,6 +636,7 @@ extern "C" int bhn_render_fwd(const bhn_model *m, int32_t mode, const void *pack
     MlpShape s;
     BHN_CHECK_ARG(images, "null images");
     mode = bhn_norm_mode(mode);
+    if (m && bhn_mlp_shape(m, &s) == BHN_OK && s.general) return gen_forward(true, m, mode, packed, geom, fr, images, (hipStream_t)stream);
     const int nw = fwd_tile_groups(m, mode, geom);
     int rc = fused_fill_args(m, mode, packed, geom, fr, true, &a, &s, nw);
     if (rc != BHN_OK) return rc;

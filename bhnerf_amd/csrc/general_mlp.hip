@@ -1,0 +1,481 @@
+// NeRF_Predictor shapes the fused kernels are not built for: posenc_deg 5..10 (network.py:98-122; 3 + 6 deg <= 63 encoded
+// features) and net_width 257..512 (network.py:154).  No reference driver sets either, so this path is written for
+// completeness, not for the roofline: f32 arithmetic in BOTH modes (v_mfma_f32_32x32x2_f32; BHN_BF16 is accepted and
+// computed in f32), activations of a 32-point group in LDS, weights streamed from L2 by every workgroup, and a backward
+// that goes through an HBM tape in chunks of groups:
+//
+//   gen_mlp_kernel<PREDICT | RENDER>   one workgroup = one 32-point group at a time: warp + posenc (emission.py:200-210,
+//                                      network.py:118-122) -> LDS, layers as [feature][point] images in two LDS buffers (the
+//                                      waves share the 32-row output tiles of a layer), sigmoid / masks, emission or ray sum;
+//   gen_mlp_kernel<CHAIN>              the same forward writing every layer input to the tape, then dout and the delta chain
+//                                      gA_{l-1} = relu' (.) K_l gA_l (transposed weight copies) writing every gA_l;
+//   gen_dw_kernel                      dK_l = in_l^T gA_l over the tape, K = points: workgroup (job, split) = one 32-row x
+//                                      128-column block of one layer over one share of the chunk's groups, into its own slab
+//                                      (the bias is the job whose input tile is a row of ones);
+//   gen_reduce_kernel                  slabs summed in split order -> flat gradient (deterministic).
+//
+// Packed image (bhn_pack_weights, all f32): per layer K_l zero-padded to [hrows | erows][outp] (hrows = width padded to 32
+// for l > 0, erows = encoded inputs padded to 32 for layer 0 and the skip layers, network.py:59-61; outp = padded width, 32
+// for the output layer whose column 0 is real), its transposed hidden part [outp][hrows] for the delta chain, its bias.
+#include <algorithm>
+#include "fused_common.h"
+
+namespace {
+
+enum { GEN_PREDICT = 0, GEN_RENDER = 1, GEN_CHAIN = 2 };
+
+struct GenLayer {
+    unsigned k_off, kt_off, b_off;     // float offsets in the packed image
+    unsigned slab_off;                 // float offset of this layer's [(hrows + erows + 32) x outp] block in a gradient slab
+    int hrows, erows, outp;
+    int h_true, e_true, out_true;      // the flat parameters: kernel ((h_true + e_true) x out_true) at pk_off, bias at pb_off
+    long long pk_off, pb_off;
+};
+
+struct GenArgs {
+    FusedArgs f;
+    GenLayer L[BHN_MAX_LAYERS];
+    int D, Wp, Ep, F;
+    const float *pk;                   // packed image
+    float *tape;                       // [tile of this chunk][tape_tile floats]: enc | h_1 .. h_D | gA_0 .. gA_{D-1} | gA_D (32 rows)
+    long long tape_tile;
+    long long tile0, ntiles;           // the chunk
+    const float *dimages;
+    float *slabs;
+    long long slab_floats;
+    int nsplit, accumulate;
+    float *dparams;
+    long long nparams;
+    const float *params;               // pack
+    float *packed_out;
+    long long packed_floats;
+};
+
+DEVI long long tape_h(const GenArgs &A, int l) { return (long long)A.Ep * 32 + (long long)(l - 1) * A.Wp * 32; }        // l = 1..D
+DEVI long long tape_ga(const GenArgs &A, int l) { return (long long)A.Ep * 32 + (long long)(A.D + l) * A.Wp * 32; }     // l = 0..D
+
+// acc (features 32 m .. 32 m + 31 x the 32 points) += sum_k K[k][32 m + i] in[k][point]: K rows `rows` (a multiple of 32)
+// of `stride` floats, `in` an LDS image [row][32].  Lane (i, h) feeds k = 2 t + h of every pair.
+DEVI f32x16 gen_rows(f32x16 acc, const float *__restrict__ K, int stride, int m, const float *in, int rows, int lane) {
+    const int i = lane & 31, h = lane >> 5;
+    const float *Kc = K + 32 * m + i + (long long)h * stride;
+    const float *ic = in + 32 * h + i;
+    float an[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) an[j] = Kc[(long long)(2 * j) * stride];
+    for (int k0 = 0; k0 < rows; k0 += 16) {
+        float ac[8], bc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { ac[j] = an[j]; bc[j] = ic[(k0 + 2 * j) * 32]; }
+        if (k0 + 16 < rows) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) an[j] = Kc[(long long)(k0 + 16 + 2 * j) * stride];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[j], bc[j], acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+// accumulator element r of lane (i, h) is feature 32 m + gen_row(r, h) of point i
+DEVI int gen_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+template <int MODE>
+__global__ __launch_bounds__(512) void gen_mlp_kernel(GenArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const FusedArgs &a = A.f;
+    const int Wp = A.Wp, Ep = A.Ep, D = A.D, MTp = Wp >> 5;
+    float *buf0 = reinterpret_cast<float *>(smem), *buf1 = buf0 + Wp * 32, *encS = buf1 + Wp * 32;
+    float *red = encS + Ep * 32;                       // [16][32] partial sums of the output layer
+    float *doutv = red + 16 * 32;                      // [32]
+    int *livev = reinterpret_cast<int *>(doutv + 32);  // [32]
+    char *seg = reinterpret_cast<char *>(livev + 32);  // RaySum<1> scratch
+    const int tid = threadIdx.x, lane = tid & 63, pl = tid & 31, part = tid >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = (int)(blockDim.x >> 6), NP = (int)(blockDim.x >> 5), NT = (int)blockDim.x;
+    const int li = lane & 31, lh = lane >> 5;
+
+    for (long long tile = A.tile0 + blockIdx.x; tile < A.tile0 + A.ntiles; tile += gridDim.x) {
+        float *tp = MODE == GEN_CHAIN ? A.tape + (tile - A.tile0) * A.tape_tile : nullptr;
+        // ---- velocity warp + positional encoding of the group's 32 points (every 32-thread part holds all of them) ----
+        const PointIn q = load_point<1>(a, tile, 0, pl);
+        bool live;
+        {
+            const double tM = q.tM0d + (double)q.tg;                       // emission.py:200-201 (t_M in double)
+            const bool pre = tM < 0.0;                                     // emission.py:204-205
+            const double rev_d = tM * (double)q.om * 0.15915494309189535;
+            const double fr = rev_d - floor(rev_d);
+            float s, c;
+            sincosf((float)(fr * 6.283185307179586), &s, &c);
+            float u[3] = {c * q.x + s * q.y, c * q.y - s * q.x, q.z};      // rot_z(-theta), utils.py:126-132
+            const bool finite_theta = !pre && (fr == fr);
+            bool valid0 = false;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const bool v = finite_theta && isfinite(u[k]);              // network.py:226
+                if (k == 0) valid0 = v;
+                u[k] = v ? u[k] / a.scale : 0.f;                            // network.py:227, 229
+            }
+            live = q.inb && q.dom && valid0;
+            // features in the reference's order [u | sin(2^i u_k) at 3 + 3 i + k | cos(...) at 3 + 3 deg + 3 i + k]
+            for (int i = part; i < a.deg; i += NP)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    float sv, cv;
+                    sincosf(u[k] * (float)(1 << i), &sv, &cv);
+                    encS[(3 + 3 * i + k) * 32 + pl] = sv;
+                    encS[(3 + 3 * a.deg + 3 * i + k) * 32 + pl] = cv;
+                }
+            if (part == NP - 1) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) encS[k * 32 + pl] = u[k];
+                livev[pl] = live ? 1 : 0;
+            }
+            for (int r = A.F + part; r < Ep; r += NP) encS[r * 32 + pl] = 0.f;
+        }
+        __syncthreads();
+        if (MODE == GEN_CHAIN)
+            for (int idx = tid; idx < Ep * 32; idx += NT) tp[idx] = encS[idx];
+        // ---- hidden layers ----
+        float *in = buf0, *out = buf1;
+        for (int l = 0; l < D; ++l) {
+            const GenLayer Lr = A.L[l];
+            for (int m = wv; m < MTp; m += nwv) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = A.pk[Lr.b_off + 32 * m + gen_row(r, lh)];
+                if (Lr.hrows) acc = gen_rows(acc, A.pk + Lr.k_off, Lr.outp, m, in, Lr.hrows, lane);
+                if (Lr.erows) acc = gen_rows(acc, A.pk + Lr.k_off + (long long)Lr.hrows * Lr.outp, Lr.outp, m, encS, Lr.erows, lane);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = acc[r] > 0.f ? acc[r] : 0.f;
+                    const int o = (32 * m + gen_row(r, lh)) * 32 + li;
+                    out[o] = v;
+                    if (MODE == GEN_CHAIN) tp[tape_h(A, l + 1) + o] = v;
+                }
+            }
+            __syncthreads();
+            float *t = in; in = out; out = t;
+        }
+        // ---- output layer (column 0 of its [rows][32] image), sigmoid(. - 10), masks ----
+        const GenLayer Lo = A.L[D];
+        {
+            const float *ko = A.pk + Lo.k_off;
+            float s = 0.f;
+            for (int k = part; k < Lo.hrows; k += NP) s += ko[(long long)k * 32] * in[k * 32 + pl];
+            for (int k = part; k < Lo.erows; k += NP) s += ko[(long long)(Lo.hrows + k) * 32] * encS[k * 32 + pl];
+            red[part * 32 + pl] = s;
+        }
+        __syncthreads();
+        float e = 0.f;
+        if (tid < 32) {
+            float o = A.pk[Lo.b_off];
+            for (int p2 = 0; p2 < NP; ++p2) o += red[p2 * 32 + pl];
+            if (live) e = 1.f / (1.f + expf(10.f - o));                      // network.py:231-233
+        }
+        if (MODE == GEN_PREDICT) {
+            if (tid < 32 && q.inb) a.emission[(long long)q.b * a.P + q.p] = e;
+        } else if (MODE == GEN_RENDER) {
+            if (wv == 0) RaySum<1>::put(a, seg, 0, q.p, q.inb, e, 0.f, false, q.b);
+            if (!a.ray_direct) {
+                __syncthreads();
+                if (wv == 0) RaySum<1>::combine(a, seg, 0, q.b);
+            }
+        } else {
+            // ---- dout = d loss / d (pre-sigmoid output): dE e (1 - e), dE = sum_s dimages[b, s, ray] w[s, p] ----
+            if (tid < 32) {
+                float d = 0.f;
+                if (q.inb && e != 0.f) {
+                    const long long ray = a.ray_idx ? (long long)a.ray_idx[q.p] : (long long)a.fd_G.div((unsigned)q.p);
+                    float dE = 0.f;
+                    for (int s = 0; s < a.Sx; ++s) dE += A.dimages[((long long)q.b * a.Sx + s) * a.R + ray] * a.w[(long long)s * a.P + q.p];
+                    d = dE * e * (1.f - e);
+                }
+                doutv[pl] = d;
+            }
+            __syncthreads();
+            // gA_D (32 rows, row 0 real) and gA_{D-1} = relu'(h_D) (.) K_out dout
+            for (int idx = tid; idx < 1024; idx += NT) tp[tape_ga(A, D) + idx] = idx < 32 ? doutv[idx] : 0.f;
+            {
+                const float *ko = A.pk + Lo.k_off;
+                for (int idx = tid; idx < Wp * 32; idx += NT) {
+                    const float g = in[idx] > 0.f ? ko[(long long)(idx >> 5) * 32] * doutv[idx & 31] : 0.f;
+                    out[idx] = g;
+                    tp[tape_ga(A, D - 1) + idx] = g;
+                }
+            }
+            __syncthreads();
+            { float *t = in; in = out; out = t; }                            // `in` = gA_l from here on
+            // ---- delta chain: gA_{l-1} = relu'(h_l) (.) K_l[hidden rows] gA_l, l = D-1 .. 1 (h_l read back from the tape) ----
+            for (int l = D - 1; l >= 1; --l) {
+                const GenLayer Lr = A.L[l];
+                for (int m = wv; m < MTp; m += nwv) {
+                    f32x16 acc = {};
+                    acc = gen_rows(acc, A.pk + Lr.kt_off, Lr.hrows, m, in, Lr.outp, lane);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int o = (32 * m + gen_row(r, lh)) * 32 + li;
+                        const float g = tp[tape_h(A, l) + o] > 0.f ? acc[r] : 0.f;
+                        out[o] = g;
+                        tp[tape_ga(A, l - 1) + o] = g;
+                    }
+                }
+                __syncthreads();
+                float *t = in; in = out; out = t;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// dK_l[in rows 32 mi ..][out columns 128 strip ..] += sum over the split's groups of in_l^T gA_l (the bias: in = a row of ones)
+__global__ __launch_bounds__(64) void gen_dw_kernel(GenArgs A) {
+    const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+    // job -> (layer, input tile, output strip)
+    int job = blockIdx.x, l = 0, mi = 0, strip = 0;
+    for (l = 0; l <= A.D; ++l) {
+        const int nin = ((A.L[l].hrows + A.L[l].erows) >> 5) + 1, nst = ((A.L[l].outp >> 5) + 3) >> 2;
+        if (job < nin * nst) { mi = job / nst; strip = job - mi * nst; break; }
+        job -= nin * nst;
+    }
+    if (l > A.D) return;
+    const GenLayer Lr = A.L[l];
+    const int nt = min(4, (Lr.outp >> 5) - 4 * strip);                     // 32-column tiles of this strip
+    const int htiles = Lr.hrows >> 5, etiles = Lr.erows >> 5;
+    const bool bias_job = mi == htiles + etiles;
+    // this lane's 16 points of a group: 16 h .. 16 h + 15 (any pairing of points with k-steps serves a sum over points)
+    long long a_off = 0;
+    if (mi < htiles) a_off = tape_h(A, l) + (long long)(32 * mi + i) * 32 + 16 * h;
+    else if (!bias_job) a_off = (long long)(32 * (mi - htiles) + i) * 32 + 16 * h;
+    const long long b_off = tape_ga(A, l) + (long long)(128 * strip + i) * 32 + 16 * h;
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const f32x16 z = {}; acc[j] = z; }
+    const long long t0 = A.ntiles * blockIdx.y / A.nsplit, t1 = A.ntiles * (blockIdx.y + 1) / A.nsplit;
+    for (long long t = t0; t < t1; ++t) {
+        const float *tp = A.tape + t * A.tape_tile;
+        f32x4 av[4], bv[4][4];
+        if (bias_job) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const float one = i == 0 ? 1.f : 0.f; av[k] = f32x4{one, one, one, one}; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) av[k] = *reinterpret_cast<const f32x4 *>(tp + a_off + 4 * k);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < nt) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) bv[j][k] = *reinterpret_cast<const f32x4 *>(tp + b_off + (long long)j * 1024 + 4 * k);
+            }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < nt) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[k >> 2][k & 3], bv[j][k >> 2][k & 3], acc[j], 0, 0, 0);
+            }
+    }
+    float *slab = A.slabs + (long long)blockIdx.y * A.slab_floats + Lr.slab_off;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (j < nt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float *d = slab + (long long)(32 * mi + gen_row(r, h)) * Lr.outp + 128 * strip + 32 * j + i;
+                *d = A.accumulate ? *d + acc[j][r] : acc[j][r];
+            }
+        }
+}
+
+__global__ void gen_reduce_kernel(GenArgs A) {
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < A.nparams; idx += (long long)gridDim.x * blockDim.x) {
+        int l = 0;
+        while (l < A.D && idx >= A.L[l + 1].pk_off) ++l;
+        const GenLayer Lr = A.L[l];
+        long long row, o;
+        if (idx >= Lr.pb_off) { row = Lr.hrows + Lr.erows; o = idx - Lr.pb_off; }
+        else {
+            const long long r = (idx - Lr.pk_off) / Lr.out_true;
+            o = (idx - Lr.pk_off) - r * Lr.out_true;
+            row = r < Lr.h_true ? r : Lr.hrows + (r - Lr.h_true);
+        }
+        const float *s = A.slabs + Lr.slab_off + row * Lr.outp + o;
+        float sum = 0.f;
+        for (int k = 0; k < A.nsplit; ++k) sum += s[(long long)k * A.slab_floats];
+        A.dparams[idx] = sum;
+    }
+}
+
+__global__ void gen_pack_fill_kernel(GenArgs A) {
+    const long long gtid = blockIdx.x * (long long)blockDim.x + threadIdx.x, gn = (long long)gridDim.x * blockDim.x;
+    for (int l = 0; l <= A.D; ++l) {
+        const GenLayer Lr = A.L[l];
+        const int rows = Lr.hrows + Lr.erows;
+        const long long nk = (long long)rows * Lr.outp;
+        for (long long idx = gtid; idx < nk; idx += gn) {
+            const int r = (int)(idx / Lr.outp), o = (int)(idx - (long long)r * Lr.outp);
+            long long fr = -1;
+            if (r < Lr.hrows) { if (r < Lr.h_true) fr = r; }
+            else if (r - Lr.hrows < Lr.e_true) fr = Lr.h_true + (r - Lr.hrows);
+            A.packed_out[Lr.k_off + idx] = (fr >= 0 && o < Lr.out_true) ? A.params[Lr.pk_off + fr * Lr.out_true + o] : 0.f;
+        }
+        if (l >= 1 && l < A.D) {
+            const long long nt = (long long)Lr.outp * Lr.hrows;
+            for (long long idx = gtid; idx < nt; idx += gn) {
+                const int o = (int)(idx / Lr.hrows), k = (int)(idx - (long long)o * Lr.hrows);
+                A.packed_out[Lr.kt_off + idx] = (k < Lr.h_true && o < Lr.out_true) ? A.params[Lr.pk_off + (long long)k * Lr.out_true + o] : 0.f;
+            }
+        }
+        for (long long o = gtid; o < Lr.outp; o += gn) A.packed_out[Lr.b_off + o] = o < Lr.out_true ? A.params[Lr.pb_off + o] : 0.f;
+    }
+}
+
+// layer tables + sizes of the packed image / a gradient slab / a tape tile
+void gen_layout(const MlpShape &s, GenArgs *A) {
+    const int Wp = (s.width_true + 31) / 32 * 32, Ep = (s.F + 31) / 32 * 32;
+    A->D = s.depth; A->Wp = Wp; A->Ep = Ep; A->F = s.F;
+    unsigned off = 0, soff = 0;
+    for (int l = 0; l <= s.depth; ++l) {
+        GenLayer &L = A->L[l];
+        L.hrows = l > 0 ? Wp : 0;
+        L.erows = (l == 0 || s.skip_in[l]) ? Ep : 0;
+        L.outp = l == s.depth ? 32 : Wp;
+        L.h_true = l > 0 ? s.width_true : 0;
+        L.e_true = (l == 0 || s.skip_in[l]) ? s.F : 0;
+        L.out_true = l == s.depth ? 1 : s.width_true;
+        L.pk_off = s.kernel_off[l]; L.pb_off = s.bias_off[l];
+        L.k_off = off; off += (unsigned)(L.hrows + L.erows) * L.outp;
+        L.kt_off = off; if (l >= 1 && l < s.depth) off += (unsigned)L.outp * L.hrows;
+        L.b_off = off; off += L.outp;
+        L.slab_off = soff; soff += (unsigned)(L.hrows + L.erows + 32) * L.outp;
+    }
+    A->packed_floats = off;
+    A->slab_floats = soff;
+    A->tape_tile = (long long)Ep * 32 + 2ll * s.depth * Wp * 32 + 1024;
+    A->nparams = s.nparams;
+}
+
+size_t gen_lds_bytes(const GenArgs &A, int Sx) { return (size_t)(2 * A.Wp + A.Ep) * 32 * 4 + (16 * 32 + 64) * 4 + RaySum<1>::bytes(Sx); }
+int gen_block(const GenArgs &A) { const int mt = A.Wp / 32; return mt >= 8 ? 512 : mt >= 4 ? 256 : 128; }
+constexpr int GEN_NSPLIT = 8;
+
+template <int MODE>
+int gen_launch_mlp(const GenArgs &A, int grid, hipStream_t st) {
+    const size_t lds = gen_lds_bytes(A, A.f.Sx);
+    static DeviceOnce once;
+    int dev = 0;
+    BHN_HIP(hipGetDevice(&dev));
+    BHN_HIP(once.run(dev, [&](int &) { return hipFuncSetAttribute((const void *)gen_mlp_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }));
+    hipLaunchKernelGGL(gen_mlp_kernel<MODE>, dim3(grid), dim3(gen_block(A)), lds, st, A);
+    BHN_HIP(hipGetLastError());
+    return BHN_OK;
+}
+
+}  // namespace
+
+size_t gen_packed_bytes(const MlpShape &s) {
+    GenArgs A;
+    gen_layout(s, &A);
+    return (size_t)A.packed_floats * 4;
+}
+
+int gen_pack_weights(const MlpShape &s, const float *params, void *packed, hipStream_t st) {
+    GenArgs A;
+    memset(&A, 0, sizeof(A));
+    gen_layout(s, &A);
+    A.params = params;
+    A.packed_out = reinterpret_cast<float *>(packed);
+    hipLaunchKernelGGL(gen_pack_fill_kernel, dim3(512), dim3(256), 0, st, A);
+    BHN_HIP(hipGetLastError());
+    return BHN_OK;
+}
+
+int fused_fill_args(const bhn_model *m, int32_t mode, const void *packed, const bhn_geom *geom, const bhn_frames *fr, bool need_w,
+                    FusedArgs *a, MlpShape *s, int nwaves);     // fused_fwd.hip
+
+// FusedArgs for the general kernels: one 32-point group per tile
+static int gen_fill(const bhn_model *m, int32_t mode, const void *packed, const bhn_geom *geom, const bhn_frames *fr, bool need_w,
+                    GenArgs *A, MlpShape *s) {
+    memset(A, 0, sizeof(*A));
+    const int rc = fused_fill_args(m, mode, packed, geom, fr, need_w, &A->f, s, 1);
+    if (rc != BHN_OK) return rc;
+    gen_layout(*s, A);
+    A->pk = reinterpret_cast<const float *>(packed);
+    A->tile0 = 0;
+    A->ntiles = A->f.total_tiles;
+    return BHN_OK;
+}
+
+int gen_forward(bool render, const bhn_model *m, int32_t mode, const void *packed, const bhn_geom *geom, const bhn_frames *fr,
+                float *out, hipStream_t st) {
+    GenArgs A;
+    MlpShape s;
+    int rc = gen_fill(m, mode, packed, geom, fr, render, &A, &s);
+    if (rc != BHN_OK) return rc;
+    int dev = 0;
+    BHN_HIP(hipGetDevice(&dev));
+    BHN_CHECK_DEVICE(dev);
+    const size_t lds = gen_lds_bytes(A, A.f.Sx);
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(160 * 1024 / lds, 2048 / gen_block(A)));
+    const int grid = (int)bhn_balanced_grid(A.ntiles, (long long)bhn_num_cus(dev) * per_cu);
+    if (render) {
+        A.f.images = out;
+        BHN_HIP(hipMemsetAsync(out, 0, sizeof(float) * (size_t)A.f.B * A.f.Sx * A.f.R, st));
+        return gen_launch_mlp<GEN_RENDER>(A, grid, st);
+    }
+    A.f.emission = out;
+    if (geom->groups) BHN_HIP(hipMemsetAsync(out, 0, sizeof(float) * (size_t)A.f.B * A.f.P, st));
+    return gen_launch_mlp<GEN_PREDICT>(A, grid, st);
+}
+
+static size_t gen_align(size_t v) { return (v + 255) & ~(size_t)255; }
+
+size_t gen_bwd_workspace_bytes(const MlpShape &s, int32_t B, int64_t P) {
+    GenArgs A;
+    gen_layout(s, &A);
+    const long long tiles = (P + 31) / 32 * B;
+    const size_t tile_bytes = (size_t)A.tape_tile * 4;
+    // the tape of one chunk of groups: all of them up to 2 GiB, never less than one frame (what gen_backward insists on)
+    const size_t cap = std::max<size_t>((size_t)2 << 30, (size_t)((P + 31) / 32) * tile_bytes);
+    return gen_align((size_t)GEN_NSPLIT * A.slab_floats * 4) + std::min<size_t>((size_t)tiles * tile_bytes, cap);
+}
+
+int gen_backward(const bhn_model *m, int32_t mode, const void *packed, const bhn_geom *geom, const bhn_frames *fr,
+                 const float *dimages, float *dparams, void *workspace, size_t workspace_bytes, hipStream_t st) {
+    GenArgs A;
+    MlpShape s;
+    int rc = gen_fill(m, mode, packed, geom, fr, true, &A, &s);
+    if (rc != BHN_OK) return rc;
+    BHN_CHECK_ARG(workspace && dimages && dparams, "null pointer");
+    int dev = 0;
+    BHN_HIP(hipGetDevice(&dev));
+    BHN_CHECK_DEVICE(dev);
+    const size_t slab_bytes = gen_align((size_t)GEN_NSPLIT * A.slab_floats * 4), tile_bytes = (size_t)A.tape_tile * 4;
+    const long long min_tiles = A.f.tiles_per_frame;                       // (the contract of bhn_render_bwd: slabs + ONE frame of tape)
+    if (workspace_bytes < slab_bytes + (size_t)min_tiles * tile_bytes) {
+        bhn_set_error("render_bwd workspace too small: %zu bytes, need >= %zu (slabs %zu + %lld groups of tape)", workspace_bytes,
+                      slab_bytes + (size_t)min_tiles * tile_bytes, slab_bytes, min_tiles);
+        return BHN_EWORKSPACE;
+    }
+    A.slabs = reinterpret_cast<float *>(workspace);
+    A.tape = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + slab_bytes);
+    A.nsplit = GEN_NSPLIT;
+    A.dimages = dimages;
+    A.dparams = dparams;
+    const long long chunk = std::min<long long>(A.f.total_tiles, (long long)((workspace_bytes - slab_bytes) / tile_bytes));
+    const size_t lds = gen_lds_bytes(A, A.f.Sx);
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(160 * 1024 / lds, 2048 / gen_block(A)));
+    int njobs = 0;
+    for (int l = 0; l <= A.D; ++l) njobs += (((A.L[l].hrows + A.L[l].erows) >> 5) + 1) * (((A.L[l].outp >> 5) + 3) >> 2);
+    for (long long c0 = 0; c0 < A.f.total_tiles; c0 += chunk) {
+        A.tile0 = c0;
+        A.ntiles = std::min<long long>(chunk, A.f.total_tiles - c0);
+        A.accumulate = c0 > 0;
+        rc = gen_launch_mlp<GEN_CHAIN>(A, (int)bhn_balanced_grid(A.ntiles, (long long)bhn_num_cus(dev) * per_cu), st);
+        if (rc != BHN_OK) return rc;
+        hipLaunchKernelGGL(gen_dw_kernel, dim3(njobs, GEN_NSPLIT), dim3(64), 0, st, A);
+        BHN_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(gen_reduce_kernel, dim3(1024), dim3(256), 0, st, A);
+    BHN_HIP(hipGetLastError());
+    return BHN_OK;
+}

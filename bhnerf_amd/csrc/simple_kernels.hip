@@ -37,14 +37,16 @@ int bhn_num_cus(int device) {
 int bhn_mlp_shape(const bhn_model *m, MlpShape *s) {
     BHN_CHECK_ARG(m && s, "null model");
     BHN_CHECK_ARG(m->net_depth >= 2 && m->net_depth <= 8, "net_depth %d outside 2..8", m->net_depth);
-    BHN_CHECK_ARG(m->net_width >= 1 && m->net_width <= 256, "net_width %d outside 1..256", m->net_width);
-    BHN_CHECK_ARG(m->posenc_deg >= 0 && m->posenc_deg <= 4, "posenc_deg %d outside 0..4", m->posenc_deg);
+    BHN_CHECK_ARG(m->net_width >= 1 && m->net_width <= BHN_GEN_WIDTH_MAX, "net_width %d outside 1..%d", m->net_width, BHN_GEN_WIDTH_MAX);
+    BHN_CHECK_ARG(m->posenc_deg >= 0 && m->posenc_deg <= BHN_GEN_DEG_MAX, "posenc_deg %d outside 0..%d", m->posenc_deg, BHN_GEN_DEG_MAX);
     memset(s, 0, sizeof(*s));
     s->depth = m->net_depth;
+    s->general = (m->posenc_deg > BHN_DEG_MAX || m->net_width > 256) ? 1 : 0;
     // the fused kernels exist for widths 32, 64, 128, 256: any other width runs on the next one with zero weights, biases
     // and gradients for the padding units (relu(0) = 0: they change nothing), the flat parameter layout keeps the true width
     s->width_true = m->net_width;
     s->width = m->net_width <= 32 ? 32 : m->net_width <= 64 ? 64 : m->net_width <= 128 ? 128 : 256;
+    if (s->general) s->width = (m->net_width + 31) / 32 * 32;
     s->F = 3 + 6 * m->posenc_deg;
     s->deg = m->posenc_deg;
     const int skip_layer = m->net_depth / 2;

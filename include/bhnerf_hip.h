@@ -52,11 +52,19 @@ enum { BHN_F32 = 0, BHN_BF16 = 1, BHN_BF16_T8 = 2 };
  * net_depth,net_width,do_skip; activation=relu and out_channel=1 are fixed as in every driver). */
 typedef struct {
     int32_t net_depth;    /* hidden Dense+ReLU layers, 2..8 (network.py:153) */
-    int32_t net_width;    /* 1..256 (network.py:154); widths other than 32/64/128/256 run zero-padded on the next one */
-    int32_t posenc_deg;   /* 0..4, 3+6*deg <= 32 features (network.py:151)   */
+    int32_t net_width;    /* 1..512 (network.py:154); widths other than 32/64/128/256 run zero-padded on the next one;
+                           * 257..512: the general layer-by-layer path (below)                                            */
+    int32_t posenc_deg;   /* 0..10 (network.py:151); the fused kernels take 0..4 (3+6*deg <= 32 features incl. a bias
+                           * slot), 5..10 run on the general path                                                          */
     int32_t do_skip;      /* skip-concat after layer depth/2 (network.py:59-61) */
     float scale, rmin, rmax, z_width;
 } bhn_model;
+
+/* The general path (csrc/general_mlp.hip; posenc_deg > 4 or net_width > 256 -- shapes no reference driver uses): every entry
+ * point below accepts these models with the same arguments and the same results, but computes in f32 WHATEVER `mode` says
+ * (BHN_BF16 is accepted; BHN_BF16_T8 is BHN_EUNSUPPORTED), layer by layer with the activations of 32 points in LDS, at
+ * 0.15-0.4 of the f32 MFMA peak.  bhn_render_fwd_train records nothing (it is bhn_render_fwd) and bhn_render_bwd_tape
+ * recomputes the forward; the workspace holds 8 gradient slabs and the tape of a chunk of 32-point groups (at least one frame's). */
 
 /* Geodesic-side inputs, prepared once per ray set by bhn_geom_prepare (arrays of P floats). */
 typedef struct {

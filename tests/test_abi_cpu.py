@@ -80,9 +80,19 @@ def test_param_layout_matches_flax_tree_order(lib, depth, width, n):
 
 def test_argument_validation_reports_errors(lib):
     from bhnerf_amd import _hip
-    bad_width = _hip.make_model(4, 300, 3, True, 1.0, 0.0, 1.0, 1.0)
+    bad_width = _hip.make_model(4, 600, 3, True, 1.0, 0.0, 1.0, 1.0)
     assert lib.bhn_param_count(C.byref(bad_width)) == -1
     assert b'net_width' in lib.bhn_last_error()
+    bad_deg = _hip.make_model(4, 64, 11, True, 1.0, 0.0, 1.0, 1.0)
+    assert lib.bhn_param_count(C.byref(bad_deg)) == -1 and b'posenc_deg' in lib.bhn_last_error()
+    # posenc_deg 5..10 / net_width 257..512: the general path (csrc/general_mlp.hip) -- same flat parameter layout, a packed
+    # image and a workspace of its own, the same for both modes (it computes in f32); no 8-bit tape
+    for general in (_hip.make_model(4, 300, 3, True, 1.0, 0.0, 1.0, 1.0), _hip.make_model(5, 128, 7, True, 1.0, 0.0, 1.0, 1.0)):
+        dims = onp.mlp_layer_dims(general.net_depth, general.net_width, 3 + 6 * general.posenc_deg)
+        assert lib.bhn_param_count(C.byref(general)) == sum(a * b + b for a, b in dims)
+        assert lib.bhn_packed_bytes(C.byref(general), 0) == lib.bhn_packed_bytes(C.byref(general), 1) > 4 * sum(a * b + b for a, b in dims)
+        assert lib.bhn_render_bwd_workspace_bytes(C.byref(general), 1, 2, 1000, 0) == lib.bhn_render_bwd_workspace_bytes(C.byref(general), 0, 2, 1000, 0) > 0
+        assert lib.bhn_render_bwd_workspace_bytes(C.byref(general), 2, 2, 1000, 0) == 0 and b'8-bit' in lib.bhn_last_error()
     skip_into_output = _hip.make_model(5, 64, 3, True, 1.0, 0.0, 1.0, 1.0)       # depth 5: concat feeds the output layer
     assert lib.bhn_param_count(C.byref(skip_into_output)) == sum(a * b + b for a, b in onp.mlp_layer_dims(5, 64, 21))
     assert onp.mlp_layer_dims(5, 64, 21)[-1] == (64 + 21, 1)

@@ -247,6 +247,67 @@ def test_random_problem_f32_and_bf16(dev, width, depth, S, deg):
         assert l2 < L2TOL[mode], (mode, l2, ties)
 
 
+@pytest.mark.parametrize('width,depth,S,deg', [(128, 4, 3, 5), (512, 4, 0, 3), (300, 3, 1, 6), (64, 2, 0, 7), (384, 8, 2, 4),
+                                               (512, 8, 0, 8), (40, 5, 3, 10)])
+def test_shapes_outside_the_fused_kernels(dev, width, depth, S, deg):
+    """posenc_deg 5..10 (network.py:98-122: 3 + 6 deg <= 63 encoded inputs) and net_width 257..512 (network.py:154) -- no
+    reference driver sets either -- run on the general layer-by-layer path (csrc/general_mlp.hip): f32 arithmetic in BOTH
+    modes, so both are held to the f32 bounds and give the same bits.  Octave i multiplies the f32 rounding of the warped
+    coordinate by 2^i before the sine: the image bound grows with the degree."""
+    prob = random_problem(width, depth, S, deg)
+    tol_img = 1e-5 * max(1.0, 2.0 ** (deg - 5))
+    grads = {}
+    for mode in ('f32', 'bf16'):
+        out = []
+        ierr, gerr, l2 = random_problem_errors(prob, mode, dev, grad_out=out)
+        print('general path %dx%d deg %d S %d %s: image %.2e  gradient max %.2e  L2 %.2e  ties %d' % (depth, width, deg, S, mode, ierr, gerr, l2, prob['ties']))
+        grads[mode] = out[0]
+        assert ierr < tol_img, (mode, ierr)
+        if prob['ties'] and not (gerr < GTOL['f32'] * tol_img / 1e-5 and l2 < L2TOL['f32'] * tol_img / 1e-5):
+            adjudicate_relu_ties(width, depth, S, deg, dev, gerr, prob['ties'])
+            continue
+        assert gerr < GTOL['f32'] * tol_img / 1e-5 and l2 < L2TOL['f32'] * tol_img / 1e-5, (mode, gerr, l2)
+    assert np.array_equal(grads['f32'], grads['bf16'])
+
+
+def test_general_path_emission_and_workspace_chunks(dev):
+    """The general path's predictor output against the float64 oracle, its gradient through the recompute entry point
+    (`bhn_render_bwd`) against the training pair (`bhn_render_fwd_train` + `bhn_render_bwd_tape`), and a workspace that holds
+    one frame of tape (three chunks of groups) against one that holds all."""
+    from bhnerf_amd import units, network, engine as E
+    prob = random_problem(320, 4, 2, 6)
+    g = prob['g']
+    hp = g['hparams']
+    pred, rt = device_setup(g, 'f32', dev)
+    tree = golden_tree(g)
+    e = pred.apply({'params': tree}, g['t_frames'], units.hr, rt['coords'], rt['Omega'], 0.0, rt['t_geos'], prob['t_inj']).cpu().numpy()
+    ks, bs = ot.tree_to_lists(tree)
+    t = lambda x: torch.tensor(x, dtype=torch.float64)
+    e_ref = ot.predictor(ks, bs, t(g['t_frames']), t(g['coords']), t(g['Omega']), 0.0, t(g['t_geos']), prob['t_inj'], onp.GM_C3_SGRA_HR,
+                         hp[0], hp[1], hp[2], hp[3], posenc_deg=6, net_depth=4).numpy().reshape(e.shape)
+    assert (e != 0).any() and np.abs(e - e_ref).max() / np.abs(e_ref).max() < 2e-5
+    eng = pred.engine()
+    geom = pred.geometry(rt['coords'], rt['Omega'], rt['t_geos'], rt['J'], rt['g'], rt['dtau'], rt['Sigma'])
+    B = len(g['t_frames'])
+    tM0 = E.frame_offsets(g['t_frames'], 0.0, prob['t_inj'], onp.GM_C3_SGRA_HR, dev)
+    flat = eng.flatten(tree)
+    eng.pack(flat)
+    dimg = torch.rand((B, geom.Sx, geom.R), device=dev) - 0.3
+    img = eng.render(geom, tM0).clone()
+    img_t = eng.render_train(geom, tM0).clone()
+    assert torch.equal(img, img_t) and float(img.abs().max()) > 0
+    g_tape = eng.render_bwd_tape(geom, tM0, dimg).clone()
+    g_rec = eng.render_bwd(geom, tM0, dimg).clone()
+    assert torch.equal(g_tape, g_rec) and float(g_rec.abs().max()) > 0
+    pred2 = network.NeRF_Predictor(hp[0], hp[1], hp[2], hp[3], posenc_deg=6, net_depth=4, net_width=320, mode='f32', device=dev)
+    eng2 = pred2.engine()
+    eng2.max_workspace_bytes = 1
+    eng2.pack(flat)
+    assert eng2.workspace(B, geom.P_eff).numel() < eng.workspace(B, geom.P_eff).numel()
+    g_chunks = eng2.render_bwd(geom, tM0, dimg)
+    assert torch.allclose(g_chunks, g_rec, rtol=1e-5, atol=1e-6 * float(g_rec.abs().max()))
+
+
 def adjudicate_relu_ties(width, depth, S, deg, dev, gerr, ties):
     """A detected ReLU tie is only an explanation if the SAME problem without the tied ray samples meets the f32 bounds:
     those samples get Doppler weight g = 0 on both sides (no contribution to the image, hence none to the gradient), every
