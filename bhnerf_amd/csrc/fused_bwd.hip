@@ -24,7 +24,8 @@
 #define BHN_JOB1_W 13          // weight of the layer-1 dW job in B tiles at width 256 (measured optimum; scaled with the width)
 #endif
 #ifndef BHN_JOBL_W
-#define BHN_JOBL_W 8            // extra weight (in tiles at width 256, scaled with the width) of the layer depth-1 dW job when it rebuilds gA_{depth-1} and carries the output row
+#define BHN_JOBL_W 7            // extra weight (in tiles at width 256, scaled with the width) of the layer depth-1 dW job when it rebuilds gA_{depth-1} and carries the output row
+                                // (round 5, re-swept without the layer-0 job, profiles/r5_dw_job_weights.txt: 6-7 beat 8 by 1.2 % of the dW kernel)
 #endif
 // Run-time measurement switches exist only in the debug build (make debug); the release kernels see the constant 0
 #ifdef BHN_DEBUG
