@@ -21,7 +21,7 @@ DEBUG_SIGNATURES = {        # include/bhnerf_hip_debug.h: only libbhnerf_hip_dbg
     'bhn_debug_read': (C.c_int, [C.c_void_p, C.c_size_t]),
 }
 
-ABI_VERSION = 3              # BHN_ABI_VERSION of include/bhnerf_hip.h this binding was written against
+ABI_VERSION = 4              # BHN_ABI_VERSION of include/bhnerf_hip.h this binding was written against
 BHN_F32, BHN_BF16, BHN_BF16_T8 = 0, 1, 2
 BHN_T8_CALIBRATE = 0x100
 MODES = {'f32': BHN_F32, 'fp32': BHN_F32, 'float32': BHN_F32, 'bf16': BHN_BF16, 'bfloat16': BHN_BF16,
@@ -42,7 +42,7 @@ class bhn_geom(C.Structure):
     _fields_ = [('R', C.c_int64), ('G', C.c_int64), ('S', C.c_int32), ('x', C.c_void_p), ('y', C.c_void_p),
                 ('z', C.c_void_p), ('Omega', C.c_void_p), ('t_geo', C.c_void_p), ('w', C.c_void_p),
                 ('dom', C.c_void_p), ('groups', C.c_void_p), ('n_groups', C.c_int64), ('ray_idx', C.c_void_p),
-                ('n_points', C.c_int64)]
+                ('n_points', C.c_int64), ('ray_span', C.c_int32)]
 
 
 class bhn_frames(C.Structure):

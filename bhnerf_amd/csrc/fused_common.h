@@ -271,7 +271,7 @@ struct FusedArgs {
     int tiles_per_frame;
     long long total_tiles;          // < 2^32 (checked on the host), as is P: the maps below use 32-bit FastDiv
     FastDiv fd_tpf, fd_G;
-    int ray_direct;                 // every ray touches at most two 32-point wave tiles: one atomic per (tile, ray) is already
+    int ray_direct;                 // every ray touches at most two 32-point wave tiles (dense: from G; compacted: bhn_geom.ray_span): one atomic per (tile, ray) is already
                                     // order-independent (RaySum::direct), no combine through LDS needed
     int debug;            // measurement builds only
     int deg;              // posenc degree 0..BHN_DEG_MAX (run time: only the prologue and the weight packing depend on it)
@@ -986,19 +986,34 @@ struct RaySum {
     // Dense layouts whose rays start on a 32-point boundary and are at most 64 samples long (G = 32, 64), or at most 33
     // samples anywhere: a pixel gets at most two adds from per-tile atomics as well -- round 1's epilogue, kept for these
     // (BASELINE config 2 is G = 64): the LDS combine and its barrier cost 3 % of the inference forward.
+    // the point's contribution to every Stokes plane, e w_s (network.py:417), loaded ONCE in front of the segment loop (round 5:
+    // inside it -- one dependent global load per (segment, plane) -- a compacted polarised ray set, three or four ray segments
+    // per 32-point group and three planes, spent 4 of the 14.5 us of a width-128 tile waiting for them)
+    static DEVI void weighted(const FusedArgs &a, long long p, bool on, float e, float w0, bool have_w0, float (&we)[SMAX]) {
+#pragma unroll
+        for (int s = 0; s < SMAX; ++s) {
+            float w = 0.f;
+            if (on && e != 0.f && s < a.Sx) w = (s == 0 && have_w0) ? w0 : a.w[(long long)s * a.P + p];
+            we[s] = w * e;
+        }
+    }
     static DEVI void direct(const FusedArgs &a, int b, long long p, bool inb, float e, float w0, bool have_w0) {
         const int lane = threadIdx.x & 63, h = lane >> 5;
-        const long long ray = inb ? (long long)a.fd_G.div((unsigned)p) : -1;
+        const long long ray = inb ? (a.ray_idx ? (long long)a.ray_idx[p] : (long long)a.fd_G.div((unsigned)p)) : -1;
+        float we[SMAX];
+        weighted(a, p, h == 0 && inb, e, w0, have_w0, we);
         unsigned long long rem = __ballot(h == 0 && inb);
         while (rem) {
             const int first = __ffsll((long long)rem) - 1;
             const long long r0 = __shfl(ray, first, 64);
             const bool mine = (h == 0) && inb && (ray == r0);
-            for (int s = 0; s < a.Sx; ++s) {
-                float v = (mine && e != 0.f) ? ((s == 0 && have_w0) ? w0 : a.w[(long long)s * a.P + p]) * e : 0.f;
-                v = half_wave_sum(v);
-                if (lane == first) atomicAdd(a.images + ((long long)b * a.Sx + s) * a.R + r0, v);
-            }
+#pragma unroll
+            for (int s = 0; s < SMAX; ++s)
+                if (s < a.Sx) {
+                    float v = mine ? we[s] : 0.f;
+                    v = half_wave_sum(v);
+                    if (lane == first) atomicAdd(a.images + ((long long)b * a.Sx + s) * a.R + r0, v);
+                }
             rem &= ~__ballot(mine);
         }
     }
@@ -1009,20 +1024,24 @@ struct RaySum {
         float *seg_val = reinterpret_cast<float *>(lds + NW * 32 * 4);                // [NW][Sx][32]
         int *seg_n = reinterpret_cast<int *>(lds + NW * 32 * 4 + NW * a.Sx * 32 * 4); // [NW]
         const long long ray = inb ? (a.ray_idx ? (long long)a.ray_idx[p] : (long long)a.fd_G.div((unsigned)p)) : -1;
+        float we[SMAX];
+        weighted(a, p, h == 0 && inb, e, w0, have_w0, we);
         unsigned long long rem = __ballot(h == 0 && inb);
         int k = 0;
         while (rem) {
             const int first = __ffsll((long long)rem) - 1;
             const long long r0 = __shfl(ray, first, 64);
             const bool mine = (h == 0) && inb && (ray == r0);
-            for (int s = 0; s < a.Sx; ++s) {
-                float v = (mine && e != 0.f) ? ((s == 0 && have_w0) ? w0 : a.w[(long long)s * a.P + p]) * e : 0.f;
-                v = half_wave_sum(v);
-                if (lane == first) {
-                    if (a.ray_direct) atomicAdd(a.images + ((long long)b * a.Sx + s) * a.R + r0, v);
-                    else seg_val[(vw * a.Sx + s) * 32 + k] = v;
+#pragma unroll
+            for (int s = 0; s < SMAX; ++s)
+                if (s < a.Sx) {
+                    float v = mine ? we[s] : 0.f;
+                    v = half_wave_sum(v);
+                    if (lane == first) {
+                        if (a.ray_direct) atomicAdd(a.images + ((long long)b * a.Sx + s) * a.R + r0, v);
+                        else seg_val[(vw * a.Sx + s) * 32 + k] = v;
+                    }
                 }
-            }
             if (lane == first && !a.ray_direct) seg_ray[vw * 32 + k] = (int)r0;
             ++k;
             rem &= ~__ballot(mine);

@@ -452,7 +452,10 @@ int fused_fill_args(const bhn_model *m, int32_t mode, const void *packed, const 
                   "problem too large for one call: %lld tiles, %lld points per frame (limit 2^31)", a->total_tiles, (long long)a->P);
     a->fd_tpf = FastDiv::make((unsigned)a->tiles_per_frame);
     a->fd_G = FastDiv::make((unsigned)a->G);
-    a->ray_direct = !a->ray_idx && (a->G <= 33 || (a->G <= 64 && a->G % 32 == 0));
+    a->ray_direct = a->ray_idx ? (geom->ray_span == 1 || geom->ray_span == 2) : (a->G <= 33 || (a->G <= 64 && a->G % 32 == 0));
+#ifdef BHN_FORCE_RAY_DIRECT          // measurement build: per-wave atomics whatever the ray layout (pixel sums then depend on the arrival order)
+    a->ray_direct = 1;
+#endif
     return BHN_OK;
 }
 

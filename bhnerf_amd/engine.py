@@ -114,6 +114,12 @@ class RayGeometry:
                                 Omega=take(self.Omega), t_geo=take(self.t_geo), w=cw, dom=take(self.dom, torch.uint8),
                                 ray=take(torch.div(torch.arange(P, device=dev), self.G, rounding_mode='floor'), torch.int32))
             self.P_eff = n_pad
+            # bhn_geom.ray_span: the most 32-point groups the (consecutive) points of one ray lie in -- 1 or 2 lets the render
+            # kernels skip the per-tile combine of ray segments (include/bhnerf_hip.h)
+            r = self.compact['ray'][:n_in]
+            starts = torch.nonzero(torch.cat([torch.ones(1, dtype=torch.bool, device=dev), r[1:] != r[:-1]])).reshape(-1)
+            ends = torch.cat([starts[1:], torch.tensor([n_in], device=dev)]) - 1
+            self.compact['ray_span'] = int((torch.div(ends, 32, rounding_mode='floor') - torch.div(starts, 32, rounding_mode='floor')).max().item()) + 1
 
     def c_struct(self):
         """Dense layout (R x G planes): voxel / grid kernels and every caller that indexes points as ray * G + sample."""
@@ -129,7 +135,7 @@ class RayGeometry:
             return self.c_struct()
         return _hip.bhn_geom(self.R, self.G, self.S, k['x'].data_ptr(), k['y'].data_ptr(), k['z'].data_ptr(),
                              k['Omega'].data_ptr(), k['t_geo'].data_ptr(), k['w'].data_ptr(), k['dom'].data_ptr(),
-                             None, k['n_pad'] // 32, k['ray'].data_ptr(), k['n_pad'])
+                             None, k['n_pad'] // 32, k['ray'].data_ptr(), k['n_pad'], k['ray_span'])
 
     @property
     def active_fraction(self):

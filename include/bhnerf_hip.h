@@ -34,7 +34,8 @@
 extern "C" {
 #endif
 
-#define BHN_ABI_VERSION 3      /* 3: BHN_BF16_T8 / BHN_T8_CALIBRATE, bhn_adam_hyper, bhn_adam_step_dev, bhn_render_bwd_tape_kernel_name_for */
+#define BHN_ABI_VERSION 4      /* 3: BHN_BF16_T8 / BHN_T8_CALIBRATE, bhn_adam_hyper, bhn_adam_step_dev, bhn_render_bwd_tape_kernel_name_for;
+                                * 4: bhn_geom.ray_span; posenc_deg <= 10, net_width <= 512 (general path) */
 
 enum { BHN_OK = 0, BHN_EINVAL = 1, BHN_EUNSUPPORTED = 2, BHN_EHIP = 3, BHN_EWORKSPACE = 4 };
 enum { BHN_F32 = 0, BHN_BF16 = 1, BHN_BF16_T8 = 2 };
@@ -88,6 +89,12 @@ typedef struct {
      * them out changes no image and no gradient.  NULL / 0 = dense layout, P = R*G. */
     const int32_t *ray_idx;
     int64_t n_points;
+    /* Point-compacted layouts only, optional (0 = not known): the largest number of consecutive 32-point groups the points of
+     * ONE ray lie in.  1 or 2: every pixel then receives at most two partial sums, so the render kernels add each wave's ray
+     * segments straight to the pixels (bitwise reproducible all the same) and skip the per-tile combine through LDS and its
+     * workgroup barriers (19 % of the width-128 forward of BASELINE config 5).  A value that is too small makes pixel sums
+     * depend on the arrival order of their addends, nothing else.  Dense layouts: decided from G by the library. */
+    int32_t ray_span;
 } bhn_geom;
 
 /* Frames of one step.  tM0[b] = (t_frames[b]-t_start_obs)/GM_c3 - t_injection, float64, device

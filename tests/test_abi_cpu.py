@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     for name in syms:
         assert hasattr(lib, name), name
     assert sorted(_hip.SIGNATURES) == syms        # the ctypes table binds exactly the declared ABI
-    assert lib.bhn_version() == _hip.ABI_VERSION == 3
+    assert lib.bhn_version() == _hip.ABI_VERSION == 4
 
 
 def test_release_library_has_no_hidden_allocation_or_environment_reads(lib):

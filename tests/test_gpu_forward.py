@@ -258,6 +258,32 @@ def test_render_is_bitwise_reproducible_for_long_and_masked_rays(dev, mode, G):
         assert torch.equal(eng.render_train(geom, tM0), ref)                  # the training forward sums the same way
 
 
+@pytest.mark.parametrize('mode,width', [('bf16', 128), ('bf16', 256), ('f32', 64)])
+def test_compacted_rays_within_two_groups_skip_the_combine(dev, mode, width):
+    """bhn_geom.ray_span (ABI 4): on a point-compacted polarised ray set whose rays lie within two 32-point groups each
+    (BASELINE configs 3 and 5 do) every wave adds its ray segments straight to the pixels -- still bitwise reproducible (a
+    pixel gets at most two partial sums), and the same image as the per-tile combine through LDS (ray_span 0: unknown)."""
+    from bhnerf_amd import network, synthetic, engine as E, constants
+    H = W = 48; G = 100
+    geo = synthetic.synthetic_geodesics(H, W, G, fov_M=40.0, inc_deg=12.0, spin=0.0, S=3, seed=3)
+    pred = network.NeRF_Predictor(20.0, 6.0, 20.0, 4.0, net_depth=4, net_width=width, mode=mode, device=dev)
+    geom = pred.geometry(geo['coords'], geo['Omega'], geo['t_geos'], geo['J'], geo['g'], geo['dtau'], geo['Sigma'])
+    assert geom.compact is not None and geom.compact['ray_span'] in (1, 2) and geom.S == 3
+    eng = pred.engine()
+    eng.pack(eng.flatten(network.MLP(4, width).init(3, 21)))
+    tM0 = E.frame_offsets(np.linspace(0.0, 1.5, 5), 0.0, geo['t_injection'], constants.GM_c3('hr'), dev)
+    imgs = [eng.render(geom, tM0).clone() for _ in range(3)]
+    train = eng.render_train(geom, tM0).clone()
+    assert float(imgs[0].abs().max()) > 0 and all(torch.equal(imgs[0], v) for v in imgs[1:]) and torch.equal(imgs[0], train)
+    span = geom.compact['ray_span']
+    geom.compact['ray_span'] = 0
+    try:
+        ref = eng.render(geom, tM0).clone()
+    finally:
+        geom.compact['ray_span'] = span
+    assert torch.allclose(imgs[0], ref, rtol=2e-6, atol=1e-7 * float(ref.abs().max()))
+
+
 def test_two_threads_two_streams_are_independent(dev):
     """ABI conventions (include/bhnerf_hip.h): no global mutable state except the thread-local error string and
     per-device one-time caches, so two host threads may drive the library on two streams of one device at the same time.

@@ -5,7 +5,7 @@ set -euo pipefail
 NAME=$1; FLAGS=${2:-}
 R=$(cd "$(dirname "$0")/.." && pwd); C=$R/bhnerf_amd/csrc; O=/tmp/bhn_$NAME
 mkdir -p $O
-for f in simple_kernels fused_fwd fused_bwd fused_bwd128 selftest; do
+for f in simple_kernels fused_fwd fused_bwd fused_bwd128 general_mlp selftest; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -Wno-pass-failed $FLAGS -c $C/$f.hip -o $O/$f.o &
 done
 wait
