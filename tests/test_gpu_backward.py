@@ -252,7 +252,7 @@ def test_random_problem_f32_and_bf16(dev, width, depth, S, deg):
 def test_shapes_outside_the_fused_kernels(dev, width, depth, S, deg):
     """posenc_deg 5..10 (network.py:98-122: 3 + 6 deg <= 63 encoded inputs) and net_width 257..512 (network.py:154) -- no
     reference driver sets either -- run on the general layer-by-layer path (csrc/general_mlp.hip): f32 arithmetic in BOTH
-    modes, so both are held to the f32 bounds and give the same bits.  Octave i multiplies the f32 rounding of the warped
+    modes, so both are held to the f32 bounds and agree to rounding.  Octave i multiplies the f32 rounding of the warped
     coordinate by 2^i before the sine: the image bound grows with the degree."""
     prob = random_problem(width, depth, S, deg)
     tol_img = 1e-5 * max(1.0, 2.0 ** (deg - 5))
@@ -267,7 +267,10 @@ def test_shapes_outside_the_fused_kernels(dev, width, depth, S, deg):
             adjudicate_relu_ties(width, depth, S, deg, dev, gerr, prob['ties'])
             continue
         assert gerr < GTOL['f32'] * tol_img / 1e-5 and l2 < L2TOL['f32'] * tol_img / 1e-5, (mode, gerr, l2)
-    assert np.array_equal(grads['f32'], grads['bf16'])
+    # the same arithmetic in both modes: equal up to the order in which a pixel receives its rays' partial sums (one float atomic
+    # per 32-point group a ray touches: rays within two groups are bitwise reproducible, longer ones to rounding)
+    scale = float(np.abs(grads['f32']).max())
+    assert np.abs(grads['f32'] - grads['bf16']).max() <= 1e-5 * scale, ('f32 vs bf16 mode', np.abs(grads['f32'] - grads['bf16']).max() / scale)
 
 
 def test_general_path_emission_and_workspace_chunks(dev):

@@ -5,7 +5,9 @@ bounds of the test are statistical on this tiny problem (3 x 63 rays): a few per
 less than a factor of two; anything beyond that, and any f32 failure, is reported as HARD (exit code 1).  f32 draws with
 detected ReLU ties are adjudicated by the test itself (tests/test_gpu_backward.py::adjudicate_relu_ties) and print a
 "relu ties adjudicated" line.
-    python tools/fuzz_parity.py [N] [seed]          (FUZZ_ONLY=i,j,...: run only these draws of the sequence)"""
+    python tools/fuzz_parity.py [N] [seed]          (FUZZ_ONLY=i,j,...: run only these draws of the sequence)
+FUZZ_GENERAL=1: every draw is a shape OUTSIDE the fused kernels (posenc degree 5..10 and / or width 257..512: csrc/general_mlp.hip),
+held to tests/test_gpu_backward.py::test_shapes_outside_the_fused_kernels (f32 bounds in both modes, f32 == bf16 bitwise)."""
 import os, sys, traceback
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,10 +17,15 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 dev = torch.device('cuda:0')
 bad = soft = 0
+GENERAL = bool(os.environ.get('FUZZ_GENERAL'))
 ONLY = set(int(v) for v in os.environ.get('FUZZ_ONLY', '').split(',') if v)        # run only these draws (the RNG sequence is replayed for all)
 for i in range(N):
     width = int(rng.choice([int(rng.integers(1, 257)), 32, 64, 128, 256]))
     depth, S, deg = int(rng.integers(2, 9)), int(rng.integers(0, 4)), int(rng.integers(0, 5))
+    if GENERAL:
+        kind = int(rng.integers(0, 3))                      # 0: high degree, 1: wide, 2: both
+        if kind != 1: deg = int(rng.integers(5, 11))
+        if kind != 0: width = int(rng.integers(257, 513))
     # ray grid, samples per ray (1 .. 140: below / at / above the 32- and 64-sample tile boundaries), frames
     T.RANDOM_PROBLEM_SHAPE = (int(rng.integers(2, 12)), int(rng.integers(2, 10)), int(rng.choice([int(rng.integers(3, 141)), 32, 33, 64, 65, 100])),
                               int(rng.integers(1, 5)))
@@ -31,7 +38,7 @@ for i in range(N):
     if ONLY and i not in ONLY:
         continue
     try:
-        T.test_random_problem_f32_and_bf16(dev, width, depth, S, deg)
+        (T.test_shapes_outside_the_fused_kernels if GENERAL else T.test_random_problem_f32_and_bf16)(dev, width, depth, S, deg)
         if ONLY:
             print('draw %d width %d depth %d S %d deg %d shape %s: passed' % (i, width, depth, S, deg, T.RANDOM_PROBLEM_SHAPE), flush=True)
     except Exception as e:                                   # noqa: BLE001 -- report and go on
