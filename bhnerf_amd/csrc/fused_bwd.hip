@@ -1403,7 +1403,8 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
         else return tr_frag(gp + boff[t % NPW], t / NPW, trl);
     };
     // 8-bit B tiles: raw read of pair u = (k-step u / (NPW/2), tiles 2 (u % (NPW/2)), +1 of the wave's share)
-    auto load_braw = [&](const char *gp, int u) -> Raw8 { return tr8_read(gp + boff[2 * (u % (NPW / 2))], u / (NPW / 2), tr8); };
+    constexpr int NPH = NPW / 2 > 0 ? NPW / 2 : 1;                    // (one B tile per wave: the 8-bit read is never instantiated)
+    auto load_braw = [&](const char *gp, int u) -> Raw8 { return tr8_read(gp + boff[2 * (u % NPH)], u / NPH, tr8); };
     auto a_load = [&](const char *gp, AState &st) {
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {

@@ -42,7 +42,7 @@
 
 namespace {
 
-constexpr int W128 = 128, MT = 4, KS = 8, TB = 2048;
+constexpr int MT = 4, KS = 8, TB = 2048;                           // width 128
 constexpr int IMG = 32768;                                         // 128 points x 128 features, bf16
 constexpr int OFF_GA = 0, OFF_H = 2 * IMG, OFF_E = 4 * IMG;         // two gA images, two h images, two encoded-input images (8 KiB)
 constexpr int ENC_IMG = 8192;
@@ -273,19 +273,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int d = 2 * half; d < 2 * half + 2; ++d) ps_o[d] = keep_where_nz(Pol::pack_a(c[mi][8 * s2 + 2 * d], c[mi][8 * s2 + 2 * d + 1]), ps_hv[d]);
         if (half == 1) lds_put(smem, ga_out + post_off(pi, j >> 1), __builtin_bit_cast(frag, ps_o));
-    };
-    auto chain_post = [&](const f32x16 (&c)[2], int pi, unsigned h_img, unsigned ga_out) {
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const unsigned off = rowb[pi] ^ (16u * (4 * (2 * wi + mi) + 2 * s2));
-                const u32x4 hv = __builtin_bit_cast(u32x4, lds_row(smem, h_img + off));
-                u32x4 o;
-#pragma unroll
-                for (int d = 0; d < 4; ++d) o[d] = keep_where_nz(Pol::pack_a(c[mi][8 * s2 + 2 * d], c[mi][8 * s2 + 2 * d + 1]), hv[d]);
-                lds_put(smem, ga_out + off, __builtin_bit_cast(frag, o));
-            }
     };
     // dW of a hidden layer: t[0..3] += gA^T h over the wave's 2 x 2 tiles; ENC: te += gA[m_e]^T enc, else bs += the bias of
     // row tile m_e (sum over the points of the A fragments); K = the 128 points
