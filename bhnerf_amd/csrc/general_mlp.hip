@@ -43,7 +43,7 @@ struct GenArgs {
     const float *dimages;
     float *slabs;
     long long slab_floats;
-    int nsplit, accumulate;
+    int nsplit, njobs, accumulate;
     float *dparams;
     long long nparams;
     const float *params;               // pack
@@ -57,22 +57,25 @@ DEVI long long tape_ga(const GenArgs &A, int l) { return (long long)A.Ep * 32 + 
 // acc (features 32 m .. 32 m + 31 x the 32 points) += sum_k K[k][32 m + i] in[k][point]: K rows `rows` (a multiple of 32)
 // of `stride` floats, `in` an LDS image [row][32].  Lane (i, h) feeds k = 2 t + h of every pair.
 DEVI f32x16 gen_rows(f32x16 acc, const float *__restrict__ K, int stride, int m, const float *in, int rows, int lane) {
+    // 16 rows (8 MFMAs) per iteration, the next iteration's 8 weight loads issued in front of them (32 rows / 16 loads in flight:
+    // measured no faster -- the kernel is bound by the f32 matrix pipe, 0.5-0.6 of its peak, not by the L2 latency)
+    constexpr int NJ = 8;
     const int i = lane & 31, h = lane >> 5;
     const float *Kc = K + 32 * m + i + (long long)h * stride;
     const float *ic = in + 32 * h + i;
-    float an[8];
+    float an[NJ];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) an[j] = Kc[(long long)(2 * j) * stride];
-    for (int k0 = 0; k0 < rows; k0 += 16) {
-        float ac[8], bc[8];
+    for (int j = 0; j < NJ; ++j) an[j] = Kc[(long long)(2 * j) * stride];
+    for (int k0 = 0; k0 < rows; k0 += 2 * NJ) {
+        float ac[NJ], bc[NJ];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { ac[j] = an[j]; bc[j] = ic[(k0 + 2 * j) * 32]; }
-        if (k0 + 16 < rows) {
+        for (int j = 0; j < NJ; ++j) { ac[j] = an[j]; bc[j] = ic[(k0 + 2 * j) * 32]; }
+        if (k0 + 2 * NJ < rows) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) an[j] = Kc[(long long)(k0 + 16 + 2 * j) * stride];
+            for (int j = 0; j < NJ; ++j) an[j] = Kc[(long long)(k0 + 2 * NJ + 2 * j) * stride];
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[j], bc[j], acc, 0, 0, 0);
+        for (int j = 0; j < NJ; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[j], bc[j], acc, 0, 0, 0);
     }
     return acc;
 }
@@ -350,13 +353,18 @@ void gen_layout(const MlpShape &s, GenArgs *A) {
     }
     A->packed_floats = off;
     A->slab_floats = soff;
+    // gen_dw_kernel: one wave per (block of one layer's gradient, share of the chunk's groups).  Narrow networks have few blocks
+    // (25 at 4x128): enough shares that ~6000 waves fill the 1024 SIMDs (8 shares left 4x128 at 200 waves: 68 % of its step)
+    int njobs = 0;
+    for (int l = 0; l <= s.depth; ++l) njobs += (((A->L[l].hrows + A->L[l].erows) >> 5) + 1) * (((A->L[l].outp >> 5) + 3) >> 2);
+    A->njobs = njobs;
+    A->nsplit = std::min(256, std::max(8, (6144 + njobs - 1) / njobs));
     A->tape_tile = (long long)Ep * 32 + 2ll * s.depth * Wp * 32 + 1024;
     A->nparams = s.nparams;
 }
 
 size_t gen_lds_bytes(const GenArgs &A, int Sx) { return (size_t)(2 * A.Wp + A.Ep) * 32 * 4 + (16 * 32 + 64) * 4 + RaySum<1>::bytes(Sx); }
 int gen_block(const GenArgs &A) { const int mt = A.Wp / 32; return mt >= 8 ? 512 : mt >= 4 ? 256 : 128; }
-constexpr int GEN_NSPLIT = 8;
 
 template <int MODE>
 int gen_launch_mlp(const GenArgs &A, int grid, hipStream_t st) {
@@ -436,7 +444,7 @@ size_t gen_bwd_workspace_bytes(const MlpShape &s, int32_t B, int64_t P) {
     const size_t tile_bytes = (size_t)A.tape_tile * 4;
     // the tape of one chunk of groups: all of them up to 2 GiB, never less than one frame (what gen_backward insists on)
     const size_t cap = std::max<size_t>((size_t)2 << 30, (size_t)((P + 31) / 32) * tile_bytes);
-    return gen_align((size_t)GEN_NSPLIT * A.slab_floats * 4) + std::min<size_t>((size_t)tiles * tile_bytes, cap);
+    return gen_align((size_t)A.nsplit * A.slab_floats * 4) + std::min<size_t>((size_t)tiles * tile_bytes, cap);
 }
 
 int gen_backward(const bhn_model *m, int32_t mode, const void *packed, const bhn_geom *geom, const bhn_frames *fr,
@@ -449,7 +457,7 @@ int gen_backward(const bhn_model *m, int32_t mode, const void *packed, const bhn
     int dev = 0;
     BHN_HIP(hipGetDevice(&dev));
     BHN_CHECK_DEVICE(dev);
-    const size_t slab_bytes = gen_align((size_t)GEN_NSPLIT * A.slab_floats * 4), tile_bytes = (size_t)A.tape_tile * 4;
+    const size_t slab_bytes = gen_align((size_t)A.nsplit * A.slab_floats * 4), tile_bytes = (size_t)A.tape_tile * 4;
     const long long min_tiles = A.f.tiles_per_frame;                       // (the contract of bhn_render_bwd: slabs + ONE frame of tape)
     if (workspace_bytes < slab_bytes + (size_t)min_tiles * tile_bytes) {
         bhn_set_error("render_bwd workspace too small: %zu bytes, need >= %zu (slabs %zu + %lld groups of tape)", workspace_bytes,
@@ -458,21 +466,18 @@ int gen_backward(const bhn_model *m, int32_t mode, const void *packed, const bhn
     }
     A.slabs = reinterpret_cast<float *>(workspace);
     A.tape = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + slab_bytes);
-    A.nsplit = GEN_NSPLIT;
     A.dimages = dimages;
     A.dparams = dparams;
     const long long chunk = std::min<long long>(A.f.total_tiles, (long long)((workspace_bytes - slab_bytes) / tile_bytes));
     const size_t lds = gen_lds_bytes(A, A.f.Sx);
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(160 * 1024 / lds, 2048 / gen_block(A)));
-    int njobs = 0;
-    for (int l = 0; l <= A.D; ++l) njobs += (((A.L[l].hrows + A.L[l].erows) >> 5) + 1) * (((A.L[l].outp >> 5) + 3) >> 2);
     for (long long c0 = 0; c0 < A.f.total_tiles; c0 += chunk) {
         A.tile0 = c0;
         A.ntiles = std::min<long long>(chunk, A.f.total_tiles - c0);
         A.accumulate = c0 > 0;
         rc = gen_launch_mlp<GEN_CHAIN>(A, (int)bhn_balanced_grid(A.ntiles, (long long)bhn_num_cus(dev) * per_cu), st);
         if (rc != BHN_OK) return rc;
-        hipLaunchKernelGGL(gen_dw_kernel, dim3(njobs, GEN_NSPLIT), dim3(64), 0, st, A);
+        hipLaunchKernelGGL(gen_dw_kernel, dim3(A.njobs, A.nsplit), dim3(64), 0, st, A);
         BHN_HIP(hipGetLastError());
     }
     hipLaunchKernelGGL(gen_reduce_kernel, dim3(1024), dim3(256), 0, st, A);

@@ -64,8 +64,9 @@ typedef struct {
 /* The general path (csrc/general_mlp.hip; posenc_deg > 4 or net_width > 256 -- shapes no reference driver uses): every entry
  * point below accepts these models with the same arguments and the same results, but computes in f32 WHATEVER `mode` says
  * (BHN_BF16 is accepted; BHN_BF16_T8 is BHN_EUNSUPPORTED), layer by layer with the activations of 32 points in LDS, at
- * 0.15-0.4 of the f32 MFMA peak.  bhn_render_fwd_train records nothing (it is bhn_render_fwd) and bhn_render_bwd_tape
- * recomputes the forward; the workspace holds 8 gradient slabs and the tape of a chunk of 32-point groups (at least one frame's). */
+ * 0.3-0.4 of the f32 MFMA peak.  bhn_render_fwd_train records nothing (it is bhn_render_fwd) and bhn_render_bwd_tape
+ * recomputes the forward; the workspace holds 8-256 gradient slabs
+ * (more for narrow networks) and the tape of a chunk of 32-point groups (at least one frame's). */
 
 /* Geodesic-side inputs, prepared once per ray set by bhn_geom_prepare (arrays of P floats). */
 typedef struct {
