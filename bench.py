@@ -744,6 +744,29 @@ def main():
       except Exception as exc:
         width128 = {'error': repr(exc)}
 
+    # ---- a network OUTSIDE the fused kernels' range (posenc_deg 5: csrc/general_mlp.hip, f32 whatever the mode), same geometry ----
+    general_path = None
+    if world == 1 and std and not args.no_width128:
+      try:
+        pred_g = network.NeRF_Predictor(*dom, posenc_deg=5, net_depth=4, net_width=128, mode='bf16', device=dev)
+        opt_g = optimization.Optimizer(hparams, pred_g, rt_args)
+        run_steps(opt_g, 2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_steps(opt_g, 4)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 4
+        fg = mlp_flops(4, 128, F=33)[3]
+        general_path = {'workload': 'config-2 geometry, 4x128 MLP with posenc_deg 5 (33 encoded inputs): the general layer-by-layer path, DESIGN.md 4.7',
+                        'dtype': 'f32 (v_mfma_f32_32x32x2_f32; the bf16 mode computes in f32 on this path)', 'ms_per_step': round(1e3 * dt, 3),
+                        'value': round(samples_step / dt, 1), 'unit': 'ray-samples/s', 'steps': 4,
+                        'step_algorithmic_tflops': round(fg * samples_step / dt / 1e12, 2),
+                        'step_mfma_frac': round(fg * samples_step / dt / 1e12 / PEAK_TFLOPS['f32'], 4), 'peak_tflops': PEAK_TFLOPS['f32']}
+        del opt_g, pred_g
+        torch.cuda.empty_cache()
+      except Exception as exc:
+        general_path = {'error': repr(exc)}
+
     # ---- stand-alone radiative-transfer scan (kgeo.radiative_trasfer, HBM-bound): achieved GB/s ---------
     # measured at the size SURVEY 8d quotes (config 3: 256x256 rays x 128 samples, B*S = 8*3 planes, ~1 GB)
     from bhnerf_amd.kgeo import _RadiativeTransfer
@@ -807,6 +830,8 @@ def main():
     }
     if width128:
         out['width128'] = width128
+    if general_path:
+        out['general_path'] = general_path
     if world == 1 and std and args.other_configs:
         try:
             out['strong_scaling_share'] = strong_scaling_share(dev, args.mode)
