@@ -391,20 +391,23 @@ def tape_bytes_per_point(depth, width, mode, fused):
     elem = 2 if mode == 'bf16' else 4
     row = width * elem                                   # one layer's activations of one point
     mt = width // 32
-    if fused:                                            # width 128, bf16, depth 4: h_2 .. h_depth, encoded inputs, e
-        b = (depth - 1) * row + 32 * elem + 4
-        return {FWD_NAME: b, FUSED_NAME: b + 4}          # (+ dout written over e by the small pre-kernel)
+    if fused:                                            # width 128, bf16, depth 4: h_2 .. h_{depth-1}, the relu bits of the last
+        b = (depth - 2) * row + ((mt + 1) // 2) * 8 + 32 * elem + 4      # hidden layer (in place of h_depth: round 5), encoded inputs, e
+        return {FWD_NAME: b, FUSED_NAME: b + 4}          # (+ dout, written beside e by the small pre-kernel)
     skip_layer = depth // 2 + 1 if depth >= 4 else None  # the layer that consumes concat[h, enc] (do_skip)
     rides = mode == 'bf16' and depth >= 3                # gA_{depth-1} and the dout tile are not on the tape
     drop_h1 = mode == 'bf16' and depth >= 2 and skip_layer != 1
     ga0c = mode == 'bf16' and width == 256 and depth >= 3    # the delta chain accumulates dW_0 itself: gA_0 never leaves the chip
     bits = depth * ((mt + 1) // 2) * 8                   # relu-bit words: 4 B per lane and pair of tiles, per 32 points
-    fwd = (depth - (1 if drop_h1 else 0)) * row + (2 if drop_h1 else 1) * 32 * elem + bits + 4
+    lbits = rides and (depth - 1) != skip_layer          # the dW job of layer depth-1 works from the relu bits (dw_body2 LBITS) ...
+    drop_hd = lbits and width == 256                     # ... and the forward does not store h_depth (TapeLayout::drop_hd)
+    fwd = (depth - (1 if drop_h1 else 0) - (1 if drop_hd else 0)) * row + (2 if drop_h1 else 1) * 32 * elem + bits + 4
     chain = (depth - (1 if rides else 0) - (1 if ga0c else 0)) * row + bits + 4 + (4 if rides else 32 * elem) + (32 * elem if ga0c else 0)
     tiles = (0 if ga0c else mt + 1) + (0 if rides else 1 + mt)      # dW reads per 32-point group and layer job: layer 0, output layer
     for l in range(1, depth):
         recomputed = l == 1 and drop_h1
-        tiles += mt + (1 if recomputed else mt) + (1 if l == skip_layer else 0)
+        a_tiles = 0.5 if (lbits and l == depth - 1) else mt          # (LBITS: 1 KiB of relu-bit words in place of the h_depth tiles)
+        tiles += a_tiles + (1 if recomputed else mt) + (1 if l == skip_layer else 0)
         if rides and l == depth - 1:
             tiles += 0.5                                 # the 1 KiB piece that starts with the group's 32 f32 dout
     return {FWD_NAME: fwd, CHAIN_NAME: chain, 'dw_kernel': tiles * (32 * 32 * elem) / 32.0}

@@ -20,6 +20,17 @@
 #ifndef BHN_CHAIN_STAMPS
 #define BHN_CHAIN_STAMPS 0      // 1: ring-step time stamps in the chain kernels (tools/dbg_chain_steps.py needs this build)
 #endif
+#ifndef BHN_JOBLB_W
+#define BHN_JOBLB_W 6           // LBITS: weight of that job's compute (mask expansion, the output row at the flush) in B tiles at width 256
+#endif
+#ifndef BHN_DROP_HD
+#define BHN_DROP_HD 0           // with LBITS, generic tape path: the training forward does not store the h_depth tiles (TapeLayout::drop_hd).
+#endif                          // OFF, as is LBITS: 9 GB less tape traffic per step at 4x256 (48.4 -> 39.5) and NOT faster -- the dW kernel does not get
+                                // faster with 18 % fewer bytes (it is issue-bound per group, not HBM-bound) and every variant of the forward's
+                                // change costs its ring steps 3 % (profiles/r5_ab_drop_hd_width256.txt).  The fused 4x128 path has it on (bwd128).
+#ifndef BHN_LBITS
+#define BHN_LBITS 0             // 1: the dW job of layer depth-1 works from the relu bits (dw_body2 LBITS) instead of the h_depth tiles (see BHN_DROP_HD)
+#endif
 #ifndef BHN_JOB1_W
 #define BHN_JOB1_W 13          // weight of the layer-1 dW job in B tiles at width 256 (measured optimum; scaled with the width)
 #endif
@@ -407,6 +418,11 @@ struct TapePost {
             }
         }
         if (edbg & 2) return;
+        if (BHN_DROP_HD != 0 && (edbg & 16)) {                // (TapeLayout::drop_hd on a ring kernel: the emission's two stores, four bytes each, `dst` = a line of the tape's scratch area)
+            __builtin_nontemporal_store(0u, reinterpret_cast<unsigned *>(dst));
+            __builtin_nontemporal_store(0u, reinterpret_cast<unsigned *>(dst) + 1);
+            return;
+        }
         if constexpr (Pol::TAPE8) store_tile8();
         else if constexpr (Pol::ELEM_BYTES == 2) TapeEmit<Pol>::store_native(dst, d0, d1, edbg);
         else TapeEmit<Pol>::store(dst, tr, edbg);
@@ -628,6 +644,8 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
         const long long q = tile * Pol::NWAVES + wvu;                    // 32-point group on the tape
         const long long qs = BHN_DBG(A.wrap) ? q % A.wrap : q;           // (debug: h / gA tiles wrap into a cache-resident window)
         unsigned *mask_g = A.t.fused128 ? nullptr : reinterpret_cast<unsigned *>(A.tape + A.t.mask_off) + q * (long long)(a.depth * MW * 64);
+        // (TapeLayout::drop_hd: the relu bits of the last hidden layer, recorded in place of its output tiles)
+        unsigned *maskd_g = (MODE == MODE_FWD_TRAIN && A.t.drop_hd && A.t.fused128) ? reinterpret_cast<unsigned *>(A.tape + A.t.maskd_off) + q * (long long)(MW * 64) + lane : nullptr;
         float *e_g = reinterpret_cast<float *>(A.tape + A.t.e_off) + q * 32;
         frag enc[2], act[KS], next[KS];
         bool live = false;
@@ -688,10 +706,16 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
                     frag &d0 = m == 0 ? act[KS - 2] : next[2 * (m > 0 ? m - 1 : 0)];
                     frag &d1 = m == 0 ? act[KS - 1] : next[2 * (m > 0 ? m - 1 : 0) + 1];
                     const int widx = (pl_layer * MW + (pm >> 1)) * 64 + lane;
-                    const bool no_h = drop_h1 && pl_layer == 0;     // layer 0's last tile: relu bits only
-                    TapePost<Pol, true> post(pend, d0, d1, 0u, em, A.tape + h_lin + (pl_layer + 1) * lin_stride + (qs * MT + pm) * TT,
-                                                 mask_g ? mask_g + widx : nullptr, nullptr,
-                                                 macc, pm & 1, pm == MT - 1, no_h ? (edbg | 2) : edbg, 1.f, t8_none);
+                    // h_depth: relu bits only (drop_hd).  fused128 (resident weights, no ring): no store at all; ring kernels: the
+                    // emission's two stores stay, four bytes each to a 256-KiB scratch area of the tape (bit 4; one line per tile: all on one line was a hot spot) -- the waits of the weight ring
+                    // count the stores of every step (YS above), and a step without them would need counts of its own
+                    constexpr bool CAN_HD = BHN_DROP_HD != 0 || (W == 128 && Pol::ELEM_BYTES == 2 && !T8);      // (fused128: width 128, bf16)
+                    const bool no_hd = CAN_HD && A.t.drop_hd && pl_layer == a.depth - 1;
+                    const bool no_h = (drop_h1 && pl_layer == 0) || (no_hd && RES);       // layer 0's last tile: relu bits only
+                    const int edbg_t = no_h ? (edbg | 2) : (no_hd ? (edbg | 16) : edbg);
+                    TapePost<Pol, true> post(pend, d0, d1, 0u, em, (no_hd && !RES) ? A.tape + A.t.scratch_off + (((q * MT + pm) & 4095) << 6) : A.tape + h_lin + (pl_layer + 1) * lin_stride + (qs * MT + pm) * TT,
+                                                 mask_g ? mask_g + widx : (no_hd && maskd_g ? maskd_g + (pm >> 1) * 64 : nullptr), nullptr,
+                                                 macc, pm & 1, pm == MT - 1, edbg_t, 1.f, t8_none);
                     // bias rows of the next tile: (l, m+1), or the first tile of the next sequence part
                     const float *bn = (out || (m == MT - 1 && l + 1 > a.depth)) ? nullptr : bl + 32 * (m + 1);
                     if (out) bn = bias_lds;                           // next tile, layer 0
@@ -1262,13 +1286,18 @@ DEVI void dw_body(const BwdArgs &A, int job, char *smem) {
 // layer depth-1 (LAST) makes the output layer's row and bias with v_dot2c / adds from the h_depth fragments and the f32
 // dout it already holds (no dout tile on the tape, no 1-row MFMAs, 32 accumulator registers fewer).
 // ---------------------------------------------------------------------------------------------
-template <int W, class Pol, int JT, bool LAST = false, bool OUTENC = false>     // OUTENC: the output layer riding on LAST takes concat[h, enc]
+// LBITS (round 5, TapeLayout::lbits): the LAST job takes relu'(a_{depth-1}) from the relu-bit words the forward records anyway
+// (1 KiB per group instead of the MT h_depth tiles: 16) and does not make the output layer's row from h_depth at all -- at the
+// flush it forms  sum_k K[k][f] G[k][f] + b[f] g[f]  from its own (un-folded) accumulators, which IS that row because
+// h_depth = relu(a) = relu'(a) a and a = K^T h_{depth-1} + b (bwd_common.h, drop_hd).
+template <int W, class Pol, int JT, bool LAST = false, bool OUTENC = false, bool LBITS = false>     // OUTENC: the output layer riding on LAST takes concat[h, enc]
 DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
     using BG = BwdGeom<W, Pol>;
     using frag = typename Pol::frag;
     static_assert(Pol::ELEM_BYTES == 2 && JT != JT_OUT && JT != JT_OUTSKIP, "bf16 jobs of layers 0 .. depth-1");
     static_assert(!LAST || JT == JT_HIDDEN || JT == JT_SKIP, "LAST: hidden / skip job");
     static_assert(!OUTENC || LAST, "OUTENC: a LAST job");
+    static_assert(!LBITS || (LAST && !Pol::TAPE8 && JT == JT_HIDDEN), "LBITS: the bf16 LAST job of a plain hidden layer");
     static_assert(BG::NBUF == 4, "ring of four group buffers");
     constexpr int MT = BG::MT, TB = BG::TILE_BYTES, TT = BG::TAPE_TILE;
     constexpr bool T8 = Pol::TAPE8;                                    // 8-bit h / gA tape tiles (tr8_read / tr8_widen)
@@ -1317,7 +1346,9 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
     const int nwg = A.wg_begin[job + 1] - A.wg_begin[job];
     const int kb = blockIdx.x - A.wg_begin[job];
     const long long q0 = uniform64(A.t.NQ * kb / nwg), q1 = uniform64(A.t.NQ * (kb + 1) / nwg);
-    const char *srcA = LAST ? A.tape + A.t.h_off[job + 1] : A.tape + A.t.ga_off[job];
+    constexpr int MWB = ((MT + 1) / 2) * 256;                           // bytes of one layer's relu-bit words of a group
+    const char *srcA = LBITS ? A.tape + A.t.mask_off + (long long)(A.f.depth - 1) * MWB
+                             : LAST ? A.tape + A.t.h_off[job + 1] : A.tape + A.t.ga_off[job];
     const char *srcD = A.tape + A.t.dout_off;
     const char *srcH = has_h ? A.tape + A.t.h_off[job] : nullptr;
     const char *srcE = A.tape + (make_h ? A.t.encp_off : A.t.enc_off);
@@ -1377,6 +1408,15 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
         const int n = nbase + ni;
         boff[ni] = has_h ? OFF_H + (n < nH ? n : 0) * (B8 ? TT : TB) : OFF_E;        // a column share that ends early repeats tile 0 (dropped at the flush)
     }
+    // LBITS: where this lane's feature (row lane & 31 of A tile T) sits in the forward's relu-bit words
+    int lb_word[MPW];
+    unsigned lb_pos[MPW];
+#pragma unroll
+    for (int mi = 0; mi < MPW; ++mi) {
+        const int T = wr * MPW + mi, i = lane & 31, hf = (i >> 2) & 1, r = (i & 3) + 4 * (i >> 3);
+        lb_word[mi] = (T >> 1) * 64 + 32 * hf + 4 * (lane >> 5);
+        lb_pos[mi] = 16u * (T & 1) + ((r & 1) ? 8u + (r >> 1) : (unsigned)(r >> 1));
+    }
     const bool bias_rows = wc == 0;                                    // this wave sums the bias column of its A tiles
     const bool out_bias_wave = LAST && wr == 0 && wc == 0;             // ... and this one the output layer's bias
     f32x16 acc[MPW][NPW], acc_e[ME];
@@ -1416,6 +1456,19 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
                         const Raw8 raw = tr8_read(gp + (wr * MPW) * TT, s2, tr8);
                         st.af[s2][0] = __builtin_bit_cast(frag, (u32x4){raw.lo[0], raw.lo[1], raw.hi[0], raw.hi[1]});
                     }
+                } else if constexpr (LBITS) {
+                    // the lane's feature i of A tile T was accumulator element r of lane half hf in the forward: bit `lb_pos[mi]` of
+                    // the word [T >> 1][point + 32 hf]; the lane's eight points of k-step s2 are two runs of four words
+                    const unsigned *wp = reinterpret_cast<const unsigned *>(gp) + lb_word[mi] + 16 * s2;
+                    const u32x4 wa = *reinterpret_cast<const u32x4 *>(wp), wb = *reinterpret_cast<const u32x4 *>(wp + 8);
+                    u32x4 on;
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const unsigned we = d < 2 ? wa[2 * d] : wb[2 * d - 4], wo = d < 2 ? wa[2 * d + 1] : wb[2 * d - 3];
+                        const unsigned lo = (unsigned)__builtin_amdgcn_sbfe((int)we, lb_pos[mi], 1u), hi = (unsigned)__builtin_amdgcn_sbfe((int)wo, lb_pos[mi], 1u);
+                        on[d] = (lo & 0xffffu) | (hi & 0xffff0000u);
+                    }
+                    st.af[s2][mi] = __builtin_bit_cast(frag, on);
                 } else st.af[s2][mi] = tr_frag(gp + (wr * MPW + mi) * TB, s2, trl);
             }
             if constexpr (LAST) {
@@ -1502,7 +1555,7 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
             const u32x4 raw = __builtin_bit_cast(u32x4, rawf);
             u32x4 ga;
             float o = 0.f;
-            const bool my_row = (mi % WCC) == wc;        // (scalar) this wave makes the output layer's row for this A tile
+            const bool my_row = !LBITS && (mi % WCC) == wc;        // (scalar) this wave makes the output layer's row for this A tile
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const f32x2 dd = {i < 2 ? da[2 * i] : db[2 * i - 4], i < 2 ? da[2 * i + 1] : db[2 * i - 3]};
@@ -1520,9 +1573,12 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
                 // so the A operand is only (h != 0) bf16(dout_p) -- three VALU per two points instead of seven (this job was
                 // VALU-bound: 237 VALU against 20 MFMAs per group) -- and the rows of dW_{depth-1} (and its bias) are scaled
                 // by W_out[f] in f32 at the flush, which is also closer to the exact product than rounding it per point.
-                const unsigned sgn = raw[i] + 0x7fff7fffu;          // bf16 h >= 0: sets the half's sign bit iff h != 0, no carry
-                const i16x2 on = __builtin_bit_cast(i16x2, sgn) >> (i16x2){15, 15};
-                ga[i] = __builtin_bit_cast(unsigned, dpk) & __builtin_bit_cast(unsigned, on);
+                if constexpr (LBITS) ga[i] = __builtin_bit_cast(unsigned, dpk) & raw[i];      // (a_load left the relu masks of the pair here)
+                else {
+                    const unsigned sgn = raw[i] + 0x7fff7fffu;          // bf16 h >= 0: sets the half's sign bit iff h != 0, no carry
+                    const i16x2 on = __builtin_bit_cast(i16x2, sgn) >> (i16x2){15, 15};
+                    ga[i] = __builtin_bit_cast(unsigned, dpk) & __builtin_bit_cast(unsigned, on);
+                }
             }
             st.af[s2][mi] = __builtin_bit_cast(frag, ga);
             if (live && my_row) orow[mi / WCC] += o;
@@ -1660,11 +1716,11 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
     };
 
     // ---- the stream: pieces (1 KiB = one wave-wide DMA) this job needs: [A tiles][h tiles][enc tile][f32 dout piece]
-    constexpr int PA = MT * TT / 1024, PH = (has_h && !make_h) ? MT * TT / 1024 : 0,
+    constexpr int PA = LBITS ? 1 : MT * TT / 1024, PH = (has_h && !make_h) ? MT * TT / 1024 : 0,
                   PE = (JT == JT_FIRST || JT == JT_SKIP || make_h || OUTENC) ? TB / 1024 : 0, PD = LAST ? 1 : 0;
     using Stream = TapeStream<Pol::NWAVES, PA, PH, PE, PD, OFF_H, OFF_E, OFF_D32>;
     constexpr int PPW = Stream::PPW;
-    const Stream stream(srcA, (long long)MT * TT, srcH, (long long)MT * TT, srcE, TB, srcD, A.t.dout_stride, wv);
+    const Stream stream(srcA, LBITS ? (long long)A.f.depth * MWB : (long long)MT * TT, srcH, (long long)MT * TT, srcE, TB, srcD, A.t.dout_stride, wv);
     auto issue = [&](long long q, char *buf) {
         q = q < q1 ? q : q1 - 1;
         if (BHN_DBG(A.wrap)) q %= A.wrap;
@@ -1774,13 +1830,70 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
         }
         if (enc_extra && (mi % WCC) == wc && m < MT) flush_tile(m, nH, acc_e[mi / WCC], true);
         flush_column0(m, nB, LAST ? bsum[mi] * wout_r[mi] : bsum[mi], bias_rows && m < MT);
-        if constexpr (LAST) {
+        if constexpr (LAST && !LBITS) {
             // the output layer's row: slab row MT, tile m, row 0, column f = lane & 31 (where reduce_kernel reads dW_out[32 m + f])
             float v = orow[mi / WCC] + __shfl_xor(orow[mi / WCC], 32, 64);
             if ((mi % WCC) == wc && m < MT && lane < 32) {
                 float *dst = slab + (long long)(MT * BG::NTMAX + m) * 1024 + lane * 4;
                 if (A.accumulate) v += *dst;
                 *dst = v;
+            }
+        }
+    }
+    if constexpr (LBITS) {
+        // The output layer's row from this workgroup's own sums (see the template comment): every lane weights its accumulator
+        // elements (row f = output unit of layer depth-1, column k = its input unit) with the bf16 weight K[k][f] the forward
+        // used, the 32 columns of a row meet through LDS, the bias term b[f] g[f] joins on wave column 0, and wave column wc leaves
+        // its share in float wc of the row's slot (slab row MT, tile m, float4 of lane f): reduce_kernel adds the four floats.
+        static_assert(WCC <= 8, "one float of the slot (two float4: lanes f and f + 32) per wave column");
+        using PKf = Pack<W, Pol>;
+        __syncthreads();                                            // every wave is out of the group ring
+        float *stg = reinterpret_cast<float *>(smem) + wv * (MPW * 32 * 33);
+        const int col = lane & 31, hh = lane >> 5;
+        if (works) {
+#pragma unroll
+            for (int mi = 0; mi < MPW; ++mi) {
+                const int m = wr * MPW + mi;
+                const char *wimg = A.f.packed + A.f.fwd_off + (size_t)(1 + (job - 1) * MT + (m < MT ? m : 0)) * PKf::CHUNK_BYTES;
+                float sr[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sr[r] = 0.f;
+#pragma unroll
+                for (int ni = 0; ni < NPW; ++ni) {
+                    const int n = nbase + ni, k = 32 * n + col;
+                    if (n < nBr) {
+                        const int fr = k >> 4, ph = k & 15, h2 = (ph >> 2) & 1, jj = (ph & 3) + 4 * (ph >> 3);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int fl = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                            const float wq = (float)reinterpret_cast<const __bf16 *>(wimg + fr * Pol::FRAG_BYTES + (fl + 32 * h2) * 16)[jj];
+                            sr[r] += wq * acc[mi][ni][r];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) stg[(mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * 33 + col] = sr[r];
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (the wave reads back what its own lanes wrote)
+#pragma unroll
+        for (int mi = 0; mi < MPW; ++mi) {
+            const int m = wr * MPW + mi;
+            float tot = 0.f;
+            if (works && lane < 32) {
+                for (int c = 0; c < 32; ++c) tot += stg[(mi * 32 + lane) * 33 + c];
+            }
+            const float g = bsum[mi] + __shfl_xor(bsum[mi], 32, 64);           // un-folded bias gradient of feature lane & 31 (wave column 0)
+            if (bias_rows && lane < 32 && m < MT) tot += reinterpret_cast<const float *>(A.f.packed + A.f.bias_off)[job * W + 32 * m + lane] * g;
+            if (works && lane < 32 && m < MT) {
+                float *dst = slab + (long long)(MT * BG::NTMAX + m) * 1024 + (lane + 32 * (wc >> 2)) * 4;
+                if (A.accumulate) tot += dst[wc & 3];
+                dst[wc & 3] = tot;
+                if (wc == 0) {                  // the slots no wave column owns, or whose column has no B tiles (narrow networks)
+#pragma unroll
+                    for (int e = 1; e < (WCC > 4 ? 8 : 4); ++e)
+                        if (e >= WCC || e * NPW >= nBr) slab[(long long)(MT * BG::NTMAX + m) * 1024 + (lane + 32 * (e >> 2)) * 4 + (e & 3)] = 0.f;
+                }
             }
         }
     }
@@ -1824,6 +1937,9 @@ __global__ __launch_bounds__(Pol::NTHREADS) __attribute__((amdgpu_waves_per_eu(P
             } else if ((A.f.skip_mask >> job) & 1) {
                 if (out_skip) dw_body2<W, Pol, JT_SKIP, true, true>(A, job, smem);
                 else dw_body2<W, Pol, JT_SKIP, true>(A, job, smem);
+            } else if (A.t.lbits) {
+                if (out_skip) dw_body2<W, Pol, JT_HIDDEN, true, true, true>(A, job, smem);
+                else dw_body2<W, Pol, JT_HIDDEN, true, false, true>(A, job, smem);
             } else {
                 if (out_skip) dw_body2<W, Pol, JT_HIDDEN, true, true>(A, job, smem);
                 else dw_body2<W, Pol, JT_HIDDEN, true>(A, job, smem);
@@ -1932,6 +2048,8 @@ __global__ __launch_bounds__(256) void reduce_kernel(BwdArgs A) {
         else if (from_chain && col == 31) is_bias = true;           // slot 31 of the recorded inputs is 1
     }
     else is_bias = col == 0;
+    float lb_tot = (sum[0] + sum[1]) + (sum[2] + sum[3]);
+    if constexpr (BG::WCC > 4) lb_tot += __shfl_xor(lb_tot, 32, 64);      // (wave columns 4 .. 7: the float4 of lane f + 32)
     if (kin < 0 && !is_bias) return;
     const int outw = out ? 1 : WT;
 #pragma unroll
@@ -1939,7 +2057,9 @@ __global__ __launch_bounds__(256) void reduce_kernel(BwdArgs A) {
         const int r = 4 * g4 + e, row = (r & 3) + 4 * hh + 8 * (r >> 2);
         const int o = out ? 0 : (Pol::TAPE8 && !from_chain) ? t8_feature(mi, row) : 32 * mi + row;      // (the chain's dW_0 tiles: bf16 staging, natural rows)
         if (out ? row != 0 : o >= WT) continue;
-        A.dparams[is_bias ? A.bias_off[l] + o : A.kernel_off[l] + kin * outw + o] = sum[e];
+        float val = sum[e];
+        if (rides && A.t.lbits && n < nH) val = lb_tot;                 // the shares of the dW job's wave columns (dw_body2 LBITS)
+        A.dparams[is_bias ? A.bias_off[l] + o : A.kernel_off[l] + kin * outw + o] = val;
     }
 }
 
@@ -2037,20 +2157,24 @@ static constexpr bool ga0_chain_ok(int depth) {
 }
 
 template <int W, class Pol>
-static void tape_layout(int depth, bool layer1_takes_enc, long long NQ, TapeLayout *t) {
+static void tape_layout(int depth, bool layer1_takes_enc, bool last_takes_enc, long long NQ, TapeLayout *t) {
     using BG = BwdGeom<W, Pol>;
     memset(t, 0, sizeof(*t));
     t->NQ = NQ;
     t->drop_h1 = Pol::ELEM_BYTES == 2 && depth >= 2 && !layer1_takes_enc;
     long long off = 0;
     const long long per_tensor = NQ * BG::MT * (long long)BG::TAPE_TILE;
+    // (lbits / drop_hd: decided before the h tensors are laid out)
+    const bool lbits = BHN_LBITS != 0 && Pol::ELEM_BYTES == 2 && !Pol::TAPE8 && bhn_folds_wout(Pol::MODE, depth) && !last_takes_enc;
+    t->drop_hd = BHN_DROP_HD != 0 && lbits;
     for (int l = 1; l <= depth; ++l) {
-        if (l == 1 && t->drop_h1) { t->h_off[l] = -1; continue; }
+        if ((l == 1 && t->drop_h1) || (l == depth && t->drop_hd)) { t->h_off[l] = -1; continue; }
         t->h_off[l] = off; off += per_tensor;
     }
     if (t->drop_h1) { t->encp_off = off; off += NQ * (long long)BG::TILE_BYTES; }
     t->drop_ga = bhn_folds_wout(Pol::MODE, depth);
     t->ga0_chain = ga0_chain_ok<W, Pol>(depth) && t->drop_ga;
+    t->lbits = BHN_LBITS != 0 && Pol::ELEM_BYTES == 2 && !Pol::TAPE8 && t->drop_ga && !last_takes_enc;
     for (int l = 0; l < depth; ++l) {
         if ((l == depth - 1 && t->drop_ga) || (l == 0 && t->ga0_chain)) { t->ga_off[l] = -1; continue; }
         t->ga_off[l] = off; off += per_tensor;
@@ -2066,7 +2190,9 @@ static void tape_layout(int depth, bool layer1_takes_enc, long long NQ, TapeLayo
     t->dout_off = off; off += NQ * t->dout_stride;
     t->mask_off = off; off += NQ * (long long)depth * ((BG::MT + 1) / 2) * 256;
     t->e_off = off; off += NQ * 128;
-    t->total = (long long)align_up((size_t)off + 1024, 256);     // +1 KiB: the last dout piece is DMA'd as a full KiB
+    off = (long long)align_up((size_t)off + 1024, 256);          // +1 KiB: the last dout piece is DMA'd as a full KiB
+    if (t->drop_hd) { t->scratch_off = off; off += 4096 * 64; }  // where the ring kernels' place-holder stores go (chain_kernel, no_hd): 4096 lines
+    t->total = off;
 }
 
 template <int W, class Pol>
@@ -2092,8 +2218,9 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
 #ifdef BHN_DEBUG
     static const int grid_override = dbg_env_int("BHN_DEBUG_DW_GRID", 0);
     static const int job1_w = dbg_env_int("BHN_DEBUG_JOB1_W", BHN_JOB1_W), jobl_w = dbg_env_int("BHN_DEBUG_JOBL_W", BHN_JOBL_W);
+    static const int joblb_w = dbg_env_int("BHN_DEBUG_JOBLB_W", BHN_JOBLB_W);
 #else
-    constexpr int grid_override = 0, job1_w = BHN_JOB1_W, jobl_w = BHN_JOBL_W;
+    constexpr int grid_override = 0, job1_w = BHN_JOB1_W, jobl_w = BHN_JOBL_W, joblb_w = BHN_JOBLB_W;
 #endif
     const int grid_dw = grid_override > 0 ? grid_override : ncu;        // one dW workgroup per CU
     MlpShape s;
@@ -2110,7 +2237,7 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
     const size_t slab_bytes = slab_dw_bytes + (ga0c ? align_up((size_t)ncu * BG::MT * 4096, 256) : 0);
     auto layout = [&](long long NQ, TapeLayout *t) {
         if (f128) bwd128_tape_layout(s.depth, NQ, t);
-        else tape_layout<W, Pol>(s.depth, s.depth >= 2 && s.skip_in[1], NQ, t);
+        else tape_layout<W, Pol>(s.depth, s.depth >= 2 && s.skip_in[1], s.depth >= 2 && s.skip_in[s.depth - 1], NQ, t);
     };
     if (what == RUN_QUERY) {
         const long long tiles = (query_P + Pol::NWAVES * 32 - 1) / (Pol::NWAVES * 32) * query_B;
@@ -2181,6 +2308,8 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
             work[l] = (double)(mtA + nB) + 0.5;
             // + the rebuild of gA and the output row (8-bit tape: the byte masks of that job are its long pole; 12 measured 2-3 % faster than 8)
             if (l == depth - 1 && t1.drop_ga) work[l] += (Pol::TAPE8 ? 12 : jobl_w) * BG::MT / 8.0;
+            // LBITS: that job streams 1 KiB of relu bits in place of its MT A tiles
+            if (l == depth - 1 && t1.lbits) work[l] = (double)nB + 1.0 + joblb_w * BG::MT / 8.0;
             if constexpr (Pol::ELEM_BYTES == 4) {
                 // f32: the jobs are MFMA-bound (a 32x32x2 MFMA is 64 cycles; one 32x32 tile product over a 32-point
                 // group = 16 of them = 0.55 us at the observed 1.87 GHz) unless they stream more than ~34 GB/s per

@@ -5,8 +5,11 @@
 // the generic backward (fused_bwd.hip) sends every layer input h_l AND every pre-activation gradient gA_l through an HBM
 // tape to a second kernel whose workgroups own one layer each: 3.3 KB per point and step.  At width 128 the whole
 // gradient is 57,344 + 128 floats = 225 KB: it fits the 512 KB register file of one CU (4 waves x 256 accumulator
-// registers), so gA_l never leaves the chip and the tape shrinks to what the forward knows (h_l, encoded inputs, e:
-// 1.1 KB per point, written once and read once).
+// registers), so gA_l never leaves the chip and the tape shrinks to what the forward knows: h_2 .. h_{depth-1}, the relu BITS of
+// the last hidden layer, the encoded inputs, e -- 600 B per point, written once and read once.  (h_1 is recomputed from the
+// encoded inputs; h_depth is not needed at all, round 5: the backward wants relu'(a_{depth-1}) -- 16 B of bits per point instead
+// of 256 B of values -- and the output layer's row sum_p dout_p h_depth[p], which equals sum_k K[k][f] G[k][f] + b[f] g[f] for
+// the layer's own gradient G, g because h = relu(a) = relu'(a) a: reduce128_kernel / wout128_kernel, TapeLayout::drop_hd.)
 //
 // Structure (one workgroup = 4 waves, one per SIMD, 512 registers each; one workgroup per CU, persistent).  A workgroup
 // iteration takes 128 points (four 32-point tape groups).  Activations live in LDS as [point][feature] images whose 256-byte
@@ -33,9 +36,9 @@
 //   dW_l    accumulator tiles m in {2i, 2i+1} x n in {2j, 2j+1} of gA_l^T h_l plus (m = 2i + j) x the encoded-input tile:
 //           the encoded inputs carry a 1 in slot 31, so that tile's column 31 is the bias gradient of EVERY layer and its
 //           other columns the skip layer's encoded-input rows (discarded for the other layers); K = the 128 points.
-// Layer 0: dW_0 = gA_0^T enc, one tile per wave.  Output layer: dW_out = sum_p dout_p h_depth by v_dot2 on transposed reads;
-// gA_{depth-1} = relu' (.) bf16(dout) with W_out folded into the weight image and applied to dW_{depth-1} at the reduce
-// (bhn_folds_wout: the same arithmetic as the generic path).
+// Layer 0: dW_0 = gA_0^T enc, one tile per wave.  gA_{depth-1} = relu' (.) bf16(dout) from the recorded relu bits, with W_out
+// folded into the weight image and applied to dW_{depth-1} at the reduce (bhn_folds_wout: the same arithmetic as the generic
+// path); the output layer's row comes out of the reduce (above), its bias is the sum of dout.
 // 16 accumulator tiles (256 registers) per wave at depth 4; deeper networks use the generic path.
 #include <type_traits>
 #include "bwd_common.h"
@@ -172,10 +175,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const float *dout_g = reinterpret_cast<const float *>(A.tape + A.t.dout_off);
     auto point_dout = [&](long long Q) -> float { return dout_g[(4 * Q + wv) * 32 + pl]; };
     auto put_dout = [&](float d) {
-        if (lane < 32) {
-            reinterpret_cast<float *>(smem + OFF_DOUT)[32 * wv + pl] = d;
-            reinterpret_cast<__bf16 *>(smem + OFF_DPK)[32 * wv + pl] = (__bf16)d;
-        }
+        if (lane < 32) reinterpret_cast<float *>(smem + OFF_DOUT)[32 * wv + pl] = d;
+    };
+    // relu bits of the last hidden layer (TapeLayout::drop_hd: recorded by the forward in place of the h_depth tiles), point blocks
+    // 2j, 2j+1 of quad Q: the word of THIS lane (point pl, half hh -- the lane that held the point in the forward) for row tiles
+    // 2i (low 16 bits) and 2i+1 (high): bit k = accumulator element 2k, bit 8+k = element 2k+1 (Pol::mask_code)
+    const unsigned *maskd_g = reinterpret_cast<const unsigned *>(A.tape + A.t.maskd_off);
+    auto load_maskd = [&](long long Qx, unsigned (&mw)[2]) {
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi) mw[pi] = maskd_g[((4 * Qx + 2 * wj + pi) * 2 + wi) * 64 + lane];
     };
     // this wave's 16 fragments of the transposed weight image of hidden layer l (rows m0, m1), plain loads from L2
     // (buffer loads: one resource over the image, the fragment as a scalar offset, 16 lane -- no 64-bit address per fragment:
@@ -230,7 +238,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     float bsum[DEPTH - 1];
 #pragma unroll
     for (int l = 0; l < DEPTH - 1; ++l) bsum[l] = 0.f;
-    float orow = 0.f, bout = 0.f;
+    float bout = 0.f;
 
     // ---- phases ------------------------------------------------------------------------------------------------------
     // delta chain through hidden layer l, point block 2j + pi: tiles m0, m1 of W_l gA_l (ga_in: image offset of gA_l) ...
@@ -340,48 +348,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             af = afn; be = ben;
         }
     };
-    // front: gA_{depth-1} (without W_out, common.h bhn_folds_wout) = relu'(a_{depth-1}) (.) bf16(dout) from the h_depth image;
-    // the output layer's row: dW_out[f] += sum_p dout_p h_depth[p][f] (feature tile wv)
-    auto front = [&](unsigned h_img, unsigned ga_out) {
-        // (all LDS reads of a part first: one wave per SIMD has nobody to hide a read-use round trip behind)
-        u32x4 hv[2][2][2];
-        float dv[2];
+    // front: gA_{depth-1} (without W_out, common.h bhn_folds_wout) = relu'(a_{depth-1}) (.) bf16(dout) from the recorded relu bits
+    // (round 5: no h_depth image any more; the output layer's row is made by the reduce from layer depth-1's own gradient,
+    //  TapeLayout::drop_hd).  Chunk (tile T, k-step s2, half hh) of point pl holds accumulator elements 8 s2 .. 8 s2 + 7 of lane
+    // (pl, hh): dword d = elements 8 s2 + 2 d, + 1 = bits 4 s2 + d and 8 + 4 s2 + d of the tile's 16-bit code.
+    auto front = [&](const unsigned (&mw)[2], unsigned ga_out) {
 #pragma unroll
         for (int pi = 0; pi < 2; ++pi) {
-            dv[pi] = reinterpret_cast<const float *>(smem + OFF_DOUT)[32 * (2 * wj + pi) + pl];
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2)
-                    hv[pi][mi][s2] = __builtin_bit_cast(u32x4, lds_row(smem, h_img + (rowb[pi] ^ (16u * (4 * (2 * wi + mi) + 2 * s2)))));
-        }
-        frag hf[8], dp[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            hf[k] = tr2(smem, h_img + trA_w + 4096u * k, h_img + trB_w + 4096u * k);
-            dp[k] = *reinterpret_cast<const frag *>(smem + OFF_DPK + 2 * (16 * k + 8 * (lane >> 5)));   // the lane's 8 points
-        }
-#pragma unroll
-        for (int pi = 0; pi < 2; ++pi) {
-            const Pol::bf16x2 d2 = {(__bf16)dv[pi], (__bf16)dv[pi]};
+            const float dvp = reinterpret_cast<const float *>(smem + OFF_DOUT)[32 * (2 * wj + pi) + pl];
+            const Pol::bf16x2 d2 = {(__bf16)dvp, (__bf16)dvp};
             const unsigned dd = __builtin_bit_cast(unsigned, d2);
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < 2; ++mi) {
+                const unsigned code = mi ? mw[pi] >> 16 : mw[pi];
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     u32x4 o;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) o[k] = keep_where_nz(dd, hv[pi][mi][s2][k]);
+                    for (int d = 0; d < 4; ++d) {
+                        const int lo = (int)(code << (31 - (4 * s2 + d))) >> 31, hi = (int)(code << (31 - (8 + 4 * s2 + d))) >> 31;
+                        o[d] = dd & (((unsigned)lo & 0xffffu) | ((unsigned)hi & 0xffff0000u));
+                    }
                     lds_put(smem, ga_out + (rowb[pi] ^ (16u * (4 * (2 * wi + mi) + 2 * s2))), __builtin_bit_cast(frag, o));
                 }
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const Pol::bf16x2 hp = {hf[k][2 * i], hf[k][2 * i + 1]}, dq = {dp[k][2 * i], dp[k][2 * i + 1]};
-                orow = __builtin_amdgcn_fdot2_f32_bf16(hp, dq, orow, false);
             }
+        }
     };
 
     // ---- h_1 = relu(W_0^T enc + b_0) recomputed into an h image (same operands, same order, same rounding as the forward's layer
@@ -423,17 +414,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     frag wf[2][KS];
     float dnext = 0.f;
     int eb = 0;
+    unsigned mnext[2] = {0u, 0u};                              // relu words of the quad whose top phase runs next
     if (Q < nquads) {
-        dma_h(DEPTH, Q, 0);
         dma_h(DEPTH - 1, Q, 1);
         dma_enc(Q, 0);
         dnext = point_dout(Q);
+        load_maskd(Q, mnext);
         load_w(DEPTH - 1, wf);
         use_w(wf);
         if (lane < 32) bout += dnext;
         put_dout(dnext);
         drain_and_barrier();                                   // the first quad's images landed, its dout visible
-        front(OFF_H + 0 * IMG, OFF_GA + 0 * IMG);              // top phase of the first quad: gA_{D-1} -> GA0, dW_out
+        front(mnext, OFF_GA + 0 * IMG);                        // top phase of the first quad: gA_{D-1} -> GA0
         drain_and_barrier();
     }
     for (; Q < nquads; Q += gridDim.x) {
@@ -459,12 +451,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             // the h image that layer l+1 has released takes h_{l-1} (l == 1: the next quad's h_D), piece by piece under the
             // first chain step's MFMAs; the epilogue of point block 0 runs under the MFMAs of point block 1, that of point block
             // 1 and the loads of the next layer's weights under the dW MFMAs
-            const u32x4 rs_h = (l - 1 >= 2) ? h_rsrc(l - 1, Q) : h_rsrc(DEPTH, Qn);
+            const u32x4 rs_h = h_rsrc(l - 1 >= 2 ? l - 1 : 2, Q);
             if (l == 2) make_h1(e_img, OFF_H + (hi ^ 1) * IMG);          // (the image h_3 has left; published by this layer's barrier)
-            if (l == 1) dnext = point_dout(Qn);                // load issued here, consumed behind this layer's dW phase
+            if (l == 1) { dnext = point_dout(Qn); load_maskd(Qn, mnext); }   // loads issued here, consumed behind this layer's dW phase / in the next top phase
             stamp();
             f32x16 c0[2], c1[2];
-            chain_mma(wf, ga_in, 0, c0, [&](int ks) { if (l != 2) dma_h_piece(rs_h, hi ^ 1, ks); });
+            chain_mma(wf, ga_in, 0, c0, [&](int ks) { if (l - 1 >= 2) dma_h_piece(rs_h, hi ^ 1, ks); });
             stamp();
             if constexpr (BHN_B128_ABL & 16) {
                 chain_mma(wf, ga_in, 1, c1, [&](int) {});
@@ -505,7 +497,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             stamp();
             // ... and the NEXT quad's top phase beside it (its h_D landed behind layer 1's barrier; GA0 was last read by layer 1):
             // one barrier and one drain fewer per iteration than a top phase of its own
-            if (!(BHN_B128_ABL & 32)) front(OFF_H + 0 * IMG, OFF_GA + 0 * IMG);
+            if (!(BHN_B128_ABL & 32)) front(mnext, OFF_GA + 0 * IMG);
             stamp();
             drain_and_barrier();                               // GA0 complete; h_{D-1} (H1) and enc of the next quad landed
         }
@@ -552,14 +544,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     }
     flush_tile(60 + wv, acc0);
-    {   // tile 64: [0..127] the output layer's row by virtual feature position, [128 + wv] this wave's share of its bias
+    {   // tile 64: [128 + wv] this wave's share of the output layer's bias (its row: reduce128_kernel, from layer depth-1's gradient)
         float *tp = slab + 64ll * 1024;
-        float v = orow + __shfl_xor(orow, 32, 64);
-        if (lane < 32) {
-            float *dst = tp + 32 * wv + lane;
-            if (A.accumulate) v += *dst;
-            *dst = v;
-        }
         float bs = bout;
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) bs += __shfl_xor(bs, o, 64);
@@ -628,18 +614,8 @@ __global__ __launch_bounds__(256) void reduce128_kernel(BwdArgs A, int nslabs, i
     }
     const int WT = A.width_true;
     const float *wout = reinterpret_cast<const float *>(A.f.packed + A.f.wout_off);
-    if (tile == 64) {                                            // output layer: float index 256 g4 + 4 lane + e of the tile
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int idx = 256 * g4 + 4 * lane + e;
-            if (idx < 128) {
-                const int f = 32 * (idx >> 5) + virt_feature(idx & 31);
-                if (f < WT) A.dparams[A.kernel_off[DEPTH] + f] = sum[e];
-            }
-        }
-        if (tid == 32) {                                         // floats 128..131: the four waves' shares of the bias
-            A.dparams[A.bias_off[DEPTH]] = (sum[0] + sum[1]) + (sum[2] + sum[3]);
-        }
+    if (tile == 64) {                                            // output layer: floats 128..131 = the four waves' shares of its bias
+        if (tid == 32) A.dparams[A.bias_off[DEPTH]] = (sum[0] + sum[1]) + (sum[2] + sum[3]);
         return;
     }
     int l, m, n;
@@ -648,6 +624,29 @@ __global__ __launch_bounds__(256) void reduce128_kernel(BwdArgs A, int nslabs, i
     if (l >= DEPTH) return;
     const bool skip = (A.f.skip_mask >> l) & 1;
     const bool fold = l == DEPTH - 1 && bhn_folds_wout(BHN_BF16, DEPTH);
+    if (l == DEPTH - 1) {
+        // The output layer's row from THIS layer's gradient (TapeLayout::drop_hd): h_D = relu(a) = relu'(a) a, a = K^T [h | enc] + b, so
+        //   dW_out[o] = sum_p dout_p h_D[p][o] = sum_k K[k][o] G[k][o] + b[o] g[o],   G, g = the un-folded sums of this tile's
+        // layer (gA without its W_out factor).  K = the bf16 weights the forward multiplied with (packed image), b in f32.
+        // This block adds its 32 input columns; wout128_kernel adds the five input tiles of a row in order.
+        const char *wimg = A.f.packed + A.f.fwd_off + (size_t)(1 + (l - 1) * MT + m) * CB;          // chunk of output tile m
+        const float *bias = reinterpret_cast<const float *>(A.f.packed + A.f.bias_off) + l * 128;
+        float *scr = reinterpret_cast<float *>(A.tape + A.t.scratch_off) + n * 128;
+        const int q = n < 4 ? 32 * n + virt_feature(col) : virt_feature(col);      // hidden input unit / encoded-input slot of this column
+        const int fr = n < 4 ? q >> 4 : KS + (q >> 4), ph = q & 15, h2 = (ph >> 2) & 1, jj = (ph & 3) + 4 * (ph >> 3);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int v = e + 8 * g4 + 4 * hh, i = virt_feature(v);
+            float wq;
+            if (n == 4 && q == 31) wq = bias[32 * m + i];
+            else if (n == 4 && !skip) wq = 0.f;
+            else wq = (float)reinterpret_cast<const __bf16 *>(wimg + fr * 1024 + (i + 32 * h2) * 16)[jj];
+            float part = wq * sum[e];
+#pragma unroll
+            for (int o2 = 16; o2 > 0; o2 >>= 1) part += __shfl_xor(part, o2, 64);
+            if (col == 0) scr[32 * m + i] = part;
+        }
+    }
     // input of this column
     long long kin = -1;
     bool is_bias = false;
@@ -674,6 +673,16 @@ __global__ __launch_bounds__(256) void reduce128_kernel(BwdArgs A, int nslabs, i
     }
 }
 
+// the output layer's row: the five partial sums of reduce128_kernel (input tiles 0..3, then the encoded-input / bias tile), in order
+__global__ __launch_bounds__(128) void wout128_kernel(BwdArgs A, int depth) {
+    const float *scr = reinterpret_cast<const float *>(A.tape + A.t.scratch_off);
+    const int o = threadIdx.x;
+    float s = scr[o];
+#pragma unroll
+    for (int n = 1; n < 5; ++n) s += scr[n * 128 + o];
+    if (o < A.width_true) A.dparams[A.kernel_off[depth] + o] = s;
+}
+
 }   // namespace
 
 // ---- host side (called from bwd_run of fused_bwd.hip) --------------------------------------------------------------------
@@ -695,7 +704,10 @@ void bwd128_tape_layout(int depth, long long NQ, TapeLayout *t) {
     long long off = 0;
     t->drop_h1 = 1;                                              // h_1 = relu(W_0^T enc + b_0) is recomputed by the backward (2 MFMAs per tile)
     t->h_off[1] = -1;
-    for (int l = 2; l <= depth; ++l) { t->h_off[l] = off; off += per_tensor; }
+    t->drop_hd = 1;                                              // h_depth: its relu bits instead (bwd_common.h)
+    for (int l = 2; l < depth; ++l) { t->h_off[l] = off; off += per_tensor; }
+    t->h_off[depth] = -1;
+    t->maskd_off = off; off += NQ * 2ll * 256;                  // [group][tile pair][lane] words
     for (int l = 0; l < depth; ++l) t->ga_off[l] = -1;
     t->lin_stride = per_tensor;
     t->h_lin = -2 * per_tensor;                                  // h_off[l] = h_lin + l * lin_stride, l >= 2
@@ -704,6 +716,8 @@ void bwd128_tape_layout(int depth, long long NQ, TapeLayout *t) {
     t->dout_off = off; off += NQ * 128;                         // f32 dout per point (dout128_kernel), beside the recorded e
     t->dout_stride = 128;
     t->mask_off = -1; t->encp_off = -1;
+    off = (off + 255) / 256 * 256;
+    t->scratch_off = off; off += 5 * 128 * 4;
     t->total = (long long)(((size_t)off + 1024 + 255) / 256 * 256);
 }
 
@@ -733,6 +747,8 @@ int reduce128_launch(const BwdArgs &A, int depth, int nslabs, hipStream_t st) {
     hipLaunchKernelGGL(reduce128_stage1, dim3(SLAB_TILES, parts), dim3(256), 0, st, A, nslabs, per);
     BHN_HIP(hipGetLastError());
     hipLaunchKernelGGL(reduce128_kernel<4>, dim3(SLAB_TILES), dim3(256), 0, st, A, nslabs, per);
+    BHN_HIP(hipGetLastError());
+    hipLaunchKernelGGL(wout128_kernel, dim3(1), dim3(128), 0, st, A, depth);
     BHN_HIP(hipGetLastError());
     return BHN_OK;
 }

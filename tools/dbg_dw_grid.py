@@ -32,7 +32,7 @@ else:
         for jl in os.environ.get('JL', '1.5 4 6 8 10 12').split():
             for j1 in os.environ.get('J1', '12 14').split():
                 print('JOBL_W', jl, 'JOB1_W', j1, flush=True)
-                subprocess.run([sys.executable, os.path.abspath(__file__), 'run'], env=dict(os.environ, BHN_DEBUG_JOBL_W=jl, BHN_DEBUG_JOB1_W=j1))
+                subprocess.run([sys.executable, os.path.abspath(__file__), 'run'], env=dict(os.environ, BHN_DEBUG_JOBL_W=jl, BHN_DEBUG_JOBLB_W=jl, BHN_DEBUG_JOB1_W=j1))      # (JL sets both the h-tile and the relu-bit form of the layer depth-1 job)
     else:
         for g in ['0', '224', '192', '160', '128', '96', '64']:
             subprocess.run([sys.executable, os.path.abspath(__file__), 'run'], env=dict(os.environ, BHN_DEBUG_DW_GRID=g))
