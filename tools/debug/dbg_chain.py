@@ -5,10 +5,10 @@ from bhnerf_amd import _hip, engine, network, synthetic, constants
 dev = torch.device('cuda:0')
 H = W = 128; G = 64; B = 8
 geo = synthetic.synthetic_geodesics(H, W, G)
-pred = network.NeRF_Predictor(8.0, 0.0, np.inf, np.inf, net_depth=4, net_width=256, mode='bf16', device=dev)
+pred = network.NeRF_Predictor(8.0, 0.0, np.inf, np.inf, net_depth=4, net_width=int(os.environ.get('WIDTH', 256)), mode='bf16', device=dev)
 eng = pred.engine()
 geom = pred.geometry(geo['coords'], geo['Omega'], geo['t_geos'], None, geo['g'], geo['dtau'], geo['Sigma'])
-flat = eng.flatten(network.MLP(4, 256).init(1, 21)); eng.pack(flat)
+flat = eng.flatten(network.MLP(4, int(os.environ.get('WIDTH', 256))).init(1, 21)); eng.pack(flat)
 tM0 = engine.frame_offsets(np.linspace(0, 1, B), 0.0, geo['t_injection'], constants.GM_c3('hr'), dev)
 dimg = torch.rand((B, 1, geom.R), device=dev) * 1e-3
 def timed(fn, reps=4):
