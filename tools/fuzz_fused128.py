@@ -5,7 +5,8 @@ recovery domains incl. point compaction and empty groups).  Two processes, becau
     BHNERF_HIP_LIB=.../libbhnerf_hip_nof128.so python tools/fuzz_fused128.py save N seed     (generic path: -DBHN_NO_FUSED128)
     python tools/fuzz_fused128.py check N seed                                             (product library)
 Both arithmetic paths round the same bf16 operands and accumulate in f32; they differ in summation order only: the check
-demands 2e-5 of the largest gradient entry per problem (observed <= 1e-6), for the recompute route AND the recorded-tape route."""
+demands 2e-5 of the largest gradient entry per problem (observed <= 1e-6), for the recompute route AND the recorded-tape route --
+except the output layer's row, which the fused path makes by another formula (held to 4e-3: the bf16 rounding of h_4 the generic path carries)."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -42,13 +43,14 @@ for i in range(N):
     if g2 is not None:
         out['t%d' % i] = g2
     out['cfg%d' % i] = np.array([width, S, deg, int(skip), H, W, G, B, geom.active_fraction])
+    out['row%d' % i] = np.array([eng.kernel_off[4], width])              # the output layer's row in the flat gradient
 if what == 'save':
     os.makedirs('gpurun_out', exist_ok=True)
     np.savez('gpurun_out/fuzz_fused128_ref.npz', **out)
     print('saved %d problems' % N)
     sys.exit(0)
 ref = np.load('gpurun_out/fuzz_fused128_ref.npz')
-bad, worst = 0, 0.0
+bad, worst, worst_row = 0, 0.0, 0.0
 for i in range(N):
     for k in ('g', 't', 'img'):
         key = '%s%d' % (k, i)
@@ -56,10 +58,21 @@ for i in range(N):
             continue
         r, g = ref[key], out[key]
         den = np.abs(r).max()
+        if k != 'img':
+            # the output layer's row: the fused path makes it from layer 3's gradient (sum_k K G + b g = the UN-rounded pre-activation
+            # times relu'), the generic path from the bf16-rounded h_4 on its tape: they differ by that rounding (2^-9 a term)
+            ko, nw = int(out['row%d' % i][0]), int(out['row%d' % i][1])
+            err_row = 0.0 if den == 0 else float(np.abs(g[ko:ko + nw] - r[ko:ko + nw]).max() / den)
+            worst_row = max(worst_row, err_row)
+            if not err_row < 4e-3:
+                bad += 1
+                print('FAIL problem %d %s (output row) cfg %s: max err %.3e of %.3e' % (i, k, out['cfg%d' % i], err_row, den))
+            g = g.copy(); g[ko:ko + nw] = r[ko:ko + nw]
         err = 0.0 if den == 0 and np.abs(g).max() == 0 else np.abs(g - r).max() / max(den, 1e-30)
         worst = max(worst, err)
         if not err < 2e-5:
             bad += 1
             print('FAIL problem %d %s cfg %s: max err %.3e of %.3e' % (i, k, out['cfg%d' % i], err, den))
-print('%d problems (width 97..128 x depth 4, bf16): %d failures, worst difference %.2e of the largest entry (fused vs generic backward; training-forward images included)' % (N, bad, worst))
+print('%d problems (width 97..128 x depth 4, bf16): %d failures, worst difference %.2e of the largest entry (fused vs generic backward; training-forward images included); '
+      'the output layer\'s row (another formula: without the bf16 rounding of h_4): worst %.2e' % (N, bad, worst, worst_row))
 sys.exit(1 if bad else 0)
