@@ -36,7 +36,7 @@ struct TapeLayout {
     // forward records those relu bits instead (maskd_off: [group][tile pair][lane] words, TapePost: 16 B per point for 256) --
     // and the output layer's row dW_out = sum_p dout_p h_depth[p], which the reduce makes from the layer's own gradient:
     // h = relu(a) = relu'(a) a and a = K^T h_{depth-1} + b give  dW_out[f] = sum_k K[k][f] G[k][f] + b[f] g[f]  with G, g the
-    // (un-folded) weight and bias gradients of layer depth-1 (fused_bwd128.hip: reduce128_kernel, wout128_kernel).
+    // (un-folded) weight and bias gradients of layer depth-1 (fused_bwd128.hip: reduce128_kernel).
     int drop_hd;
     // generic bf16 path (round 5): the dW job of layer depth-1 reads the relu-bit words instead of the h_depth tiles and makes the
     // output layer's row at its flush (dw_body2 LBITS); with drop_hd the forward does not store those tiles either

@@ -9,7 +9,7 @@
 // the last hidden layer, the encoded inputs, e -- 600 B per point, written once and read once.  (h_1 is recomputed from the
 // encoded inputs; h_depth is not needed at all, round 5: the backward wants relu'(a_{depth-1}) -- 16 B of bits per point instead
 // of 256 B of values -- and the output layer's row sum_p dout_p h_depth[p], which equals sum_k K[k][f] G[k][f] + b[f] g[f] for
-// the layer's own gradient G, g because h = relu(a) = relu'(a) a: reduce128_kernel / wout128_kernel, TapeLayout::drop_hd.)
+// the layer's own gradient G, g because h = relu(a) = relu'(a) a: reduce128_kernel, TapeLayout::drop_hd.)
 //
 // Structure (one workgroup = 4 waves, one per SIMD, 512 registers each; one workgroup per CU, persistent).  A workgroup
 // iteration takes 128 points (four 32-point tape groups).  Activations live in LDS as [point][feature] images whose 256-byte
@@ -564,6 +564,8 @@ __global__ __launch_bounds__(256) void dout128_kernel(BwdArgs A) {
     const long long n = A.t.NQ * 32;
     const float *eg = reinterpret_cast<const float *>(A.tape + A.t.e_off);
     float *dg = reinterpret_cast<float *>(A.tape + A.t.dout_off);
+    if (blockIdx.x == 0 && threadIdx.x == 0)            // the arrival counter of reduce128_kernel's output-row blocks (this kernel runs first in every backward call)
+        *reinterpret_cast<unsigned *>(reinterpret_cast<float *>(A.tape + A.t.scratch_off) + 5 * 128) = 0u;
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const long long q = i >> 5;
         int b; long long p; bool inb;
@@ -628,7 +630,7 @@ __global__ __launch_bounds__(256) void reduce128_kernel(BwdArgs A, int nslabs, i
         // The output layer's row from THIS layer's gradient (TapeLayout::drop_hd): h_D = relu(a) = relu'(a) a, a = K^T [h | enc] + b, so
         //   dW_out[o] = sum_p dout_p h_D[p][o] = sum_k K[k][o] G[k][o] + b[o] g[o],   G, g = the un-folded sums of this tile's
         // layer (gA without its W_out factor).  K = the bf16 weights the forward multiplied with (packed image), b in f32.
-        // This block adds its 32 input columns; wout128_kernel adds the five input tiles of a row in order.
+        // This block adds its 32 input columns; the last block of the layer adds the five input tiles of every row, in order.
         const char *wimg = A.f.packed + A.f.fwd_off + (size_t)(1 + (l - 1) * MT + m) * CB;          // chunk of output tile m
         const float *bias = reinterpret_cast<const float *>(A.f.packed + A.f.bias_off) + l * 128;
         float *scr = reinterpret_cast<float *>(A.tape + A.t.scratch_off) + n * 128;
@@ -645,6 +647,24 @@ __global__ __launch_bounds__(256) void reduce128_kernel(BwdArgs A, int nslabs, i
 #pragma unroll
             for (int o2 = 16; o2 > 0; o2 >>= 1) part += __shfl_xor(part, o2, 64);
             if (col == 0) scr[32 * m + i] = part;
+        }
+        // the LAST of the layer's twenty blocks to get here adds the five partial sums of every row, in order (a fixed order: the
+        // result does not depend on which block is last) -- a third kernel for 128 floats cost 3 us per step, 3 % of a config-5 share
+        __shared__ unsigned ticket;
+        __threadfence();
+        __syncthreads();
+        unsigned *count = reinterpret_cast<unsigned *>(reinterpret_cast<float *>(A.tape + A.t.scratch_off) + 5 * 128);   // zeroed by dout128_kernel
+        if (tid == 0) ticket = atomicAdd(count, 1u);
+        __syncthreads();
+        if (ticket == 4 * 5 - 1) {
+            __threadfence();
+            const volatile float *all = reinterpret_cast<const volatile float *>(A.tape + A.t.scratch_off);
+            if (tid < 128) {
+                float s = all[tid];
+#pragma unroll
+                for (int k = 1; k < 5; ++k) s += all[k * 128 + tid];
+                if (tid < WT) A.dparams[A.kernel_off[DEPTH] + tid] = s;
+            }
         }
     }
     // input of this column
@@ -671,16 +691,6 @@ __global__ __launch_bounds__(256) void reduce128_kernel(BwdArgs A, int nslabs, i
         if (fold) val *= wout[o];
         A.dparams[is_bias ? A.bias_off[l] + o : A.kernel_off[l] + kin * WT + o] = val;
     }
-}
-
-// the output layer's row: the five partial sums of reduce128_kernel (input tiles 0..3, then the encoded-input / bias tile), in order
-__global__ __launch_bounds__(128) void wout128_kernel(BwdArgs A, int depth) {
-    const float *scr = reinterpret_cast<const float *>(A.tape + A.t.scratch_off);
-    const int o = threadIdx.x;
-    float s = scr[o];
-#pragma unroll
-    for (int n = 1; n < 5; ++n) s += scr[n * 128 + o];
-    if (o < A.width_true) A.dparams[A.kernel_off[depth] + o] = s;
 }
 
 }   // namespace
@@ -717,7 +727,7 @@ void bwd128_tape_layout(int depth, long long NQ, TapeLayout *t) {
     t->dout_stride = 128;
     t->mask_off = -1; t->encp_off = -1;
     off = (off + 255) / 256 * 256;
-    t->scratch_off = off; off += 5 * 128 * 4;
+    t->scratch_off = off; off += 5 * 128 * 4 + 256;             // + the arrival counter
     t->total = (long long)(((size_t)off + 1024 + 255) / 256 * 256);
 }
 
@@ -747,8 +757,6 @@ int reduce128_launch(const BwdArgs &A, int depth, int nslabs, hipStream_t st) {
     hipLaunchKernelGGL(reduce128_stage1, dim3(SLAB_TILES, parts), dim3(256), 0, st, A, nslabs, per);
     BHN_HIP(hipGetLastError());
     hipLaunchKernelGGL(reduce128_kernel<4>, dim3(SLAB_TILES), dim3(256), 0, st, A, nslabs, per);
-    BHN_HIP(hipGetLastError());
-    hipLaunchKernelGGL(wout128_kernel, dim3(1), dim3(128), 0, st, A, depth);
     BHN_HIP(hipGetLastError());
     return BHN_OK;
 }
