@@ -116,10 +116,7 @@ class RayGeometry:
             self.P_eff = n_pad
             # bhn_geom.ray_span: the most 32-point groups the (consecutive) points of one ray lie in -- 1 or 2 lets the render
             # kernels skip the per-tile combine of ray segments (include/bhnerf_hip.h)
-            r = self.compact['ray'][:n_in]
-            starts = torch.nonzero(torch.cat([torch.ones(1, dtype=torch.bool, device=dev), r[1:] != r[:-1]])).reshape(-1)
-            ends = torch.cat([starts[1:], torch.tensor([n_in], device=dev)]) - 1
-            self.compact['ray_span'] = int((torch.div(ends, 32, rounding_mode='floor') - torch.div(starts, 32, rounding_mode='floor')).max().item()) + 1
+            self.compact['ray_span'] = ray_span(self.compact['ray'][:n_in])
 
     def c_struct(self):
         """Dense layout (R x G planes): voxel / grid kernels and every caller that indexes points as ray * G + sample."""
@@ -146,6 +143,18 @@ class RayGeometry:
     def visited_fraction(self):
         """Fraction of ray samples the fused kernels evaluate after compaction (points, else 32-point groups)."""
         return self.P_eff / float(self.n_groups_total * 32)
+
+
+def ray_span(ray):
+    """bhn_geom.ray_span of a point-compacted layout: `ray` = the ray of every in-domain point in ray-major order (a 1-D integer
+    tensor, runs of equal values); the result is the largest number of consecutive 32-point groups one run lies in."""
+    n = int(ray.numel())
+    if n == 0:
+        return 0
+    first = torch.ones(1, dtype=torch.bool, device=ray.device)
+    starts = torch.nonzero(torch.cat([first, ray[1:] != ray[:-1]])).reshape(-1)
+    ends = torch.cat([starts[1:], torch.tensor([n], device=ray.device)]) - 1
+    return int((torch.div(ends, 32, rounding_mode='floor') - torch.div(starts, 32, rounding_mode='floor')).max().item()) + 1
 
 
 def frame_offsets(t_frames, t_start_obs, t_injection, GM_c3, device):

@@ -207,3 +207,20 @@ def test_lds_swizzle_of_the_fused_width128_backward_is_conflict_free():
         assert len({swz(4 * a + b) >> 2 for b in range(4)}) == 4
     old = lambda r: ((r & 3) << 2) | ((r >> 2) & 3)
     assert len({old(i) & 7 for i in range(8)}) == 4                          # round 4: every bank hit twice by a row store
+
+
+def test_ray_span_of_a_compacted_layout():
+    """engine.ray_span (bhn_geom.ray_span, ABI 4): the most 32-point groups the consecutive points of one ray lie in."""
+    import torch
+    from bhnerf_amd import engine
+    t = lambda v: torch.tensor(v, dtype=torch.int32)
+    assert engine.ray_span(t([])) == 0
+    assert engine.ray_span(t([5] * 32)) == 1                                  # one ray filling one group exactly
+    assert engine.ray_span(t([0] * 31 + [1] * 2)) == 2                        # the second ray straddles the boundary
+    assert engine.ray_span(t([0] * 10 + [3] * 22 + [4] * 32 + [9] * 1)) == 1  # runs that end on group boundaries
+    assert engine.ray_span(t([0] * 31 + [1] * 34)) == 3                       # points 31 .. 64: groups 0, 1 and 2
+    assert engine.ray_span(t([7] * 100)) == 4
+    rng = torch.Generator().manual_seed(3)
+    counts = torch.randint(1, 23, (500,), generator=rng)                      # config-3-like: at most 22 in-domain samples per ray
+    ray = torch.repeat_interleave(torch.arange(500, dtype=torch.int32), counts)
+    assert engine.ray_span(ray) == 2
