@@ -70,6 +70,7 @@ struct BwdArgs {
     float *slab0;
     int n_chain_wg;
     int chain_step;                            // stride of the dW_0 slabs that hold the stage-1 sums (chain_slab_stage1)
+    int fwd_nw;                                // 32-point groups per tile of the training forward that recorded the tape (8; fused 4x128: 12, PolBF16X)
 };
 
 

@@ -2239,22 +2239,33 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
         if (f128) bwd128_tape_layout(s.depth, NQ, t);
         else tape_layout<W, Pol>(s.depth, s.depth >= 2 && s.skip_in[1], s.depth >= 2 && s.skip_in[s.depth - 1], NQ, t);
     };
+    // the fused 4x128 path's training forward runs on 12-wave workgroups (PolBF16X, fused_common.h): 12 groups per tile
+    constexpr bool CAN_X = W == 128 && Pol::ELEM_BYTES == 2 && !Pol::TAPE8;
+    using FPol = std::conditional_t<CAN_X, PolBF16X, Pol>;
+    const bool x12 = CAN_X && f128 && bhn_fwd_w12(Pol::MODE, W, s.depth, what == RUN_QUERY ? (query_P + 31) / 32 : bhn_groups_per_frame(geom));
+    const int nwf = x12 ? FPol::NWAVES : Pol::NWAVES;
     if (what == RUN_QUERY) {
-        const long long tiles = (query_P + Pol::NWAVES * 32 - 1) / (Pol::NWAVES * 32) * query_B;
-        TapeLayout t;
-        layout(tiles * Pol::NWAVES, &t);
-        *query_bytes = slab_bytes + t8_bytes + (size_t)t.total;
+        // (the caller's P may be the dense point count of a ray set that is walked compacted, or the other way round: room for either tile size)
+        size_t need = 0;
+        for (int nw : {(int)Pol::NWAVES, CAN_X && f128 ? (int)FPol::NWAVES : (int)Pol::NWAVES}) {
+            const long long tiles = (query_P + nw * 32 - 1) / (nw * 32) * query_B;
+            TapeLayout t;
+            layout(tiles * nw, &t);
+            if ((size_t)t.total > need) need = (size_t)t.total;
+        }
+        *query_bytes = slab_bytes + t8_bytes + need;
         return BHN_OK;
     }
     BwdArgs A;
     memset(&A, 0, sizeof(A));
-    int rc = fused_fill_args(m, mode, packed, geom, fr, true, &A.f, &s, Pol::NWAVES);
+    int rc = fused_fill_args(m, mode, packed, geom, fr, true, &A.f, &s, nwf);
+    A.fwd_nw = nwf;
     if (rc != BHN_OK) return rc;
     BHN_CHECK_ARG(workspace, "null workspace");
     BHN_CHECK_ARG(what == RUN_FWD_TRAIN ? images != nullptr : (dimages && dparams), "null pointer");
     const int depth = s.depth;
     // frames per pass so that the tape fits the workspace (same layout function as the size query)
-    const long long groups_per_frame = (long long)A.f.tiles_per_frame * Pol::NWAVES;
+    const long long groups_per_frame = (long long)A.f.tiles_per_frame * nwf;
     TapeLayout t1;
     layout(groups_per_frame, &t1);
     if (workspace_bytes < slab_bytes + t8_bytes + (size_t)t1.total) {
@@ -2360,16 +2371,25 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
     constexpr bool CAN_RES = BHN_RESIDENT != 0 && W <= 128 && BHN_CHAIN_STAMPS == 0;     // (width 256: no second instantiation)
     const bool rf = CAN_RES && res_fwd <= 160 * 1024, rch = CAN_RES && res_chn <= 160 * 1024;
     auto k_fwd = rf ? chain_kernel<W, Pol, 3, MODE_FWD_TRAIN, CAN_RES> : chain_kernel<W, Pol, 3, MODE_FWD_TRAIN, false>;
+    // (x12: the resident image + the ray-sum scratch of 12 groups: 154 KB at four Stokes planes)
+    const size_t res_fwd_x = res_fwd - RaySum<Pol::NWAVES>::bytes(A.f.Sx) + RaySum<FPol::NWAVES>::bytes(A.f.Sx);
+    if constexpr (CAN_X) {
+        if (x12) {
+            BHN_CHECK_ARG(CAN_RES && res_fwd_x <= 160 * 1024, "internal: the 12-wave training forward needs its weights resident (%zu bytes)", res_fwd_x);
+            k_fwd = chain_kernel<W, FPol, 3, MODE_FWD_TRAIN, CAN_RES>;
+        }
+    }
+    const unsigned nthr_fwd = (unsigned)nwf * 64u;
     constexpr bool CAN_GA0C = ga0_chain_ok<W, Pol>(3);                // (compile-time part of the condition: which widths instantiate it)
     auto k_chn = rch ? chain_kernel<W, Pol, 3, MODE_CHAIN, CAN_RES> : chain_kernel<W, Pol, 3, MODE_CHAIN, false>;
     if (ga0c) k_chn = chain_kernel<W, Pol, 3, MODE_CHAIN, false, CAN_GA0C>;
     // ga0_chain: a ring of BHN_GA0C_DIST + 1 buffers of the KS fragments the chain streams, the fixed part, 4 staging images of one tile per wave
     const size_t lds_ga0c = (size_t)(BHN_GA0C_DIST + 1) * PK::KS * Pol::FRAG_BYTES + lds_fixed + (size_t)4 * Pol::NWAVES * BG::TILE_BYTES;
-    const size_t lds_fwd = rf ? res_fwd : (EncBlock<W, Pol>::ON ? lds_fwd_encr : lds_taped), lds_chn = ga0c ? lds_ga0c : rch ? res_chn : lds_taped;
+    const size_t lds_fwd = x12 ? res_fwd_x : rf ? res_fwd : (EncBlock<W, Pol>::ON ? lds_fwd_encr : lds_taped), lds_chn = ga0c ? lds_ga0c : rch ? res_chn : lds_taped;
     auto kdw = dw_kernel<W, Pol>;
     static DeviceOnce once;                 // per template instantiation and device
     BHN_HIP(once.run(device, [&](int &) {
-        for (const void *k : {(const void *)chain_kernel<W, Pol, 3, MODE_FWD_TRAIN, CAN_RES>, (const void *)chain_kernel<W, Pol, 3, MODE_FWD_TRAIN, false>,
+        for (const void *k : {(const void *)chain_kernel<W, FPol, 3, MODE_FWD_TRAIN, CAN_RES>, (const void *)chain_kernel<W, Pol, 3, MODE_FWD_TRAIN, CAN_RES>, (const void *)chain_kernel<W, Pol, 3, MODE_FWD_TRAIN, false>,
                               (const void *)chain_kernel<W, Pol, 3, MODE_CHAIN, CAN_RES>, (const void *)chain_kernel<W, Pol, 3, MODE_CHAIN, false>,
                               (const void *)chain_kernel<W, Pol, 3, MODE_CHAIN, false, CAN_GA0C>, (const void *)kdw}) {
             const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -2400,7 +2420,7 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
         A.f.tM0 = tM0 + b0;
         A.f.dimages = dimages ? dimages + (long long)b0 * A.f.Sx * A.f.R : nullptr;
         A.f.total_tiles = (long long)A.f.tiles_per_frame * nb;
-        layout(A.f.total_tiles * Pol::NWAVES, &A.t);
+        layout(A.f.total_tiles * nwf, &A.t);
         A.accumulate = pass > 0;
         A.debug = g_bwd_debug;
 #ifdef BHN_DEBUG
@@ -2412,7 +2432,7 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
         const long long grid = bhn_balanced_grid(A.f.total_tiles, (pass > 0 && A.n_chain_wg > 0 && A.n_chain_wg < ncu) ? A.n_chain_wg : ncu);
         if (pass == 0) A.n_chain_wg = (int)grid;
         if (what == RUN_FWD_TRAIN) {
-            hipLaunchKernelGGL(k_fwd, dim3((unsigned)grid), dim3(Pol::NTHREADS), lds_fwd, st, A);
+            hipLaunchKernelGGL(k_fwd, dim3((unsigned)grid), dim3(nthr_fwd), lds_fwd, st, A);
             BHN_HIP(hipGetLastError());
             continue;
         }
@@ -2423,7 +2443,7 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
         BHN_HIP(mark(0));
         if (f128) {                          // kernel slot 0 = the fused chain + dW kernel, slot 1 empty
             if (what == RUN_RECOMPUTE) {
-                hipLaunchKernelGGL(k_fwd, dim3((unsigned)grid), dim3(Pol::NTHREADS), lds_fwd, st, A);
+                hipLaunchKernelGGL(k_fwd, dim3((unsigned)grid), dim3(nthr_fwd), lds_fwd, st, A);
                 BHN_HIP(hipGetLastError());
             }
             // (later passes ACCUMULATE onto the slabs of the first: never more workgroups than the first pass had)
@@ -2437,7 +2457,7 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
         }
         if (g_bwd_stages & 1) {
             if (what == RUN_RECOMPUTE) {     // forward again (tape only: A.f.images is null), then the chain
-                hipLaunchKernelGGL(k_fwd, dim3((unsigned)grid), dim3(Pol::NTHREADS), lds_fwd, st, A);
+                hipLaunchKernelGGL(k_fwd, dim3((unsigned)grid), dim3(nthr_fwd), lds_fwd, st, A);
                 BHN_HIP(hipGetLastError());
             }
             if constexpr (Pol::TAPE8) {

@@ -569,7 +569,11 @@ __global__ __launch_bounds__(256) void dout128_kernel(BwdArgs A) {
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const long long q = i >> 5;
         int b; long long p; bool inb;
-        tile_point<8>(a, q >> 3, (int)(q & 7), (int)(i & 31), b, p, inb);
+        // (groups per forward tile: 12 (PolBF16X) or 8 -- constants, so that the division is a multiply: a 64-bit run-time
+        //  division here cost this kernel 0.08 ms at config 2)
+        const unsigned qu = (unsigned)q;
+        if (A.fwd_nw == 12) tile_point_nw(a, qu / 12u, (int)(qu % 12u), (int)(i & 31), 12, b, p, inb);
+        else tile_point_nw(a, qu >> 3, (int)(qu & 7u), (int)(i & 31), 8, b, p, inb);
         const float e = eg[i];
         float d = 0.f;
         if (inb && e != 0.f) {
@@ -710,7 +714,10 @@ void bwd128_tape_layout(int depth, long long NQ, TapeLayout *t) {
     memset(t, 0, sizeof(*t));
     t->NQ = NQ;
     t->fused128 = 1;
-    const long long per_tensor = NQ * (long long)MT * TB;
+#ifndef BHN_F128_PAD
+#define BHN_F128_PAD 0             // (measurement builds: bytes between the h tensors of the tape beyond their size)
+#endif
+    const long long per_tensor = NQ * (long long)MT * TB + BHN_F128_PAD;
     long long off = 0;
     t->drop_h1 = 1;                                              // h_1 = relu(W_0^T enc + b_0) is recomputed by the backward (2 MFMAs per tile)
     t->h_off[1] = -1;

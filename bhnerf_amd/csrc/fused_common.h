@@ -163,6 +163,37 @@ struct PolBF16H : PolBF16 {
     static constexpr int FWD_DIST = BHN_FWD_DIST_H;      // (DIST + 1) chunks per workgroup: two workgroups must fit 160 KB
 };
 
+// PolBF16 on 12-wave workgroups (three per SIMD) for the two forward kernels of the fused 4x128 path (round 5): at width 128 the
+// forward is bound by per-point vector work and its latencies, not by the matrix pipe -- a third wave per SIMD
+// hides more of them (inference -5 %, training forward -5 %; 146 / 167 of the 170 registers a wave may have at that occupancy).
+// The training forward and the inference forward share the tile size: `render` and `render_train` give bit-identical images.
+#ifndef BHN_W12
+#define BHN_W12 1
+#endif
+struct PolBF16X : PolBF16 {
+    static constexpr int NWAVES = 12;
+    static constexpr int NTHREADS = NWAVES * 64;
+    static constexpr int WPE = 3;
+};
+// bf16, kernel width 128, depth 4 (= bwd128_supported) and at least one round of 12-group tiles per frame on a 256-CU device: the
+// problems whose forward kernels run on PolBF16X (a small ray set -- config 5: 1,460 groups per frame -- is better off with more,
+// smaller tiles: 0.253 against 0.256 ms per step).  A function of the MODEL and the RAY SET only, never of the batch: the
+// inference forward and the training forward of one problem always agree on the tile size.
+__host__ __device__ static inline bool bhn_fwd_w12(int mode, int kernel_width, int depth, long long groups_per_frame) {
+#ifdef BHN_NO_FUSED128
+    return false;
+#else
+    return BHN_W12 != 0 && mode == BHN_BF16 && kernel_width == 128 && depth == 4 && groups_per_frame >= 12 * 256;
+#endif
+}
+// 32-point groups per frame of a ray set as the fused kernels walk it (fused_fill_args: n_groups)
+static inline long long bhn_groups_per_frame(const bhn_geom *geom) {
+    if (!geom) return 0;
+    if (geom->groups) return geom->n_groups;
+    const long long P = geom->ray_idx ? geom->n_points : geom->R * geom->G;
+    return (P + 31) / 32;
+}
+
 struct PolF32 {
     static constexpr int MODE = BHN_F32;
     static constexpr int NWAVES = 4;            // 1 wave per SIMD, 512 registers each
@@ -308,6 +339,17 @@ DEVI void tile_point(const FusedArgs &a, long long tile, int wv, int pl, int &b,
     const unsigned tq = a.fd_tpf.div((unsigned)tile);
     b = (int)tq;
     const long long gi = (long long)((unsigned)tile - tq * (unsigned)a.tiles_per_frame) * NWAVES + wv;
+    const bool gok = gi < a.n_groups;
+    const long long grp = gok ? (a.groups ? (long long)a.groups[gi] : gi) : 0;
+    p = grp * 32 + pl;
+    inb = gok && p < a.P;
+}
+
+// the same with the groups per tile as a run-time number (kernels that walk the tape of a forward of another policy)
+DEVI void tile_point_nw(const FusedArgs &a, long long tile, int wv, int pl, int nw, int &b, long long &p, bool &inb) {
+    const unsigned tq = a.fd_tpf.div((unsigned)tile);
+    b = (int)tq;
+    const long long gi = (long long)((unsigned)tile - tq * (unsigned)a.tiles_per_frame) * nw + wv;
     const bool gok = gi < a.n_groups;
     const long long grp = gok ? (a.groups ? (long long)a.groups[gi] : gi) : 0;
     p = grp * 32 + pl;

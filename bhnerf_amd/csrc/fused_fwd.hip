@@ -540,6 +540,7 @@ static int fwd_tile_groups(const bhn_model *m, int mode, const bhn_geom *geom) {
     MlpShape s;
     if (m && geom && bhn_mlp_shape(m, &s) == BHN_OK && fwd_pair_ok(mode, s, geom->S > 0 ? geom->S : 1)) return 16;
     if (BHN_FWD_HALF && mode == BHN_BF16 && m && bhn_mlp_shape(m, &s) == BHN_OK && s.width == 256) return PolBF16H::NWAVES;
+    if (m && bhn_mlp_shape(m, &s) == BHN_OK && !s.general && bhn_fwd_w12(mode, s.width, s.depth, bhn_groups_per_frame(geom))) return PolBF16X::NWAVES;
     return (mode == BHN_BF16) ? PolBF16::NWAVES : PolF32::NWAVES;
 }
 #if BHN_FWD_PAIR
@@ -581,7 +582,11 @@ static int launch_fwd(FusedArgs &a, int width, hipStream_t st) {
     switch (width) {
         case 32: return launch_fwd_w<32, Pol, RENDER>(a, st);
         case 64: return launch_fwd_w<64, Pol, RENDER>(a, st);
-        case 128: return launch_fwd_w<128, Pol, RENDER>(a, st);
+        case 128:
+            if constexpr (Pol::ELEM_BYTES == 2) {
+                if (bhn_fwd_w12(BHN_BF16, 128, a.depth, a.n_groups)) return launch_fwd_w<128, PolBF16X, RENDER>(a, st);
+            }
+            return launch_fwd_w<128, Pol, RENDER>(a, st);
         case 256:
             if constexpr (BHN_FWD_HALF != 0 && Pol::ELEM_BYTES == 2) return launch_fwd_w<256, PolBF16H, RENDER>(a, st);
             else return launch_fwd_w<256, Pol, RENDER>(a, st);
