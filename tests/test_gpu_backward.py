@@ -311,6 +311,58 @@ def test_general_path_emission_and_workspace_chunks(dev):
     assert torch.allclose(g_chunks, g_rec, rtol=1e-5, atol=1e-6 * float(g_rec.abs().max()))
 
 
+@pytest.mark.parametrize('rows', [48, 47])
+def test_reference_default_network_on_twelve_and_eight_group_tiles(dev, rows):
+    """The fused 4x128 path runs its two forward kernels on 12-wave workgroups (tiles of 12 point groups, PolBF16X) when the ray set has
+    >= 3072 groups per frame and on 8-wave ones below: 48 x 32 rays x 64 samples = 3072 groups, 47 x 32 = 3008.  On both sides of the
+    threshold: images and the chi^2 gradient against the f64 oracle on the WHOLE problem, `render` == `render_train` bit for bit, the
+    recorded-tape gradient == the recompute route bit for bit (the fused backward walks either tape in quads of groups)."""
+    from bhnerf_amd import network, synthetic, units, engine as E
+    H, Wd, G, B = rows, 32, 64, 2
+    geo = synthetic.synthetic_geodesics(H, Wd, G, fov_M=16.0, inc_deg=60.0, seed=7)
+    dom = (8.0, 0.0, np.inf, np.inf)
+    rng = np.random.default_rng(21)
+    tree = onp.he_uniform_params(rng, 4, 128, 21, dtype=np.float32)
+    for i in range(5):
+        tree['MLP_0']['Dense_%d' % i]['bias'] = rng.uniform(-0.05, 0.05, tree['MLP_0']['Dense_%d' % i]['bias'].shape).astype(np.float32)
+    tree['MLP_0']['Dense_4']['bias'] = tree['MLP_0']['Dense_4']['bias'] + 9.0
+    t_frames = np.array([0.1, 0.6])
+    target = rng.uniform(0, 1e-2, (B, H, Wd)); sigma = rng.uniform(0.5, 2.0, (B, H, Wd)); offset = np.zeros((B, H, Wd))
+    t64 = lambda x: torch.tensor(np.asarray(x, dtype=np.float64))
+    f32r = lambda v: np.asarray(v, dtype=np.float32).astype(np.float64)
+    ks, bs = ot.tree_to_lists(tree, torch.float64)
+    geom_t = dict(coords=t64(f32r(geo['coords'])), Omega=t64(f32r(geo['Omega'])), t_geos=t64(f32r(geo['t_geos'])), g=t64(f32r(geo['g'])),
+                  dtau=t64(f32r(geo['dtau'])), Sigma=t64(f32r(geo['Sigma'])), J=None, t_start_obs=0.0, t_injection=float(geo['t_injection']))
+    hp = dict(GM_c3=onp.GM_C3_SGRA_HR, scale=dom[0], rmin=dom[1], rmax=dom[2], z_width=dom[3], posenc_deg=3, net_depth=4)
+    tr = ot.CpuTrainer(ks, bs, geom_t, hp)
+    loss_ref, img_ref, grads_ref = tr.loss_and_grad(t64(t_frames), t64(target), t64(sigma), t64(offset), 1.0, 'full')
+    n = len(tr.k)
+    gref = np.concatenate([np.concatenate([grads_ref[i].numpy().ravel(), grads_ref[n + i].numpy().ravel()]) for i in range(n)])
+    pred = network.NeRF_Predictor(*dom, net_depth=4, net_width=128, mode='bf16', device=dev)
+    eng = pred.engine()
+    geom = pred.geometry(geo['coords'], geo['Omega'], geo['t_geos'], None, geo['g'], geo['dtau'], geo['Sigma'])
+    assert geom.compact is None and geom.P_eff // 32 == rows * 64                       # dense layout: rows * 32 * 64 / 32 groups per frame
+    params = eng.flatten(tree).requires_grad_(True)
+    ptree = network.ParamTree(); ptree.flat = params
+    loss, [images] = network.loss_fn_image(ptree, pred.apply, target, sigma, offset, t_frames, geo['coords'], geo['Omega'], 1.0, geo['g'],
+                                           geo['dtau'], geo['Sigma'], 0.0, geo['t_geos'], float(geo['t_injection']), 1.0, units.hr, 'full')
+    loss.backward()
+    img = images.detach().cpu().numpy().reshape(img_ref.shape)
+    assert np.abs(img - img_ref.numpy()).max() < 1e-2 * float(img_ref.abs().max())
+    gdev = params.grad.cpu().numpy().astype(np.float64)
+    err = float(np.linalg.norm(gdev - gref) / np.linalg.norm(gref))
+    print('4x128 bf16, %d x 32 rays (%d groups per frame): gradient vs f64 oracle rel L2 %.3e, max-norm %.3e' % (rows, rows * 64, err, float(np.abs(gdev - gref).max() / np.abs(gref).max())))
+    assert err < 3e-2 and abs(loss.item() - loss_ref.item()) < 2e-2 * abs(loss_ref.item())
+    tM0 = E.frame_offsets(t_frames, 0.0, float(geo['t_injection']), onp.GM_C3_SGRA_HR, dev)
+    eng.pack(eng.flatten(tree))
+    a = eng.render(geom, tM0).clone(); b = eng.render_train(geom, tM0).clone()
+    assert torch.equal(a, b) and float(a.abs().max()) > 0
+    dimg = torch.rand((B, 1, geom.R), device=dev) - 0.4
+    g_tape = eng.render_bwd_tape(geom, tM0, dimg).clone()
+    g_rec = eng.render_bwd(geom, tM0, dimg).clone()
+    assert torch.equal(g_tape, g_rec) and float(g_tape.abs().max()) > 0
+
+
 def adjudicate_relu_ties(width, depth, S, deg, dev, gerr, ties):
     """A detected ReLU tie is only an explanation if the SAME problem without the tied ray samples meets the f32 bounds:
     those samples get Doppler weight g = 0 on both sides (no contribution to the image, hence none to the gradient), every
