@@ -30,7 +30,12 @@ between the kernels of the backward); `roofline.step_mfma_frac` is the whole ste
 over the whole movie; `parity_mode` is the same step in the f32 (1e-5 parity) arithmetic; `tape8_mode` the same step with the
 backward's tape in 8 bits (BHN_BF16_T8: bf16 arithmetic, e4m3 dW operands -- an A/B beside the headline, never the headline);
 `cpu_baseline` is the oracle's PyTorch-CPU restatement timed on the host cores on a bounded sample BEFORE the GPU work starts
-(best of a thread-count sweep).
+(best of a thread-count sweep): `value` for the training step, `fwd_images_per_s` for the forward (test) path.
+`roofline.kernels[*]`: each MLP kernel timed INSIDE the K timed steps (HIP events on the launch stream, engine.step_timer), the
+flops it executes of the algorithm (kernel_flops), the tape bytes the library's layout makes it stream (bhn_tape_info) and the
+core clock it sustained (`sustained_clock_mhz`: s_memtime / s_memrealtime stamps of its workgroup 0, bhn_frames.clock_probe);
+`roofline.mfma_peak_this_box`: a register-operand bf16 MFMA loop on random data run in the same process (bhn_mfma_probe) -- what
+the matrix pipes of THIS board deliver under its power cap, against the 2.5 PFLOP/s the fractions are quoted on.
 """
 import argparse
 import ctypes as C
@@ -53,11 +58,29 @@ PROFILE_TAG = 'r5'                                  # profiles/<tag>_pmc_traffic
 
 
 def mlp_flops(depth, width, F=21):
-    """Algorithmic MLP flops per evaluated point: forward, delta chain, weight gradient."""
+    """Algorithmic MLP flops per evaluated point: forward, delta chain, weight gradient, training step."""
     fwd = 2 * (F * width + (depth - 2) * width * width + (width + F) * width + width)
     chain = 2 * (depth - 1) * width * width
     train = 3 * fwd - 2 * F * width
     return fwd, chain, train - fwd - chain, train
+
+
+def kernel_flops(depth, width, flags, F=21):
+    """Flops per evaluated point that each MLP kernel of the step EXECUTES of the algorithm (no recompute, no padding): the
+    forward; the delta chain = the hidden layers' transposed products + the output layer's delta (2 W) -- and, where the chain
+    accumulates dW_0 itself (TapeLayout::ga0_chain), layer 0's weight gradient (2 F W); the weight-gradient kernel = every
+    layer's dW (= the forward's flops) minus what the chain took over.  SURVEY 8(d)'s step figure, 3 fwd - 2 F W, also counts
+    an input gradient of the skip layer's encoded features (2 F W) that no kernel needs: the per-kernel figures add up to
+    2 F W less than it.  The fused width-128 backward executes chain + dW in one kernel."""
+    fwd = mlp_flops(depth, width, F)[0]
+    chain = 2 * (depth - 1) * width * width + 2 * width
+    dw = fwd
+    if flags.get('ga0_chain'):
+        chain += 2 * F * width
+        dw -= 2 * F * width
+    if flags.get('fused128'):
+        return {FWD_NAME: fwd, FUSED_NAME: chain + dw}
+    return {FWD_NAME: fwd, CHAIN_NAME: chain, 'dw_kernel': dw}
 
 
 def parse():
@@ -158,10 +181,26 @@ def cpu_baseline(args, geo, GM_c3):
             tr.step(tf, target, sigma, target, 1.0, 'full')
             times.append(time.perf_counter() - t0)
         sweep[nthr] = min(times)
-    torch.set_num_threads(default_threads)
     best = min(sweep, key=sweep.get)
     dt = sweep[best]
+    # the second half of BASELINE's metric, `fwd images/sec`: the test path (optimization.py:14-66: forward render + chi^2 per
+    # batch of frames, no gradient) on the same sample at the best thread count, scaled to whole frames of R rays
+    torch.set_num_threads(best)
+    ks, bs = ot.tree_to_lists(tree, torch.float32)
+    tr = ot.CpuTrainer(ks, bs, geom, hp, num_iters=1000)
+    fwd_times = []
+    with torch.no_grad():
+        for i in range(3):
+            t0 = time.perf_counter()
+            img = tr.forward(tf)
+            ot.loss_image(img, target, sigma, target, 1.0, 'full')
+            fwd_times.append(time.perf_counter() - t0)
+    dt_f = min(fwd_times[1:])
+    torch.set_num_threads(default_threads)
     return {'value': nr * args.ngeo / dt, 'unit': 'ray-samples/s', 'cores': best, 'host_cores': ncores, 'kind': 'port',
+            'fwd_images_per_s': round(nr / (R * dt_f), 4),
+            'fwd_sample': 'forward render + chi^2 (no gradient) of the same %d-ray sample at %d threads: %.3f s, scaled to frames of %d rays '
+                          '(the path of optimization.total_movie_loss, optimization.py:14-66)' % (nr, best, dt_f, R),
             'threads_sweep_s_per_step': {str(k): round(v, 4) for k, v in sweep.items()},
             'sample': '1 frame x %d rays x %d samples as one (%d, features) matrix, 4x%d MLP, float32 torch-CPU fwd+bwd+Adam, '
                       'best of 2 steps at the best of the thread counts tried (%.3f s/step at %d threads)'
@@ -345,80 +384,120 @@ class HipEvents:
         return float(ms.value)
 
 
+class StepTimer:
+    """engine.step_timer: times the MLP kernels of every render_train / render_bwd_tape call it sees -- torch events around the
+    training forward (one kernel), the library's own event marks between the kernels of the backward (bhn_render_bwd_tape_timed)
+    -- so that the per-kernel figures of the bench line come from the SAME steps as `ms_per_step`."""
+
+    def __init__(self, eng):
+        from bhnerf_amd import _hip
+        self.names = [_hip.lib().bhn_render_bwd_tape_kernel_name_for(C.byref(eng.model), eng.mode, i).decode() for i in range(3)]
+        self.reset()
+
+    def reset(self):
+        self.fwd, self.bwd, self._open = [], [], None
+
+    def fwd_mark(self, i):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        if i == 0:
+            self._open = ev
+        else:
+            self.fwd.append((self._open, ev))
+
+    def bwd_events(self):
+        self.bwd.append(HipEvents(4))
+        return self.bwd[-1].ev, 4
+
+    def kernel_ms(self, steps):
+        """Mean ms per STEP of each kernel (a step may be several calls: frame groups); call after a device synchronisation."""
+        acc = {FWD_NAME: sum(a.elapsed_time(b) for a, b in self.fwd) / steps}
+        for i, n in enumerate(self.names):
+            acc[n] = sum(e.elapsed(i, i + 1) for e in self.bwd) / steps
+        acc.pop('-', None)                          # (an empty kernel slot of the fused width-128 backward)
+        return acc
+
+
 def kernel_times(eng, geom, tM0, dimg, reps=5):
-    """Per-kernel ms of one rank's step share, HIP events on the launch stream: training forward (torch events around
-    the one-kernel call), and the kernels of the tape backward (events recorded by the library between them)."""
-    from bhnerf_amd import _hip
-    lib = _hip.lib()
-    nk = 3
-    names = [lib.bhn_render_bwd_tape_kernel_name_for(C.byref(eng.model), eng.mode, i).decode() for i in range(nk)]
+    """Per-kernel ms of one rank's step share outside a step loop (the side blocks: parity mode, 8-bit tape): the training
+    forward and the kernels of the tape backward, back to back, through the same StepTimer as the headline."""
     B = int(tM0.numel())
     taped = eng.fits_tape(B, geom.P_eff)
     group = B if taped else eng.tape_group(B, geom.P_eff)
     assert group, 'the tape of one frame does not fit the workspace'
     slices = [slice(b0, min(b0 + group, B)) for b0 in range(0, B, group)]
-    ws = eng.workspace(group, geom.P_eff)
-    out = torch.empty((eng.nparams,), dtype=torch.float32, device=eng.device)
-    acc = {'chain_kernel<MODE_FWD_TRAIN>': 0.0, **{n: 0.0 for n in names}}
-    sets = [HipEvents(nk + 1) for _ in range(reps * len(slices))]
-    fwd_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps * len(slices))]
-    gs = geom.c_struct_fused()
-    for rep in range(-1, reps):                       # rep -1: warm-up
-        for si, sl in enumerate(slices):
-            k = max(rep, 0) * len(slices) + si
-            a, b = fwd_ev[k]
-            a.record(); eng.render_train(geom, tM0[sl]); b.record()
-            fs = eng._frames(tM0[sl])
-            d = dimg[sl].contiguous()
-            bmode = eng._bwd_mode()
-            _hip.check(lib.bhn_render_bwd_tape_timed(C.byref(eng.model), bmode, _hip.ptr(eng.packed), C.byref(gs), C.byref(fs),
-                                                     _hip.ptr(d), _hip.ptr(out), _hip.ptr(ws), ws.numel(),
-                                                     _hip.stream_ptr(eng.device), sets[k].ev, nk + 1))
-            eng._bwd_done(bmode)
+    timer = StepTimer(eng)
+    eng.step_timer = timer
+    try:
+        for rep in range(-1, reps):                       # rep -1: warm-up
+            if rep == 0:
+                torch.cuda.synchronize(); timer.reset()
+            for sl in slices:
+                eng.render_train(geom, tM0[sl])
+                eng.render_bwd_tape(geom, tM0[sl], dimg[sl].contiguous())
         torch.cuda.synchronize()
-    for k in range(reps * len(slices)):
-        a, b = fwd_ev[k]
-        acc['chain_kernel<MODE_FWD_TRAIN>'] += a.elapsed_time(b) / reps
-        for i, n in enumerate(names):
-            acc[n] += sets[k].elapsed(i, i + 1) / reps
-    acc.pop('-', None)                              # (an empty kernel slot of the fused width-128 backward)
-    return acc, group
+    finally:
+        eng.step_timer = None
+    return timer.kernel_ms(reps), group
 
 
-def tape_bytes_per_point(depth, width, mode, fused):
-    """ALGORITHMIC tape bytes per evaluated point that each MLP kernel of the step moves through HBM: what the
-    design chose to stream, written once and read once -- no re-reads in these figures."""
-    elem = 2 if mode == 'bf16' else 4
-    row = width * elem                                   # one layer's activations of one point
-    mt = width // 32
-    if fused:                                            # width 128, bf16, depth 4: h_2 .. h_{depth-1}, the relu bits of the last
-        b = (depth - 2) * row + ((mt + 1) // 2) * 8 + 32 * elem + 4      # hidden layer (in place of h_depth: round 5), encoded inputs, e
-        return {FWD_NAME: b, FUSED_NAME: b + 4}          # (+ dout, written beside e by the small pre-kernel)
-    skip_layer = depth // 2 + 1 if depth >= 4 else None  # the layer that consumes concat[h, enc] (do_skip)
-    rides = mode == 'bf16' and depth >= 3                # gA_{depth-1} and the dout tile are not on the tape (DESIGN.md 3)
-    drop_h1 = mode == 'bf16' and depth >= 2 and skip_layer != 1
-    ga0c = mode == 'bf16' and width == 256 and depth >= 3    # the delta chain accumulates dW_0 itself: gA_0 never leaves the chip (DESIGN.md 4.2)
-    bits = depth * ((mt + 1) // 2) * 8                   # relu-bit words: 4 B per lane and pair of tiles, per 32 points
-    lbits = rides and (depth - 1) != skip_layer          # the dW job of layer depth-1 works from the relu bits (dw_body2 LBITS) ...
-    drop_hd = lbits and width == 256                     # ... and the forward does not store h_depth (TapeLayout::drop_hd)
-    fwd = (depth - (1 if drop_h1 else 0) - (1 if drop_hd else 0)) * row + (2 if drop_h1 else 1) * 32 * elem + bits + 4
-    chain = (depth - (1 if rides else 0) - (1 if ga0c else 0)) * row + bits + 4 + (4 if rides else 32 * elem) + (32 * elem if ga0c else 0)
-    tiles = (0 if ga0c else mt + 1) + (0 if rides else 1 + mt)      # dW reads per 32-point group and layer job: layer 0, output layer
-    for l in range(1, depth):
-        recomputed = l == 1 and drop_h1
-        a_tiles = 0.5 if (lbits and l == depth - 1) else mt          # (LBITS: 1 KiB of relu-bit words in place of the h_depth tiles)
-        tiles += a_tiles + (1 if recomputed else mt) + (1 if l == skip_layer else 0)
-        if rides and l == depth - 1:
-            tiles += 0.5                                 # the 1 KiB piece that starts with the group's 32 f32 dout
-    return {FWD_NAME: fwd, CHAIN_NAME: chain, 'dw_kernel': tiles * (32 * 32 * elem) / 32.0}
+def tape_bytes_per_point(info):
+    """Tape bytes per evaluated point that each MLP kernel of the step moves through HBM, from the library's own layout
+    (bhn_tape_info -> engine.tape_info): what the design streams, written once and read once."""
+    if info['flags']['fused128']:
+        return {FWD_NAME: info['fwd_write'] / 32.0, FUSED_NAME: info['dw_read'] / 32.0}
+    return {FWD_NAME: info['fwd_write'] / 32.0, CHAIN_NAME: (info['chain_write'] + info['chain_read']) / 32.0, 'dw_kernel': info['dw_read'] / 32.0}
 
 
-def roofline_block(eng, geom, tM0, dimg, depth, width, mode, frames_per_gpu, std):
-    """Live per-kernel timings (HIP events on the launch stream) of one rank's share of a step, and for each MLP kernel both
-    roofline fractions: MFMA (SURVEY 8(d)'s algorithmic flops / dense peak) and HBM (algorithmic tape bytes / 8 TB/s).  The
-    kernel with the largest share of the step is `roofline`; its `bound` is the resource it sits closer to."""
+CLK_SLOT = {FWD_NAME: 1, CHAIN_NAME: 2, FUSED_NAME: 2, 'dw_kernel': 3, INFER_NAME: 0}      # BHN_CLK_* of include/bhnerf_hip.h
+
+
+def clock_mhz(stamps, slot):
+    """Sustained core clock of the kernel in `slot` from its four stamps {s_memtime, s_memrealtime} x {start, end} of workgroup 0
+    (s_memrealtime counts at 100 MHz)."""
+    t0, r0, t1, r1 = (int(v) for v in stamps[4 * slot:4 * slot + 4])
+    return round(100.0 * (t1 - t0) / (r1 - r0), 1) if r1 > r0 and t1 > t0 else None
+
+
+def mfma_peak_this_box(dev, seconds=0.25):
+    """bhn_mfma_probe: dependent bf16 MFMA chains with every operand in registers, random data, 8 waves on every CU, run for
+    `seconds` back to back: the matrix-pipe ceiling of THIS board under its power cap, and the clock it sustains there."""
     from bhnerf_amd import _hip
-    kern_ms, group = kernel_times(eng, geom, tM0, dimg)
+    lib = _hip.lib()
+    ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+    clk = torch.zeros((2 * ncu,), dtype=torch.int64, device=dev)
+    sink = torch.zeros((1024,), dtype=torch.float32, device=dev)
+    iters = 20000
+    run = lambda: _hip.check(lib.bhn_mfma_probe(ncu, iters, _hip.ptr(clk), _hip.ptr(sink), _hip.stream_ptr(dev)))
+    run(); torch.cuda.synchronize()
+    ms, t_end = [], time.perf_counter() + seconds
+    while time.perf_counter() < t_end or len(ms) < 3:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); run(); b.record(); torch.cuda.synchronize()
+        ms.append(a.elapsed_time(b))
+    c = clk.cpu().numpy().reshape(ncu, 2)
+    flop = ncu * 8 * iters * 16 * 32768.0
+    return {'tflops': round(flop / (float(np.median(ms[1:])) * 1e-3) / 1e12, 1), 'clock_mhz': round(float(np.median(100.0 * c[:, 0] / c[:, 1])), 1),
+            'launches': len(ms), 'ms_per_launch': round(float(np.median(ms[1:])), 3),
+            'what': 'bhn_mfma_probe: %d workgroups x 8 waves x %d x 16 dependent v_mfma_f32_32x32x16_bf16, register operands, random data' % (ncu, iters)}
+
+
+def roofline_block(eng, geom, tM0, dimg, depth, width, mode, frames_per_gpu, std, kern_ms=None, clocks=None):
+    """Per-kernel timings of one rank's share of a step (`kern_ms`: measured by a StepTimer inside the caller's step loop; None:
+    measured here, back to back) and for each MLP kernel the MFMA fraction on the flops it executes of the algorithm
+    (kernel_flops) beside the tape bytes it streams (bhn_tape_info).  The kernel with the largest share of the step is `roofline`."""
+    from bhnerf_amd import _hip
+    in_loop = kern_ms is not None
+    group = frames_per_gpu if eng.fits_tape(frames_per_gpu, geom.P_eff) else eng.tape_group(frames_per_gpu, geom.P_eff)
+    clk = torch.zeros((4 * _hip.BHN_CLK_SLOTS,), dtype=torch.int64, device=eng.device)
+    if kern_ms is None:
+        eng.clock_probe = clk
+        try:
+            kern_ms, group = kernel_times(eng, geom, tM0, dimg)
+        finally:
+            eng.clock_probe = None
+        clocks = clk.cpu().numpy().copy()
+    kern_ms = dict(kern_ms)
     fused = FUSED_NAME in kern_ms
 
     def timed(fn, reps=5):
@@ -429,19 +508,27 @@ def roofline_block(eng, geom, tM0, dimg, depth, width, mode, frames_per_gpu, std
         torch.cuda.synchronize()
         return float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
-    kern_ms[INFER_NAME] = timed(lambda: eng.render(geom, tM0))
+    eng.clock_probe = clk
+    try:
+        kern_ms[INFER_NAME] = timed(lambda: eng.render(geom, tM0))
+    finally:
+        eng.clock_probe = None
+    infer_clock = clock_mhz(clk.cpu().numpy(), CLK_SLOT[INFER_NAME])
     pts = frames_per_gpu * geom.P * geom.visited_fraction     # points that go through the MLP
-    f_fwd, f_chain, f_dw, f_train = mlp_flops(depth, width)
-    alg = {FWD_NAME: f_fwd, FUSED_NAME: f_chain + f_dw} if fused else {FWD_NAME: f_fwd, CHAIN_NAME: f_chain, 'dw_kernel': f_dw}
-    bpp = tape_bytes_per_point(depth, width, mode, fused)
+    f_fwd = mlp_flops(depth, width)[0]
+    tinfo = eng.tape_info((geom.P_eff + 31) // 32)
+    alg = kernel_flops(depth, width, tinfo['flags'])
+    assert fused == tinfo['flags']['fused128']
+    bpp = tape_bytes_per_point(tinfo)
     peak = PEAK_TFLOPS[mode]
     per = {}
     for k in alg:
         tf = alg[k] * pts / (kern_ms[k] * 1e-3) / 1e12
         gb = bpp[k] * pts / (kern_ms[k] * 1e-3) / 1e9
-        per[k] = {'ms': round(kern_ms[k], 4), 'mfma_tflops': round(tf, 1), 'mfma_frac': round(tf / peak, 4),
+        per[k] = {'ms': round(kern_ms[k], 4), 'flop_per_point': alg[k], 'mfma_tflops': round(tf, 1), 'mfma_frac': round(tf / peak, 4),
                   'tape_GB_per_s': round(gb, 1), 'hbm_frac': round(gb / 8000.0, 4), 'tape_bytes_per_point': round(bpp[k], 1),
-                  'closer_to': 'hbm (tape stream)' if gb / 8000.0 > tf / peak else 'mfma'}
+                  'closer_to': 'hbm (tape stream)' if gb / 8000.0 > tf / peak else 'mfma',
+                  'sustained_clock_mhz': clock_mhz(clocks, CLK_SLOT[k]) if clocks is not None else None}
     dom_k = max(alg, key=lambda k: kern_ms[k])
     d = per[dom_k]
     # what the committed counter passes say about this workload (NOT measured in this run; see the module docstring)
@@ -471,7 +558,8 @@ def roofline_block(eng, geom, tM0, dimg, depth, width, mode, frames_per_gpu, std
         pass
     # the fused MLP is on the MFMA roofline, on ALGORITHMIC flops; the tape bytes are design overhead, shown beside it
     roofline = {'bound': 'mfma', 'kernel': dom_k, 'achieved': d['mfma_tflops'], 'peak': peak, 'unit': 'TFLOP/s', 'frac': d['mfma_frac'],
-                'algorithmic_flop_per_point': alg[dom_k],
+                'algorithmic_flop_per_point': alg[dom_k], 'sustained_clock_mhz': d['sustained_clock_mhz'],
+                'tape_layout': {k: v for k, v in tinfo['flags'].items() if v},
                 'tape_stream': {'GB_per_s': d['tape_GB_per_s'], 'frac_of_8TBps': d['hbm_frac'], 'tape_bytes_per_point': d['tape_bytes_per_point'],
                                 'note': 'bytes of tape this kernel moves through HBM per evaluated point (DESIGN.md 3): the design\'s own traffic, not algorithmic work'}}
     roofline.update({'points_per_launch': int(pts),
@@ -485,7 +573,8 @@ def roofline_block(eng, geom, tM0, dimg, depth, width, mode, frames_per_gpu, std
     roofline['kernels'] = per
     roofline['kernel_ms'] = {k: round(v, 4) for k, v in kern_ms.items()}
     roofline['kernel_ms_sum'] = round(sum(v for k, v in kern_ms.items() if 'inference' not in k), 4)
-    roofline['kernel_ms_note'] = 'each kernel timed separately from the step loop (HIP events around / between the launches)'
+    roofline['kernel_ms_note'] = ('HIP events around / between the kernels INSIDE the timed steps (engine.step_timer): the same steps as ms_per_step' if in_loop
+                                  else 'each kernel timed in a loop of its own (HIP events around / between the launches)')
     if prof['pmc']:
         tk = [k for k in alg]
         if all(k in prof['pmc'] and 'hbm_bytes' in prof['pmc'][k] for k in tk):
@@ -500,7 +589,8 @@ def roofline_block(eng, geom, tM0, dimg, depth, width, mode, frames_per_gpu, std
         if all(k in busy and pms.get(k) for k in tk):
             roofline['step_mfma_busy_frac_from_profiles'] = round(sum(busy[k] * pms[k] for k in tk) / sum(pms[k] for k in tk), 3)
     inf_tf = f_fwd * pts / (kern_ms[INFER_NAME] * 1e-3) / 1e12
-    roofline['inference_forward'] = {'ms': round(kern_ms[INFER_NAME], 4), 'mfma_tflops': round(inf_tf, 1), 'mfma_frac': round(inf_tf / peak, 4)}
+    roofline['inference_forward'] = {'ms': round(kern_ms[INFER_NAME], 4), 'mfma_tflops': round(inf_tf, 1), 'mfma_frac': round(inf_tf / peak, 4),
+                                     'sustained_clock_mhz': infer_clock}
     roofline['_std'] = std
     roofline['_alg'] = alg
     return roofline, kern_ms, group
@@ -581,14 +671,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # the MLP kernels are timed INSIDE the K steps (HIP events on the launch stream around / between them: engine.step_timer)
+    # and workgroup 0 of each stamps its clock counters (bhn_frames.clock_probe): roofline.frac and ms_per_step are one loop
+    from bhnerf_amd import _hip
+    eng = pred.engine()
+    timer = None if eng.tape_info(1)['flags']['general'] else StepTimer(eng)      # (the general path has no per-kernel event marks)
+    clk_main = torch.zeros((4 * _hip.BHN_CLK_SLOTS,), dtype=torch.int64, device=dev)
+    eng.step_timer, eng.clock_probe = timer, clk_main
     run_steps(opt, args.warmup)
     opt.state.finish_allreduce()
     barrier()
+    if timer:
+        timer.reset()
     t0 = time.perf_counter()
     run_steps(opt, args.steps)
     opt.state.finish_allreduce()        # (--overlap-allreduce: the last gradient's all-reduce + Adam belong to the K steps)
     barrier()
     elapsed = time.perf_counter() - t0
+    eng.step_timer, eng.clock_probe = None, None
+    kern_loop = timer.kernel_ms(args.steps) if timer else None
+    clocks_loop = clk_main.cpu().numpy().copy()
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -599,7 +701,6 @@ def main():
     loss_now = float(torch.as_tensor(opt.loss).float().mean())
 
     # ---- per-kernel timing of one rank's share (HIP events on the launch stream) ----------------
-    eng = pred.engine()
     geom = pred.geometry(rt_args['coords'], rt_args['Omega'], rt_args['t_geos'], None, rt_args['g'], rt_args['dtau'],
                          rt_args['Sigma'])
     tM0 = engine.frame_offsets(t_frames[:args.frames_per_gpu], 0.0, geo['t_injection'], GM_c3, dev)
@@ -616,7 +717,12 @@ def main():
 
     roofline, kern_ms, group = roofline_block(eng, geom, tM0, dimg, args.depth, args.width, args.mode, args.frames_per_gpu,
                                               std=(H == 128 and G == 64 and args.frames_per_gpu == 8 and args.width == 256 and args.depth == 4
-                                                   and args.mode == 'bf16' and not args.masked))
+                                                   and args.mode == 'bf16' and not args.masked), kern_ms=kern_loop, clocks=clocks_loop)
+    if world == 1 and args.mode == 'bf16':
+        try:
+            roofline['mfma_peak_this_box'] = mfma_peak_this_box(dev)
+        except Exception as exc:                     # a side block must never cost the headline line
+            roofline['mfma_peak_this_box'] = {'error': repr(exc)}
     std = roofline.pop('_std')
     f_train = mlp_flops(args.depth, args.width)[3]
     pts = args.frames_per_gpu * geom.P * geom.visited_fraction
@@ -666,7 +772,7 @@ def main():
                   'peak_tflops': PEAK_TFLOPS['f32'], 'tape_frame_group': grp,
                   'kernel_ms': {k: round(v, 3) for k, v in kms.items()},
                   'mfma_frac': {k: round(v * pts / (kms[k] * 1e-3) / 1e12 / PEAK_TFLOPS['f32'], 4)
-                                for k, v in zip((FWD_NAME, CHAIN_NAME, 'dw_kernel'), mlp_flops(args.depth, args.width)[:3])},
+                                for k, v in kernel_flops(args.depth, args.width, eng_p.tape_info(1)['flags']).items()},
                   'loss': float(torch.as_tensor(opt_p.loss).float().mean())}
         del opt_p, pred_p, eng_p, geom_p
         torch.cuda.empty_cache()
@@ -711,17 +817,22 @@ def main():
       try:
         pred_w = network.NeRF_Predictor(*dom, net_depth=4, net_width=128, mode='bf16', device=dev)
         opt_w = optimization.Optimizer(hparams, pred_w, rt_args)
+        eng_w = pred_w.engine()
+        timer_w, clk_w = StepTimer(eng_w), torch.zeros((4 * _hip.BHN_CLK_SLOTS,), dtype=torch.int64, device=dev)
+        eng_w.step_timer, eng_w.clock_probe = timer_w, clk_w
         run_steps(opt_w, max(args.warmup, 3))
         torch.cuda.synchronize()
+        timer_w.reset()
         n_w = max(10, args.steps // 2)
         t0 = time.perf_counter()
         run_steps(opt_w, n_w)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n_w
-        eng_w = pred_w.engine()
+        eng_w.step_timer, eng_w.clock_probe = None, None
         geom_w = pred_w.geometry(rt_args['coords'], rt_args['Omega'], rt_args['t_geos'], None, rt_args['g'], rt_args['dtau'], rt_args['Sigma'])
         eng_w.pack(opt_w.state.flat)
-        roof_w, _, grp_w = roofline_block(eng_w, geom_w, tM0, dimg, 4, 128, 'bf16', args.frames_per_gpu, std=False)
+        roof_w, _, grp_w = roofline_block(eng_w, geom_w, tM0, dimg, 4, 128, 'bf16', args.frames_per_gpu, std=False,
+                                          kern_ms=timer_w.kernel_ms(n_w), clocks=clk_w.cpu().numpy().copy())
         roof_w.pop('_std'); roof_w.pop('_alg')
         f_train_w = mlp_flops(4, 128)[3]
         tfw = f_train_w * samples_step / dt / 1e12

@@ -21,9 +21,12 @@ DEBUG_SIGNATURES = {        # include/bhnerf_hip_debug.h: only libbhnerf_hip_dbg
     'bhn_debug_read': (C.c_int, [C.c_void_p, C.c_size_t]),
 }
 
-ABI_VERSION = 4              # BHN_ABI_VERSION of include/bhnerf_hip.h this binding was written against
+ABI_VERSION = 5              # BHN_ABI_VERSION of include/bhnerf_hip.h this binding was written against
 BHN_F32, BHN_BF16, BHN_BF16_T8 = 0, 1, 2
 BHN_T8_CALIBRATE = 0x100
+BHN_CLK_FWD, BHN_CLK_FWD_TRAIN, BHN_CLK_CHAIN, BHN_CLK_DW, BHN_CLK_SLOTS = 0, 1, 2, 3, 4      # kernel slots of bhn_frames.clock_probe
+BHN_TAPE_INFO_N = 8
+TAPE_FLAGS = {'drop_h1': 1, 'drop_ga': 2, 'ga0_chain': 4, 'fused128': 8, 'drop_hd': 16, 'lbits': 32, 'general': 64}
 MODES = {'f32': BHN_F32, 'fp32': BHN_F32, 'float32': BHN_F32, 'bf16': BHN_BF16, 'bfloat16': BHN_BF16,
          'bf16_t8': BHN_BF16_T8}            # bf16 arithmetic, 8-bit (e4m3) backward tape: include/bhnerf_hip.h
 
@@ -46,7 +49,7 @@ class bhn_geom(C.Structure):
 
 
 class bhn_frames(C.Structure):
-    _fields_ = [('B', C.c_int32), ('tM0', C.c_void_p)]
+    _fields_ = [('B', C.c_int32), ('tM0', C.c_void_p), ('clock_probe', C.c_void_p)]      # clock_probe: NULL unless bench.py measures the kernels' clocks
 
 
 _P, _I32, _I64, _F, _SZ = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
@@ -83,6 +86,8 @@ SIGNATURES = {
     'bhn_render_bwd_tape_timed': (C.c_int, [_MP, _I32, _P, _GP, _FP, _P, _P, _P, _SZ, _P, C.POINTER(C.c_void_p), _I32]),
     'bhn_render_bwd_tape_kernel_name': (C.c_char_p, [_I32]),
     'bhn_render_bwd_tape_kernel_name_for': (C.c_char_p, [_MP, _I32, _I32]),
+    'bhn_tape_info': (C.c_int, [_MP, _I32, _I64, C.POINTER(_I64), _I32]),
+    'bhn_mfma_probe': (C.c_int, [_I32, _I32, _P, _P, _P]),
     'bhn_selftest': (C.c_int, [C.POINTER(_I32), _P, _SZ]),
 }
 

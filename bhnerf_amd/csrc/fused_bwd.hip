@@ -53,6 +53,9 @@
 #ifndef BHN_GA0C_DIST
 #define BHN_GA0C_DIST 4          // weight chunks in flight in that delta chain (its LDS also holds 64 KB of staging images)
 #endif
+#ifndef BHN_GA0C_SWZ
+#define BHN_GA0C_SWZ 1           // staging images of the gA_0 tiles with swizzled rows (chain_kernel: stage_off); 0: A/B builds
+#endif
 #ifndef BHN_TAPED_DIST
 #define BHN_TAPED_DIST 7         // weight chunks in flight in the training-forward / delta-chain kernels (bf16; 4 measured 2 % slower)
 #endif
@@ -294,7 +297,8 @@ __host__ __device__ static inline int t8_feature(int t, int n) {
 // step body) it cost the consumer the same ~1000 cycles and every OTHER step ~150 more (profiles/r5_chain_stamps.txt).
 struct Ga0Consumer {
     const char *ga, *enc;        // staged gA_0 tiles / encoded-input tiles of the eight source waves (2 KiB apart)
-    int trl;                     // tr_lane_off()
+    int trl;                     // tr_lane_off(): the encoded-input tiles (DMA'd from the tape: its slot layout)
+    int trl_ga;                  // the same for the staged gA_0 tiles, whose odd 256-byte rows swap their 64-byte lane halves (ga0_stage_swz)
 #ifndef BHN_GA0C_PF
 #define BHN_GA0C_PF 3            // fragment pairs in flight in the consumer block (8 registers each)
 #endif
@@ -303,14 +307,14 @@ struct Ga0Consumer {
         bf16x8 a[PF], b[PF];
 #pragma unroll
         for (int p = 0; p < PF - 1; ++p) {
-            a[p] = tr_frag(ga + (p >> 1) * 2048, p & 1, trl);
+            a[p] = tr_frag(ga + (p >> 1) * 2048, p & 1, trl_ga);
             b[p] = tr_frag(enc + (p >> 1) * 2048, p & 1, trl);
         }
 #pragma unroll
         for (int p = 0; p < npairs; ++p) {
             const int q = p + PF - 1;
             if (q < npairs) {
-                a[q % PF] = tr_frag(ga + (q >> 1) * 2048, q & 1, trl);
+                a[q % PF] = tr_frag(ga + (q >> 1) * 2048, q & 1, trl_ga);
                 b[q % PF] = tr_frag(enc + (q >> 1) * 2048, q & 1, trl);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -483,6 +487,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
     constexpr int TT = BG::TAPE_TILE;                                  // an h / gA tile on the tape (8-bit tape: 1 KiB)
     constexpr bool T8 = Pol::TAPE8;
     const FusedArgs &a = A.f;
+    clock_stamp(a.clk, MODE == MODE_CHAIN ? BHN_CLK_CHAIN : BHN_CLK_FWD_TRAIN, 0);
     const int edbg = BHN_DBG(((A.debug >> 6) & 3) | (A.policy << 2));  // measurement aid for the tape emission (bits 2,3: store policy)
     constexpr int sdbg = 0;                        // (a run-time MFMA-skip flag put every MFMA in its own basic block)
     // the delta chain's transposed image never uses the two encoded-input fragments of a chunk: its ring copies (and its steps
@@ -527,7 +532,11 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
     char *encS = seg_lds + RaySum<Pol::NWAVES>::bytes(A.f.Sx);
     char *gaS = encS + 2 * STG;
     char *encblk = encS;                                               // training forward (ENCR): the resident encoded-input weight block
-    const int stage_off = TapeEmit<Pol>::native_off(0);
+    // Staging images of the gA_0 tiles: the tape's slot layout with the two 64-byte lane halves of every ODD 256-byte row (points
+    // 4 r .. 4 r + 3) swapped.  A ds_write_b128 retires 8 consecutive lanes (128 bytes) per LDS cycle -- points 8 i .. 8 i + 7 of one lane
+    // half, i.e. the first 64 bytes of two consecutive rows: the same 16 banks twice in the plain layout (SQ_LDS_BANK_CONFLICT 6.7 % of
+    // this kernel's LDS cycles in round 5).  The consumer's transposed reads gather whole rows and only swap the halves back.
+    const int stage_off = TapeEmit<Pol>::native_off(0) ^ ((GA0C && BHN_GA0C_SWZ) ? ((int)(threadIdx.x >> 2) & 1) << 6 : 0);
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 31, h = lane >> 5;
     const int wvu = __builtin_amdgcn_readfirstlane(wv);           // the wave index as a scalar: tape addresses stay in SGPRs
@@ -631,6 +640,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
     f32x16 cacc0 = {}, cacc1 = {};
     Ga0Consumer cons;
     cons.trl = tr_lane_off(); cons.ga = cons.enc = nullptr;
+    cons.trl_ga = cons.trl ^ ((GA0C && BHN_GA0C_SWZ) ? ((int)(threadIdx.x >> 5) & 1) << 6 : 0);      // (a read's two row pairs: rows g >> 1 and + 2 -- the parity is lane >> 5)
     int tpar = 0;                                    // parity of the tile: which encS image it uses
     bool have_prev = false;                          // the previous tile's gA_0 tiles MT-2, MT-1 are staged and not yet consumed
     bool has_next = false;                           // this workgroup has another tile after the running one (its inputs are being prefetched)
@@ -966,6 +976,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may land after the workgroup has released its LDS
+    clock_stamp(a.clk, MODE == MODE_CHAIN ? BHN_CLK_CHAIN : BHN_CLK_FWD_TRAIN, 1);
     if constexpr (T8 && MODE == MODE_CHAIN) {
         // the workgroup's largest |gA_l| per recorded layer -> the state block (t8_update_kernel turns it into the next call's scale)
         __syncthreads();
@@ -1919,6 +1930,7 @@ template <int W, class Pol>
 __global__ __launch_bounds__(Pol::NTHREADS) __attribute__((amdgpu_waves_per_eu(Pol::NWAVES == 4 ? 1 : (W <= 128 ? 4 : 2)))) void dw_kernel(BwdArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];       // NBUF x GROUP_BYTES
     const int depth = A.f.depth;
+    clock_stamp(A.f.clk, BHN_CLK_DW, 0);
     int job = 0;
     while (job < depth && (int)blockIdx.x >= A.wg_begin[job + 1]) ++job;
     if (BHN_DBG(A.debug >> 2) && (A.debug >> 2) - 1 != job) return;
@@ -1955,6 +1967,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) __attribute__((amdgpu_waves_per_eu(P
         else if ((A.f.skip_mask >> job) & 1) dw_body<W, Pol, JT_SKIP>(A, job, smem);
         else dw_body<W, Pol, JT_HIDDEN>(A, job, smem);
     }
+    clock_stamp(A.f.clk, BHN_CLK_DW, 1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2201,7 +2214,38 @@ static long long bytes_per_group(int depth) {
     return (long long)(2 * depth * BG::MT + 1) * BG::TILE_BYTES + 128;
 }
 
-enum { RUN_QUERY = 0, RUN_RECOMPUTE = 1, RUN_FWD_TRAIN = 2, RUN_BWD_TAPE = 3 };
+// bhn_tape_info: the bytes of tape each kernel of the training step moves per 32-point group, from the SAME flags the layout
+// and the job table are built from (bench.py's `tape_stream` figures; round 5 re-derived them in Python and got depths != 4 wrong)
+template <int W, class Pol>
+static void tape_traffic(const MlpShape &s, const TapeLayout &t, int64_t *o) {
+    using BG = BwdGeom<W, Pol>;
+    const long long TT = BG::TAPE_TILE, TB = BG::TILE_BYTES, MT = BG::MT, MW = (MT + 1) / 2, depth = s.depth;
+    long long fw = 0, cw = 0, cr = 0, dr = 0;
+    if (t.fused128) {
+        fw = (depth - 2) * MT * TB + MW * 256 + TB + 128;      // h_2 .. h_{depth-1}, relu bits of the last hidden layer, encoded inputs, e
+        dr = fw + 128;                                         // the fused backward reads all of it + dout (dout128_kernel: 128 read + 128 written)
+        cw = 128; cr = 128;
+    } else {
+        fw = TB + (t.drop_h1 ? TB : 0) + depth * MW * 256 + 128;
+        for (int l = 1; l <= depth; ++l) if (t.h_off[l] >= 0) fw += MT * TT;
+        for (int l = 0; l < depth; ++l) if (t.ga_off[l] >= 0) cw += MT * TT;
+        cw += t.dout_stride;
+        cr = depth * MW * 256 + 128 + (t.ga0_chain ? TB : 0);
+        const int last_job = t.drop_ga ? (int)depth - 1 : (int)depth;
+        for (int l = 0; l <= last_job; ++l) {
+            if (l == 0) { if (!t.ga0_chain) dr += MT * TT + TB; continue; }
+            if (l == depth) { dr += t.dout_stride + MT * TT + (s.skip_in[l] ? TB : 0); continue; }
+            const bool last = l == depth - 1 && t.drop_ga;
+            dr += last ? (t.lbits ? MW * 256 : MT * TT) + 1024 : MT * TT;            // A: gA_l, or h_depth (its relu bits) + the KiB that starts with dout
+            dr += (l == 1 && t.drop_h1) ? TB : MT * TT;                              // B: h_l (layer 1: the encoded inputs it is recomputed from)
+            if (s.skip_in[l] || (last && s.skip_in[depth])) dr += TB;
+        }
+    }
+    o[0] = fw; o[1] = cw; o[2] = cr; o[3] = dr;
+    o[4] = (t.drop_h1 ? 1 : 0) | (t.drop_ga ? 2 : 0) | (t.ga0_chain ? 4 : 0) | (t.fused128 ? 8 : 0) | (t.drop_hd ? 16 : 0) | (t.lbits ? 32 : 0);
+}
+
+enum { RUN_QUERY = 0, RUN_RECOMPUTE = 1, RUN_FWD_TRAIN = 2, RUN_BWD_TAPE = 3, RUN_INFO = 4 };
 
 template <int W, class Pol>
 static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packed, const bhn_geom *geom,
@@ -2254,6 +2298,14 @@ static int bwd_run(int what, const bhn_model *m, int32_t mode, const void *packe
             if ((size_t)t.total > need) need = (size_t)t.total;
         }
         *query_bytes = slab_bytes + t8_bytes + need;
+        return BHN_OK;
+    }
+    if (what == RUN_INFO) {        // query_bytes: int64_t out[8] (bhn_tape_info); query_P: 32-point groups per frame
+        TapeLayout t;
+        layout(query_P > 0 ? query_P : 1, &t);
+        int64_t *o = reinterpret_cast<int64_t *>(query_bytes);
+        tape_traffic<W, Pol>(s, t, o);
+        o[5] = bhn_fwd_w12(Pol::MODE, W, s.depth, query_P) && CAN_X && f128 ? (int)FPol::NWAVES : (int)Pol::NWAVES;
         return BHN_OK;
     }
     BwdArgs A;
@@ -2568,6 +2620,26 @@ extern "C" size_t bhn_render_bwd_workspace_bytes(const bhn_model *m, int32_t mod
                  ? bwd_dispatch<PolBF16>(RUN_QUERY, s.width, m, mode, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, &q, B, P, device)
                  : bwd_dispatch<PolF32>(RUN_QUERY, s.width, m, mode, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, &q, B, P, device);
     return rc == BHN_OK ? q : 0;
+}
+
+extern "C" int bhn_tape_info(const bhn_model *m, int32_t mode, int64_t groups_per_frame, int64_t *info, int32_t n_info) {
+    BHN_CHECK_ARG(m && info && n_info >= BHN_TAPE_INFO_N, "bhn_tape_info: info must hold %d entries", BHN_TAPE_INFO_N);
+    MlpShape s;
+    const int rcs = bhn_mlp_shape(m, &s);
+    if (rcs != BHN_OK) return rcs;
+    for (int i = 0; i < BHN_TAPE_INFO_N; ++i) info[i] = 0;
+    const bool t8 = (mode & 0xff) == BHN_BF16_T8 && bhn_norm_mode(mode) == BHN_BF16;
+    BHN_CHECK_ARG(mode == BHN_F32 || mode == BHN_BF16 || t8, "bad mode %d", mode);
+    if (s.general) { info[4] = 64; info[5] = 1; return BHN_OK; }       // (the general path: one 32-point group per workgroup, an f32 tape in chunks)
+    static_assert(sizeof(size_t) == sizeof(int64_t), "RUN_INFO passes the output array through the size query's pointer");
+    size_t *q = reinterpret_cast<size_t *>(info);
+    if (t8) {
+        if (s.width != 256 || s.depth < 3) { bhn_set_error("BHN_BF16_T8: net_width 256, net_depth >= 3"); return BHN_EUNSUPPORTED; }
+        return bwd_run<256, PolBF16T8>(RUN_INFO, m, mode, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, q, 1, groups_per_frame, 0);
+    }
+    return (mode == BHN_BF16)
+               ? bwd_dispatch<PolBF16>(RUN_INFO, s.width, m, mode, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, q, 1, groups_per_frame, 0)
+               : bwd_dispatch<PolF32>(RUN_INFO, s.width, m, mode, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, q, 1, groups_per_frame, 0);
 }
 
 extern "C" int bhn_render_bwd(const bhn_model *m, int32_t mode, const void *packed, const bhn_geom *geom,

@@ -107,6 +107,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     static_assert(DEPTH >= 2 && DEPTH <= 4, "14 accumulator tiles per wave at depth 4");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const FusedArgs &a = A.f;
+    clock_stamp(a.clk, BHN_CLK_CHAIN, 0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wi = wv >> 1, wj = wv & 1;
@@ -555,6 +556,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             *dst = bs;
         }
     }
+    clock_stamp(a.clk, BHN_CLK_CHAIN, 1);
 }
 
 // dout = dE e (1 - e) per point from the e the forward recorded (sigmoid'(out - 10) = e (1 - e); dE = sum_s dimg w) -> the tape's

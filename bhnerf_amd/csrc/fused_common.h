@@ -306,7 +306,18 @@ struct FusedArgs {
                                     // order-independent (RaySum::direct), no combine through LDS needed
     int debug;            // measurement builds only
     int deg;              // posenc degree 0..BHN_DEG_MAX (run time: only the prologue and the weight packing depend on it)
+    long long *clk;       // bhn_frames.clock_probe (NULL: off): clock stamps of workgroup 0, four per kernel slot (clock_stamp)
 };
+
+// bhn_frames.clock_probe: thread 0 of workgroup 0 stamps the shader clock counter (s_memtime: counts GPU core cycles) and the
+// constant 100-MHz counter (s_memrealtime) at the start (`end` = 0) and the end (1) of the kernel into clk[4 slot ..]: the ratio
+// of the two differences is the clock the kernel sustained (bench.py: sustained_clock_mhz).  Slots: BHN_CLK_* of bhnerf_hip.h.
+DEVI void clock_stamp(long long *clk, int slot, int end) {
+    if (clk && blockIdx.x == 0 && threadIdx.x == 0) {
+        clk[4 * slot + 2 * end] = (long long)__builtin_amdgcn_s_memtime();
+        clk[4 * slot + 2 * end + 1] = (long long)__builtin_amdgcn_s_memrealtime();
+    }
+}
 
 // Packed-weight geometry for hidden width W
 template <int W, class Pol>

@@ -146,6 +146,7 @@ extern "C" int bhn_pack_weights(const bhn_model *m, int32_t mode, const float *p
 template <int W, class Pol, int DEG, bool RENDER, bool DBG = false, bool RES = false>
 __global__ __launch_bounds__(Pol::NTHREADS) __attribute__((amdgpu_waves_per_eu(Pol::WPE, Pol::WPE))) void fused_fwd_kernel(FusedArgs a) {
     const int dbg = DBG ? a.debug : 0;
+    clock_stamp(a.clk, BHN_CLK_FWD, 0);
     using PK = Pack<W, Pol>;
     using frag = typename Pol::frag;
     constexpr int CB = PK::CHUNK_BYTES, MT = PK::MT, KS = PK::KS;
@@ -232,6 +233,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) __attribute__((amdgpu_waves_per_eu(P
     }
     if (!rs.lag) rs.idle_step();                        // every wave runs the same number of ring steps (barriers)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may land after the workgroup has released its LDS
+    clock_stamp(a.clk, BHN_CLK_FWD, 1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -440,6 +442,7 @@ int fused_fill_args(const bhn_model *m, int32_t mode, const void *packed, const 
     }
     a->Sx = geom->S > 0 ? geom->S : 1;
     a->tM0 = fr->tM0; a->B = fr->B;
+    a->clk = reinterpret_cast<long long *>(fr->clock_probe);
     a->packed = (const char *)packed;
     a->fwd_off = (unsigned)L.fwd_off; a->bwd_off = (unsigned)L.bwd_off;
     a->bias_off = (unsigned)L.bias_off; a->wout_off = (unsigned)L.wout_off;

@@ -175,3 +175,36 @@ extern "C" int bhn_selftest(int32_t *results_host, void *scratch_dev, size_t scr
     }
     return BHN_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// bhn_mfma_probe: the matrix-pipe ceiling of THIS board (bench.py: mfma_peak_this_box).  8 waves per workgroup (two per SIMD),
+// each a chain of dependent v_mfma_f32_32x32x16_bf16 with every operand in registers, random operands (the data pattern sets the
+// power a matrix instruction draws and with it the clock the board sustains: zeros run a third faster than real data).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void mfma_probe_kernel(float *sink, int iters, long long *clk) {
+    unsigned seed = 1234567u + threadIdx.x * 7919u + blockIdx.x * 104729u;
+    auto rnd = [&]() { seed = seed * 1664525u + 1013904223u; return seed; };
+    bf16x8 b[16];
+    for (int i = 0; i < 16; ++i)
+        for (int j = 0; j < 8; ++j) b[i][j] = (__bf16)(((rnd() >> 8) & 0xffff) * (1.f / 65536.f) - 0.5f);
+    f32x16 acc = {};
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[(ks + 1) & 15], b[ks], acc, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = acc[j] * 0.03125f + 0.25f;      // bounded and data-dependent
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (clk && threadIdx.x == 0) { clk[2 * blockIdx.x] = (long long)(t1 - t0); clk[2 * blockIdx.x + 1] = (long long)(r1 - r0); }
+    float s = 0.f;
+    for (int j = 0; j < 16; ++j) s += acc[j];
+    if (s == 12345.678f) sink[threadIdx.x] = s;
+}
+
+extern "C" int bhn_mfma_probe(int32_t grid, int32_t iters, int64_t *clk_dev, float *sink_dev, void *stream) {
+    BHN_CHECK_ARG(grid > 0 && grid <= 65536 && iters > 0 && sink_dev, "bhn_mfma_probe: grid 1..65536, iters > 0, a sink buffer");
+    hipLaunchKernelGGL(mfma_probe_kernel, dim3((unsigned)grid), dim3(512), 0, (hipStream_t)stream, sink_dev, iters, reinterpret_cast<long long *>(clk_dev));
+    BHN_HIP(hipGetLastError());
+    return BHN_OK;
+}

@@ -214,9 +214,22 @@ class FusedPredictor:
                                                _hip.stream_ptr(self.device)))
 
     # -- fused calls ---------------------------------------------------------------------------
+    step_timer = None       # measurement aid (bench.py): an object with fwd_mark(i) / bwd_events() that times the kernels of render_train / render_bwd_tape INSIDE the step loop
+    clock_probe = None      # measurement aid (bench.py): an int64 device tensor of 4 * BHN_CLK_SLOTS entries -> bhn_frames.clock_probe
+
     def _frames(self, tM0):
         assert tM0.dtype == torch.float64 and tM0.is_cuda and tM0.is_contiguous()
-        return _hip.bhn_frames(int(tM0.numel()), tM0.data_ptr())
+        cp = self.clock_probe
+        assert cp is None or (cp.dtype == torch.int64 and cp.is_cuda and cp.numel() >= 4 * _hip.BHN_CLK_SLOTS)
+        return _hip.bhn_frames(int(tM0.numel()), tM0.data_ptr(), None if cp is None else cp.data_ptr())
+
+    def tape_info(self, groups_per_frame):
+        """bhn_tape_info: bytes of tape per 32-point group each kernel of the training step moves, and the layout flags."""
+        info = (C.c_int64 * _hip.BHN_TAPE_INFO_N)()
+        _hip.check(_hip.lib().bhn_tape_info(C.byref(self.model), self.mode, int(groups_per_frame), info, _hip.BHN_TAPE_INFO_N))
+        flags = {k: bool(info[4] & v) for k, v in _hip.TAPE_FLAGS.items()}
+        return {'fwd_write': info[0], 'chain_write': info[1], 'chain_read': info[2], 'dw_read': info[3], 'flags': flags,
+                'fwd_groups_per_tile': info[5]}
 
     @_on_device
     def predict(self, geom, tM0):
@@ -325,9 +338,14 @@ class FusedPredictor:
             out = torch.empty((B, geom.Sx, geom.R), dtype=torch.float32, device=self.device)
         ws = self.workspace(B, geom.P_eff)
         gs, fs = geom.c_struct_fused(), self._frames(tM0)
+        timer = self.step_timer
+        if timer is not None:
+            timer.fwd_mark(0)
         _hip.check(_hip.lib().bhn_render_fwd_train(C.byref(self.model), self.mode, _hip.ptr(self.packed), C.byref(gs),
                                                    C.byref(fs), _hip.ptr(out), _hip.ptr(ws), ws.numel(),
                                                    _hip.stream_ptr(self.device)))
+        if timer is not None:
+            timer.fwd_mark(1)
         return out
 
     @_on_device
@@ -339,9 +357,16 @@ class FusedPredictor:
         ws = self.workspace(int(tM0.numel()), geom.P_eff)
         gs, fs = geom.c_struct_fused(), self._frames(tM0)
         mode = self._bwd_mode()
-        _hip.check(_hip.lib().bhn_render_bwd_tape(C.byref(self.model), mode, _hip.ptr(self.packed), C.byref(gs),
-                                                  C.byref(fs), _hip.ptr(dimages), _hip.ptr(out), _hip.ptr(ws), ws.numel(),
-                                                  _hip.stream_ptr(self.device)))
+        timer = self.step_timer
+        if timer is not None:       # bench.py: the caller's HIP events between the kernels of this call (bhn_render_bwd_tape_timed)
+            ev, n_ev = timer.bwd_events()
+            _hip.check(_hip.lib().bhn_render_bwd_tape_timed(C.byref(self.model), mode, _hip.ptr(self.packed), C.byref(gs),
+                                                            C.byref(fs), _hip.ptr(dimages), _hip.ptr(out), _hip.ptr(ws), ws.numel(),
+                                                            _hip.stream_ptr(self.device), ev, n_ev))
+        else:
+            _hip.check(_hip.lib().bhn_render_bwd_tape(C.byref(self.model), mode, _hip.ptr(self.packed), C.byref(gs),
+                                                      C.byref(fs), _hip.ptr(dimages), _hip.ptr(out), _hip.ptr(ws), ws.numel(),
+                                                      _hip.stream_ptr(self.device)))
         self._bwd_done(mode)
         return out
 

@@ -12,12 +12,12 @@ extern "C" {
 #endif
 /* Run only some kernels of the backward on this thread: bit 0 = chain kernel, bit 1 = dW GEMM kernel, bit 2 = slab
  * reduction (default 7); bits 3.. = ablation flags of the kernels (fused_bwd.hip). */
-int bhn_debug_set_bwd_stages(int32_t mask);
+BHN_API int bhn_debug_set_bwd_stages(int32_t mask);
 /* bf16 forward kernel variant.  Low 4 bits: 1 = production kernel (default), 3 = ablation build of the 4x256 render
  * kernel; bits 4.. = its ablation flags (fused_fwd.hip). */
-int bhn_debug_set_fwd_variant(int32_t variant);
+BHN_API int bhn_debug_set_fwd_variant(int32_t variant);
 /* Copy the first `bytes` (<= 4096) of the ablation build's stamp buffer (allocated by the library) to the host. */
-int bhn_debug_read(void *dst_host, size_t bytes);
+BHN_API int bhn_debug_read(void *dst_host, size_t bytes);
 /* Environment variables read by the debug build: BHN_DEBUG_DW_GRID, BHN_DEBUG_JOB1_W, BHN_DEBUG_JOBL_W. */
 #ifdef __cplusplus
 }

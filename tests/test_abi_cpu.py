@@ -34,7 +34,51 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     for name in syms:
         assert hasattr(lib, name), name
     assert sorted(_hip.SIGNATURES) == syms        # the ctypes table binds exactly the declared ABI
-    assert lib.bhn_version() == _hip.ABI_VERSION == 4
+    assert lib.bhn_version() == _hip.ABI_VERSION == 5
+
+
+def test_dynamic_symbol_table_is_the_declared_abi_and_nothing_else(lib):
+    """The library is built with -fvisibility=hidden: `nm -D --defined-only` lists the entry points of include/bhnerf_hip.h
+    (BHN_API) and no C++ internals (round 5 exported 31 mangled launch functions and device stubs beside them, which a second
+    library in the process could interpose)."""
+    import shutil
+    import subprocess
+    from bhnerf_amd import _hip
+    nm = shutil.which('nm')
+    if nm is None:
+        pytest.skip('nm not available')
+    so = os.path.join(_hip.CSRC, 'libbhnerf_hip.so')
+    out = subprocess.run([nm, '-D', '--defined-only', so], capture_output=True, text=True, check=True).stdout
+    defined = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    assert defined == header_symbols(), sorted(set(defined) ^ set(header_symbols()))
+
+
+def test_tape_info_reports_the_layout_the_kernels_use(lib):
+    """bhn_tape_info (host-only): bytes of tape per 32-point group and the layout flags, for the networks the bench line quotes."""
+    from bhnerf_amd import _hip
+    info = (C.c_int64 * _hip.BHN_TAPE_INFO_N)()
+    F = _hip.TAPE_FLAGS
+
+    def q(depth, width, mode, deg=3, groups=8192):
+        m = _hip.make_model(depth, width, deg, True, 8.0, 0.0, 8.0, 4.0)
+        assert lib.bhn_tape_info(C.byref(m), mode, groups, info, _hip.BHN_TAPE_INFO_N) == 0, lib.bhn_last_error()
+        return list(info)
+
+    # 4x256 bf16 (BASELINE config 2): h_2..h_4 + both encoded-input copies + relu bits + e; gA_1, gA_2 + dout; three dW jobs
+    fw, cw, cr, dr, flags, nw = q(4, 256, _hip.BHN_BF16)[:6]
+    assert flags == F['drop_h1'] | F['drop_ga'] | F['ga0_chain'] and nw == 8
+    assert fw == 3 * 8 * 2048 + 2 * 2048 + 4 * 4 * 256 + 128 == 57472            # 1796 B per point
+    assert cw == 2 * 8 * 2048 + 128 and cr == 4 * 4 * 256 + 128 + 2048
+    assert dr == (16384 + 2048) + (16384 + 16384) + (16384 + 1024 + 16384 + 2048) == 87040      # 2720 B per point
+    # 4x128 bf16: the fused backward (12-group tiles for >= 3072 groups per frame)
+    fw, cw, cr, dr, flags, nw = q(4, 128, _hip.BHN_BF16)[:6]
+    assert flags & F['fused128'] and flags & F['drop_hd'] and nw == 12 and q(4, 128, _hip.BHN_BF16, groups=1460)[5] == 8
+    assert fw == 2 * 4 * 2048 + 512 + 2048 + 128 == 19072 and dr == fw + 128     # 596 / 600 B per point
+    # f32 keeps everything; depth 6 at width 256: LBITS / DROP_HD are compiled out (round 5's Python re-derivation assumed them on)
+    assert q(4, 256, _hip.BHN_F32)[4] == 0
+    f6 = q(6, 256, _hip.BHN_BF16)
+    assert not f6[4] & (F['lbits'] | F['drop_hd']) and f6[0] == 5 * 8 * 2048 + 2 * 2048 + 6 * 4 * 256 + 128
+    assert q(4, 128, _hip.BHN_BF16, deg=5)[4] == F['general']
 
 
 def test_release_library_has_no_hidden_allocation_or_environment_reads(lib):
