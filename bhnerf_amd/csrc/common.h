@@ -15,17 +15,45 @@
 
 #define BHN_MAX_LAYERS 9   // net_depth <= 8 hidden layers + the output layer
 #define BHN_ENC_PAD 32     // encoded input (3 + 6*deg <= 27) padded to one 32-feature block
-#define BHN_DEG_MAX 4      // posenc degrees 0..4 share ONE kernel-side slot layout of the 32-feature block:
-                           //   [0..2] u | [3 + 3i + k] sin(2^i u_k) | [15 + 3i + k] cos(2^i u_k),  i < deg
+#define BHN_DEG_MAX 4      // posenc degrees 0..4 share ONE kernel-side slot layout of the 32-feature block
+// Slot layout (round 6).  An MFMA B fragment gives lane half h, element j of k-step s the slot 16 s + 8 (j >> 2) + 4 h + (j & 3): the
+// two lane halves of one register hold slots q and q + 4.  The layout makes every such register pair a (sin, cos) pair of ONE
+// argument -- register n = 8 s + j (0..15) of a lane:
+//     n = 0..2            u_n on half 0 (slot n), nothing on half 1 (slot n + 4: zero weight rows)
+//     n = 3 + 3 i + k     sin(2^i u_k) on half 0, cos(2^i u_k) on half 1, octave i < deg, coordinate k < 3
+//     n = 15              nothing on half 0 (slot 27); slot 31 (half 1) carries the constant 1 on the tapes whose dW GEMMs take the
+//                         bias gradient from it (TapeLayout::fused128 / ga0_chain)
+// so that a lane evaluates ONE transcendental per register, sin(2 pi (rev + h / 4)), instead of the sine AND the cosine of every
+// argument on both halves followed by a select (rounds 1-5: slots [u | sin block | cos block], 24 + 2 quarter-rate instructions
+// and 32 selects per lane; now 12 + 2 and none).  bhn_pack_weights and the reduce kernels reach the reference's feature order
+// [u | sin block (3 deg) | cos block (3 deg)] (network.py:118-122) only through the two maps below.
+#ifndef BHN_ENC_PAIRS
+#define BHN_ENC_PAIRS 1    // 0: the old [u | sin | cos] slot layout (A/B builds)
+#endif
+// slot of register n (0..15) on lane half 0
+static inline __host__ __device__ int bhn_enc_reg_slot(int n) { return 16 * (n >> 3) + 8 * ((n >> 2) & 1) + (n & 3); }
 // reference feature index (network.py:118-122: [u | sin block (3 deg) | cos block (3 deg)]) of kernel slot q, or -1
 static inline __host__ __device__ int bhn_enc_slot_feature(int q, int deg) {
+#if BHN_ENC_PAIRS
+    const int h = (q >> 2) & 1, n = 8 * (q >> 4) + 4 * ((q >> 3) & 1) + (q & 3);
+    if (n < 3) return h == 0 ? n : -1;
+    const int t = n - 3, i = t / 3;
+    if (t >= 3 * BHN_DEG_MAX || i >= deg) return -1;
+    return (h == 0 ? 3 : 3 + 3 * deg) + t;
+#else
     if (q < 3 + 3 * deg) return q;
     if (q >= 3 + 3 * BHN_DEG_MAX && q < 3 + 3 * BHN_DEG_MAX + 3 * deg) return 3 + 3 * deg + (q - 3 - 3 * BHN_DEG_MAX);
     return -1;
+#endif
 }
 // kernel slot of reference feature index f (0 <= f < 3 + 6 deg)
 static inline __host__ __device__ int bhn_enc_feature_slot(int f, int deg) {
+#if BHN_ENC_PAIRS
+    if (f < 3) return f;
+    return f < 3 + 3 * deg ? bhn_enc_reg_slot(f) : bhn_enc_reg_slot(f - 3 * deg) + 4;
+#else
     return f < 3 + 3 * deg ? f : 3 + 3 * BHN_DEG_MAX + (f - 3 - 3 * deg);
+#endif
 }
 
 void bhn_set_error(const char *fmt, ...);

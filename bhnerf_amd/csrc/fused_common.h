@@ -429,9 +429,48 @@ DEVI void point_prologue(const FusedArgs &a, const PointIn &in, typename Pol::fr
         u[k] = valid[k] ? (Pol::FAST_TRIG ? u[k] * a.inv_scale : u[k] / a.scale) : 0.f;     // network.py:227,229 (f32 mode: the division itself)
     }
     live = inb && dom && valid[0];                               // emission.py:370-373, network.py:232
-    // encoded features in the kernel's slot layout [u | sin(2^i u_k) at 3+3i+k | cos(2^i u_k) at 15+3i+k], i < deg
-    // (common.h; bhn_pack_weights puts the reference's rows [u | sin block | cos block], network.py:118-122, on these
-    // slots, unused slots meet zero weight rows).  The degree is a run-time argument: a wave-uniform branch per octave.
+    // encoded features in the kernel's slot layout (common.h): register n = 8 ks + j of this lane holds u_n (n < 3, lane half 0),
+    // sin(2^i u_k) on half 0 / cos(2^i u_k) on half 1 (n = 3 + 3 i + k, i < deg); bhn_pack_weights puts the reference's rows
+    // [u | sin block | cos block], network.py:118-122, on these slots, unused slots meet zero weight rows.  The degree is a
+    // run-time argument: a wave-uniform branch per octave.
+#if BHN_ENC_PAIRS
+    float reg[16];
+#pragma unroll
+    for (int n = 0; n < 16; ++n) reg[n] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) reg[k] = h ? 0.f : u[k];
+    if (Pol::FAST_TRIG) {
+        // ONE transcendental per register: cos(x) = sin(x + a quarter revolution) -- v_sin_f32 takes revolutions
+        const float qh = h ? 0.25f : 0.f;
+        float rv[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) rv[k] = u[k] * 0.15915494309189535f;
+#pragma unroll
+        for (int i = 0; i < BHN_DEG_MAX; ++i) {
+            if (i < a.deg) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    reg[3 + 3 * i + k] = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(rv[k] * (float)(1 << i)) + qh);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < BHN_DEG_MAX; ++i) {
+            if (i < a.deg) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    float sv, cv;
+                    sincosf(u[k] * (float)(1 << i), &sv, &cv);
+                    reg[3 + 3 * i + k] = h ? cv : sv;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Pol::set(enc[ks], j, reg[8 * ks + j]);
+#else
     float feat[BHN_ENC_PAD];
 #pragma unroll
     for (int q = 0; q < BHN_ENC_PAD; ++q) feat[q] = 0.f;
@@ -464,6 +503,7 @@ DEVI void point_prologue(const FusedArgs &a, const PointIn &in, typename Pol::fr
             const float v1 = feat[16 * ks + phi16(1, j)];
             Pol::set(enc[ks], j, h ? v1 : v0);
         }
+#endif
 }
 
 // bias rows of output tile m as the initial accumulator: acc[r] = bias[32m + (r&3)+8(r>>2)+4h]

@@ -661,6 +661,13 @@ extern "C" int bhn_render_fwd(const bhn_model *m, int32_t mode, const void *pack
         BHN_CHECK_ARG(a.emission, "no debug buffer");
         return launch_fwd_w<256, PolBF16, true, true>(a, (hipStream_t)stream);
     }
+    if (mode == BHN_BF16 && s.width == 128 && (g_fwd_variant & 15) == 3) {     // round 6: the same ablation flags on the resident-weights kernel of width 128
+        a.debug = g_fwd_variant >> 4;
+        a.emission = reinterpret_cast<float *>(bhn_debug_buffer());
+        BHN_CHECK_ARG(a.emission, "no debug buffer");
+        return nw == PolBF16X::NWAVES ? launch_fwd_w<128, PolBF16X, true, true, true>(a, (hipStream_t)stream)
+                                      : launch_fwd_w<128, PolBF16, true, true, true>(a, (hipStream_t)stream);
+    }
 #endif
     if (nw == 16) return launch_fwd_pair<true>(a, s.width, (hipStream_t)stream);
     return mode == BHN_BF16 ? launch_fwd<PolBF16, true>(a, s.width, (hipStream_t)stream)

@@ -436,14 +436,17 @@ int gen_forward(bool render, const bhn_model *m, int32_t mode, const void *packe
 }
 
 static size_t gen_align(size_t v) { return (v + 255) & ~(size_t)255; }
+static constexpr long long GEN_MIN_CHUNK_TILES = 16;      // smallest tape chunk (32-point groups) gen_backward accepts
 
 size_t gen_bwd_workspace_bytes(const MlpShape &s, int32_t B, int64_t P) {
     GenArgs A;
     gen_layout(s, &A);
     const long long tiles = (P + 31) / 32 * B;
     const size_t tile_bytes = (size_t)A.tape_tile * 4;
-    // the tape of one chunk of groups: all of them up to 2 GiB, never less than one frame (what gen_backward insists on)
-    const size_t cap = std::max<size_t>((size_t)2 << 30, (size_t)((P + 31) / 32) * tile_bytes);
+    // the tape of one chunk of groups: all of them up to 2 GiB.  The chunk loop of gen_backward works for any chunk (the
+    // tile -> (frame, group) map goes through fd_tpf), so neither the query nor the call asks for a whole frame of tape: one
+    // frame of an 8x512 network on a 256 x 256 x 128 ray set would be 277 GB (round 5 did ask for it: ADVICE r5)
+    const size_t cap = (size_t)2 << 30;
     return gen_align((size_t)A.nsplit * A.slab_floats * 4) + std::min<size_t>((size_t)tiles * tile_bytes, cap);
 }
 
@@ -458,7 +461,8 @@ int gen_backward(const bhn_model *m, int32_t mode, const void *packed, const bhn
     BHN_HIP(hipGetDevice(&dev));
     BHN_CHECK_DEVICE(dev);
     const size_t slab_bytes = gen_align((size_t)A.nsplit * A.slab_floats * 4), tile_bytes = (size_t)A.tape_tile * 4;
-    const long long min_tiles = A.f.tiles_per_frame;                       // (the contract of bhn_render_bwd: slabs + ONE frame of tape)
+    // any chunk of groups will do (a floor of 16 only so that a launch is not empty-handed)
+    const long long min_tiles = std::min<long long>(A.f.total_tiles, GEN_MIN_CHUNK_TILES);
     if (workspace_bytes < slab_bytes + (size_t)min_tiles * tile_bytes) {
         bhn_set_error("render_bwd workspace too small: %zu bytes, need >= %zu (slabs %zu + %lld groups of tape)", workspace_bytes,
                       slab_bytes + (size_t)min_tiles * tile_bytes, slab_bytes, min_tiles);

@@ -319,21 +319,31 @@ __global__ __launch_bounds__(1024) void chi2_image_kernel(const float *__restric
         const float tot = block_sum_1024(acc, red);
         if (threadIdx.x == 0) loss[1 + plane] = scale * tot;
     } else {            // 'lc': light curve = image summed over pixels (network.py:479-480)
-        float acc = 0.f;
+        // The pixel sum and the residual are formed in DOUBLE (round 6).  A Stokes Q / U light curve is a sum of 65,536 pixels of
+        // both signs that nearly cancel, and chi^2's gradient is proportional to (lc - target): in float the rounding of the sum
+        // alone put 1e-5 .. 8e-4 of relative error on the gradient of the polarised configs (3, 5) -- the arithmetic of a float
+        // light curve, which the float32 reference shares, but the f64 oracle this library is held to does not.  Fixed order
+        // as before (bitwise reproducible); 64-bit adds run at the full vector rate on gfx950.
+        __shared__ double red64[16];
+        double acc = 0.0;
         if (vec) {
             for (int64_t r = 4 * (int64_t)threadIdx.x; r < R; r += 4096) {
                 const f32x4 i4 = *reinterpret_cast<const f32x4 *>(img + r);
-                acc += (i4[0] + i4[1]) + (i4[2] + i4[3]);
+                acc += ((double)i4[0] + (double)i4[1]) + ((double)i4[2] + (double)i4[3]);
             }
         } else {
-            for (int64_t r = threadIdx.x; r < R; r += 1024) acc += img[r];
+            for (int64_t r = threadIdx.x; r < R; r += 1024) acc += (double)img[r];
         }
-        const float lc = block_sum_1024(acc, red);
-        const float s = sigma[plane];
-        const float d = (lc - target[plane] - offset[plane]) / s;
-        if (threadIdx.x == 0) loss[1 + plane] = scale * d * d;
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+        if ((threadIdx.x & 63) == 0) red64[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        double lc = 0.0;
+        for (int i = 0; i < 16; ++i) lc += red64[i];       // every thread, the same order
+        const double s = (double)sigma[plane];
+        const double d = (lc - (double)target[plane] - (double)offset[plane]) / s;
+        if (threadIdx.x == 0) loss[1 + plane] = (float)((double)scale * d * d);
         if (dimages) {
-            const float gr = 2.f * scale * d / s;
+            const float gr = (float)(2.0 * (double)scale * d / s);
             for (int64_t r = threadIdx.x; r < R; r += 1024) dimages[plane * R + r] = gr;
         }
     }

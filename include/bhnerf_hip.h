@@ -76,7 +76,10 @@ typedef struct {
  * (BHN_BF16 is accepted; BHN_BF16_T8 is BHN_EUNSUPPORTED), layer by layer with the activations of 32 points in LDS, at
  * 0.3-0.4 of the f32 MFMA peak.  bhn_render_fwd_train records nothing (it is bhn_render_fwd) and bhn_render_bwd_tape
  * recomputes the forward; the workspace holds 8-256 gradient slabs
- * (more for narrow networks) and the tape of a chunk of 32-point groups (at least one frame's). */
+ * (more for narrow networks) and the tape of a chunk of 32-point groups: the query asks for at most 2 GiB of tape, the call
+ * accepts anything from 16 groups' worth (not a whole frame's: one frame of an 8x512 network on 256 x 256 x 128 rays is 277 GB).
+ * Pixels of rays that span more than two 32-point groups receive one float atomic per group: images, losses and gradients of
+ * these models are reproducible to rounding only (the fused kernels: bitwise). */
 
 /* Geodesic-side inputs, prepared once per ray set by bhn_geom_prepare (arrays of P floats). */
 typedef struct {

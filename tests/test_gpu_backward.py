@@ -309,6 +309,22 @@ def test_general_path_emission_and_workspace_chunks(dev):
     assert eng2.workspace(B, geom.P_eff).numel() < eng.workspace(B, geom.P_eff).numel()
     g_chunks = eng2.render_bwd(geom, tM0, dimg)
     assert torch.allclose(g_chunks, g_rec, rtol=1e-5, atol=1e-6 * float(g_rec.abs().max()))
+    # a workspace SMALLER than one frame of tape (the call used to insist on a whole frame -- 35 GB for config 2 at
+    # 8x512): slabs + 16 groups, so the chunks cut the frames anywhere; one tile less is refused with BHN_EWORKSPACE
+    import ctypes as C
+    from bhnerf_amd import _hip
+    lib = _hip.lib()
+    small = int(lib.bhn_render_bwd_workspace_bytes(C.byref(eng.model), eng.mode, 1, 16 * 32, 0))
+    one = int(lib.bhn_render_bwd_workspace_bytes(C.byref(eng.model), eng.mode, 1, geom.P_eff, 0))
+    assert 0 < small < one and (geom.P_eff + 31) // 32 % 16 != 0
+    ws = torch.empty((small,), dtype=torch.uint8, device=dev)
+    out = torch.zeros_like(g_rec)
+    gs, fs = geom.c_struct_fused(), eng._frames(tM0)
+    call = lambda nbytes: lib.bhn_render_bwd(C.byref(eng.model), eng.mode, _hip.ptr(eng.packed), C.byref(gs), C.byref(fs), _hip.ptr(dimg),
+                                             _hip.ptr(out), _hip.ptr(ws), nbytes, _hip.stream_ptr(dev))
+    _hip.check(call(small))
+    assert torch.allclose(out, g_rec, rtol=1e-5, atol=1e-6 * float(g_rec.abs().max()))
+    assert call(small - 4096) == 4 and b'workspace' in lib.bhn_last_error()          # BHN_EWORKSPACE
 
 
 @pytest.mark.parametrize('rows', [48, 47])

@@ -189,7 +189,15 @@ def test_polarised_lightcurve_gradient_against_oracle_on_a_ray_subset(dev, name,
     256 rays of the full geometry (rays are independent; the light curve of a subset is the subset's own sum).  Config 5 is
     the reference-default 4x128 network: in bf16 its gradient comes out of bwd128_kernel (fused delta chain + dW), held
     here to the ORACLE and not to the library's other backward route.  Tolerances: f32 2e-5, bf16 3e-2 relative L2
-    (observed values are printed)."""
+    (observed values are printed).
+
+    Why the f32 bound is 2e-5 and not north_star's 1e-5 (round 6): round 5 blamed the float rounding of the
+    light curve's PIXEL SUM for the 1.3e-5 / 1.7e-5 observed here.  The sum (and the residual) are formed in double since round 6
+    (chi2_image_kernel, 'lc' branch) -- and the figures did not move (config 5: 1.681e-5 before and after).  What limits them is
+    upstream of the sum: the pixels themselves are float32 (each within 1e-6 of the image maximum of the oracle's), the Q and U
+    light curves are sums of signed pixels that cancel to a few per cent of the I light curve, and chi^2's gradient is proportional
+    to the residual of every light curve: a 2e-7 error of the pixels is a 1e-5 error of lc_Q.  The test prints that figure
+    (`lc rel diff`); the float32 reference has the same pixels."""
     from oracle import oracle_torch as ot
     from bhnerf_amd import network, units
     p = make_problem(name, dev)
@@ -233,15 +241,84 @@ def test_polarised_lightcurve_gradient_against_oracle_on_a_ray_subset(dev, name,
         params = pred.engine().flatten(p['tree']).requires_grad_(True)
         tree = network.ParamTree()
         tree.flat = params
-        loss, _ = network.loss_fn_image(tree, pred.apply, target, sigma, offset, p['t_frames'], g['coords'], g['Omega'], g['J'],
-                                        g['g'], g['dtau'], g['Sigma'], 0.0, g['t_geos'], float(geo['t_injection']), 1.0, units.hr, 'lc')
+        loss, [images] = network.loss_fn_image(tree, pred.apply, target, sigma, offset, p['t_frames'], g['coords'], g['Omega'], g['J'],
+                                               g['g'], g['dtau'], g['Sigma'], 0.0, g['t_geos'], float(geo['t_injection']), 1.0, units.hr, 'lc')
         loss.backward()
+        lc_dev = images.detach().double().sum(dim=(-1, -2)).cpu().numpy()                   # the device's float32 pixels, summed in double
+        lc_diff = np.abs(lc_dev - lc0).max(axis=0) / np.abs(lc0).max(axis=0)               # per Stokes parameter
         gdev = params.grad.cpu().numpy().astype(np.float64)
         lerr = abs(loss.item() - loss_ref.item()) / abs(loss_ref.item())
         err = float(np.linalg.norm(gdev - gref) / np.linalg.norm(gref))
         emax = float(np.abs(gdev - gref).max() / np.abs(gref).max())
         with capsys.disabled():
-            print('\n[%s %s] lc gradient vs f64 oracle on 256 rays: rel L2 %.3e, max-norm %.3e, loss rel err %.3e (active fraction %.3f)'
-                  % (name, mode, err, emax, lerr, gm.active_fraction))
+            print('\n[%s %s] lc gradient vs f64 oracle on 256 rays: rel L2 %.3e, max-norm %.3e, loss rel err %.3e (active fraction %.3f); lc rel diff I %.1e Q %.1e U %.1e'
+                  % (name, mode, err, emax, lerr, gm.active_fraction, lc_diff[0], lc_diff[1], lc_diff[2]))
         assert lerr <= (1e-5 if mode == 'f32' else 3e-2)
         assert err < l2tol, (mode, err)
+
+
+@pytest.mark.parametrize('name', ['config5', 'config5_128sq'])
+def test_polarised_gradient_on_the_full_geometry_against_oracle(dev, name, capsys):
+    """the oracle gradient on the FULL geometry, not on a 16 x 16-ray extract of it.  A 'full' chi-square whose
+    noise level is infinite on every pixel but 256 (those pixels then contribute exactly 0 to the loss and to d loss / d image) is,
+    for the oracle, a loss on 256 independent rays -- while the HIP path renders, records and back-propagates the WHOLE
+    point-compacted ray set: every workgroup tile, the per-wave direct ray sums (`ray_span` <= 2) and the fused 4x128 backward
+    run at their real sizes.  `config5` is BASELINE config 5 (64 x 64 rays x 100 samples: 8-group tiles); `config5_128sq` the same
+    geometry on 128 x 128 rays -- more than 3,072 in-domain groups per frame, so the forward pair runs on 12-wave workgroups
+    (PolBF16X) in front of bwd128_kernel.  Tolerances: f32 2e-5, bf16 3e-2 relative L2 (observed values are printed)."""
+    from oracle import oracle_torch as ot
+    from bhnerf_amd import constants, engine, network, synthetic, units
+    c = dict(CONFIGS['config5'])
+    if name == 'config5_128sq':
+        c.update(H=128, W=128)
+    geo = synthetic.synthetic_geodesics(c['H'], c['W'], c['G'], fov_M=c['fov'], inc_deg=c['inc'], spin=c['spin'], S=3, seed=3)
+    p = make_problem('config5', dev)                                                    # (weights and frames of the 'config5' problem)
+    G, HW = c['G'], c['H'] * c['W']
+    r2 = (geo['coords'] ** 2).sum(0).reshape(HW, G)
+    inside = ((r2 >= c['rmin'] ** 2) & (r2 <= c['rmax'] ** 2) & (np.abs(geo['coords'][2].reshape(HW, G)) <= c['z_width'])).sum(1)
+    rays = np.sort(np.random.default_rng(43).choice(np.nonzero(inside >= 4)[0], size=256, replace=False))
+    sub = lambda v: np.ascontiguousarray(v.reshape((-1, G))[rays].reshape(16, 16, G))
+    t64 = lambda x: torch.tensor(np.asarray(x, dtype=np.float64))
+    ks, bs = ot.tree_to_lists(p['tree'], torch.float64)
+    geom_t = dict(coords=t64(np.stack([sub(geo['coords'][i]) for i in range(3)])), Omega=t64(sub(geo['Omega'])), t_geos=t64(sub(geo['t_geos'])),
+                  g=t64(sub(geo['g'])), dtau=t64(sub(geo['dtau'])), Sigma=t64(sub(geo['Sigma'])), J=t64(np.stack([sub(geo['J'][s]) for s in range(3)])),
+                  t_start_obs=0.0, t_injection=float(geo['t_injection']))
+    hp = dict(GM_c3=p['GM_c3'], scale=c['rmax'], rmin=c['rmin'], rmax=c['rmax'], z_width=c['z_width'], posenc_deg=3, net_depth=4)
+    tr = ot.CpuTrainer(ks, bs, geom_t, hp)
+    with torch.no_grad():
+        img0 = tr.forward(t64(p['t_frames'])).numpy()                                     # (B, 3, 16, 16)
+    rng = np.random.default_rng(44)
+    tgt_s = img0 * rng.uniform(0.3, 0.6, img0.shape)
+    sig_s = np.abs(img0[:, :1]).mean() * rng.uniform(0.05, 0.2, img0.shape)
+    loss_ref, _, grads_ref = tr.loss_and_grad(t64(p['t_frames']), t64(tgt_s), t64(sig_s), t64(np.zeros_like(img0)), 1.0, 'full')
+    n = len(tr.k)
+    gref = np.concatenate([np.concatenate([grads_ref[i].numpy().ravel(), grads_ref[n + i].numpy().ravel()]) for i in range(n)])
+    assert np.linalg.norm(gref) > 0
+    # the same loss on the full image plane: target 0 and sigma = inf wherever the oracle has no ray
+    target = np.zeros((B, 3, HW), dtype=np.float32); sigma = np.full((B, 3, HW), np.inf, dtype=np.float32)
+    target[:, :, rays] = tgt_s.reshape(B, 3, 256); sigma[:, :, rays] = sig_s.reshape(B, 3, 256)
+    shp = (B, 3, c['H'], c['W'])
+    for mode, l2tol in (('f32', 2e-5), ('bf16', 3e-2)):
+        pred = network.NeRF_Predictor(c['rmax'], c['rmin'], c['rmax'], c['z_width'], net_depth=4, net_width=c['width'], mode=mode, device=dev)
+        gm = pred.geometry(geo['coords'], geo['Omega'], geo['t_geos'], geo['J'], geo['g'], geo['dtau'], geo['Sigma'])
+        assert gm.compact is not None and gm.S == 3 and gm.compact['ray_span'] in (1, 2)
+        groups = (gm.P_eff + 31) // 32
+        assert (groups >= 3072) == (name == 'config5_128sq')                              # the 12-wave tiles of the fused 4x128 forward pair
+        params = pred.engine().flatten(p['tree']).requires_grad_(True)
+        tree = network.ParamTree()
+        tree.flat = params
+        loss, _ = network.loss_fn_image(tree, pred.apply, target.reshape(shp), sigma.reshape(shp), np.zeros(shp, dtype=np.float32), p['t_frames'],
+                                        geo['coords'], geo['Omega'], geo['J'], geo['g'], geo['dtau'], geo['Sigma'], 0.0, geo['t_geos'],
+                                        float(geo['t_injection']), 1.0, units.hr, 'full')
+        loss.backward()
+        gdev = params.grad.cpu().numpy().astype(np.float64)
+        assert np.isfinite(gdev).all()
+        lerr = abs(loss.item() - loss_ref.item()) / abs(loss_ref.item())
+        err = float(np.linalg.norm(gdev - gref) / np.linalg.norm(gref))
+        with capsys.disabled():
+            print('\n[%s %s, full geometry: %d in-domain groups per frame, ray span %d] gradient vs f64 oracle (loss on 256 rays): rel L2 %.3e, loss rel err %.3e'
+                  % (name, mode, groups, gm.compact['ray_span'], err, lerr))
+        assert lerr <= (1e-5 if mode == 'f32' else 3e-2)
+        assert err < l2tol, (mode, err)
+        del pred, gm, params, tree, loss
+        torch.cuda.empty_cache()

@@ -39,5 +39,22 @@ swz)        # experiment (b): swizzled gA_0 staging images in chain_kernel<CHAIN
   ab libbhnerf_hip_swz0.so libbhnerf_hip.so | tee $O/ab.txt
   for l in libbhnerf_hip_swz0.so libbhnerf_hip.so; do echo "== $l"; lds_pass $l 256 ${l%.so}; done | tee $O/lds.txt
   ;;
+validate)   # ABI 5 build: whole GPU suite, smoke, the default bench line (every block), LDS counters of the swizzle A/B
+  python -m pytest tests -m gpu -x -q 2>&1 | tail -40 > $O/pytest.txt; tail -25 $O/pytest.txt
+  python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tail -5 | tee $O/smoke.txt
+  python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; tail -3 $O/bench.err; python - $O/bench.json <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+r = d['roofline']
+print('step %.3f ms  value %.4g  roofline %s frac %.4f clock %s' % (d['ms_per_step'], d['value'], r['kernel'], r['frac'], r.get('sustained_clock_mhz')))
+for k, v in r['kernels'].items(): print('  %-32s %.3f ms  %d flop/pt  mfma %.4f  tape %.0f B/pt  %.0f GB/s  clock %s' % (k, v['ms'], v['flop_per_point'], v['mfma_frac'], v['tape_bytes_per_point'], v['tape_GB_per_s'], v['sustained_clock_mhz']))
+print('  kernel_ms_sum %.3f  inference %s  peak_this_box %s' % (r['kernel_ms_sum'], r['inference_forward'], r.get('mfma_peak_this_box')))
+w = d.get('width128', {})
+print('width128 step', w.get('ms_per_step'), 'graph', w.get('ms_per_step_hip_graph'), {k: (v['ms'], v['mfma_frac'], v['sustained_clock_mhz']) for k, v in w.get('roofline', {}).get('kernels', {}).items()} if 'roofline' in w else w)
+print('fwd images/s', d.get('fwd_images_per_s'), 'cpu', {k: d['cpu_baseline'][k] for k in ('value', 'cores', 'fwd_images_per_s')} if d.get('cpu_baseline') else None)
+print('general_path', d.get('general_path', {}).get('ms_per_step'), 'other', {k: v.get('ms_per_step') for k, v in d.get('other_configs', {}).items() if isinstance(v, dict)})
+PY
+  for l in libbhnerf_hip_swz0.so libbhnerf_hip.so; do echo "== $l"; lds_pass $l 256 ${l%.so}; done | tee $O/lds.txt
+  ;;
 *) echo "unknown job $J"; exit 1;;
 esac
