@@ -98,9 +98,9 @@ int bhn_mlp_shape(const bhn_model *m, MlpShape *s);   // validates, returns BHN_
 size_t gen_packed_bytes(const MlpShape &s);
 int gen_pack_weights(const MlpShape &s, const float *params, void *packed, hipStream_t st);
 int gen_forward(bool render, const bhn_model *m, int32_t mode, const void *packed, const bhn_geom *geom, const bhn_frames *fr,
-                float *out, hipStream_t st);
+                float *out, hipStream_t st, void *workspace = nullptr, size_t workspace_bytes = 0);     // (workspace: bhn_render_fwd_train records the tape)
 size_t gen_bwd_workspace_bytes(const MlpShape &s, int32_t B, int64_t P);
-int gen_backward(const bhn_model *m, int32_t mode, const void *packed, const bhn_geom *geom, const bhn_frames *fr,
+int gen_backward(bool tape_only, const bhn_model *m, int32_t mode, const void *packed, const bhn_geom *geom, const bhn_frames *fr,
                  const float *dimages, float *dparams, void *workspace, size_t workspace_bytes, hipStream_t st);
 
 // bf16 networks with >= 3 hidden layers: the backward never materialises gA_{depth-1} = W_out (.) dout (.) relu' --

@@ -495,7 +495,11 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
     // (KS >= 8: the A-fragment prefetch of a step runs LDS_PREFETCH - 1 fragments into the NEXT chunk, which must have that many)
     using EB = EncBlock<W, Pol>;
     constexpr bool ENCR = MODE != MODE_CHAIN && EB::ON && !RES;
-    constexpr int NFR = ((MODE == MODE_CHAIN && KS >= 8) || ENCR) ? KS : KS + 2;
+#ifndef BHN_RES_ENCW
+#define BHN_RES_ENCW 1           // 0: the resident training forward streams all KS + 2 fragments of every chunk (rounds 4-5; A/B builds)
+#endif
+    constexpr bool ENCW = BHN_RES_ENCW != 0 && MODE != MODE_CHAIN && EB::ON && RES;     // (fused_common.h: hidden_layer ENC_IN_CHUNK)
+    constexpr int NFR = ((MODE == MODE_CHAIN && KS >= 8) || ENCR || ENCW) ? KS : KS + 2;
     using RG = DmaRing<RES ? CB : NFR * Pol::FRAG_BYTES, Pol::NWAVES, GA0C>;     // (GA0C: transposed LDS reads in the kernel -> asm DMA)
     constexpr int DIST = GA0C ? BHN_GA0C_DIST : BG::RING_DIST_TAPED;
     using RS = std::conditional_t<RES, ResidentRing<RG, CB, MT>, RingState<RG, CB, DIST, false, MT, BHN_CHAIN_STAMPS != 0>>;
@@ -730,7 +734,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
                     const float *bn = (out || (m == MT - 1 && l + 1 > a.depth)) ? nullptr : bl + 32 * (m + 1);
                     if (out) bn = bias_lds;                           // next tile, layer 0
                     const f32x16 acc = ring_step<W, Pol, RG, TapePost<Pol, true>, NFR>(ch, chn, ap, act, enc, sk, bn, post, dj, sdbg,
-                                                                                       encblk + 2 * (out ? MT : m) * Pol::FRAG_BYTES);
+                                                                                       ENCW ? ch + KS * Pol::FRAG_BYTES : encblk + 2 * (out ? MT : m) * Pol::FRAG_BYTES);
                     // without the h_1 emission the interval after this layer's first DMA issue holds no store: the
                     // three step ends that count it allow one emission less in flight (small widths: none)
                     if (drop_h1 && l == 1 && m <= 2) rs.template step_end<YS_L1>();
@@ -1699,9 +1703,15 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
         } else {
             bq[0] = bc[0]; bq[1] = bc[1];
         }
+#ifndef BHN_DW_ABL_READS
+#define BHN_DW_ABL_READS 0       // measurement builds (dW wrong): 1 = every second B fragment is not read (the previous one is used again):
+#endif                           // 8 instead of 12 transposed fragment reads per 16 MFMAs -- the LDS traffic of 4 x 4 register blocking
 #pragma unroll
         for (int t = 0; t < NTOT; ++t) {
-            if (t + 2 < NTOT) bq[(t + 2) % 3] = load_b(gp, t + 2);
+            if (t + 2 < NTOT) {
+                if (BHN_DW_ABL_READS && ((t + 2) & 1)) bq[(t + 2) % 3] = bq[(t + 1) % 3];
+                else bq[(t + 2) % 3] = load_b(gp, t + 2);
+            }
             if (enc_extra && (t % NPW) == (NPW >= 2 ? NPW - 2 : 0)) benc = tr_frag(gp + OFF_E, t / NPW, trl);     // used at ni == NPW-1
             if (t == 0) a_load(gnext, nx);
             __builtin_amdgcn_sched_barrier(0);
@@ -1720,7 +1730,7 @@ DEVI void dw_body2(const BwdArgs &A, int job, char *smem) {
                 if (t == (T_PREP + k < NTOT ? T_PREP + k : NTOT - 1)) a_prep(nx, k, live_next);
             if constexpr (!make_h) {
                 if (t == (NTOT >= 2 ? NTOT - 2 : 0)) bn[0] = load_b(gnext, 0);
-                if (t == NTOT - 1) bn[1] = load_b(gnext, NTOT > 1 ? 1 : 0);
+                if (t == NTOT - 1) bn[1] = BHN_DW_ABL_READS ? bn[0] : load_b(gnext, NTOT > 1 ? 1 : 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -2579,15 +2589,15 @@ static int bwd_entry(int what, const bhn_model *m, int32_t mode, const void *pac
     if (rcs != BHN_OK) return rcs;
     const int kernel_width = shape.width;
     if (shape.general) {
-        // shapes outside the fused kernels (general_mlp.hip, f32 in both modes): the training forward is the plain render, the
-        // backward recomputes what it needs
+        // shapes outside the fused kernels (general_mlp.hip, f32 in both modes): the training forward records the tape when the
+        // workspace holds it, bhn_render_bwd recomputes chunk by chunk
         if (t8) { bhn_set_error("BHN_BF16_T8 (8-bit tape) is built for net_width 256, posenc_deg <= 4; use BHN_BF16"); return BHN_EUNSUPPORTED; }
         BHN_CHECK_ARG(!ev, "per-kernel events are not available for posenc_deg > 4 / net_width > 256");
         if (what == RUN_FWD_TRAIN) {
             BHN_CHECK_ARG(images, "null pointer");
-            return gen_forward(true, m, mode, packed, geom, fr, images, (hipStream_t)stream);
+            return gen_forward(true, m, mode, packed, geom, fr, images, (hipStream_t)stream, workspace, workspace_bytes);
         }
-        return gen_backward(m, mode, packed, geom, fr, dimages, dparams, workspace, workspace_bytes, (hipStream_t)stream);
+        return gen_backward(what == RUN_BWD_TAPE, m, mode, packed, geom, fr, dimages, dparams, workspace, workspace_bytes, (hipStream_t)stream);
     }
     if (t8) {
         if (kernel_width != 256 || shape.depth < 3) {

@@ -2,13 +2,19 @@
 // features) and net_width 257..512 (network.py:154).  No reference driver sets either, so this path is written for
 // completeness, not for the roofline: f32 arithmetic in BOTH modes (v_mfma_f32_32x32x2_f32; BHN_BF16 is accepted and
 // computed in f32), activations of a 32-point group in LDS, weights streamed from L2 by every workgroup, and a backward
-// that goes through an HBM tape in chunks of groups:
+// that goes through an HBM tape:
 //
-//   gen_mlp_kernel<PREDICT | RENDER>   one workgroup = one 32-point group at a time: warp + posenc (emission.py:200-210,
-//                                      network.py:118-122) -> LDS, layers as [feature][point] images in two LDS buffers (the
-//                                      waves share the 32-row output tiles of a layer), sigmoid / masks, emission or ray sum;
-//   gen_mlp_kernel<CHAIN>              the same forward writing every layer input to the tape, then dout and the delta chain
-//                                      gA_{l-1} = relu' (.) K_l gA_l (transposed weight copies) writing every gA_l;
+//   gen_mlp_kernel<PREDICT | RENDER>   one workgroup = a TILE of eight consecutive 32-point groups, one group at a time: warp +
+//                                      posenc (emission.py:200-210, network.py:118-122) -> LDS, layers as [feature][point] images
+//                                      in two LDS buffers (the waves share the 32-row output tiles of a layer), sigmoid / masks,
+//                                      emission or ray sums -- the eight groups' ray segments are combined in LDS (RaySum<8>), so a
+//                                      pixel receives one float atomic per tile its ray touches: at most two for rays of <= 257
+//                                      samples, bitwise reproducible like the fused kernels (round 5: one atomic per group);
+//   gen_mlp_kernel<RECORD>             bhn_render_fwd_train: RENDER + every layer input, the encoded inputs and e on the tape (round 6:
+//                                      the training step no longer runs its forward twice);
+//   gen_mlp_kernel<CHAIN_TAPE>         bhn_render_bwd_tape: dout and the delta chain gA_{l-1} = relu' (.) K_l gA_l (transposed weight
+//                                      copies) from that tape, writing every gA_l;
+//   gen_mlp_kernel<CHAIN>              bhn_render_bwd (any workspace from 16 groups of tape on): both, chunk by chunk;
 //   gen_dw_kernel                      dK_l = in_l^T gA_l over the tape, K = points: workgroup (job, split) = one 32-row x
 //                                      128-column block of one layer over one share of the chunk's groups, into its own slab
 //                                      (the bias is the job whose input tile is a row of ones);
@@ -22,7 +28,8 @@
 
 namespace {
 
-enum { GEN_PREDICT = 0, GEN_RENDER = 1, GEN_CHAIN = 2 };
+enum { GEN_PREDICT = 0, GEN_RENDER = 1, GEN_CHAIN = 2, GEN_RECORD = 3, GEN_CHAIN_TAPE = 4 };
+constexpr int GEN_TG = 8;             // 32-point groups per workgroup tile (the unit of the ray-sum combine and of the tape chunks)
 
 struct GenLayer {
     unsigned k_off, kt_off, b_off;     // float offsets in the packed image
@@ -37,9 +44,9 @@ struct GenArgs {
     GenLayer L[BHN_MAX_LAYERS];
     int D, Wp, Ep, F;
     const float *pk;                   // packed image
-    float *tape;                       // [tile of this chunk][tape_tile floats]: enc | h_1 .. h_D | gA_0 .. gA_{D-1} | gA_D (32 rows)
+    float *tape;                       // [group of this chunk][tape_tile floats]: enc | h_1 .. h_D | gA_0 .. gA_{D-1} | gA_D (32 rows) | e (32)
     long long tape_tile;
-    long long tile0, ntiles;           // the chunk
+    long long tile0, ntiles;           // the chunk, in tiles of GEN_TG groups
     const float *dimages;
     float *slabs;
     long long slab_floats;
@@ -53,6 +60,7 @@ struct GenArgs {
 
 DEVI long long tape_h(const GenArgs &A, int l) { return (long long)A.Ep * 32 + (long long)(l - 1) * A.Wp * 32; }        // l = 1..D
 DEVI long long tape_ga(const GenArgs &A, int l) { return (long long)A.Ep * 32 + (long long)(A.D + l) * A.Wp * 32; }     // l = 0..D
+DEVI long long tape_e(const GenArgs &A) { return A.tape_tile - 32; }
 
 // acc (features 32 m .. 32 m + 31 x the 32 points) += sum_k K[k][32 m + i] in[k][point]: K rows `rows` (a multiple of 32)
 // of `stride` floats, `in` an LDS image [row][32].  Lane (i, h) feeds k = 2 t + h of every pair.
@@ -85,6 +93,10 @@ DEVI int gen_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 template <int MODE>
 __global__ __launch_bounds__(512) void gen_mlp_kernel(GenArgs A) {
+    constexpr bool FWD = MODE != GEN_CHAIN_TAPE;                             // runs the forward
+    constexpr bool REC = MODE == GEN_RECORD || MODE == GEN_CHAIN;            // writes the layer inputs to the tape
+    constexpr bool IMG = MODE == GEN_RENDER || MODE == GEN_RECORD;           // adds the ray sums to the images
+    constexpr bool BWD = MODE == GEN_CHAIN || MODE == GEN_CHAIN_TAPE;        // dout and the delta chain
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const FusedArgs &a = A.f;
     const int Wp = A.Wp, Ep = A.Ep, D = A.D, MTp = Wp >> 5;
@@ -92,15 +104,21 @@ __global__ __launch_bounds__(512) void gen_mlp_kernel(GenArgs A) {
     float *red = encS + Ep * 32;                       // [16][32] partial sums of the output layer
     float *doutv = red + 16 * 32;                      // [32]
     int *livev = reinterpret_cast<int *>(doutv + 32);  // [32]
-    char *seg = reinterpret_cast<char *>(livev + 32);  // RaySum<1> scratch
+    char *seg = reinterpret_cast<char *>(livev + 32);  // RaySum<GEN_TG> scratch
     const int tid = threadIdx.x, lane = tid & 63, pl = tid & 31, part = tid >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = (int)(blockDim.x >> 6), NP = (int)(blockDim.x >> 5), NT = (int)blockDim.x;
     const int li = lane & 31, lh = lane >> 5;
 
     for (long long tile = A.tile0 + blockIdx.x; tile < A.tile0 + A.ntiles; tile += gridDim.x) {
-        float *tp = MODE == GEN_CHAIN ? A.tape + (tile - A.tile0) * A.tape_tile : nullptr;
+      int tile_b = 0;
+      for (int g = 0; g < GEN_TG; ++g) {
+        float *tp = (REC || BWD) ? A.tape + ((tile - A.tile0) * GEN_TG + g) * A.tape_tile : nullptr;
         // ---- velocity warp + positional encoding of the group's 32 points (every 32-thread part holds all of them) ----
-        const PointIn q = load_point<1>(a, tile, 0, pl);
+        const PointIn q = load_point<GEN_TG>(a, tile, g, pl);
+        tile_b = q.b;
+        float *in = buf0, *out = buf1;
+        float e = 0.f;
+        if constexpr (FWD) {
         bool live;
         {
             const double tM = q.tM0d + (double)q.tg;                       // emission.py:200-201 (t_M in double)
@@ -136,10 +154,9 @@ __global__ __launch_bounds__(512) void gen_mlp_kernel(GenArgs A) {
             for (int r = A.F + part; r < Ep; r += NP) encS[r * 32 + pl] = 0.f;
         }
         __syncthreads();
-        if (MODE == GEN_CHAIN)
+        if (REC)
             for (int idx = tid; idx < Ep * 32; idx += NT) tp[idx] = encS[idx];
         // ---- hidden layers ----
-        float *in = buf0, *out = buf1;
         for (int l = 0; l < D; ++l) {
             const GenLayer Lr = A.L[l];
             for (int m = wv; m < MTp; m += nwv) {
@@ -153,37 +170,44 @@ __global__ __launch_bounds__(512) void gen_mlp_kernel(GenArgs A) {
                     const float v = acc[r] > 0.f ? acc[r] : 0.f;
                     const int o = (32 * m + gen_row(r, lh)) * 32 + li;
                     out[o] = v;
-                    if (MODE == GEN_CHAIN) tp[tape_h(A, l + 1) + o] = v;
+                    if (REC) tp[tape_h(A, l + 1) + o] = v;
                 }
             }
             __syncthreads();
             float *t = in; in = out; out = t;
         }
         // ---- output layer (column 0 of its [rows][32] image), sigmoid(. - 10), masks ----
-        const GenLayer Lo = A.L[D];
         {
+            const GenLayer Lo = A.L[D];
             const float *ko = A.pk + Lo.k_off;
             float s = 0.f;
             for (int k = part; k < Lo.hrows; k += NP) s += ko[(long long)k * 32] * in[k * 32 + pl];
             for (int k = part; k < Lo.erows; k += NP) s += ko[(long long)(Lo.hrows + k) * 32] * encS[k * 32 + pl];
             red[part * 32 + pl] = s;
+            __syncthreads();
+            if (tid < 32) {
+                float o = A.pk[Lo.b_off];
+                for (int p2 = 0; p2 < NP; ++p2) o += red[p2 * 32 + pl];
+                if (live) e = 1.f / (1.f + expf(10.f - o));                      // network.py:231-233
+                if (REC) tp[tape_e(A) + pl] = e;
+            }
         }
-        __syncthreads();
-        float e = 0.f;
-        if (tid < 32) {
-            float o = A.pk[Lo.b_off];
-            for (int p2 = 0; p2 < NP; ++p2) o += red[p2 * 32 + pl];
-            if (live) e = 1.f / (1.f + expf(10.f - o));                      // network.py:231-233
+        } else {
+            // ---- bhn_render_bwd_tape: e and h_D as the forward recorded them ----
+            if (tid < 32) e = tp[tape_e(A) + pl];
+            for (int idx = tid; idx < Wp * 32; idx += NT) in[idx] = tp[tape_h(A, D) + idx];
+            __syncthreads();
         }
         if (MODE == GEN_PREDICT) {
             if (tid < 32 && q.inb) a.emission[(long long)q.b * a.P + q.p] = e;
-        } else if (MODE == GEN_RENDER) {
-            if (wv == 0) RaySum<1>::put(a, seg, 0, q.p, q.inb, e, 0.f, false, q.b);
-            if (!a.ray_direct) {
-                __syncthreads();
-                if (wv == 0) RaySum<1>::combine(a, seg, 0, q.b);
-            }
-        } else {
+        }
+        if constexpr (IMG) {
+            // the group's ray segments: straight to the pixels where that is order-independent already (ray_direct), else to the
+            // tile's scratch (combined behind the eighth group)
+            if (wv == 0) RaySum<GEN_TG>::put(a, seg, g, q.p, q.inb, e, 0.f, false, q.b);
+        }
+        if constexpr (BWD) {
+            const GenLayer Lo = A.L[D];
             // ---- dout = d loss / d (pre-sigmoid output): dE e (1 - e), dE = sum_s dimages[b, s, ray] w[s, p] ----
             if (tid < 32) {
                 float d = 0.f;
@@ -201,9 +225,9 @@ __global__ __launch_bounds__(512) void gen_mlp_kernel(GenArgs A) {
             {
                 const float *ko = A.pk + Lo.k_off;
                 for (int idx = tid; idx < Wp * 32; idx += NT) {
-                    const float g = in[idx] > 0.f ? ko[(long long)(idx >> 5) * 32] * doutv[idx & 31] : 0.f;
-                    out[idx] = g;
-                    tp[tape_ga(A, D - 1) + idx] = g;
+                    const float gv = in[idx] > 0.f ? ko[(long long)(idx >> 5) * 32] * doutv[idx & 31] : 0.f;
+                    out[idx] = gv;
+                    tp[tape_ga(A, D - 1) + idx] = gv;
                 }
             }
             __syncthreads();
@@ -217,9 +241,9 @@ __global__ __launch_bounds__(512) void gen_mlp_kernel(GenArgs A) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int o = (32 * m + gen_row(r, lh)) * 32 + li;
-                        const float g = tp[tape_h(A, l) + o] > 0.f ? acc[r] : 0.f;
-                        out[o] = g;
-                        tp[tape_ga(A, l - 1) + o] = g;
+                        const float gv = tp[tape_h(A, l) + o] > 0.f ? acc[r] : 0.f;
+                        out[o] = gv;
+                        tp[tape_ga(A, l - 1) + o] = gv;
                     }
                 }
                 __syncthreads();
@@ -227,6 +251,14 @@ __global__ __launch_bounds__(512) void gen_mlp_kernel(GenArgs A) {
             }
         }
         __syncthreads();
+      }
+      if constexpr (IMG) {
+          // the tile's ray segments -> pixels: every ray of the tile gets ONE atomic, its segments added in group order
+          if (!a.ray_direct) {
+              for (int vw = wv; vw < GEN_TG; vw += nwv) RaySum<GEN_TG>::combine(a, seg, vw, tile_b);
+              __syncthreads();
+          }
+      }
     }
 }
 
@@ -253,7 +285,8 @@ __global__ __launch_bounds__(64) void gen_dw_kernel(GenArgs A) {
     f32x16 acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { const f32x16 z = {}; acc[j] = z; }
-    const long long t0 = A.ntiles * blockIdx.y / A.nsplit, t1 = A.ntiles * (blockIdx.y + 1) / A.nsplit;
+    const long long ngr = A.ntiles * GEN_TG;                              // groups of the chunk
+    const long long t0 = ngr * blockIdx.y / A.nsplit, t1 = ngr * (blockIdx.y + 1) / A.nsplit;
     for (long long t = t0; t < t1; ++t) {
         const float *tp = A.tape + t * A.tape_tile;
         f32x4 av[4], bv[4][4];
@@ -359,11 +392,11 @@ void gen_layout(const MlpShape &s, GenArgs *A) {
     for (int l = 0; l <= s.depth; ++l) njobs += (((A->L[l].hrows + A->L[l].erows) >> 5) + 1) * (((A->L[l].outp >> 5) + 3) >> 2);
     A->njobs = njobs;
     A->nsplit = std::min(256, std::max(8, (6144 + njobs - 1) / njobs));
-    A->tape_tile = (long long)Ep * 32 + 2ll * s.depth * Wp * 32 + 1024;
+    A->tape_tile = (long long)Ep * 32 + 2ll * s.depth * Wp * 32 + 1024 + 32;
     A->nparams = s.nparams;
 }
 
-size_t gen_lds_bytes(const GenArgs &A, int Sx) { return (size_t)(2 * A.Wp + A.Ep) * 32 * 4 + (16 * 32 + 64) * 4 + RaySum<1>::bytes(Sx); }
+size_t gen_lds_bytes(const GenArgs &A, int Sx) { return (size_t)(2 * A.Wp + A.Ep) * 32 * 4 + (16 * 32 + 64) * 4 + RaySum<GEN_TG>::bytes(Sx); }
 int gen_block(const GenArgs &A) { const int mt = A.Wp / 32; return mt >= 8 ? 512 : mt >= 4 ? 256 : 128; }
 
 template <int MODE>
@@ -400,11 +433,11 @@ int gen_pack_weights(const MlpShape &s, const float *params, void *packed, hipSt
 int fused_fill_args(const bhn_model *m, int32_t mode, const void *packed, const bhn_geom *geom, const bhn_frames *fr, bool need_w,
                     FusedArgs *a, MlpShape *s, int nwaves);     // fused_fwd.hip
 
-// FusedArgs for the general kernels: one 32-point group per tile
+// FusedArgs for the general kernels: tiles of GEN_TG consecutive 32-point groups of one frame
 static int gen_fill(const bhn_model *m, int32_t mode, const void *packed, const bhn_geom *geom, const bhn_frames *fr, bool need_w,
                     GenArgs *A, MlpShape *s) {
     memset(A, 0, sizeof(*A));
-    const int rc = fused_fill_args(m, mode, packed, geom, fr, need_w, &A->f, s, 1);
+    const int rc = fused_fill_args(m, mode, packed, geom, fr, need_w, &A->f, s, GEN_TG);
     if (rc != BHN_OK) return rc;
     gen_layout(*s, A);
     A->pk = reinterpret_cast<const float *>(packed);
@@ -413,8 +446,19 @@ static int gen_fill(const bhn_model *m, int32_t mode, const void *packed, const 
     return BHN_OK;
 }
 
+static size_t gen_align(size_t v) { return (v + 255) & ~(size_t)255; }
+static int gen_grid(const GenArgs &A, long long ntiles, int dev) {
+    const size_t lds = gen_lds_bytes(A, A.f.Sx);
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(160 * 1024 / lds, 2048 / gen_block(A)));
+    return (int)bhn_balanced_grid(ntiles, (long long)bhn_num_cus(dev) * per_cu);
+}
+// bytes of the gradient slabs / of the tape of ALL tiles of a call
+static size_t gen_slab_bytes(const GenArgs &A) { return gen_align((size_t)A.nsplit * A.slab_floats * 4); }
+static size_t gen_tape_bytes(const GenArgs &A, long long tiles) { return (size_t)tiles * GEN_TG * (size_t)A.tape_tile * 4; }
+
+// bhn_predict_fwd / bhn_render_fwd; with a workspace that holds the whole tape (bhn_render_fwd_train): the render that records it
 int gen_forward(bool render, const bhn_model *m, int32_t mode, const void *packed, const bhn_geom *geom, const bhn_frames *fr,
-                float *out, hipStream_t st) {
+                float *out, hipStream_t st, void *workspace, size_t workspace_bytes) {
     GenArgs A;
     MlpShape s;
     int rc = gen_fill(m, mode, packed, geom, fr, render, &A, &s);
@@ -422,12 +466,16 @@ int gen_forward(bool render, const bhn_model *m, int32_t mode, const void *packe
     int dev = 0;
     BHN_HIP(hipGetDevice(&dev));
     BHN_CHECK_DEVICE(dev);
-    const size_t lds = gen_lds_bytes(A, A.f.Sx);
-    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(160 * 1024 / lds, 2048 / gen_block(A)));
-    const int grid = (int)bhn_balanced_grid(A.ntiles, (long long)bhn_num_cus(dev) * per_cu);
+    const int grid = gen_grid(A, A.ntiles, dev);
     if (render) {
         A.f.images = out;
         BHN_HIP(hipMemsetAsync(out, 0, sizeof(float) * (size_t)A.f.B * A.f.Sx * A.f.R, st));
+        // the training forward records the tape when the workspace holds ALL of it (what bhn_render_bwd_tape then asks for);
+        // with a smaller workspace it is the plain render and the gradient comes from bhn_render_bwd, chunk by chunk
+        if (workspace && workspace_bytes >= gen_slab_bytes(A) + gen_tape_bytes(A, A.ntiles)) {
+            A.tape = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + gen_slab_bytes(A));
+            return gen_launch_mlp<GEN_RECORD>(A, grid, st);
+        }
         return gen_launch_mlp<GEN_RENDER>(A, grid, st);
     }
     A.f.emission = out;
@@ -435,22 +483,21 @@ int gen_forward(bool render, const bhn_model *m, int32_t mode, const void *packe
     return gen_launch_mlp<GEN_PREDICT>(A, grid, st);
 }
 
-static size_t gen_align(size_t v) { return (v + 255) & ~(size_t)255; }
-static constexpr long long GEN_MIN_CHUNK_TILES = 16;      // smallest tape chunk (32-point groups) gen_backward accepts
+static constexpr long long GEN_MIN_CHUNK_TILES = 2;       // smallest tape chunk (tiles of GEN_TG groups) gen_backward accepts
 
+// slabs + the tape of all B frames: what the training pair (bhn_render_fwd_train / bhn_render_bwd_tape) needs.  bhn_render_bwd
+// takes ANY workspace from slabs + 16 groups of tape on and walks the tiles in chunks (the tile -> (frame, group) map goes through
+// fd_tpf: a chunk may start and end anywhere) -- callers that cannot afford the whole tape (one frame of an 8x512 network on a
+// 256 x 256 x 128 ray set is 277 GB) allocate what they have and call that (engine.workspace).
 size_t gen_bwd_workspace_bytes(const MlpShape &s, int32_t B, int64_t P) {
     GenArgs A;
     gen_layout(s, &A);
-    const long long tiles = (P + 31) / 32 * B;
-    const size_t tile_bytes = (size_t)A.tape_tile * 4;
-    // the tape of one chunk of groups: all of them up to 2 GiB.  The chunk loop of gen_backward works for any chunk (the
-    // tile -> (frame, group) map goes through fd_tpf), so neither the query nor the call asks for a whole frame of tape: one
-    // frame of an 8x512 network on a 256 x 256 x 128 ray set would be 277 GB (round 5 did ask for it: ADVICE r5)
-    const size_t cap = (size_t)2 << 30;
-    return gen_align((size_t)A.nsplit * A.slab_floats * 4) + std::min<size_t>((size_t)tiles * tile_bytes, cap);
+    const long long tiles = ((P + 31) / 32 + GEN_TG - 1) / GEN_TG * B;
+    return gen_slab_bytes(A) + gen_tape_bytes(A, tiles);
 }
 
-int gen_backward(const bhn_model *m, int32_t mode, const void *packed, const bhn_geom *geom, const bhn_frames *fr,
+// tape_only: bhn_render_bwd_tape (the tape of the whole call was recorded by gen_forward); else bhn_render_bwd (recompute, chunks)
+int gen_backward(bool tape_only, const bhn_model *m, int32_t mode, const void *packed, const bhn_geom *geom, const bhn_frames *fr,
                  const float *dimages, float *dparams, void *workspace, size_t workspace_bytes, hipStream_t st) {
     GenArgs A;
     MlpShape s;
@@ -460,26 +507,25 @@ int gen_backward(const bhn_model *m, int32_t mode, const void *packed, const bhn
     int dev = 0;
     BHN_HIP(hipGetDevice(&dev));
     BHN_CHECK_DEVICE(dev);
-    const size_t slab_bytes = gen_align((size_t)A.nsplit * A.slab_floats * 4), tile_bytes = (size_t)A.tape_tile * 4;
-    // any chunk of groups will do (a floor of 16 only so that a launch is not empty-handed)
-    const long long min_tiles = std::min<long long>(A.f.total_tiles, GEN_MIN_CHUNK_TILES);
-    if (workspace_bytes < slab_bytes + (size_t)min_tiles * tile_bytes) {
-        bhn_set_error("render_bwd workspace too small: %zu bytes, need >= %zu (slabs %zu + %lld groups of tape)", workspace_bytes,
-                      slab_bytes + (size_t)min_tiles * tile_bytes, slab_bytes, min_tiles);
+    const size_t slab_bytes = gen_slab_bytes(A);
+    const long long min_tiles = tape_only ? A.f.total_tiles : std::min<long long>(A.f.total_tiles, GEN_MIN_CHUNK_TILES);
+    if (workspace_bytes < slab_bytes + gen_tape_bytes(A, min_tiles)) {
+        bhn_set_error(tape_only ? "the recorded-tape path needs a workspace for the whole tape (%zu bytes given, need >= %zu: slabs %zu + %lld groups of tape); "
+                                  "use bhn_render_fwd + bhn_render_bwd, which walk the groups in chunks"
+                                : "render_bwd workspace too small: %zu bytes, need >= %zu (slabs %zu + %lld groups of tape)",
+                      workspace_bytes, slab_bytes + gen_tape_bytes(A, min_tiles), slab_bytes, min_tiles * GEN_TG);
         return BHN_EWORKSPACE;
     }
     A.slabs = reinterpret_cast<float *>(workspace);
     A.tape = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + slab_bytes);
     A.dimages = dimages;
     A.dparams = dparams;
-    const long long chunk = std::min<long long>(A.f.total_tiles, (long long)((workspace_bytes - slab_bytes) / tile_bytes));
-    const size_t lds = gen_lds_bytes(A, A.f.Sx);
-    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(160 * 1024 / lds, 2048 / gen_block(A)));
+    const long long chunk = std::min<long long>(A.f.total_tiles, (long long)((workspace_bytes - slab_bytes) / gen_tape_bytes(A, 1)));
     for (long long c0 = 0; c0 < A.f.total_tiles; c0 += chunk) {
         A.tile0 = c0;
         A.ntiles = std::min<long long>(chunk, A.f.total_tiles - c0);
         A.accumulate = c0 > 0;
-        rc = gen_launch_mlp<GEN_CHAIN>(A, (int)bhn_balanced_grid(A.ntiles, (long long)bhn_num_cus(dev) * per_cu), st);
+        rc = tape_only ? gen_launch_mlp<GEN_CHAIN_TAPE>(A, gen_grid(A, A.ntiles, dev), st) : gen_launch_mlp<GEN_CHAIN>(A, gen_grid(A, A.ntiles, dev), st);
         if (rc != BHN_OK) return rc;
         hipLaunchKernelGGL(gen_dw_kernel, dim3(A.njobs, A.nsplit), dim3(64), 0, st, A);
         BHN_HIP(hipGetLastError());

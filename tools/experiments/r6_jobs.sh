@@ -8,6 +8,12 @@ cd $R
 
 # A/B of library variants on this box: step + kernel times, two interleaved rounds (tools/ab.sh)
 ab() { bash tools/ab.sh "$@" 2>&1 | grep -v amdgpu.ids; }
+# the same with the 4x128 block of bench.py: step, [training forward, fused backward], inference, of both networks
+ab128() {
+  for r in 1 2; do for l in "$@"; do echo -n "$l "; BHNERF_HIP_LIB=$C/$l python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-tutorial-domain --no-parity-mode --no-other-configs --no-tape8 2>/dev/null | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; w=d['width128']; rw=w['roofline']
+print('4x256 step %.3f' % d['ms_per_step'], [round(v,3) for v in r['kernel_ms'].values()], '| 4x128 step %.3f graph %.3f' % (w['ms_per_step'], w.get('ms_per_step_hip_graph', 0)), [round(v,3) for v in rw['kernel_ms'].values()])"; done; done
+}
 # one SQ counter pass (group 3: LDS) over the step's kernels for library $1, width $2
 lds_pass() {
   local lib=$1 width=${2:-256} tag=$3
@@ -55,6 +61,21 @@ print('fwd images/s', d.get('fwd_images_per_s'), 'cpu', {k: d['cpu_baseline'][k]
 print('general_path', d.get('general_path', {}).get('ms_per_step'), 'other', {k: v.get('ms_per_step') for k, v in d.get('other_configs', {}).items() if isinstance(v, dict)})
 PY
   for l in libbhnerf_hip_swz0.so libbhnerf_hip.so; do echo "== $l"; lds_pass $l 256 ${l%.so}; done | tee $O/lds.txt
+  ;;
+pairs)      # item 3: paired (sin, cos) slot layout of the encoded inputs -- parity, A/B on both networks, ablation of the 4x128 forward
+  python -m pytest tests -m gpu -x -q 2>&1 | tail -25 > $O/pytest.txt; tail -12 $O/pytest.txt
+  ab128 libbhnerf_hip_pairs0.so libbhnerf_hip.so | tee $O/ab.txt
+  python tools/dbg_fwd128_ablate.py 2>&1 | grep -v amdgpu.ids | tee $O/ablate128.txt
+  ;;
+flags)      # experiment (c): per-slot FULL / FREE words instead of the per-chunk barrier, 4x256 inference forward
+  BHNERF_HIP_LIB=$C/libbhnerf_hip_flags.so timeout 600 python -m pytest tests/test_gpu_forward.py tests/test_gpu_fullsize.py -m gpu -x -q 2>&1 | tail -6 | tee $O/pytest.txt
+  for r in 1 2 3; do for l in libbhnerf_hip.so libbhnerf_hip_flags.so; do BHNERF_HIP_LIB=$C/$l timeout 300 python tools/ab_infer.py 256 4 2>&1 | tail -1; done; done | tee $O/ab.txt
+  for l in libbhnerf_hip.so libbhnerf_hip_flags.so; do BHNERF_HIP_LIB=$C/$l timeout 300 python tools/ab_infer.py 256 8 2>&1 | tail -1; done | tee -a $O/ab.txt
+  for l in libbhnerf_hip.so libbhnerf_hip_flags.so; do echo "== $l"; lds_pass $l 256 ${l%.so}; done | grep -E "==|inference" | tee $O/sq.txt
+  ;;
+encw)       # resident-weights kernels stream KS fragments per chunk (encoded-input pair read in place): parity + A/B at 4x128
+  python -m pytest tests -m gpu -x -q 2>&1 | tail -8 > $O/pytest.txt; tail -4 $O/pytest.txt
+  ab128 libbhnerf_hip_encw0.so libbhnerf_hip.so | tee $O/ab.txt
   ;;
 *) echo "unknown job $J"; exit 1;;
 esac
