@@ -495,11 +495,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
     // (KS >= 8: the A-fragment prefetch of a step runs LDS_PREFETCH - 1 fragments into the NEXT chunk, which must have that many)
     using EB = EncBlock<W, Pol>;
     constexpr bool ENCR = MODE != MODE_CHAIN && EB::ON && !RES;
-#ifndef BHN_RES_ENCW
-#define BHN_RES_ENCW 1           // 0: the resident training forward streams all KS + 2 fragments of every chunk (rounds 4-5; A/B builds)
-#endif
-    constexpr bool ENCW = BHN_RES_ENCW != 0 && MODE != MODE_CHAIN && EB::ON && RES;     // (fused_common.h: hidden_layer ENC_IN_CHUNK)
-    constexpr int NFR = ((MODE == MODE_CHAIN && KS >= 8) || ENCR || ENCW) ? KS : KS + 2;
+    constexpr int NFR = ((MODE == MODE_CHAIN && KS >= 8) || ENCR) ? KS : KS + 2;
     using RG = DmaRing<RES ? CB : NFR * Pol::FRAG_BYTES, Pol::NWAVES, GA0C>;     // (GA0C: transposed LDS reads in the kernel -> asm DMA)
     constexpr int DIST = GA0C ? BHN_GA0C_DIST : BG::RING_DIST_TAPED;
     using RS = std::conditional_t<RES, ResidentRing<RG, CB, MT>, RingState<RG, CB, DIST, false, MT, BHN_CHAIN_STAMPS != 0>>;
@@ -734,7 +730,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) void chain_kernel(BwdArgs A) {
                     const float *bn = (out || (m == MT - 1 && l + 1 > a.depth)) ? nullptr : bl + 32 * (m + 1);
                     if (out) bn = bias_lds;                           // next tile, layer 0
                     const f32x16 acc = ring_step<W, Pol, RG, TapePost<Pol, true>, NFR>(ch, chn, ap, act, enc, sk, bn, post, dj, sdbg,
-                                                                                       ENCW ? ch + KS * Pol::FRAG_BYTES : encblk + 2 * (out ? MT : m) * Pol::FRAG_BYTES);
+                                                                                       encblk + 2 * (out ? MT : m) * Pol::FRAG_BYTES);
                     // without the h_1 emission the interval after this layer's first DMA issue holds no store: the
                     // three step ends that count it allow one emission less in flight (small widths: none)
                     if (drop_h1 && l == 1 && m <= 2) rs.template step_end<YS_L1>();

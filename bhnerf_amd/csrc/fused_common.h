@@ -613,38 +613,7 @@ struct DmaJob {
     int wvu;                                    // the issuing wave's index, held in an SGPR by the ring (hipcc otherwise
                                                 // re-derives it from threadIdx with v_readfirstlane + shifts in every step)
     u32x4 rsa;                                  // the same resource as four dwords (DmaRing<.., ASM = true>)
-    // RG::FLAGS (EXPERIMENT, -DBHN_RING_FLAGS=1): per-slot handshake words in LDS instead of the per-chunk workgroup barrier
-    unsigned free_w = 0u, free_need = 0u;       // LDS byte address of the NW FREE words of the slot the DMA overwrites; value they must have reached
-    unsigned full_w = 0u, full_need = 0u;       // ... of the NW FULL words of the NEXT chunk's slot (read from k-step KS - PF + 1 on)
 };
-
-// ---- EXPERIMENT (round 6; -DBHN_RING_FLAGS=1, bf16 width-256 inference forward only) ------------------------
-// The ring's per-chunk workgroup barrier replaced by per-slot words in LDS: FULL[slot][wave] = c + 1 once that wave's DMA pieces of
-// chunk c have landed (behind its counted vmcnt wait), FREE[slot][wave] = c + 1 once it has read the last fragment of chunk c.  A
-// wave reads chunk c + 1's head (its A prefetch) only when all FULL words of that slot have reached c + 2, and overwrites the slot
-// of chunk c - 1 (DMA of chunk c + DIST) only when all FREE words of it have reached c: the eight waves -- and in particular the two
-// of a SIMD -- may then drift up to ~0.8 ring steps apart instead of meeting at every chunk.
-#ifndef BHN_RING_FLAGS
-#define BHN_RING_FLAGS 0
-#endif
-typedef __attribute__((address_space(3))) unsigned lds_u32;
-DEVI unsigned lds_addr(const void *p) { return (unsigned)reinterpret_cast<unsigned long long>(p); }      // (LDS byte address = low half of the flat address)
-DEVI unsigned flag_read(unsigned words, int nw) {
-    return *reinterpret_cast<volatile lds_u32 *>((unsigned long long)(words + 4u * ((threadIdx.x & 63) & (nw - 1))));
-}
-template <int NW>
-DEVI void flag_wait(unsigned words, unsigned need, unsigned first) {
-    static_assert((NW & (NW - 1)) == 0, "waves per workgroup: a power of two");
-    // fast path: the words fetched a few k-steps ago already say yes (a COUNTED lgkmcnt wait: the A fragments fetched behind them
-    // stay in flight; as one loop hipcc drains the whole LDS queue in front of every check)
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64((int)(first - need) < 0) != 0, 0)) {
-        unsigned v;
-        do {
-            __builtin_amdgcn_s_sleep(1);
-            v = flag_read(words, NW);                                    // (every lane reads one of the NW words)
-        } while (__builtin_amdgcn_ballot_w64((int)(v - need) < 0));
-    }
-}
 
 // Work folded into the MFMA shadows of a ring step ("Post" objects): at(t) is called right after MFMA t of the
 // step (t is a constant after unrolling) when the layer has >= 16 k-steps, all() before the first MFMA otherwise.
@@ -720,23 +689,13 @@ DEVI f32x16 ring_step(const char *ch, const char *chn, APipe<Pol> &ap, const typ
     if constexpr (ZB) { const f32x16 z = {}; acc = z; } else acc = ap.bias;
     const bool do_post = !(dbg & 2), do_mma = !(dbg & 1);
     if (do_post && KS < 16) post.all();
-    [[maybe_unused]] unsigned fw_free = 0u, fw_full = 0u;
-    static_assert(!RG::FLAGS || (KS >= 16 && NF == KS && PF == 4), "ring flags: built for the 16-fragment steps of width 256");
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < KS; ++t) {
         prio_flip(t, dma.wvu);
         a[(t + PF - 1) % PF] = stream_frag<Pol, NF>(ch, chn, t + PF - 1, lane);
-        if constexpr (RG::FLAGS) {        // the handshake words are fetched four k-steps ahead of their use
-            if (t == 5 && dma.on) fw_free = flag_read(dma.free_w, RG::NW);
-            if (t == 8) fw_full = flag_read(dma.full_w, RG::NW);
-        }
         if (do_mma) acc = Pol::mma(a[t % PF], src[t], acc);
         if (do_post && KS >= 16) post.at(t);
-        if constexpr (RG::FLAGS) {
-            if (t == 9 && dma.on) flag_wait<RG::NW>(dma.free_w, dma.free_need, fw_free);
-            if (t == 12) flag_wait<RG::NW>(dma.full_w, dma.full_need, fw_full);      // k-step 13 reads the next chunk's first fragment
-        }
         if (t == (KS >= 16 ? 9 : 0) && dma.on) RG::issue(dma);
         if constexpr (!ZB) { if (t == (KS >= 16 ? 13 : 0)) ap.bias = bias_acc(bias_next, 0, lane >> 5); }   // next tile's bias, before the barrier
         __builtin_amdgcn_sched_barrier(0);
@@ -830,11 +789,9 @@ DEVI void dma_1k_asm(const char *src, char *dst) {
 
 // ASM: the pieces are issued from inline asm (dma_1k_asm's reason: kernels that also read LDS with ds_read_b64_tr_b16 -- the
 // builtin carries no memory operand and hipcc's waitcnt pass then drains EVERY LDS-DMA it knows about in front of each such read)
-template <int CHUNK_BYTES, int NWAVES, bool ASM_ = false, bool FLAGS_ = false>
+template <int CHUNK_BYTES, int NWAVES, bool ASM_ = false>
 struct DmaRing {
     static constexpr bool ASM = ASM_;
-    static constexpr bool FLAGS = FLAGS_;      // per-slot handshake words instead of the per-chunk barrier (BHN_RING_FLAGS experiment)
-    static constexpr int NW = NWAVES;
     static constexpr int NPIECE = CHUNK_BYTES / 1024;
     static constexpr int PPW = (NPIECE + NWAVES - 1) / NWAVES;
     static_assert(CHUNK_BYTES % 1024 == 0, "chunks are whole KiB");
@@ -925,12 +882,6 @@ struct RingState {
     // and rotated at the step end (3 SALU) instead of being derived from `cur` each time (three wrap()s and multiplies:
     // ~25 of the 140-190 instructions of a ring step, round-2 ISA census).
     int o_cur, o_nxt, o_prv, wvu;
-    // RG::FLAGS: handshake words FULL[NB][NW], FREE[NB][NW] (LDS byte addresses), chunks consumed so far, slot of the running chunk
-    static constexpr bool FLAGS = RG::FLAGS;
-    static_assert(!FLAGS || !LAG, "ring flags: no phase lag");
-    static constexpr int FLAG_BYTES = 2 * NB * RG::NW * 4;
-    unsigned fl_full, fl_free;
-    int seq, s_cur;
     DEVI const char *ch() const { return ring + opaque(LAG ? wrap(cur - lag) * CBL : o_cur); }
     DEVI const char *chn() const { return ring + opaque(LAG ? wrap(cur - lag + 1) * CBL : o_nxt); }
     DEVI unsigned next_src() {
@@ -945,12 +896,7 @@ struct RingState {
     }
     DEVI DmaJob job() {
         if (dbg & 4) return DmaJob{false, 0u, nullptr, rs, wvu, rsa};
-        DmaJob j{true, next_src(), ring + (LAG ? wrap(cur - 2) * CBL : o_prv), rs, wvu, rsa};
-        if constexpr (FLAGS) {
-            j.free_w = fl_free + (unsigned)(wrap(s_cur - 1) * RG::NW * 4); j.free_need = (unsigned)seq;          // chunk seq - 1 released by every wave
-            j.full_w = fl_full + (unsigned)(wrap(s_cur + 1) * RG::NW * 4); j.full_need = (unsigned)seq + 2u;     // chunk seq + 1 landed for every wave
-        }
-        return j;
+        return DmaJob{true, next_src(), ring + (LAG ? wrap(cur - 2) * CBL : o_prv), rs, wvu, rsa};
     }
     // STORES: global stores this wave is GUARANTEED to have issued after the DMA pieces of chunk c+2 (issued in the
     // middle of step c-2) other than the two younger chunks: vmcnt retires in order and counts stores, so they may
@@ -960,16 +906,7 @@ struct RingState {
         long long t1 = 0;
         if (STAMPS && ts) t1 = __builtin_readcyclecounter();
         if (!(dbg & 4)) RG::template wait_younger<RG::PPW * (DIST - 2) + STORES>();
-        if constexpr (FLAGS) {
-            // this wave's pieces of chunk seq + 2 have landed (the wait above); its reads of chunk seq have all returned (the step's
-            // last MFMA consumed the last fragment) and the two stores queue behind them in the wave's LDS stream
-            if ((threadIdx.x & 63) == 0) {
-                *reinterpret_cast<volatile lds_u32 *>((unsigned long long)(fl_free + (unsigned)((s_cur * RG::NW + wvu) * 4))) = (unsigned)seq + 1u;
-                *reinterpret_cast<volatile lds_u32 *>((unsigned long long)(fl_full + (unsigned)((wrap(s_cur + 2) * RG::NW + wvu) * 4))) = (unsigned)seq + 3u;
-            }
-            ++seq;
-            s_cur = wrap(s_cur + 1);
-        } else if (!(dbg & 8)) lds_barrier();
+        if (!(dbg & 8)) lds_barrier();
         if (STAMPS && ts) {
             const long long t3 = __builtin_readcyclecounter();
             if ((threadIdx.x & 63) == 0) { ts[0] = t1; ts[1] = t3; }
@@ -984,11 +921,10 @@ struct RingState {
     }
     DEVI void idle_step() {      // a step in which this wave consumes nothing (lagging waves: first; the others: last)
         const DmaJob j = job();
-        if constexpr (FLAGS) { if (j.on) flag_wait<RG::NW>(j.free_w, j.free_need, flag_read(j.free_w, RG::NW)); }
         if (j.on) RG::issue(j);
         step_end();
     }
-    DEVI void start(char *ring_, const char *a_, int nca, const char *b_, int nlb_, int dbg_, int lag_, char *flags_ = nullptr) {
+    DEVI void start(char *ring_, const char *a_, int nca, const char *b_, int nlb_, int dbg_, int lag_) {
         ring = ring_; img_a = a_; NCA = nca; nlb = nlb_; NC = nca + nlb_ * MT;
         off_b = b_ ? (unsigned)(b_ - a_) : 0u;                  // (the transposed image follows the forward image)
         rs = RG::resource(a_);
@@ -999,18 +935,7 @@ struct RingState {
         if constexpr (BHN_PRIO_MODE == 1) { if (wvu >= 4) __builtin_amdgcn_s_setprio(1); }
 #pragma unroll
         for (int j = 0; j < DIST; ++j) RG::issue(DmaJob{true, next_src(), ring + j * CBL, rs, wvu, rsa});
-        if constexpr (FLAGS) {
-            // chunks 0 .. DIST - 1 are in slots 0 .. DIST - 1: all of this wave's pieces landed, its FULL words say so; nothing released yet
-            fl_full = (unsigned)opaque((int)__builtin_amdgcn_readfirstlane(lds_addr(flags_))); fl_free = fl_full + (unsigned)(NB * RG::NW * 4);
-            seq = opaque(0); s_cur = opaque(0);                  // (wave-uniform state: kept in SGPRs)
-            RG::template wait_younger<0>();
-            if ((threadIdx.x & 63) == 0) {
-                for (int j = 0; j < NB; ++j) {
-                    *reinterpret_cast<volatile lds_u32 *>((unsigned long long)(fl_full + (unsigned)((j * RG::NW + wvu) * 4))) = j < DIST ? (unsigned)j + 1u : 0u;
-                    *reinterpret_cast<volatile lds_u32 *>((unsigned long long)(fl_free + (unsigned)((j * RG::NW + wvu) * 4))) = 0u;
-                }
-            }
-        } else RG::template wait_younger<RG::PPW * (DIST - 2)>();
+        RG::template wait_younger<RG::PPW * (DIST - 2)>();
         lds_barrier();
     }
 };
@@ -1084,7 +1009,6 @@ DEVI void layer0_step(RS &rs, APipe<Pol> &ap, const typename Pol::frag (&enc)[2]
     for (int i = 0; i < PF - 1; ++i) a[i] = ap.f[i];
     f32x16 prev = {};
     f32x16 acc = ap.bias;
-    [[maybe_unused]] unsigned fw_free = 0u, fw_full = 0u;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const f32x16 nb = bias_acc(bias_lds + 32 * (m + 1), 0, h);       // tile m+1 (m = MT-1: first tile of layer 1)
@@ -1095,13 +1019,6 @@ DEVI void layer0_step(RS &rs, APipe<Pol> &ap, const typename Pol::frag (&enc)[2]
             acc = Pol::mma(a[t % PF], enc[ks], acc);
         }
         if (m > 0) l0.tile(m - 1, prev, act[2 * (m > 0 ? m - 1 : 0)], act[2 * (m > 0 ? m - 1 : 0) + 1]);
-        if constexpr (RG::FLAGS) {        // (width 256: MT = 8 tiles of two k-steps; tile 6's second k-step reads the next chunk's first fragment)
-            static_assert(!RG::FLAGS || (MT == 8 && NF == KS && PF == 4), "ring flags: width 256");
-            if (m == 0 && dj.on) fw_free = flag_read(dj.free_w, RG::NW);
-            if (m == 3) fw_full = flag_read(dj.full_w, RG::NW);
-            if (m == 1 && dj.on) flag_wait<RG::NW>(dj.free_w, dj.free_need, fw_free);
-            if (m == 5) flag_wait<RG::NW>(dj.full_w, dj.full_need, fw_full);
-        }
         if (m == (MT > 1 ? 1 : 0) && dj.on) RG::issue(dj);
         __builtin_amdgcn_sched_barrier(0);
         prev = acc;
@@ -1119,10 +1036,7 @@ DEVI void layer0_step(RS &rs, APipe<Pol> &ap, const typename Pol::frag (&enc)[2]
 // hidden layer l: src -> dst.  On entry `pend` is the last tile of the previous layer (destination src[KS-2],
 // src[KS-1]); on exit it is this layer's last tile (destination dst[KS-2], dst[KS-1]).  bl = this layer's bias
 // rows; the rows of the next layer (or of the output layer) follow them at bl + W.
-// ENC_IN_CHUNK (resident weight images streamed as KS fragments per chunk, round 6): the tile's two encoded-input weight fragments
-// are read where they lie, behind the chunk's KS hidden fragments -- and only by the one layer that uses them.  (Rounds 4-5
-// streamed all KS + 2 fragments of every chunk through the prefetch pipe: at width 128 a fifth of the kernel's LDS reads.)
-template <int W, class Pol, class RG, class RS, int NFR = W / 16 + 2, bool ENC_IN_CHUNK = false>
+template <int W, class Pol, class RG, class RS, int NFR = W / 16 + 2>
 DEVI void hidden_layer(RS &rs, APipe<Pol> &ap, typename Pol::frag (&src)[W / 16], typename Pol::frag (&dst)[W / 16],
                        const typename Pol::frag (&enc)[2], bool sk, const float *bl, f32x16 &pend, const char *encblk = nullptr) {
     constexpr int KS = W / 16, MT = W / 32;
@@ -1132,7 +1046,7 @@ DEVI void hidden_layer(RS &rs, APipe<Pol> &ap, typename Pol::frag (&src)[W / 16]
         const DmaJob dj = rs.job();
         PackPost<Pol> post(pend, m == 0 ? src[KS - 2] : dst[2 * (m > 0 ? m - 1 : 0)], m == 0 ? src[KS - 1] : dst[2 * (m > 0 ? m - 1 : 0) + 1]);
         const f32x16 acc = ring_step<W, Pol, RG, PackPost<Pol>, NFR>(ch, chn, ap, src, enc, sk, bl + 32 * (m + 1), post, dj, rs.dbg,
-                                                                     ENC_IN_CHUNK ? ch + KS * Pol::FRAG_BYTES : encblk + 2 * m * Pol::FRAG_BYTES);
+                                                                     encblk + 2 * m * Pol::FRAG_BYTES);
         rs.step_end();
         pend = acc;
     }

@@ -152,14 +152,8 @@ __global__ __launch_bounds__(Pol::NTHREADS) __attribute__((amdgpu_waves_per_eu(P
     constexpr int CB = PK::CHUNK_BYTES, MT = PK::MT, KS = PK::KS;
     using EB = EncBlock<W, Pol>;
     constexpr bool ENCR = EB::ON && !RES;                           // the ring copies the hidden fragments only; encoded-input block resident (EncBlock)
-#ifndef BHN_RES_ENCW
-#define BHN_RES_ENCW 1           // 0: resident kernels stream all KS + 2 fragments of every chunk (rounds 4-5; A/B builds)
-#endif
-    constexpr bool ENCW = BHN_RES_ENCW != 0 && EB::ON && RES && !DBG;   // resident image: KS streamed fragments per chunk, the encoded-input pair read in place
-    constexpr int NFR = (ENCR || ENCW) ? KS : KS + 2;
-    // EXPERIMENT (-DBHN_RING_FLAGS=1): per-slot handshake words instead of the per-chunk barrier, bf16 width 256 (fused_common.h)
-    constexpr bool RFLAGS = BHN_RING_FLAGS != 0 && ENCR && W == 256 && Pol::NWAVES == 8 && !DBG && !Pol::PHASE_LAG;
-    using RG = DmaRing<ENCR ? KS * Pol::FRAG_BYTES : CB, Pol::NWAVES, false, RFLAGS>;
+    constexpr int NFR = ENCR ? KS : KS + 2;
+    using RG = DmaRing<ENCR ? KS * Pol::FRAG_BYTES : CB, Pol::NWAVES>;
     constexpr int DIST = Pol::FWD_DIST;                                                // LDS-DMA weight ring: chunks in flight
     using RS = std::conditional_t<RES, ResidentRing<RG, CB, MT>, RingState<RG, CB, DIST, Pol::PHASE_LAG, MT, DBG>>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -175,8 +169,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) __attribute__((amdgpu_waves_per_eu(P
 
     // weight ring (LDS-DMA), software-pipelined steps: fused_common.h "Software-pipelined ring steps"
     RS rs;
-    if constexpr (RFLAGS) rs.start(ring, a.packed + a.fwd_off, PK::fwd_chunks(a.depth), nullptr, 0, dbg, 0, encblk + EB::BYTES);
-    else rs.start(ring, a.packed + a.fwd_off, PK::fwd_chunks(a.depth), nullptr, 0, dbg, (wv >= Pol::NWAVES / 2 && !(a.debug & 64)) ? 1 : 0);
+    rs.start(ring, a.packed + a.fwd_off, PK::fwd_chunks(a.depth), nullptr, 0, dbg, (wv >= Pol::NWAVES / 2 && !(a.debug & 64)) ? 1 : 0);
     if (rs.lag) rs.idle_step();
     APipe<Pol> ap;
     ap.prime(rs.ch(), bias_lds);
@@ -211,7 +204,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) __attribute__((amdgpu_waves_per_eu(P
             // every step then paid ~1000 cycles of instruction fetch); the price is 56 v_mov per layer
 #pragma nounroll
             for (int l = 1; l < a.depth; ++l) {
-                hidden_layer<W, Pol, RG, RS, NFR, ENCW>(rs, ap, act, next, enc, (a.skip_mask >> l) & 1, bias_lds + l * W, pend, encblk);
+                hidden_layer<W, Pol, RG, RS, NFR>(rs, ap, act, next, enc, (a.skip_mask >> l) & 1, bias_lds + l * W, pend, encblk);
 #pragma unroll
                 for (int ks = 0; ks < KS - 2; ++ks) act[ks] = next[ks];      // the pending tile lands in act[KS-2], act[KS-1]
             }
@@ -220,7 +213,7 @@ __global__ __launch_bounds__(Pol::NTHREADS) __attribute__((amdgpu_waves_per_eu(P
             const DmaJob dj = rs.job();
             PackPost<Pol> post(pend, act[KS - 2], act[KS - 1]);
             const f32x16 acc = ring_step<W, Pol, RG, PackPost<Pol>, NFR>(ch, chn, ap, act, enc, (a.skip_mask >> a.depth) & 1, bias_lds /* next tile, layer 0 */, post, dj, dbg,
-                                                                         ENCW ? ch + KS * Pol::FRAG_BYTES : encblk + 2 * MT * Pol::FRAG_BYTES);
+                                                                         encblk + 2 * MT * Pol::FRAG_BYTES);
             outv = acc[0];
             rs.step_end();
         }
@@ -508,7 +501,7 @@ static int launch_fwd_w(FusedArgs &a, hipStream_t st) {
     constexpr bool ENCR = EncBlock<W, Pol>::ON && !RES;             // (the kernel's own condition)
     const size_t lds = RES ? (size_t)PK::fwd_chunks(a.depth) * PK::CHUNK_BYTES + lds_fixed
                            : (size_t)(Pol::FWD_DIST + (Pol::PHASE_LAG ? 2 : 1)) * (ENCR ? (size_t)PK::KS * Pol::FRAG_BYTES : (size_t)PK::CHUNK_BYTES) + lds_fixed +
-                             (ENCR ? (size_t)EncBlock<W, Pol>::BYTES : 0) + (BHN_RING_FLAGS != 0 ? 1024 : 0);
+                             (ENCR ? (size_t)EncBlock<W, Pol>::BYTES : 0);
     auto kern = fused_fwd_kernel<W, Pol, 3, RENDER, DBG, RES>;
     int dev = 0;
     BHN_HIP(hipGetDevice(&dev));
