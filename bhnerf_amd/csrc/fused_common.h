@@ -1038,15 +1038,16 @@ DEVI void layer0_step(RS &rs, APipe<Pol> &ap, const typename Pol::frag (&enc)[2]
 // rows; the rows of the next layer (or of the output layer) follow them at bl + W.
 template <int W, class Pol, class RG, class RS, int NFR = W / 16 + 2>
 DEVI void hidden_layer(RS &rs, APipe<Pol> &ap, typename Pol::frag (&src)[W / 16], typename Pol::frag (&dst)[W / 16],
-                       const typename Pol::frag (&enc)[2], bool sk, const float *bl, f32x16 &pend, const char *encblk = nullptr) {
+                       const typename Pol::frag (&enc)[2], bool sk, const float *bl, f32x16 &pend, const char *encblk) {
     constexpr int KS = W / 16, MT = W / 32;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const char *ch = rs.ch(), *chn = rs.chn();
         const DmaJob dj = rs.job();
         PackPost<Pol> post(pend, m == 0 ? src[KS - 2] : dst[2 * (m > 0 ? m - 1 : 0)], m == 0 ? src[KS - 1] : dst[2 * (m > 0 ? m - 1 : 0) + 1]);
-        const f32x16 acc = ring_step<W, Pol, RG, PackPost<Pol>, NFR>(ch, chn, ap, src, enc, sk, bl + 32 * (m + 1), post, dj, rs.dbg,
-                                                                     encblk + 2 * m * Pol::FRAG_BYTES);
+        const char *encw = nullptr;                     // (only the KS-fragment streams read the resident encoded-input block)
+        if constexpr (NFR == KS) encw = encblk + 2 * m * Pol::FRAG_BYTES;
+        const f32x16 acc = ring_step<W, Pol, RG, PackPost<Pol>, NFR>(ch, chn, ap, src, enc, sk, bl + 32 * (m + 1), post, dj, rs.dbg, encw);
         rs.step_end();
         pend = acc;
     }

@@ -313,20 +313,38 @@ class GraphedImageStep:
         for t, k in zip((st.flat, st.m, st.v), keep):
             t.copy_(k)
         graph = torch.cuda.CUDAGraph()
+        captured, why = True, None
         try:
             with torch.cuda.graph(graph):
                 self.loss, self.lossv, self.buf = self._body()
-        except Exception:
+        except RuntimeError as exc:                       # (what a failed stream capture raises; anything else is a bug and propagates)
             if not self.collective_in_graph:
                 raise
-            # the collective refused capture: keep the exchange and Adam outside the graph
-            self.collective_in_graph, self.with_adam = False, False
-            torch.cuda.synchronize(self.eng.device)
-            for t, k in zip((st.flat, st.m, st.v), keep):
-                t.copy_(k)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                self.loss, self.lossv, self.buf = self._body()
+            captured, why = False, exc
+        if self.collective_in_graph:
+            # The ranks must AGREE on where the exchange runs: a rank that fell back on its own would issue the collective
+            # eagerly while the others replay it inside their graphs -- another operation order, a hang.  One eager all-reduce
+            # (MIN) of the outcome; if any rank could not capture the collective, every rank keeps the exchange and Adam
+            # outside the graph and captures again.
+            rank, world = network._world()
+            if world > 1:
+                import torch.distributed as dist
+                flag = torch.tensor([1.0 if captured else 0.0], device=self.eng.device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                everywhere = bool(flag.item() > 0)
+            else:
+                everywhere = captured
+            if not everywhere:
+                import warnings
+                warnings.warn('hip_graph: the gradient all-reduce could not be captured into the step graph on %s (%r); the exchange and '
+                              'Adam stay outside the graph on every rank' % ('this rank' if not captured else 'another rank', why))
+                self.collective_in_graph, self.with_adam = False, False
+                torch.cuda.synchronize(self.eng.device)
+                for t, k in zip((st.flat, st.m, st.v), keep):
+                    t.copy_(k)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    self.loss, self.lossv, self.buf = self._body()
         for t, k in zip((st.flat, st.m, st.v), keep):                          # (capture does not execute, but stay safe)
             t.copy_(k)
         self.graph = graph

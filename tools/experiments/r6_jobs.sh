@@ -77,5 +77,11 @@ encw)       # resident-weights kernels stream KS fragments per chunk (encoded-in
   python -m pytest tests -m gpu -x -q 2>&1 | tail -8 > $O/pytest.txt; tail -4 $O/pytest.txt
   ab128 libbhnerf_hip_encw0.so libbhnerf_hip.so | tee $O/ab.txt
   ;;
+dwub)       # experiment (a), upper bound first: the dW kernel with the LDS traffic of 4 x 4 register blocking (every second B fragment
+            # not read: results wrong), with the LBITS / DROP_HD byte cut, and with both; + the general path's tests and step time
+  python -m pytest tests/test_gpu_backward.py -m gpu -x -q -k "general or outside" 2>&1 | tail -12 | tee $O/pytest.txt
+  ab libbhnerf_hip.so libbhnerf_hip_rd.so libbhnerf_hip_lb.so libbhnerf_hip_lbrd.so | tee $O/ab.txt
+  python tools/general_path_bench.py 8 2 2>&1 | grep -v amdgpu | tail -8 | tee $O/general.txt
+  ;;
 *) echo "unknown job $J"; exit 1;;
 esac
