@@ -151,18 +151,6 @@ struct PolBF16T8 : PolBF16 {
     static constexpr bool TAPE8 = true;
 };
 
-// PolBF16 on HALF-size workgroups: 4 waves (one per SIMD, 256 registers each), TWO workgroups per CU, each with its own weight
-// ring.  The two waves of a SIMD then belong to different workgroups: no barrier couples them, their per-tile prologues and
-// epilogues drift apart and the wave that wins the issue arbitration no longer waits for the one that loses it.
-struct PolBF16H : PolBF16 {
-    static constexpr int NWAVES = 4;
-    static constexpr int NTHREADS = NWAVES * 64;
-#ifndef BHN_FWD_DIST_H
-#define BHN_FWD_DIST_H 3
-#endif
-    static constexpr int FWD_DIST = BHN_FWD_DIST_H;      // (DIST + 1) chunks per workgroup: two workgroups must fit 160 KB
-};
-
 // PolBF16 on 12-wave workgroups (three per SIMD) for the two forward kernels of the fused 4x128 path (round 5): at width 128 the
 // forward is bound by per-point vector work and its latencies, not by the matrix pipe -- a third wave per SIMD
 // hides more of them (inference -5 %, training forward -5 %; 146 / 167 of the 170 registers a wave may have at that occupancy).

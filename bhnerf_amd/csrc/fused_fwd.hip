@@ -237,179 +237,6 @@ __global__ __launch_bounds__(Pol::NTHREADS) __attribute__((amdgpu_waves_per_eu(P
 }
 
 // ---------------------------------------------------------------------------------------------
-// Wide forward (EXPERIMENT, only with -DBHN_WIDE_FWD; not part of the product build): 4 waves x 64 points.  Every A
-// fragment read from LDS feeds TWO MFMAs (two independent accumulator chains per wave, one wave per SIMD, up to 512
-// registers): half the LDS fragment reads, waits, ring bookkeeping and barriers per MFMA of the 8 x 32 kernel, whose time
-// is 64 % LDS fragment stream.  bf16 only; same tile -> group map (a workgroup tile = 8 consecutive groups).
-// MEASURED (round 2, same box): 3.55 ms against 3.00 ms -- 18 % SLOWER, as a first version in round 1 was.  The ISA
-// shows why: 481 registers, so half of the activations live in AGPRs, which the VALU cannot read or write: 51
-// v_accvgpr_read/write per step and ~250 at every layer boundary; a step is 256 instructions for 36 MFMAs, and a
-// single wave per SIMD issues one instruction per 4 cycles: 1024 cycles of issue against 1152 of MFMA with nothing to
-// overlap them.  Kept as a record of the experiment (results equal: tests/test_gpu_forward.py pass with it).
-// ---------------------------------------------------------------------------------------------
-template <int W, class Pol, class RG>
-DEVI void wide_step(const char *ch, const char *chn, APipe<Pol> &ap, const typename Pol::frag (&s0)[W / 16], const typename Pol::frag (&s1)[W / 16],
-                    const typename Pol::frag (&e0)[2], const typename Pol::frag (&e1)[2], bool with_enc, f32x16 &acc0, f32x16 &acc1,
-                    const float *bias_next, PackPost<Pol> &p0, PackPost<Pol> &p1, DmaJob dma) {
-    const int lane = threadIdx.x & 63;
-    constexpr int KS = W / 16, NF = KS + 2, PF = Pol::LDS_PREFETCH;
-    typename Pol::frag a[PF];
-#pragma unroll
-    for (int i = 0; i < PF - 1; ++i) a[i] = ap.f[i];
-    acc0 = ap.bias; acc1 = ap.bias;
-    if (KS < 16) { p0.all(); p1.all(); }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int t = 0; t < KS; ++t) {
-        a[(t + PF - 1) % PF] = stream_frag<Pol, NF>(ch, chn, t + PF - 1, lane);
-        acc0 = Pol::mma(a[t % PF], s0[t], acc0);
-        acc1 = Pol::mma(a[t % PF], s1[t], acc1);
-        if (KS >= 16) { p0.at(t); p1.at(t); }
-        if (t == (KS >= 16 ? 9 : 0) && dma.on) RG::issue(dma);
-        if (t == (KS >= 16 ? 13 : 0)) ap.bias = bias_acc(bias_next, 0, lane >> 5);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int t = KS; t < NF; ++t) {
-        a[(t + PF - 1) % PF] = stream_frag<Pol, NF>(ch, chn, t + PF - 1, lane);
-        if (with_enc) {
-            acc0 = Pol::mma(a[t % PF], e0[t - KS], acc0);
-            acc1 = Pol::mma(a[t % PF], e1[t - KS], acc1);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int i = 0; i < PF - 1; ++i) ap.f[i] = a[(NF + i) % PF];
-}
-
-// NW = 8, RES (the product's forward of width <= 128 networks whose weight image fits LDS, launch_fwd_pair): eight waves
-// x 64 points over the RESIDENT weight image.  There the register argument above does not apply -- two activation sets of a
-// 128-wide layer are 128 registers, everything fits the 256 VGPRs of a wave at two waves per SIMD -- and the LDS argument
-// does: one 1-KiB A fragment per MFMA and wave is exactly the LDS bandwidth of a CU; feeding two MFMAs per
-// fragment halves it.
-template <int W, class Pol, int DEG, bool RENDER, int NW = 4, bool RES = false>
-__global__ __launch_bounds__(NW * 64) void fused_fwd_wide_kernel(FusedArgs a) {
-    using PK = Pack<W, Pol>;
-    using frag = typename Pol::frag;
-    static_assert(Pol::ELEM_BYTES == 2, "bf16");
-    constexpr int CB = PK::CHUNK_BYTES, MT = PK::MT, KS = PK::KS, NF = KS + 2, PF = Pol::LDS_PREFETCH, VW = 2 * NW;
-    using RG = DmaRing<CB, NW>;
-    constexpr int DIST = BHN_FWD_DIST;
-    using RS = std::conditional_t<RES, ResidentRing<RG, CB, MT>, RingState<RG, CB, DIST, false, MT, false>>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *ring = smem;
-    float *bias_lds = reinterpret_cast<float *>(smem + RS::lds_bytes(PK::fwd_chunks(a.depth)));
-    char *seg_lds = reinterpret_cast<char *>(bias_lds + (a.depth + 1) * W);
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 31, h = lane >> 5;
-    for (int i = tid; i < (a.depth + 1) * W; i += NW * 64) bias_lds[i] = reinterpret_cast<const float *>(a.packed + a.bias_off)[i];
-    RS rs;
-    rs.start(ring, a.packed + a.fwd_off, PK::fwd_chunks(a.depth), nullptr, 0, 0, 0);
-    APipe<Pol> ap;
-    ap.prime(rs.ch(), bias_lds);
-    // wave wv owns the 32-point groups 2 wv and 2 wv + 1 of the workgroup tile (virtual waves of a 2 NW-group tile)
-    PointIn nx0 = load_point<VW>(a, blockIdx.x, 2 * wv, pl), nx1 = load_point<VW>(a, blockIdx.x, 2 * wv + 1, pl);
-    for (long long tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
-        const PointIn in0 = nx0, in1 = nx1;
-        frag enc0[2], enc1[2];
-        bool live0, live1;
-        point_prologue<Pol, DEG>(a, in0, enc0, live0);
-        point_prologue<Pol, DEG>(a, in1, enc1, live1);
-        nx0 = load_point<VW>(a, tile + gridDim.x, 2 * wv, pl);
-        nx1 = load_point<VW>(a, tile + gridDim.x, 2 * wv + 1, pl);
-        float w00 = 0.f, w01 = 0.f;
-        if (RENDER && h == 0 && in0.inb) w00 = a.w[in0.p];
-        if (RENDER && h == 0 && in1.inb) w01 = a.w[in1.p];
-        frag act0[KS], act1[KS], nxt0[KS], nxt1[KS];
-        f32x16 pend0, pend1;
-        // ---- layer 0: fragment 2m+ks of chunk 0, B = enc[ks]; tile m-1 is packed behind the MFMAs of tile m
-        {
-            const char *ch = rs.ch(), *chn = rs.chn();
-            const DmaJob dj = rs.job();
-            frag af[PF];
-#pragma unroll
-            for (int i = 0; i < PF - 1; ++i) af[i] = ap.f[i];
-            f32x16 prev0 = {}, prev1 = {};
-            f32x16 c0 = ap.bias, c1 = ap.bias;
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const f32x16 nb = bias_acc(bias_lds + 32 * (m + 1), 0, h);
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const int t = 2 * m + ks;
-                    af[(t + PF - 1) % PF] = stream_frag<Pol, NF>(ch, chn, t + PF - 1, lane);
-                    c0 = Pol::mma(af[t % PF], enc0[ks], c0);
-                    c1 = Pol::mma(af[t % PF], enc1[ks], c1);
-                }
-                if (m > 0) {
-                    unsigned mk = 0;
-                    pack_elems<Pol, 0, 16>(prev0, act0[2 * (m > 0 ? m - 1 : 0)], act0[2 * (m > 0 ? m - 1 : 0) + 1], mk);
-                    pack_elems<Pol, 0, 16>(prev1, act1[2 * (m > 0 ? m - 1 : 0)], act1[2 * (m > 0 ? m - 1 : 0) + 1], mk);
-                }
-                if (m == (MT > 1 ? 1 : 0) && dj.on) RG::issue(dj);
-                __builtin_amdgcn_sched_barrier(0);
-                prev0 = c0; prev1 = c1;
-                c0 = nb; c1 = nb;
-            }
-#pragma unroll
-            for (int t = KS; t < NF; ++t) af[(t + PF - 1) % PF] = stream_frag<Pol, NF>(ch, chn, t + PF - 1, lane);
-#pragma unroll
-            for (int i = 0; i < PF - 1; ++i) ap.f[i] = af[(NF + i) % PF];
-            ap.bias = c0;
-            pend0 = prev0; pend1 = prev1;
-            rs.step_end();
-        }
-        // ---- hidden layers: ping-pong act <-> nxt
-#pragma nounroll
-        for (int l = 1; l < a.depth; ++l) {
-            const bool sk = (a.skip_mask >> l) & 1;
-            const float *bl = bias_lds + l * W;
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const char *ch = rs.ch(), *chn = rs.chn();
-                const DmaJob dj = rs.job();
-                PackPost<Pol> p0(pend0, m == 0 ? act0[KS - 2] : nxt0[2 * (m > 0 ? m - 1 : 0)], m == 0 ? act0[KS - 1] : nxt0[2 * (m > 0 ? m - 1 : 0) + 1]);
-                PackPost<Pol> p1(pend1, m == 0 ? act1[KS - 2] : nxt1[2 * (m > 0 ? m - 1 : 0)], m == 0 ? act1[KS - 1] : nxt1[2 * (m > 0 ? m - 1 : 0) + 1]);
-                f32x16 c0, c1;
-                wide_step<W, Pol, RG>(ch, chn, ap, act0, act1, enc0, enc1, sk, c0, c1, bl + 32 * (m + 1), p0, p1, dj);
-                rs.step_end();
-                pend0 = c0; pend1 = c1;
-            }
-#pragma unroll
-            for (int ks = 0; ks < KS - 2; ++ks) { act0[ks] = nxt0[ks]; act1[ks] = nxt1[ks]; }
-        }
-        float out0, out1;
-        {
-            const char *ch = rs.ch(), *chn = rs.chn();
-            const DmaJob dj = rs.job();
-            PackPost<Pol> p0(pend0, act0[KS - 2], act0[KS - 1]);
-            PackPost<Pol> p1(pend1, act1[KS - 2], act1[KS - 1]);
-            f32x16 c0, c1;
-            wide_step<W, Pol, RG>(ch, chn, ap, act0, act1, enc0, enc1, (a.skip_mask >> a.depth) & 1, c0, c1, bias_lds, p0, p1, dj);
-            out0 = c0[0]; out1 = c1[0];
-            rs.step_end();
-        }
-        float e0 = 0.f, e1 = 0.f;
-        if (h == 0 && live0) e0 = 1.f / (1.f + Pol::fexp(10.f - out0));
-        if (h == 0 && live1) e1 = 1.f / (1.f + Pol::fexp(10.f - out1));
-        if (!RENDER) {
-            if (h == 0 && in0.inb) a.emission[(long long)in0.b * a.P + in0.p] = e0;
-            if (h == 0 && in1.inb) a.emission[(long long)in1.b * a.P + in1.p] = e1;
-        } else {
-            RaySum<VW>::put(a, seg_lds, 2 * wv, in0.p, in0.inb, e0, w00, true, in0.b);
-            RaySum<VW>::put(a, seg_lds, 2 * wv + 1, in1.p, in1.inb, e1, w01, true, in1.b);
-            if (!a.ray_direct) {
-                lds_barrier();
-                RaySum<VW>::combine(a, seg_lds, 2 * wv, in0.b);
-                RaySum<VW>::combine(a, seg_lds, 2 * wv + 1, in1.b);
-                if constexpr (RES) lds_barrier();      // (no ring barriers between this tile's combine and the next tile's segment sums)
-            }
-        }
-    }
-    rs.idle_step();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 int fused_fill_args(const bhn_model *m, int32_t mode, const void *packed, const bhn_geom *geom,
@@ -462,36 +289,12 @@ int fused_fill_args(const bhn_model *m, int32_t mode, const void *packed, const 
     return BHN_OK;
 }
 
-#ifdef BHN_WIDE_FWD
-template <int W, class Pol, bool RENDER>
-static int launch_fwd_wide(FusedArgs &a, hipStream_t st) {
-    using PK = Pack<W, Pol>;
-    const size_t lds = (size_t)(BHN_FWD_DIST + 1) * PK::CHUNK_BYTES + (size_t)(a.depth + 1) * W * 4 + RaySum<8>::bytes(a.Sx);
-    auto kern = fused_fwd_wide_kernel<W, Pol, 3, RENDER>;
-    int dev = 0;
-    BHN_HIP(hipGetDevice(&dev));
-    BHN_CHECK_DEVICE(dev);
-    static DeviceOnce once;
-    BHN_HIP(once.run(dev, [&](int &occ) {
-        occ = 1;
-        return hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    }));
-    long long grid = (long long)bhn_num_cus(dev);
-    if (grid > a.total_tiles) grid = a.total_tiles;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, a);
-    BHN_HIP(hipGetLastError());
-    return BHN_OK;
-}
-#endif
 
 #ifndef BHN_RESIDENT
 #define BHN_RESIDENT 1           // 0: never keep the weight image resident in LDS (A/B builds)
 #endif
 template <int W, class Pol, bool RENDER, bool DBG = false, bool RES = false>
 static int launch_fwd_w(FusedArgs &a, hipStream_t st) {
-#ifdef BHN_WIDE_FWD
-    if constexpr (Pol::ELEM_BYTES == 2 && W == 256 && !DBG) return launch_fwd_wide<W, Pol, RENDER>(a, st);
-#endif
     using PK = Pack<W, Pol>;
     const size_t lds_fixed = (size_t)(a.depth + 1) * W * 4 + RaySum<Pol::NWAVES>::bytes(a.Sx);
     if constexpr (!RES && !DBG && W <= 128 && BHN_RESIDENT != 0 && Pol::ELEM_BYTES == 2) {     // (f32, one wave per SIMD: measured 11 % slower resident)
@@ -521,64 +324,12 @@ static int launch_fwd_w(FusedArgs &a, hipStream_t st) {
     return BHN_OK;
 }
 
-// ---- 64 points per wave over a resident weight image (fused_fwd_wide_kernel<.., 8, true>): bf16 networks of width <= 128 whose
-//      forward image, biases and the ray-sum scratch of 16 point groups fit LDS.  A workgroup tile is 16 groups: the caller
-//      fills FusedArgs with nwaves = 16 (fwd_tile_groups). ----
-//      EXPERIMENT (-DBHN_FWD_PAIR=1; round 4, one box): 4x128 render 0.995 -> 0.914 ms, 8x64 0.767 -> 0.665, but 4x64 0.404 ->
-//      0.445 and 6x32 0.314 -> 0.357 (the small kernels are bound by their point prologue, not by LDS), and the images of
-//      `render` are no longer bit-identical to the training forward's (16-group instead of 8-group tiles: another summation
-//      order for rays that straddle a tile).  Not in the product build.
-#ifndef BHN_FWD_PAIR
-#define BHN_FWD_PAIR 0
-#endif
-static bool fwd_pair_ok(int mode, const MlpShape &s, int Sx) {
-    if (!BHN_FWD_PAIR || mode != BHN_BF16 || s.width > 128) return false;
-    const size_t chunk = (size_t)(s.width / 16 + 2) * PolBF16::FRAG_BYTES, chunks = 1 + (size_t)(s.depth - 1) * (s.width / 32) + 1;
-    return chunks * chunk + (size_t)(s.depth + 1) * s.width * 4 + RaySum<16>::bytes(Sx) <= 160 * 1024;
-}
-#ifndef BHN_FWD_HALF
-#define BHN_FWD_HALF 0           // 1: bf16 width-256 forward on half-size workgroups, two per CU (PolBF16H)
-#endif
+// 32-point groups per workgroup tile of the forward kernels a model and ray set take (fused_fill_args: nwaves)
 static int fwd_tile_groups(const bhn_model *m, int mode, const bhn_geom *geom) {
     MlpShape s;
-    if (m && geom && bhn_mlp_shape(m, &s) == BHN_OK && fwd_pair_ok(mode, s, geom->S > 0 ? geom->S : 1)) return 16;
-    if (BHN_FWD_HALF && mode == BHN_BF16 && m && bhn_mlp_shape(m, &s) == BHN_OK && s.width == 256) return PolBF16H::NWAVES;
     if (m && bhn_mlp_shape(m, &s) == BHN_OK && !s.general && bhn_fwd_w12(mode, s.width, s.depth, bhn_groups_per_frame(geom))) return PolBF16X::NWAVES;
     return (mode == BHN_BF16) ? PolBF16::NWAVES : PolF32::NWAVES;
 }
-#if BHN_FWD_PAIR
-template <int W, bool RENDER>
-static int launch_fwd_pair_w(FusedArgs &a, hipStream_t st) {
-    using PK = Pack<W, PolBF16>;
-    const size_t lds = (size_t)PK::fwd_chunks(a.depth) * PK::CHUNK_BYTES + (size_t)(a.depth + 1) * W * 4 + RaySum<16>::bytes(a.Sx);
-    auto kern = fused_fwd_wide_kernel<W, PolBF16, 3, RENDER, 8, true>;
-    int dev = 0;
-    BHN_HIP(hipGetDevice(&dev));
-    BHN_CHECK_DEVICE(dev);
-    static DeviceOnce once;
-    BHN_HIP(once.run(dev, [&](int &occ) {
-        occ = 1;
-        return hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    }));
-    long long grid = (long long)bhn_num_cus(dev);
-    if (grid > a.total_tiles) grid = a.total_tiles;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, st, a);
-    BHN_HIP(hipGetLastError());
-    return BHN_OK;
-}
-template <bool RENDER>
-static int launch_fwd_pair(FusedArgs &a, int width, hipStream_t st) {
-    switch (width) {
-        case 32: return launch_fwd_pair_w<32, RENDER>(a, st);
-        case 64: return launch_fwd_pair_w<64, RENDER>(a, st);
-        case 128: return launch_fwd_pair_w<128, RENDER>(a, st);
-        default: bhn_set_error("internal: paired forward at width %d", width); return BHN_EINVAL;
-    }
-}
-#else
-template <bool RENDER>
-static int launch_fwd_pair(FusedArgs &, int, hipStream_t) { return BHN_EINVAL; }
-#endif
 
 template <class Pol, bool RENDER>
 static int launch_fwd(FusedArgs &a, int width, hipStream_t st) {
@@ -591,8 +342,7 @@ static int launch_fwd(FusedArgs &a, int width, hipStream_t st) {
             }
             return launch_fwd_w<128, Pol, RENDER>(a, st);
         case 256:
-            if constexpr (BHN_FWD_HALF != 0 && Pol::ELEM_BYTES == 2) return launch_fwd_w<256, PolBF16H, RENDER>(a, st);
-            else return launch_fwd_w<256, Pol, RENDER>(a, st);
+            return launch_fwd_w<256, Pol, RENDER>(a, st);
         default:
             bhn_set_error("net_width %d: fused kernels are built for 32, 64, 128, 256", width);
             return BHN_EUNSUPPORTED;
@@ -636,7 +386,6 @@ extern "C" int bhn_predict_fwd(const bhn_model *m, int32_t mode, const void *pac
     a.emission = emission;
     if (geom->groups)   // points of skipped groups are outside the domain: emission 0
         BHN_HIP(hipMemsetAsync(emission, 0, sizeof(float) * (size_t)a.B * a.P, (hipStream_t)stream));
-    if (nw == 16) return launch_fwd_pair<false>(a, s.width, (hipStream_t)stream);
     return mode == BHN_BF16 ? launch_fwd<PolBF16, false>(a, s.width, (hipStream_t)stream)
                             : launch_fwd<PolF32, false>(a, s.width, (hipStream_t)stream);
 }
@@ -669,7 +418,6 @@ extern "C" int bhn_render_fwd(const bhn_model *m, int32_t mode, const void *pack
                                       : launch_fwd_w<128, PolBF16, true, true, true>(a, (hipStream_t)stream);
     }
 #endif
-    if (nw == 16) return launch_fwd_pair<true>(a, s.width, (hipStream_t)stream);
     return mode == BHN_BF16 ? launch_fwd<PolBF16, true>(a, s.width, (hipStream_t)stream)
                             : launch_fwd<PolF32, true>(a, s.width, (hipStream_t)stream);
 }
