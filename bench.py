@@ -54,7 +54,7 @@ sys.path.insert(0, os.path.join(ROOT, 'tools'))
 from kernel_names import short_name, FWD_NAME, CHAIN_NAME, FUSED_NAME, INFER_NAME      # (kernel names as rocprofv3 prints them)
 
 PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}      # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
-PROFILE_TAG = 'r5'                                  # profiles/<tag>_pmc_traffic.json etc. (tools/collect_profiles.sh)
+PROFILE_TAG = 'r6'                                  # profiles/<tag>_pmc_traffic.json etc. (tools/collect_profiles.sh)
 
 
 def mlp_flops(depth, width, F=21):
@@ -858,7 +858,7 @@ def main():
       except Exception as exc:
         width128 = {'error': repr(exc)}
 
-    # ---- a network OUTSIDE the fused kernels' range (posenc_deg 5: csrc/general_mlp.hip, f32 whatever the mode), same geometry ----
+    # ---- a network OUTSIDE the fused kernels' range (posenc_deg 5: csrc/general_mlp.hip, its bf16 kernels), same geometry ----
     general_path = None
     if world == 1 and std and not args.no_width128:
       try:
@@ -872,10 +872,10 @@ def main():
         dt = (time.perf_counter() - t0) / 4
         fg = mlp_flops(4, 128, F=33)[3]
         general_path = {'workload': 'config-2 geometry, 4x128 MLP with posenc_deg 5 (33 encoded inputs): the general layer-by-layer path, DESIGN.md 4.7',
-                        'dtype': 'f32 (v_mfma_f32_32x32x2_f32; the bf16 mode computes in f32 on this path)', 'ms_per_step': round(1e3 * dt, 3),
+                        'dtype': 'bf16 (v_mfma_f32_32x32x16_bf16 on fragment-ordered operands: gen_mlp16_kernel / gen_dw16_kernel, round 6)', 'ms_per_step': round(1e3 * dt, 3),
                         'value': round(samples_step / dt, 1), 'unit': 'ray-samples/s', 'steps': 4,
                         'step_algorithmic_tflops': round(fg * samples_step / dt / 1e12, 2),
-                        'step_mfma_frac': round(fg * samples_step / dt / 1e12 / PEAK_TFLOPS['f32'], 4), 'peak_tflops': PEAK_TFLOPS['f32']}
+                        'step_mfma_frac': round(fg * samples_step / dt / 1e12 / PEAK_TFLOPS['bf16'], 4), 'peak_tflops': PEAK_TFLOPS['bf16']}
         del opt_g, pred_g
         torch.cuda.empty_cache()
       except Exception as exc:

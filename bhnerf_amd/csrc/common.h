@@ -95,11 +95,11 @@ int bhn_mlp_shape(const bhn_model *m, MlpShape *s);   // validates, returns BHN_
 // general_mlp.hip: the f32 layer-by-layer path of the shapes the fused kernels are not built for (MlpShape::general)
 #define BHN_GEN_DEG_MAX 10     // 3 + 6 deg <= 63 encoded features
 #define BHN_GEN_WIDTH_MAX 512
-size_t gen_packed_bytes(const MlpShape &s);
-int gen_pack_weights(const MlpShape &s, const float *params, void *packed, hipStream_t st);
+size_t gen_packed_bytes(const MlpShape &s, int32_t mode);
+int gen_pack_weights(const MlpShape &s, int32_t mode, const float *params, void *packed, hipStream_t st);
 int gen_forward(bool render, const bhn_model *m, int32_t mode, const void *packed, const bhn_geom *geom, const bhn_frames *fr,
                 float *out, hipStream_t st, void *workspace = nullptr, size_t workspace_bytes = 0);     // (workspace: bhn_render_fwd_train records the tape)
-size_t gen_bwd_workspace_bytes(const MlpShape &s, int32_t B, int64_t P);
+size_t gen_bwd_workspace_bytes(const MlpShape &s, int32_t mode, int32_t B, int64_t P);
 int gen_backward(bool tape_only, const bhn_model *m, int32_t mode, const void *packed, const bhn_geom *geom, const bhn_frames *fr,
                  const float *dimages, float *dparams, void *workspace, size_t workspace_bytes, hipStream_t st);
 

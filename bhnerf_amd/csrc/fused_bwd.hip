@@ -2614,7 +2614,7 @@ extern "C" size_t bhn_render_bwd_workspace_bytes(const bhn_model *m, int32_t mod
     MlpShape s;
     if (bhn_mlp_shape(m, &s) != BHN_OK || B <= 0 || P <= 0) return 0;
     size_t q = 0;
-    if (s.general && (mode & 0xff) != BHN_BF16_T8) return gen_bwd_workspace_bytes(s, B, P);
+    if (s.general && (mode & 0xff) != BHN_BF16_T8) return gen_bwd_workspace_bytes(s, mode, B, P);
     if ((mode & 0xff) == BHN_BF16_T8 && bhn_norm_mode(mode) == BHN_BF16) {
         if (s.general || s.width != 256 || s.depth < 3) {
             bhn_set_error("BHN_BF16_T8 (8-bit tape) is built for net_width 256 and net_depth >= 3 (got %d x %d); use BHN_BF16", s.depth, s.width_true);

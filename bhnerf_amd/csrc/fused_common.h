@@ -153,7 +153,8 @@ struct PolBF16T8 : PolBF16 {
 
 // PolBF16 on 12-wave workgroups (three per SIMD) for the two forward kernels of the fused 4x128 path (round 5): at width 128 the
 // forward is bound by per-point vector work and its latencies, not by the matrix pipe -- a third wave per SIMD
-// hides more of them (inference -5 %, training forward -5 %; 146 / 167 of the 170 registers a wave may have at that occupancy).
+// hides more of them (one box, profiles/r5_ab_twelve_waves_width128.txt: inference forward 0.92 -> 0.85 ms, -7 %; training forward
+// 1.43 -> 1.25 ms, -12 %; 146 / 167 of the 170 registers a wave may have at that occupancy).
 // The training forward and the inference forward share the tile size: `render` and `render_train` give bit-identical images.
 #ifndef BHN_W12
 #define BHN_W12 1

@@ -29,7 +29,7 @@ extern "C" size_t bhn_packed_bytes(const bhn_model *m, int32_t mode) {
     mode = bhn_norm_mode(mode);
     MlpShape s;
     if (bhn_mlp_shape(m, &s) != BHN_OK) return 0;
-    if (s.general) return gen_packed_bytes(s);
+    if (s.general) return gen_packed_bytes(s, bhn_norm_mode(mode));
     PackedLayout L;
     packed_layout(s, mode, &L);
     return L.total;
@@ -127,7 +127,7 @@ extern "C" int bhn_pack_weights(const bhn_model *m, int32_t mode, const float *p
     PackArgs a;
     int rc = bhn_mlp_shape(m, &a.s);
     if (rc != BHN_OK) return rc;
-    if (a.s.general) return gen_pack_weights(a.s, params, packed, (hipStream_t)stream);
+    if (a.s.general) return gen_pack_weights(a.s, mode, params, packed, (hipStream_t)stream);
     packed_layout(a.s, mode, &a.L);
     a.mode = mode;
     a.params = params;

@@ -39,8 +39,22 @@ struct GenLayer {
     long long pk_off, pb_off;
 };
 
+// bf16 mode (round 6): byte offsets of the bf16 fragment images behind the f32 image, and of the parts of one group's tape
+struct Gen16 {
+    unsigned f_off[BHN_MAX_LAYERS];    // forward A fragments of layer l: [output tile m][k-step over (hidden | encoded) inputs][1 KiB]
+    unsigned t_off[BHN_MAX_LAYERS];    // transposed A fragments (delta chain through layer l, 1 <= l < D): [input tile][k-step over outputs][1 KiB]
+    int ksf[BHN_MAX_LAYERS];           // k-steps of the forward image of layer l: (hrows + erows) / 16
+    unsigned image_off, image_bytes;   // the bf16 images inside the packed buffer
+    // tape of one 32-point group: encT | hT_1 .. hT_D | gaT_0 .. gaT_{D-1} | relu bits of h_1 .. h_D | e | dout; "T" tiles are 2 KiB with
+    // the FEATURE on the lane and 16 points in the two fragments: the operand layout of the weight-gradient GEMMs (K = points)
+    long long encT, hT, gaT, bits, e, dout, bytes;
+};
+
 struct GenArgs {
     FusedArgs f;
+    Gen16 g16;
+    int bf16;                          // 1: the bf16 kernels (mode BHN_BF16)
+    char *tape16;
     GenLayer L[BHN_MAX_LAYERS];
     int D, Wp, Ep, F;
     const float *pk;                   // packed image
@@ -365,6 +379,390 @@ __global__ void gen_pack_fill_kernel(GenArgs A) {
     }
 }
 
+// =============================================================================================================================
+// bf16 mode (BHN_BF16) of the general path, round 6: v_mfma_f32_32x32x16_bf16 with every operand in MFMA fragment order.
+//   * weights: bf16 fragment images (gen_pack16_kernel), the A operand straight from L2 / L1 -- one 16-byte load per lane and
+//     MFMA, shared by the NG groups a workgroup runs side by side (NG accumulator tiles per wave);
+//   * activations: per group two LDS images of B fragments ([k-step][lane][8 bf16]); as in the fused kernels the accumulator of
+//     an output tile IS the pair of B fragments of the next layer's k-steps 2 m, 2 m + 1 (fused_common.h), so a finished tile is
+//     relu'd, rounded and written back with two ds_write_b128;
+//   * tape: what the weight-gradient GEMMs (K = points) read -- layer inputs and pre-activation gradients as 2-KiB "T" tiles
+//     (feature on the lane, 16 points in the two fragments), transposed on the way out by two MFMAs against identity fragments
+//     (exact: one product by 1.0 per element) -- plus the relu bits, e and dout.  gen_dw16_kernel loads its operands from it with
+//     16-byte global loads: no LDS, no conversions.  2.2 KB per point at 4x128 / degree 5 (f32 tape: 4.4 KB).
+// Same tiles of eight groups, the same modes, slabs and reduce as the f32 kernels above.
+// =============================================================================================================================
+typedef __bf16 g16frag __attribute__((ext_vector_type(8)));
+
+DEVI g16frag g16_ident(int s, int lane) {          // identity k-step s: element j of lane (n, h) is 1 where 16 s + phi16(h, j) == n
+    const int n = lane & 31, h = lane >> 5;
+    g16frag f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (phi16(h, j) + 16 * s == n) ? (__bf16)1.f : (__bf16)0.f;
+    return f;
+}
+// a 32-feature block held as two B fragments (point on the lane) -> its T tile in global memory (feature on the lane; register r of
+// the transposed accumulator is point (r & 3) + 8 (r >> 2) + 4 (lane >> 5): fragment s element j = point (j & 3) + 8 (j >> 2) + 16 s + 4 h)
+DEVI void g16_store_T(char *tile, const g16frag &f0, const g16frag &f1, const g16frag (&id)[2], int lane) {
+    f32x16 t = {};
+    t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, id[0], t, 0, 0, 0);
+    t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1, id[1], t, 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        g16frag o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (__bf16)t[8 * s + j];
+        *reinterpret_cast<g16frag *>(tile + s * 1024 + lane * 16) = o;
+    }
+}
+// the point a T-tile fragment element stands for
+DEVI int g16_point(int s, int j, int h) { return (j & 3) + 8 * (j >> 2) + 16 * s + 4 * h; }
+
+__global__ void gen_pack16_kernel(GenArgs A) {
+    // from the f32 image gen_pack_fill_kernel has just written (zero-padded [rows][outp] per layer)
+    const long long gtid = blockIdx.x * (long long)blockDim.x + threadIdx.x, gn = (long long)gridDim.x * blockDim.x;
+    __bf16 *img = reinterpret_cast<__bf16 *>(reinterpret_cast<char *>(A.packed_out) + A.g16.image_off);
+    for (int l = 0; l <= A.D; ++l) {
+        const GenLayer Lr = A.L[l];
+        const int ksf = A.g16.ksf[l];
+        const long long nf = (long long)(Lr.outp / 32) * ksf * 512;
+        for (long long idx = gtid; idx < nf; idx += gn) {
+            const int j = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+            const long long frag = idx >> 9;
+            const int m = (int)(frag / ksf), ks = (int)(frag - (long long)m * ksf);
+            const int k = 16 * ks + phi16(lane >> 5, j), o = 32 * m + (lane & 31);
+            img[A.g16.f_off[l] / 2 + idx] = (__bf16)A.packed_out[Lr.k_off + (long long)k * Lr.outp + o];
+        }
+        if (l >= 1 && l < A.D) {
+            const int kst = Lr.outp / 16;
+            const long long nt = (long long)(Lr.hrows / 32) * kst * 512;
+            for (long long idx = gtid; idx < nt; idx += gn) {
+                const int j = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+                const long long frag = idx >> 9;
+                const int m = (int)(frag / kst), ks = (int)(frag - (long long)m * kst);
+                const int kin = 32 * m + (lane & 31), o = 16 * ks + phi16(lane >> 5, j);
+                img[A.g16.t_off[l] / 2 + idx] = (__bf16)A.packed_out[Lr.k_off + (long long)kin * Lr.outp + o];
+            }
+        }
+    }
+}
+
+// acc[g] += sum over `nks` k-steps of A fragment (global image, 1 KiB apart) x B fragment of group g (LDS image `bbase + g * slot`)
+template <int NG>
+DEVI void g16_ksteps(f32x16 (&acc)[NG], const char *afrag, const char *bbase, int slot, int nks, int lane) {
+    const char *ap = afrag + lane * 16;
+    const char *bp = bbase + lane * 16;
+    g16frag an = *reinterpret_cast<const g16frag *>(ap);
+    for (int ks = 0; ks < nks; ++ks) {
+        const g16frag a = an;
+        if (ks + 1 < nks) an = *reinterpret_cast<const g16frag *>(ap + (long long)(ks + 1) * 1024);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const g16frag b = *reinterpret_cast<const g16frag *>(bp + g * slot + ks * 1024);
+            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[g], 0, 0, 0);
+        }
+    }
+}
+
+template <int MODE, int NG>
+__global__ __launch_bounds__(512) void gen_mlp16_kernel(GenArgs A) {
+    constexpr bool FWD = MODE != GEN_CHAIN_TAPE, REC = MODE == GEN_RECORD || MODE == GEN_CHAIN;
+    constexpr bool IMG = MODE == GEN_RENDER || MODE == GEN_RECORD, BWD = MODE == GEN_CHAIN || MODE == GEN_CHAIN_TAPE;
+    static_assert(GEN_TG % NG == 0, "a tile is a whole number of rounds");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const FusedArgs &a = A.f;
+    const Gen16 &G = A.g16;
+    const int Wp = A.Wp, Ep = A.Ep, D = A.D, MTp = Wp >> 5;
+    const int BUF = Wp * 64, SLOT = 2 * BUF + Ep * 64;                    // per group: two activation images + the encoded inputs (B fragments)
+    float *ev = reinterpret_cast<float *>(smem + NG * SLOT);              // [NG][32]
+    float *doutv = ev + NG * 32;
+    int *livev = reinterpret_cast<int *>(doutv + NG * 32);
+    char *seg = reinterpret_cast<char *>(livev + NG * 32);                // RaySum<GEN_TG> scratch
+    const int tid = threadIdx.x, lane = tid & 63, pl = tid & 31, part = tid >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = (int)(blockDim.x >> 6), NP = (int)(blockDim.x >> 5), NT = (int)blockDim.x;
+    const int li = lane & 31, lh = lane >> 5;
+    const char *pk16 = reinterpret_cast<const char *>(A.pk) + G.image_off;
+    g16frag id[2] = {g16_ident(0, lane), g16_ident(1, lane)};
+    // the unused slots of the encoded-input images stay zero for the whole launch
+    for (int idx = tid; idx < NG * Ep * 16; idx += NT) {
+        const int g = idx / (Ep * 16), w = idx - g * (Ep * 16);
+        reinterpret_cast<unsigned *>(smem + g * SLOT + 2 * BUF)[w] = 0u;
+    }
+    __syncthreads();
+    auto enc_put = [&](char *encb, int q, int pt, float v) {             // feature q of point pt -> its place in the B fragments
+        const int s = q >> 4, c = q & 15, h = (c >> 2) & 1, j = 4 * (c >> 3) + (c & 3);
+        *reinterpret_cast<__bf16 *>(encb + s * 1024 + (32 * h + pt) * 16 + 2 * j) = (__bf16)v;
+    };
+
+    for (long long tile = A.tile0 + blockIdx.x; tile < A.tile0 + A.ntiles; tile += gridDim.x) {
+      for (int g0 = 0; g0 < GEN_TG; g0 += NG) {
+        char *tp0 = (REC || BWD) ? A.tape16 + ((tile - A.tile0) * GEN_TG + g0) * G.bytes : nullptr;      // group g0 + g: + g * G.bytes
+        int cur = 0;                                                       // which activation image holds the running layer's input
+        if constexpr (FWD) {
+            // ---- velocity warp + positional encoding: 32-thread part (gsel, sub) does group gsel's octaves sub, sub + nsub, ... ----
+            {
+                const int gsel = part % NG, sub = part / NG, nsub = NP / NG;
+                const PointIn q = load_point<GEN_TG>(a, tile, g0 + gsel, pl);
+                const double tM = q.tM0d + (double)q.tg;                   // emission.py:200-201 (t_M in double)
+                const bool pre = tM < 0.0;                                 // emission.py:204-205
+                const double rev_d = tM * (double)q.om * 0.15915494309189535;
+                const double fr = rev_d - floor(rev_d);
+                const float s0 = __builtin_amdgcn_sinf((float)fr), c0 = __builtin_amdgcn_cosf((float)fr);
+                float u[3] = {c0 * q.x + s0 * q.y, c0 * q.y - s0 * q.x, q.z};    // rot_z(-theta), utils.py:126-132
+                const bool finite_theta = !pre && (fr == fr);
+                bool valid0 = false;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const bool v = finite_theta && isfinite(u[k]);          // network.py:226
+                    if (k == 0) valid0 = v;
+                    u[k] = v ? u[k] * a.inv_scale : 0.f;                    // network.py:227, 229
+                }
+                char *encb = smem + gsel * SLOT + 2 * BUF;
+                if (sub < nsub) {
+                    for (int i = sub; i < a.deg; i += nsub)
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            const float rev = __builtin_amdgcn_fractf(u[k] * (float)(1 << i) * 0.15915494309189535f);
+                            enc_put(encb, 3 + 3 * i + k, pl, __builtin_amdgcn_sinf(rev));
+                            enc_put(encb, 3 + 3 * a.deg + 3 * i + k, pl, __builtin_amdgcn_cosf(rev));
+                        }
+                    if (sub == 0) {
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) enc_put(encb, k, pl, u[k]);
+                        livev[gsel * 32 + pl] = (q.inb && q.dom && valid0) ? 1 : 0;
+                    }
+                }
+            }
+            __syncthreads();
+            if constexpr (REC) {                                            // the encoded inputs as T tiles (dW_0 and the skip layer)
+                for (int it = wv; it < NG * (Ep >> 5); it += nwv) {
+                    const int g = it % NG, eb = it / NG;
+                    const char *encb = smem + g * SLOT + 2 * BUF;
+                    const g16frag f0 = *reinterpret_cast<const g16frag *>(encb + (2 * eb) * 1024 + lane * 16);
+                    const g16frag f1 = *reinterpret_cast<const g16frag *>(encb + (2 * eb + 1) * 1024 + lane * 16);
+                    g16_store_T(tp0 + g * G.bytes + G.encT + eb * 2048, f0, f1, id, lane);
+                }
+            }
+            // ---- hidden layers ----
+            for (int l = 0; l < D; ++l) {
+                const GenLayer Lr = A.L[l];
+                const int hks = Lr.hrows >> 4, eks = Lr.erows >> 4;
+                for (int m = wv; m < MTp; m += nwv) {
+                    f32x16 acc[NG];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float bv = A.pk[Lr.b_off + 32 * m + gen_row(r, lh)];
+#pragma unroll
+                        for (int g = 0; g < NG; ++g) acc[g][r] = bv;
+                    }
+                    const char *af = pk16 + G.f_off[l] + (long long)m * G.ksf[l] * 1024;
+                    if (hks) g16_ksteps<NG>(acc, af, smem + cur * BUF, SLOT, hks, lane);
+                    if (eks) g16_ksteps<NG>(acc, af + (long long)hks * 1024, smem + 2 * BUF, SLOT, eks, lane);
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        g16frag f[2];
+                        unsigned mask = 0;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const bool on = acc[g][r] > 0.f;
+                            f[r >> 3][r & 7] = (__bf16)(on ? acc[g][r] : 0.f);
+                            mask |= (on ? 1u : 0u) << r;
+                        }
+                        char *ob = smem + g * SLOT + (cur ^ 1) * BUF;
+                        *reinterpret_cast<g16frag *>(ob + (2 * m) * 1024 + lane * 16) = f[0];
+                        *reinterpret_cast<g16frag *>(ob + (2 * m + 1) * 1024 + lane * 16) = f[1];
+                        if constexpr (REC) {
+                            char *tg = tp0 + g * G.bytes;
+                            g16_store_T(tg + G.hT + ((long long)l * MTp + m) * 2048, f[0], f[1], id, lane);
+                            *reinterpret_cast<unsigned *>(tg + G.bits + ((long long)l * MTp + m) * 256 + lane * 4) = mask;
+                        }
+                    }
+                }
+                __syncthreads();
+                cur ^= 1;
+            }
+            // ---- output layer: one tile whose row 0 is real; sigmoid(. - 10), masks (network.py:231-233) ----
+            {
+                const GenLayer Lo = A.L[D];
+                const int hks = Lo.hrows >> 4, eks = Lo.erows >> 4;
+                for (int g = wv; g < NG; g += nwv) {
+                    f32x16 acc1[1];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc1[0][r] = 0.f;
+                    const char *af = pk16 + G.f_off[D];
+                    g16_ksteps<1>(acc1, af, smem + g * SLOT + cur * BUF, 0, hks, lane);
+                    if (eks) g16_ksteps<1>(acc1, af + (long long)hks * 1024, smem + g * SLOT + 2 * BUF, 0, eks, lane);
+                    if (lh == 0) {
+                        float e = 0.f;
+                        if (livev[g * 32 + li]) e = 1.f / (1.f + __expf(10.f - (acc1[0][0] + A.pk[Lo.b_off])));
+                        ev[g * 32 + li] = e;
+                        if constexpr (REC) *reinterpret_cast<float *>(tp0 + g * G.bytes + G.e + li * 4) = e;
+                    }
+                }
+            }
+            __syncthreads();
+        } else {
+            if (tid < 32 * NG) ev[tid] = *reinterpret_cast<const float *>(tp0 + (tid >> 5) * G.bytes + G.e + pl * 4);
+            __syncthreads();
+        }
+        // ---- emission / ray sums / dout: one 32-thread part per group ----
+        if (tid < 32 * NG) {
+            const int g = tid >> 5;
+            const PointIn q = load_point<GEN_TG>(a, tile, g0 + g, pl);
+            const float e = ev[g * 32 + pl];
+            if (MODE == GEN_PREDICT) { if (q.inb) a.emission[(long long)q.b * a.P + q.p] = e; }
+            if constexpr (BWD) {
+                float d = 0.f;
+                if (q.inb && e != 0.f) {
+                    const long long ray = a.ray_idx ? (long long)a.ray_idx[q.p] : (long long)a.fd_G.div((unsigned)q.p);
+                    float dE = 0.f;
+                    for (int s = 0; s < a.Sx; ++s) dE += A.dimages[((long long)q.b * a.Sx + s) * a.R + ray] * a.w[(long long)s * a.P + q.p];
+                    d = dE * e * (1.f - e);
+                }
+                doutv[g * 32 + pl] = d;
+                *reinterpret_cast<float *>(tp0 + g * G.bytes + G.dout + pl * 4) = d;
+            }
+        }
+        if constexpr (IMG) {
+            if (wv == 0) {
+                for (int g = 0; g < NG; ++g) {
+                    const PointIn q = load_point<GEN_TG>(a, tile, g0 + g, li);
+                    RaySum<GEN_TG>::put(a, seg, g0 + g, q.p, q.inb, lh == 0 ? ev[g * 32 + li] : 0.f, 0.f, false, q.b);
+                }
+            }
+        }
+        if constexpr (BWD) {
+            __syncthreads();
+            // ---- gA_{D-1} = relu'(h_D) (.) K_out dout as B fragments, from the recorded relu bits ----
+            const GenLayer Lo = A.L[D];
+            for (int m = wv; m < MTp; m += nwv) {
+                float kf[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) kf[r] = A.pk[Lo.k_off + (long long)(32 * m + gen_row(r, lh)) * 32];
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    char *tg = tp0 + g * G.bytes;
+                    const unsigned mask = *reinterpret_cast<const unsigned *>(tg + G.bits + ((long long)(D - 1) * MTp + m) * 256 + lane * 4);
+                    const float dv = doutv[g * 32 + li];
+                    g16frag f[2];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) f[r >> 3][r & 7] = (__bf16)(((mask >> r) & 1u) ? kf[r] * dv : 0.f);
+                    char *ob = smem + g * SLOT + (cur ^ 1) * BUF;
+                    *reinterpret_cast<g16frag *>(ob + (2 * m) * 1024 + lane * 16) = f[0];
+                    *reinterpret_cast<g16frag *>(ob + (2 * m + 1) * 1024 + lane * 16) = f[1];
+                    g16_store_T(tg + G.gaT + ((long long)(D - 1) * MTp + m) * 2048, f[0], f[1], id, lane);
+                }
+            }
+            __syncthreads();
+            cur ^= 1;
+            // ---- delta chain: gA_{l-1} = relu'(h_l) (.) K_l[hidden rows] gA_l, l = D-1 .. 1 ----
+            for (int l = D - 1; l >= 1; --l) {
+                const GenLayer Lr = A.L[l];
+                const int kst = Lr.outp >> 4;
+                for (int m = wv; m < MTp; m += nwv) {
+                    f32x16 acc[NG];
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) { const f32x16 z = {}; acc[g] = z; }
+                    g16_ksteps<NG>(acc, pk16 + G.t_off[l] + (long long)m * kst * 1024, smem + cur * BUF, SLOT, kst, lane);
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        char *tg = tp0 + g * G.bytes;
+                        const unsigned mask = *reinterpret_cast<const unsigned *>(tg + G.bits + ((long long)(l - 1) * MTp + m) * 256 + lane * 4);
+                        g16frag f[2];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) f[r >> 3][r & 7] = (__bf16)(((mask >> r) & 1u) ? acc[g][r] : 0.f);
+                        char *ob = smem + g * SLOT + (cur ^ 1) * BUF;
+                        *reinterpret_cast<g16frag *>(ob + (2 * m) * 1024 + lane * 16) = f[0];
+                        *reinterpret_cast<g16frag *>(ob + (2 * m + 1) * 1024 + lane * 16) = f[1];
+                        g16_store_T(tg + G.gaT + ((long long)(l - 1) * MTp + m) * 2048, f[0], f[1], id, lane);
+                    }
+                }
+                __syncthreads();
+                cur ^= 1;
+            }
+        }
+        __syncthreads();
+      }
+      if constexpr (IMG) {
+          if (!a.ray_direct) {
+              for (int vw = wv; vw < GEN_TG; vw += nwv) RaySum<GEN_TG>::combine(a, seg, vw, (int)a.fd_tpf.div((unsigned)tile));
+              __syncthreads();
+          }
+      }
+    }
+}
+
+// dK_l[in rows 32 mi ..][out columns 128 strip ..] += sum over the split's groups of in_l^T gA_l, both operands T tiles of the tape
+__global__ __launch_bounds__(64) void gen_dw16_kernel(GenArgs A) {
+    const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+    const Gen16 &G = A.g16;
+    const int MTp = A.Wp >> 5;
+    int job = blockIdx.x, l = 0, mi = 0, strip = 0;
+    for (l = 0; l <= A.D; ++l) {
+        const int nin = ((A.L[l].hrows + A.L[l].erows) >> 5) + 1, nst = ((A.L[l].outp >> 5) + 3) >> 2;
+        if (job < nin * nst) { mi = job / nst; strip = job - mi * nst; break; }
+        job -= nin * nst;
+    }
+    if (l > A.D) return;
+    const GenLayer Lr = A.L[l];
+    const int nt = min(4, (Lr.outp >> 5) - 4 * strip);                     // 32-column tiles of this strip
+    const int htiles = Lr.hrows >> 5, etiles = Lr.erows >> 5;
+    const bool bias_job = mi == htiles + etiles, out_job = l == A.D;
+    long long a_off = 0;                                                   // the input tile: h_l tile mi, or encoded-input tile mi - htiles
+    if (mi < htiles) a_off = G.hT + ((long long)(l - 1) * MTp + mi) * 2048;
+    else if (!bias_job) a_off = G.encT + (long long)(mi - htiles) * 2048;
+    const long long b_off = out_job ? G.dout : G.gaT + ((long long)l * MTp + 4 * strip) * 2048;
+    g16frag ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (i == 0) ? (__bf16)1.f : (__bf16)0.f;
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const f32x16 z = {}; acc[j] = z; }
+    const long long ngr = A.ntiles * GEN_TG;
+    const long long t0 = ngr * blockIdx.y / A.nsplit, t1 = ngr * (blockIdx.y + 1) / A.nsplit;
+    struct Ops { g16frag a[2], b[4][2]; };
+    auto load = [&](long long t) {
+        Ops o;
+        const char *tp = A.tape16 + t * G.bytes;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            o.a[s] = bias_job ? ones : *reinterpret_cast<const g16frag *>(tp + a_off + s * 1024 + lane * 16);
+            if (out_job) {                                                 // gA_D: column 0 = dout of the fragment's eight points
+                const float *dv = reinterpret_cast<const float *>(tp + b_off);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o.b[0][s][j] = (i == 0) ? (__bf16)dv[g16_point(s, j, h)] : (__bf16)0.f;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (j < nt) o.b[j][s] = *reinterpret_cast<const g16frag *>(tp + b_off + (long long)j * 2048 + s * 1024 + lane * 16);
+            }
+        }
+        return o;
+    };
+    if (t0 < t1) {
+        Ops nx = load(t0);
+        for (long long t = t0; t < t1; ++t) {
+            const Ops c = nx;
+            if (t + 1 < t1) nx = load(t + 1);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (j < nt) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c.a[s], c.b[j][s], acc[j], 0, 0, 0);
+        }
+    }
+    float *slab = A.slabs + (long long)blockIdx.y * A.slab_floats + Lr.slab_off;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (j < nt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float *d = slab + (long long)(32 * mi + gen_row(r, h)) * Lr.outp + 128 * strip + 32 * j + i;
+                *d = A.accumulate ? *d + acc[j][r] : acc[j][r];
+            }
+        }
+}
+
 // layer tables + sizes of the packed image / a gradient slab / a tape tile
 void gen_layout(const MlpShape &s, GenArgs *A) {
     const int Wp = (s.width_true + 31) / 32 * 32, Ep = (s.F + 31) / 32 * 32;
@@ -394,13 +792,45 @@ void gen_layout(const MlpShape &s, GenArgs *A) {
     A->nsplit = std::min(256, std::max(8, (6144 + njobs - 1) / njobs));
     A->tape_tile = (long long)Ep * 32 + 2ll * s.depth * Wp * 32 + 1024 + 32;
     A->nparams = s.nparams;
+    // bf16 mode: fragment images (1 KiB per 32 x 16 fragment) and the per-group tape
+    Gen16 &g = A->g16;
+    unsigned o16 = 0;
+    for (int l = 0; l <= s.depth; ++l) {
+        const GenLayer &L = A->L[l];
+        g.ksf[l] = (L.hrows + L.erows) / 16;
+        g.f_off[l] = o16; o16 += (unsigned)(L.outp / 32) * g.ksf[l] * 1024u;
+        g.t_off[l] = o16; if (l >= 1 && l < s.depth) o16 += (unsigned)(L.hrows / 32) * (L.outp / 16) * 1024u;
+    }
+    g.image_off = (unsigned)((A->packed_floats * 4 + 255) / 256 * 256);
+    g.image_bytes = o16;
+    const long long mt = Wp / 32;
+    g.encT = 0; g.hT = (long long)(Ep / 32) * 2048; g.gaT = g.hT + s.depth * mt * 2048; g.bits = g.gaT + s.depth * mt * 2048;
+    g.e = g.bits + s.depth * mt * 256; g.dout = g.e + 128; g.bytes = g.dout + 128;
 }
 
 size_t gen_lds_bytes(const GenArgs &A, int Sx) { return (size_t)(2 * A.Wp + A.Ep) * 32 * 4 + (16 * 32 + 64) * 4 + RaySum<GEN_TG>::bytes(Sx); }
 int gen_block(const GenArgs &A) { const int mt = A.Wp / 32; return mt >= 8 ? 512 : mt >= 4 ? 256 : 128; }
 
+// bf16 kernels: groups a workgroup runs side by side (4 when their LDS images fit, else 2) and the LDS bytes of that choice
+size_t gen_lds16_bytes(const GenArgs &A, int Sx, int ng) { return (size_t)ng * (2 * A.Wp * 64 + A.Ep * 64) + (size_t)ng * 32 * 4 * 3 + RaySum<GEN_TG>::bytes(Sx); }
+int gen_ng16(const GenArgs &A, int Sx) { return gen_lds16_bytes(A, Sx, 4) <= 160 * 1024 ? 4 : 2; }
+
+template <int MODE, int NG>
+int gen_launch_mlp16(const GenArgs &A, int grid, hipStream_t st) {
+    const size_t lds = gen_lds16_bytes(A, A.f.Sx, NG);
+    BHN_CHECK_ARG(lds <= 160 * 1024, "internal: general bf16 path needs %zu bytes of LDS", lds);
+    static DeviceOnce once;
+    int dev = 0;
+    BHN_HIP(hipGetDevice(&dev));
+    BHN_HIP(once.run(dev, [&](int &) { return hipFuncSetAttribute((const void *)gen_mlp16_kernel<MODE, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }));
+    hipLaunchKernelGGL((gen_mlp16_kernel<MODE, NG>), dim3(grid), dim3(gen_block(A)), lds, st, A);
+    BHN_HIP(hipGetLastError());
+    return BHN_OK;
+}
+
 template <int MODE>
 int gen_launch_mlp(const GenArgs &A, int grid, hipStream_t st) {
+    if (A.bf16) return gen_ng16(A, A.f.Sx) == 4 ? gen_launch_mlp16<MODE, 4>(A, grid, st) : gen_launch_mlp16<MODE, 2>(A, grid, st);
     const size_t lds = gen_lds_bytes(A, A.f.Sx);
     static DeviceOnce once;
     int dev = 0;
@@ -413,19 +843,21 @@ int gen_launch_mlp(const GenArgs &A, int grid, hipStream_t st) {
 
 }  // namespace
 
-size_t gen_packed_bytes(const MlpShape &s) {
+// f32 image; bf16 mode: + the bf16 fragment images behind it
+size_t gen_packed_bytes(const MlpShape &s, int32_t mode) {
     GenArgs A;
     gen_layout(s, &A);
-    return (size_t)A.packed_floats * 4;
+    return mode == BHN_BF16 ? (size_t)A.g16.image_off + A.g16.image_bytes : (size_t)A.packed_floats * 4;
 }
 
-int gen_pack_weights(const MlpShape &s, const float *params, void *packed, hipStream_t st) {
+int gen_pack_weights(const MlpShape &s, int32_t mode, const float *params, void *packed, hipStream_t st) {
     GenArgs A;
     memset(&A, 0, sizeof(A));
     gen_layout(s, &A);
     A.params = params;
     A.packed_out = reinterpret_cast<float *>(packed);
     hipLaunchKernelGGL(gen_pack_fill_kernel, dim3(512), dim3(256), 0, st, A);
+    if (mode == BHN_BF16) hipLaunchKernelGGL(gen_pack16_kernel, dim3(512), dim3(256), 0, st, A);
     BHN_HIP(hipGetLastError());
     return BHN_OK;
 }
@@ -440,6 +872,7 @@ static int gen_fill(const bhn_model *m, int32_t mode, const void *packed, const 
     const int rc = fused_fill_args(m, mode, packed, geom, fr, need_w, &A->f, s, GEN_TG);
     if (rc != BHN_OK) return rc;
     gen_layout(*s, A);
+    A->bf16 = mode == BHN_BF16 ? 1 : 0;
     A->pk = reinterpret_cast<const float *>(packed);
     A->tile0 = 0;
     A->ntiles = A->f.total_tiles;
@@ -448,13 +881,13 @@ static int gen_fill(const bhn_model *m, int32_t mode, const void *packed, const 
 
 static size_t gen_align(size_t v) { return (v + 255) & ~(size_t)255; }
 static int gen_grid(const GenArgs &A, long long ntiles, int dev) {
-    const size_t lds = gen_lds_bytes(A, A.f.Sx);
+    const size_t lds = A.bf16 ? gen_lds16_bytes(A, A.f.Sx, gen_ng16(A, A.f.Sx)) : gen_lds_bytes(A, A.f.Sx);
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(160 * 1024 / lds, 2048 / gen_block(A)));
     return (int)bhn_balanced_grid(ntiles, (long long)bhn_num_cus(dev) * per_cu);
 }
 // bytes of the gradient slabs / of the tape of ALL tiles of a call
 static size_t gen_slab_bytes(const GenArgs &A) { return gen_align((size_t)A.nsplit * A.slab_floats * 4); }
-static size_t gen_tape_bytes(const GenArgs &A, long long tiles) { return (size_t)tiles * GEN_TG * (size_t)A.tape_tile * 4; }
+static size_t gen_tape_bytes(const GenArgs &A, long long tiles) { return (size_t)tiles * GEN_TG * (A.bf16 ? (size_t)A.g16.bytes : (size_t)A.tape_tile * 4); }
 
 // bhn_predict_fwd / bhn_render_fwd; with a workspace that holds the whole tape (bhn_render_fwd_train): the render that records it
 int gen_forward(bool render, const bhn_model *m, int32_t mode, const void *packed, const bhn_geom *geom, const bhn_frames *fr,
@@ -474,6 +907,7 @@ int gen_forward(bool render, const bhn_model *m, int32_t mode, const void *packe
         // with a smaller workspace it is the plain render and the gradient comes from bhn_render_bwd, chunk by chunk
         if (workspace && workspace_bytes >= gen_slab_bytes(A) + gen_tape_bytes(A, A.ntiles)) {
             A.tape = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + gen_slab_bytes(A));
+            A.tape16 = reinterpret_cast<char *>(A.tape);
             return gen_launch_mlp<GEN_RECORD>(A, grid, st);
         }
         return gen_launch_mlp<GEN_RENDER>(A, grid, st);
@@ -489,9 +923,10 @@ static constexpr long long GEN_MIN_CHUNK_TILES = 2;       // smallest tape chunk
 // takes ANY workspace from slabs + 16 groups of tape on and walks the tiles in chunks (the tile -> (frame, group) map goes through
 // fd_tpf: a chunk may start and end anywhere) -- callers that cannot afford the whole tape (one frame of an 8x512 network on a
 // 256 x 256 x 128 ray set is 277 GB) allocate what they have and call that (engine.workspace).
-size_t gen_bwd_workspace_bytes(const MlpShape &s, int32_t B, int64_t P) {
+size_t gen_bwd_workspace_bytes(const MlpShape &s, int32_t mode, int32_t B, int64_t P) {
     GenArgs A;
     gen_layout(s, &A);
+    A.bf16 = mode == BHN_BF16 ? 1 : 0;
     const long long tiles = ((P + 31) / 32 + GEN_TG - 1) / GEN_TG * B;
     return gen_slab_bytes(A) + gen_tape_bytes(A, tiles);
 }
@@ -518,6 +953,7 @@ int gen_backward(bool tape_only, const bhn_model *m, int32_t mode, const void *p
     }
     A.slabs = reinterpret_cast<float *>(workspace);
     A.tape = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + slab_bytes);
+    A.tape16 = reinterpret_cast<char *>(A.tape);
     A.dimages = dimages;
     A.dparams = dparams;
     const long long chunk = std::min<long long>(A.f.total_tiles, (long long)((workspace_bytes - slab_bytes) / gen_tape_bytes(A, 1)));
@@ -527,7 +963,8 @@ int gen_backward(bool tape_only, const bhn_model *m, int32_t mode, const void *p
         A.accumulate = c0 > 0;
         rc = tape_only ? gen_launch_mlp<GEN_CHAIN_TAPE>(A, gen_grid(A, A.ntiles, dev), st) : gen_launch_mlp<GEN_CHAIN>(A, gen_grid(A, A.ntiles, dev), st);
         if (rc != BHN_OK) return rc;
-        hipLaunchKernelGGL(gen_dw_kernel, dim3(A.njobs, A.nsplit), dim3(64), 0, st, A);
+        if (A.bf16) hipLaunchKernelGGL(gen_dw16_kernel, dim3(A.njobs, A.nsplit), dim3(64), 0, st, A);
+        else hipLaunchKernelGGL(gen_dw_kernel, dim3(A.njobs, A.nsplit), dim3(64), 0, st, A);
         BHN_HIP(hipGetLastError());
     }
     hipLaunchKernelGGL(gen_reduce_kernel, dim3(1024), dim3(256), 0, st, A);

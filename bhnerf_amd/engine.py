@@ -184,12 +184,8 @@ class FusedPredictor:
         self.packed = torch.empty((int(lib.bhn_packed_bytes(C.byref(self.model), self.mode)),), dtype=torch.uint8,
                                   device=self.device)
         self._ws = None
-        # posenc_deg > 4 or net_width > 256: the general layer-by-layer path (csrc/general_mlp.hip) -- f32 arithmetic whatever `mode` says
+        # posenc_deg > 4 or net_width > 256: the general layer-by-layer path (csrc/general_mlp.hip)
         self.general = posenc_deg > 4 or net_width > 256
-        if self.general and self.mode == _hip.BHN_BF16:
-            import warnings
-            warnings.warn('NeRF_Predictor(posenc_deg=%d, net_width=%d) is outside the fused bf16 kernels (posenc_deg <= 4, net_width <= 256): '
-                          'it runs on the general f32 path, several times slower than mode="bf16" suggests (DESIGN.md 4.7)' % (posenc_deg, net_width))
         # queried once, here: torch's device-property query is not safe to call from two host threads at the same time
         self._total_memory = int(torch.cuda.get_device_properties(self.device).total_memory)
 

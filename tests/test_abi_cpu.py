@@ -130,12 +130,13 @@ def test_argument_validation_reports_errors(lib):
     bad_deg = _hip.make_model(4, 64, 11, True, 1.0, 0.0, 1.0, 1.0)
     assert lib.bhn_param_count(C.byref(bad_deg)) == -1 and b'posenc_deg' in lib.bhn_last_error()
     # posenc_deg 5..10 / net_width 257..512: the general path (csrc/general_mlp.hip) -- same flat parameter layout, a packed
-    # image and a workspace of its own, the same for both modes (it computes in f32); no 8-bit tape
+    # image and a workspace of its own per mode; no 8-bit tape
     for general in (_hip.make_model(4, 300, 3, True, 1.0, 0.0, 1.0, 1.0), _hip.make_model(5, 128, 7, True, 1.0, 0.0, 1.0, 1.0)):
         dims = onp.mlp_layer_dims(general.net_depth, general.net_width, 3 + 6 * general.posenc_deg)
         assert lib.bhn_param_count(C.byref(general)) == sum(a * b + b for a, b in dims)
-        assert lib.bhn_packed_bytes(C.byref(general), 0) == lib.bhn_packed_bytes(C.byref(general), 1) > 4 * sum(a * b + b for a, b in dims)
-        assert lib.bhn_render_bwd_workspace_bytes(C.byref(general), 1, 2, 1000, 0) == lib.bhn_render_bwd_workspace_bytes(C.byref(general), 0, 2, 1000, 0) > 0
+        # the bf16 mode keeps the f32 image (biases, output weights) and adds bf16 fragment images; its tape is half the f32 tape
+        assert lib.bhn_packed_bytes(C.byref(general), 1) > lib.bhn_packed_bytes(C.byref(general), 0) > 4 * sum(a * b + b for a, b in dims)
+        assert lib.bhn_render_bwd_workspace_bytes(C.byref(general), 0, 2, 1000, 0) > lib.bhn_render_bwd_workspace_bytes(C.byref(general), 1, 2, 1000, 0) > 0
         assert lib.bhn_render_bwd_workspace_bytes(C.byref(general), 2, 2, 1000, 0) == 0 and b'8-bit' in lib.bhn_last_error()
     skip_into_output = _hip.make_model(5, 64, 3, True, 1.0, 0.0, 1.0, 1.0)       # depth 5: concat feeds the output layer
     assert lib.bhn_param_count(C.byref(skip_into_output)) == sum(a * b + b for a, b in onp.mlp_layer_dims(5, 64, 21))

@@ -11,7 +11,7 @@
 #   <tag>_telemetry_bench.txt     board power / SMI clock during 400 training steps of bench.py (tools/smi_sample.py)
 # The files land in gpurun_out/profiles/ (merged back by gpurun); copy them to profiles/ and commit.
 set -euo pipefail
-TAG=${1:-r5}
+TAG=${1:-r6}
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/profiles

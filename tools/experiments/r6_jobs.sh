@@ -83,5 +83,9 @@ dwub)       # experiment (a), upper bound first: the dW kernel with the LDS traf
   ab libbhnerf_hip.so libbhnerf_hip_rd.so libbhnerf_hip_lb.so libbhnerf_hip_lbrd.so | tee $O/ab.txt
   python tools/general_path_bench.py 8 2 2>&1 | grep -v amdgpu | tail -8 | tee $O/general.txt
   ;;
+gen16)      # general path in bf16 (gen_mlp16_kernel / gen_dw16_kernel): parity and step times
+  timeout 900 python -m pytest tests/test_gpu_backward.py -m gpu -x -q -s -k "general or outside" 2>&1 | grep -v Warning | tail -40 | tee $O/pytest.txt
+  timeout 900 python tools/general_path_bench.py 8 2 2>&1 | grep -v amdgpu | tail -12 | tee $O/general.txt
+  ;;
 *) echo "unknown job $J"; exit 1;;
 esac

@@ -15,7 +15,8 @@ rt = network.raytracing_args(dict(x=geo['coords'][0], y=geo['coords'][1], z=geo[
                                   t=geo['t_geos'], g=geo['g']), geo['Omega'], geo['t_injection'], 0.0 * units.hr, J=1.0)
 target = np.random.default_rng(5).uniform(0.0, 1e-3, (nt, H, W)).astype(np.float32)
 ONLY = os.environ.get('GEN_ONLY')          # e.g. GEN_ONLY=2: only the third shape of the list (for rocprofv3 --stats)
-for ci, (depth, width, deg, mode) in enumerate(((4, 256, 3, 'bf16'), (4, 256, 3, 'f32'), (4, 128, 5, 'f32'), (4, 256, 6, 'f32'), (4, 512, 3, 'f32'), (8, 512, 10, 'f32'))):
+for ci, (depth, width, deg, mode) in enumerate(((4, 256, 3, 'bf16'), (4, 128, 5, 'bf16'), (4, 256, 6, 'bf16'), (4, 512, 3, 'bf16'), (8, 512, 10, 'bf16'),
+                                                (4, 256, 3, 'f32'), (4, 128, 5, 'f32'), (4, 256, 6, 'f32'), (4, 512, 3, 'f32'), (8, 512, 10, 'f32'))):
     if ONLY is not None and int(ONLY) != ci:
         continue
     pred = network.NeRF_Predictor(16.0, 0.0, np.inf, np.inf, posenc_deg=deg, net_depth=depth, net_width=width, mode=mode, device=dev)
