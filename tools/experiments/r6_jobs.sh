@@ -60,7 +60,7 @@ print('width128 step', w.get('ms_per_step'), 'graph', w.get('ms_per_step_hip_gra
 print('fwd images/s', d.get('fwd_images_per_s'), 'cpu', {k: d['cpu_baseline'][k] for k in ('value', 'cores', 'fwd_images_per_s')} if d.get('cpu_baseline') else None)
 print('general_path', d.get('general_path', {}).get('ms_per_step'), 'other', {k: v.get('ms_per_step') for k, v in d.get('other_configs', {}).items() if isinstance(v, dict)})
 PY
-  for l in libbhnerf_hip_swz0.so libbhnerf_hip.so; do echo "== $l"; lds_pass $l 256 ${l%.so}; done | tee $O/lds.txt
+  for l in libbhnerf_hip.so; do echo "== $l"; lds_pass $l 256 ${l%.so}; done | tee $O/lds.txt
   ;;
 pairs)      # item 3: paired (sin, cos) slot layout of the encoded inputs -- parity, A/B on both networks, ablation of the 4x128 forward
   python -m pytest tests -m gpu -x -q 2>&1 | tail -25 > $O/pytest.txt; tail -12 $O/pytest.txt
@@ -86,6 +86,24 @@ dwub)       # experiment (a), upper bound first: the dW kernel with the LDS traf
 gen16)      # general path in bf16 (gen_mlp16_kernel / gen_dw16_kernel): parity and step times
   timeout 900 python -m pytest tests/test_gpu_backward.py -m gpu -x -q -s -k "general or outside" 2>&1 | grep -v Warning | tail -40 | tee $O/pytest.txt
   timeout 900 python tools/general_path_bench.py 8 2 2>&1 | grep -v amdgpu | tail -12 | tee $O/general.txt
+  ;;
+genprof)    # which kernel of the bf16 general path dominates (4x128 deg 5: GEN_ONLY=1; 4x512: GEN_ONLY=3)
+  for only in 1 3; do
+    ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/kg && GEN_ONLY=$only rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kg -o k -- python3 $R/tools/general_path_bench.py 8 3 > $O/run$only.txt 2>&1
+      f=$(find /tmp/kg -name "*kernel_stats.csv" | head -1); python3 - "$f" <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1]))); rows.sort(key=lambda r: -float(r['TotalDurationNs']))
+for r in rows[:8]: print('%-90s calls %5s  avg %10.1f us  %5s %%' % (r['Name'][:90], r['Calls'], float(r['AverageNs']) / 1e3, r['Percentage']))
+PY
+    ); grep general $O/run$only.txt
+  done | tee $O/stats.txt
+  ;;
+fuzz)       # randomised parity sweeps on the final library: fused shapes, general shapes, fused-vs-generic 4x128 backward, stress
+  timeout 1500 python tools/fuzz_parity.py ${1:-300} 6 2>&1 | grep -v amdgpu | tail -40 | tee $O/fuzz.txt
+  FUZZ_GENERAL=1 timeout 900 python tools/fuzz_parity.py ${2:-60} 7 2>&1 | grep -v amdgpu | tail -20 | tee $O/fuzz_general.txt
+  BHNERF_HIP_LIB=$C/libbhnerf_hip_nof128.so timeout 900 python tools/fuzz_fused128.py save 100 8 2>&1 | grep -v amdgpu | tail -2
+  timeout 900 python tools/fuzz_fused128.py check 100 8 2>&1 | grep -v amdgpu | tail -5 | tee $O/fuzz_fused128.txt
+  timeout 600 python tools/debug/dbg_stress.py 2>&1 | grep -v amdgpu | tail -8 | tee $O/stress.txt
   ;;
 *) echo "unknown job $J"; exit 1;;
 esac

@@ -7,7 +7,8 @@ detected ReLU ties are adjudicated by the test itself (tests/test_gpu_backward.p
 "relu ties adjudicated" line.
     python tools/fuzz_parity.py [N] [seed]          (FUZZ_ONLY=i,j,...: run only these draws of the sequence)
 FUZZ_GENERAL=1: every draw is a shape OUTSIDE the fused kernels (posenc degree 5..10 and / or width 257..512: csrc/general_mlp.hip),
-held to tests/test_gpu_backward.py::test_shapes_outside_the_fused_kernels (f32 bounds in both modes, f32 == bf16 bitwise)."""
+held to tests/test_gpu_backward.py::test_shapes_outside_the_fused_kernels (f32 mode: f32 bounds; bf16 mode -- its own MFMA kernels since
+round 6 -- the bf16 bounds; each mode bitwise reproducible run to run)."""
 import os, sys, traceback
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
