@@ -19,11 +19,11 @@ mkdir -p $O
 need() { [ -s "$1" ] || { echo "collect_profiles: missing or empty $1" >&2; exit 1; }; }
 python3 $R/bench.py > $O/${TAG}_bench_line.json 2> $O/bench.err
 need $O/${TAG}_bench_line.json
-rm -rf /tmp/kt; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o kt -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity-mode --no-tape8 --no-tutorial-domain --no-other-configs --no-width128 > /tmp/kt.log 2>&1
+rm -rf /tmp/kt; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o kt -- python3 $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-parity-mode --no-tape8 --no-tutorial-domain --no-other-configs --no-width128 > /tmp/kt.log 2>&1
 f=$(find /tmp/kt -name "*kernel_stats.csv" | head -1); need "$f"; cp "$f" $O/${TAG}_bench_kernel_stats.csv
 rm -rf /tmp/ktf; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ktf -o kt -- python3 $R/bench.py --mode f32 --steps 3 --warmup 1 --no-cpu-baseline --no-tutorial-domain --no-other-configs --no-width128 > /tmp/ktf.log 2>&1
 f=$(find /tmp/ktf -name "*kernel_stats.csv" | head -1); need "$f"; cp "$f" $O/${TAG}_f32_kernel_stats.csv
-rm -rf /tmp/ktw; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ktw -o kt -- python3 $R/bench.py --width 128 --steps 5 --warmup 2 --no-cpu-baseline --no-parity-mode --no-tape8 --no-tutorial-domain --no-other-configs --no-width128 > /tmp/ktw.log 2>&1
+rm -rf /tmp/ktw; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ktw -o kt -- python3 $R/bench.py --width 128 --steps 40 --warmup 5 --no-cpu-baseline --no-parity-mode --no-tape8 --no-tutorial-domain --no-other-configs --no-width128 > /tmp/ktw.log 2>&1
 f=$(find /tmp/ktw -name "*kernel_stats.csv" | head -1); need "$f"; cp "$f" $O/${TAG}_w128_kernel_stats.csv
 # bf16 against the 8-bit tape mode (BHN_BF16_T8), kernel by kernel, at config 2's shape
 rm -rf /tmp/kt8; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt8 -o kt -- python3 $R/tools/debug/dbg_t8.py time > $O/${TAG}_t8_times.txt 2>&1
