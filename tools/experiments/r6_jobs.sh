@@ -105,5 +105,10 @@ fuzz)       # randomised parity sweeps on the final library: fused shapes, gener
   timeout 900 python tools/fuzz_fused128.py check 100 8 2>&1 | grep -v amdgpu | tail -5 | tee $O/fuzz_fused128.txt
   timeout 600 python tools/debug/dbg_stress.py 2>&1 | grep -v amdgpu | tail -8 | tee $O/stress.txt
   ;;
+fuzzold)    # the HARD draws of the round-6 sweep (bf16, deep narrow networks on tiny ray sets) on round 5's library, built from a
+            # tree of commit 89fdb6c under tools/_r5tree (git archive 89fdb6c | tar -x -C tools/_r5tree; make -C .../csrc): regression or statistics?
+  echo "== round-6 library"; FUZZ_ONLY=$1 timeout 900 python tools/fuzz_parity.py 1000 6 2>&1 | grep -E "draw|random conf" | tee $O/new.txt
+  echo "== round-5 library (commit 89fdb6c)"; ( cd tools/_r5tree && FUZZ_ONLY=$1 timeout 900 python tools/fuzz_parity.py 1000 6 2>&1 | grep -E "draw|random conf" ) | tee $O/old.txt
+  ;;
 *) echo "unknown job $J"; exit 1;;
 esac
