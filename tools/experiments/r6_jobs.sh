@@ -110,5 +110,9 @@ fuzzold)    # the HARD draws of the round-6 sweep (bf16, deep narrow networks on
   echo "== round-6 library"; FUZZ_ONLY=$1 timeout 900 python tools/fuzz_parity.py 1000 6 2>&1 | grep -E "draw|random conf" | tee $O/new.txt
   echo "== round-5 library (commit 89fdb6c)"; ( cd tools/_r5tree && FUZZ_ONLY=$1 timeout 900 python tools/fuzz_parity.py 1000 6 2>&1 | grep -E "draw|random conf" ) | tee $O/old.txt
   ;;
+final)      # everything under profiles/r6_* that comes from tools/collect_profiles.sh, on the final library; then the two examples
+  bash tools/collect_profiles.sh r6 2>&1 | tail -15
+  timeout 600 python examples/image_plane_recovery.py 2>&1 | grep -v amdgpu | tail -4 | tee $O/example_recovery.txt
+  ;;
 *) echo "unknown job $J"; exit 1;;
 esac
