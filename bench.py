@@ -482,6 +482,56 @@ def mfma_peak_this_box(dev, seconds=0.25):
             'what': 'bhn_mfma_probe: %d workgroups x 8 waves x %d x 16 dependent v_mfma_f32_32x32x16_bf16, register operands, random data' % (ncu, iters)}
 
 
+def attach_profiles(roofline, width, std, lib_md5):
+    """What the committed counter passes say about this workload (NOT measured in this run; see the module docstring): `traffic`
+    (PMC bytes of the dominant kernel) and the `*_from_profiles` keys, from profiles/<PROFILE_TAG>_*; `profiles_match_this_build`
+    compares the library they were collected on with the one loaded here.  Also run offline on a stored bench line
+    (tools/attach_profiles.py: the line tools/collect_profiles.sh writes is produced BEFORE the passes it would quote)."""
+    dom_k = roofline['kernel']
+    step_kernels = [k for k in roofline['kernels']]
+    sfx = '_w128' if (width == 128 and not std) else ''      # the width-128 passes of tools/collect_profiles.sh
+    use = std or sfx == '_w128'
+    prof = {'pmc': {}, 'sq': {}, 'stats': {}, 'match': None}
+    traffic_file = 'profiles/%s_pmc_traffic%s.json' % (PROFILE_TAG, sfx)
+    try:
+        j = json.load(open(os.path.join(ROOT, traffic_file)))
+        prof['pmc'] = j['kernels'] if use else {}
+        prof['match'] = (j.get('lib_md5') == lib_md5) if j.get('lib_md5') else None
+    except Exception:
+        pass
+    try:
+        prof['sq'] = json.load(open(os.path.join(ROOT, 'profiles', PROFILE_TAG + sfx + '_sq_summary.json')))['kernels'] if use else {}
+    except Exception:
+        pass
+    try:                                             # rocprofv3 --kernel-trace --stats averages of the same workload
+        import csv
+        stats_file = os.path.join(ROOT, 'profiles', PROFILE_TAG + ('_w128' if sfx else '_bench') + '_kernel_stats.csv')
+        for r in csv.DictReader(open(stats_file)):
+            n = short_name(r['Name'])                 # template arguments by position (tools/kernel_names.py)
+            if n and use:
+                prof['stats'][n] = float(r['AverageNs']) * 1e-6
+    except Exception:
+        pass
+    roofline.update({'traffic': prof['pmc'].get(dom_k, {}).get('hbm_bytes'),
+                     'traffic_source': '%s (rocprofv3 --pmc passes, not measured in this run)' % traffic_file,
+                     'profiles_tag': PROFILE_TAG, 'profiles_match_this_build': prof['match']})
+    if dom_k in prof['stats']:                       # the same fraction on the rocprofv3 average duration of the committed profile
+        ms_p = prof['stats'][dom_k]
+        roofline['frac_from_profiles'] = round(roofline['frac'] * roofline['kernel_ms'][dom_k] / ms_p, 4)
+        roofline['kernel_ms_from_profiles'] = round(ms_p, 4)
+    if prof['pmc']:
+        if all(k in prof['pmc'] and 'hbm_bytes' in prof['pmc'][k] for k in step_kernels):
+            roofline['step_mlp_traffic_from_profiles'] = int(sum(prof['pmc'][k]['hbm_bytes'] for k in step_kernels))
+    if prof['sq']:    # matrix-pipe busy fraction of SIMD cycles from the committed SQ counter passes (keys: short kernel names)
+        busy = {k: v['mfma_busy_frac'] for k, v in prof['sq'].items() if 'mfma_busy_frac' in v}
+        roofline['mfma_busy_frac_from_profiles'] = busy
+        conf = {k: v['lds_bank_conflict_frac'] for k, v in prof['sq'].items() if 'lds_bank_conflict_frac' in v}
+        roofline['lds_bank_conflict_frac_from_profiles'] = conf
+        pms = {k: v.get('ms') for k, v in prof['sq'].items()}
+        if all(k in busy and pms.get(k) for k in step_kernels):
+            roofline['step_mfma_busy_frac_from_profiles'] = round(sum(busy[k] * pms[k] for k in step_kernels) / sum(pms[k] for k in step_kernels), 3)
+
+
 def roofline_block(eng, geom, tM0, dimg, depth, width, mode, frames_per_gpu, std, kern_ms=None, clocks=None):
     """Per-kernel timings of one rank's share of a step (`kern_ms`: measured by a StepTimer inside the caller's step loop; None:
     measured here, back to back) and for each MLP kernel the MFMA fraction on the flops it executes of the algorithm
@@ -531,63 +581,19 @@ def roofline_block(eng, geom, tM0, dimg, depth, width, mode, frames_per_gpu, std
                   'sustained_clock_mhz': clock_mhz(clocks, CLK_SLOT[k]) if clocks is not None else None}
     dom_k = max(alg, key=lambda k: kern_ms[k])
     d = per[dom_k]
-    # what the committed counter passes say about this workload (NOT measured in this run; see the module docstring)
-    lib_md5 = file_md5(_hip_lib_path())
-    sfx = '_w128' if (width == 128 and not std) else ''      # the width-128 passes of tools/collect_profiles.sh
-    use = std or sfx == '_w128'
-    prof = {'pmc': {}, 'sq': {}, 'stats': {}, 'match': None}
-    traffic_file = 'profiles/%s_pmc_traffic%s.json' % (PROFILE_TAG, sfx)
-    try:
-        j = json.load(open(os.path.join(ROOT, traffic_file)))
-        prof['pmc'] = j['kernels'] if use else {}
-        prof['match'] = (j.get('lib_md5') == lib_md5) if j.get('lib_md5') else None
-    except Exception:
-        pass
-    try:
-        prof['sq'] = json.load(open(os.path.join(ROOT, 'profiles', PROFILE_TAG + sfx + '_sq_summary.json')))['kernels'] if use else {}
-    except Exception:
-        pass
-    try:                                             # rocprofv3 --kernel-trace --stats averages of the same workload
-        import csv
-        stats_file = os.path.join(ROOT, 'profiles', PROFILE_TAG + ('_w128' if sfx else '_bench') + '_kernel_stats.csv')
-        for r in csv.DictReader(open(stats_file)):
-            n = short_name(r['Name'])                 # template arguments by position (tools/kernel_names.py)
-            if n and use:
-                prof['stats'][n] = float(r['AverageNs']) * 1e-6
-    except Exception:
-        pass
     # the fused MLP is on the MFMA roofline, on ALGORITHMIC flops; the tape bytes are design overhead, shown beside it
     roofline = {'bound': 'mfma', 'kernel': dom_k, 'achieved': d['mfma_tflops'], 'peak': peak, 'unit': 'TFLOP/s', 'frac': d['mfma_frac'],
                 'algorithmic_flop_per_point': alg[dom_k], 'sustained_clock_mhz': d['sustained_clock_mhz'],
                 'tape_layout': {k: v for k, v in tinfo['flags'].items() if v},
                 'tape_stream': {'GB_per_s': d['tape_GB_per_s'], 'frac_of_8TBps': d['hbm_frac'], 'tape_bytes_per_point': d['tape_bytes_per_point'],
                                 'note': 'bytes of tape this kernel moves through HBM per evaluated point (DESIGN.md 3): the design\'s own traffic, not algorithmic work'}}
-    roofline.update({'points_per_launch': int(pts),
-                     'traffic': prof['pmc'].get(dom_k, {}).get('hbm_bytes'),
-                     'traffic_source': '%s (rocprofv3 --pmc passes, not measured in this run)' % traffic_file,
-                     'profiles_tag': PROFILE_TAG, 'profiles_match_this_build': prof['match']})
-    if dom_k in prof['stats']:                       # the same fraction on the rocprofv3 average duration of the committed profile
-        ms_p = prof['stats'][dom_k]
-        roofline['frac_from_profiles'] = round(d['mfma_frac'] * kern_ms[dom_k] / ms_p, 4)
-        roofline['kernel_ms_from_profiles'] = round(ms_p, 4)
+    roofline['points_per_launch'] = int(pts)
     roofline['kernels'] = per
     roofline['kernel_ms'] = {k: round(v, 4) for k, v in kern_ms.items()}
     roofline['kernel_ms_sum'] = round(sum(v for k, v in kern_ms.items() if 'inference' not in k), 4)
     roofline['kernel_ms_note'] = ('HIP events around / between the kernels INSIDE the timed steps (engine.step_timer): the same steps as ms_per_step' if in_loop
                                   else 'each kernel timed in a loop of its own (HIP events around / between the launches)')
-    if prof['pmc']:
-        tk = [k for k in alg]
-        if all(k in prof['pmc'] and 'hbm_bytes' in prof['pmc'][k] for k in tk):
-            roofline['step_mlp_traffic_from_profiles'] = int(sum(prof['pmc'][k]['hbm_bytes'] for k in tk))
-    if prof['sq']:    # matrix-pipe busy fraction of SIMD cycles from the committed SQ counter passes (keys: short kernel names)
-        busy = {k: v['mfma_busy_frac'] for k, v in prof['sq'].items() if 'mfma_busy_frac' in v}
-        roofline['mfma_busy_frac_from_profiles'] = busy
-        conf = {k: v['lds_bank_conflict_frac'] for k, v in prof['sq'].items() if 'lds_bank_conflict_frac' in v}
-        roofline['lds_bank_conflict_frac_from_profiles'] = conf
-        tk = [k for k in alg]
-        pms = {k: v.get('ms') for k, v in prof['sq'].items()}
-        if all(k in busy and pms.get(k) for k in tk):
-            roofline['step_mfma_busy_frac_from_profiles'] = round(sum(busy[k] * pms[k] for k in tk) / sum(pms[k] for k in tk), 3)
+    attach_profiles(roofline, width, std, file_md5(_hip_lib_path()))
     inf_tf = f_fwd * pts / (kern_ms[INFER_NAME] * 1e-3) / 1e12
     roofline['inference_forward'] = {'ms': round(kern_ms[INFER_NAME], 4), 'mfma_tflops': round(inf_tf, 1), 'mfma_frac': round(inf_tf / peak, 4),
                                      'sustained_clock_mhz': infer_clock}

@@ -17,6 +17,8 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/profiles
 mkdir -p $O
 need() { [ -s "$1" ] || { echo "collect_profiles: missing or empty $1" >&2; exit 1; }; }
+# TAIL_ONLY=1: only the ring-ceiling micro-benchmark and the telemetry runs at the end (they do not depend on the passes above)
+if [ -z "${TAIL_ONLY:-}" ]; then
 python3 $R/bench.py > $O/${TAG}_bench_line.json 2> $O/bench.err
 need $O/${TAG}_bench_line.json
 rm -rf /tmp/kt; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o kt -- python3 $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-parity-mode --no-tape8 --no-tutorial-domain --no-other-configs --no-width128 > /tmp/kt.log 2>&1
@@ -109,7 +111,8 @@ PY
 done
 need $O/${TAG}_sq_summary.json
 need $O/${TAG}_w128_sq_summary.json
-hipcc -O3 -std=c++17 --offload-arch=gfx950 -I$R/bhnerf_amd/csrc -I$R/include $R/tools/step_bench.hip -o /tmp/step_bench > /tmp/step_bench.log 2>&1
+fi      # (TAIL_ONLY)
+hipcc -O3 -std=c++17 --offload-arch=gfx950 -I$R/bhnerf_amd/csrc -I$R/include $R/tools/step_bench.hip -o /tmp/step_bench > /tmp/step_bench.log 2>&1 || { tail -5 /tmp/step_bench.log >&2; exit 1; }
 : > $O/${TAG}_telemetry_ceiling.txt
 python3 $R/tools/smi_sample.py >> $O/${TAG}_telemetry_ceiling.txt & SMI=$!
 sleep 2; /tmp/step_bench ceiling 8 > $O/${TAG}_ring_ceiling_microbench.txt 2>&1; sleep 1; kill $SMI || true

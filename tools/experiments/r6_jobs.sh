@@ -114,5 +114,8 @@ final)      # everything under profiles/r6_* that comes from tools/collect_profi
   bash tools/collect_profiles.sh r6 2>&1 | tail -15
   timeout 600 python examples/image_plane_recovery.py 2>&1 | grep -v amdgpu | tail -4 | tee $O/example_recovery.txt
   ;;
+ceiling)    # the tail of tools/collect_profiles.sh alone (ring-ceiling micro-benchmark + telemetry; round 6: tools/step_bench.hip did not compile in the first collection)
+  TAIL_ONLY=1 bash tools/collect_profiles.sh r6 2>&1 | tail -8
+  ;;
 *) echo "unknown job $J"; exit 1;;
 esac

@@ -28,8 +28,8 @@ __global__ __launch_bounds__(512) void k(const char *img, float *out, int steps)
     f32x16 pend = {};
     unsigned mk[8] = {};
     for (int it = 0; it < steps; it += 16) {
-        hidden_layer<W, Pol, RG>(rs, ap, act, next, enc, false, bias_lds + W, pend);
-        hidden_layer<W, Pol, RG>(rs, ap, next, act, enc, false, bias_lds + 2 * W, pend);
+        hidden_layer<W, Pol, RG>(rs, ap, act, next, enc, false, bias_lds + W, pend, nullptr);
+        hidden_layer<W, Pol, RG>(rs, ap, next, act, enc, false, bias_lds + 2 * W, pend, nullptr);
     }
     if (!rs.lag) rs.idle_step();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -272,8 +272,8 @@ __global__ __launch_bounds__(512) void k2(const char *img, const bf16x8 *bsrc, f
             hidden_layer16<W, Pol, RG>(rs, ap, act, next, enc, (MODE & 8) != 0, bias_lds + W, pend);
             hidden_layer16<W, Pol, RG>(rs, ap, next, act, enc, (MODE & 8) != 0, bias_lds + 2 * W, pend);
         } else {
-            hidden_layer<W, Pol, RG>(rs, ap, act, next, enc, (MODE & 8) != 0, bias_lds + W, pend);
-            hidden_layer<W, Pol, RG>(rs, ap, next, act, enc, (MODE & 8) != 0, bias_lds + 2 * W, pend);
+            hidden_layer<W, Pol, RG>(rs, ap, act, next, enc, (MODE & 8) != 0, bias_lds + W, pend, nullptr);
+            hidden_layer<W, Pol, RG>(rs, ap, next, act, enc, (MODE & 8) != 0, bias_lds + 2 * W, pend, nullptr);
         }
         if (!(MODE & 1)) {      // without the pack the activations would be dead: keep them random
             for (int i = 0; i < KS; ++i) asm volatile("" : "+v"(act[i]), "+v"(next[i]));
