@@ -224,3 +224,42 @@ def test_ray_span_of_a_compacted_layout():
     counts = torch.randint(1, 23, (500,), generator=rng)                      # config-3-like: at most 22 in-domain samples per ray
     ray = torch.repeat_interleave(torch.arange(500, dtype=torch.int32), counts)
     assert engine.ray_span(ray) == 2
+
+
+def test_bench_roofline_bookkeeping():
+    """bench.py's per-kernel figures: flops each MLP kernel EXECUTES of the algorithm, tape bytes from the
+    library's own layout (bhn_tape_info, host-only), the clock from the kernels' stamps."""
+    import ctypes as C
+    import os
+    import sys
+    import __graft_entry__ as entry
+    entry.build()
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from bhnerf_amd import _hip
+    lib = _hip.lib()
+
+    def info(depth, width, mode):
+        m = _hip.make_model(depth, width, 3, True, 8.0, 0.0, 8.0, 4.0)
+        out = (C.c_int64 * _hip.BHN_TAPE_INFO_N)()
+        assert lib.bhn_tape_info(C.byref(m), mode, 8192, out, _hip.BHN_TAPE_INFO_N) == 0
+        return {'fwd_write': out[0], 'chain_write': out[1], 'chain_read': out[2], 'dw_read': out[3],
+                'flags': {k: bool(out[4] & v) for k, v in _hip.TAPE_FLAGS.items()}}
+
+    fwd, chain, dw, train = bench.mlp_flops(4, 256)
+    assert (fwd, train) == (415232, 1234944) and fwd + chain + dw == train                  # SURVEY 8(d)
+    i256 = info(4, 256, _hip.BHN_BF16)
+    k = bench.kernel_flops(4, 256, i256['flags'])
+    # under ga0_chain the delta chain carries dW_0 (2 F W = 10,752) and the output layer's delta (2 W = 512); the dW kernel has no layer-0 job
+    assert k == {bench.FWD_NAME: 415232, bench.CHAIN_NAME: 393216 + 512 + 10752, 'dw_kernel': 415232 - 10752}
+    assert sum(k.values()) == train - 10752              # SURVEY's step figure also counts an input gradient of the skip features nobody computes
+    kf = bench.kernel_flops(4, 256, info(4, 256, _hip.BHN_F32)['flags'])
+    assert kf[bench.CHAIN_NAME] == 393216 + 512 and kf['dw_kernel'] == 415232
+    i128 = info(4, 128, _hip.BHN_BF16)
+    assert bench.kernel_flops(4, 128, i128['flags']) == {bench.FWD_NAME: 109312, bench.FUSED_NAME: 98304 + 256 + 109312}
+    assert bench.tape_bytes_per_point(i256) == {bench.FWD_NAME: 1796.0, bench.CHAIN_NAME: 1224.0, 'dw_kernel': 2720.0}
+    assert bench.tape_bytes_per_point(i128) == {bench.FWD_NAME: 596.0, bench.FUSED_NAME: 600.0}
+    # four stamps per kernel slot {s_memtime, s_memrealtime} x {start, end}; s_memrealtime counts at 100 MHz
+    stamps = np.zeros(16, dtype=np.int64)
+    stamps[8:12] = [1000, 50, 1000 + 1_850_000, 50 + 100_000]                              # slot 2: 1.85e6 core cycles in 1 ms
+    assert bench.clock_mhz(stamps, bench.CLK_SLOT[bench.CHAIN_NAME]) == 1850.0 and bench.clock_mhz(stamps, 0) is None
