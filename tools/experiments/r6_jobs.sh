@@ -117,5 +117,14 @@ final)      # everything under profiles/r6_* that comes from tools/collect_profi
 ceiling)    # the tail of tools/collect_profiles.sh alone (ring-ceiling micro-benchmark + telemetry; round 6: tools/step_bench.hip did not compile in the first collection)
   TAIL_ONLY=1 bash tools/collect_profiles.sh r6 2>&1 | tail -8
   ;;
+spread)     # one default bench.py run on whatever box this call gets: the box-to-box spread of the final library (profiles/r6_box_spread.txt)
+  python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; w=d['width128']; rw=w['roofline']; pk=r['mfma_peak_this_box']
+print('4x256 step %.3f ms frac %.4f | fwd %.3f chain %.3f dW %.3f | clocks %s | infer %.3f (%.3f) | peak_this_box %.0f TF @ %.0f MHz | 4x128 step %.3f [%.3f %.3f] infer %.3f | images/s %.0f | general %.1f ms | cfg3 %.2f cfg5 %.3f' % (
+  d['ms_per_step'], r['step_mfma_frac'], r['kernel_ms'][list(r['kernels'])[0]], r['kernel_ms'][list(r['kernels'])[1]], r['kernel_ms'][list(r['kernels'])[2]],
+  [int(v['sustained_clock_mhz']) for v in r['kernels'].values()], r['inference_forward']['ms'], r['inference_forward']['mfma_frac'], pk['tflops'], pk['clock_mhz'],
+  w['ms_per_step'], *[v['ms'] for v in rw['kernels'].values()], rw['inference_forward']['ms'], d['fwd_images_per_s'], d['general_path']['ms_per_step'],
+  d['other_configs']['config3']['ms_per_step'], d['other_configs']['config5']['ms_per_step']))" | tee $O/line_$(date +%s).txt
+  ;;
 *) echo "unknown job $J"; exit 1;;
 esac
