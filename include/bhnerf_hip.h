@@ -72,14 +72,15 @@ typedef struct {
 } bhn_model;
 
 /* The general path (csrc/general_mlp.hip; posenc_deg > 4 or net_width > 256 -- shapes no reference driver uses): every entry
- * point below accepts these models with the same arguments and the same results, but computes in f32 WHATEVER `mode` says
- * (BHN_BF16 is accepted; BHN_BF16_T8 is BHN_EUNSUPPORTED), layer by layer with the activations of 32 points in LDS, at
- * 0.3-0.4 of the f32 MFMA peak.  bhn_render_fwd_train records nothing (it is bhn_render_fwd) and bhn_render_bwd_tape
- * recomputes the forward; the workspace holds 8-256 gradient slabs
- * (more for narrow networks) and the tape of a chunk of 32-point groups: the query asks for at most 2 GiB of tape, the call
- * accepts anything from 16 groups' worth (not a whole frame's: one frame of an 8x512 network on 256 x 256 x 128 rays is 277 GB).
- * Pixels of rays that span more than two 32-point groups receive one float atomic per group: images, losses and gradients of
- * these models are reproducible to rounding only (the fused kernels: bitwise). */
+ * point below accepts these models with the same arguments and the same results, computed layer by layer on tiles of eight
+ * 32-point groups: BHN_F32 with f32 MFMAs, BHN_BF16 with bf16 MFMAs on fragment-ordered operands (round 6; BHN_BF16_T8 is
+ * BHN_EUNSUPPORTED).  bhn_packed_bytes differs by mode (BHN_BF16: the f32 image + bf16 fragment images).
+ * bhn_render_bwd_workspace_bytes(B, P) = gradient slabs + the tape of all B frames: with a workspace of that size
+ * bhn_render_fwd_train records the tape and bhn_render_bwd_tape runs the delta chain and the weight gradients from it (with less:
+ * BHN_EWORKSPACE, as for the fused paths).  bhn_render_bwd recomputes chunk by chunk and accepts ANY workspace from the slabs + 16
+ * groups of tape on (not a whole frame's: one frame of an 8x512 network on 256 x 256 x 128 rays is 277 GB of f32 tape).
+ * Images, losses and gradients of these models are bitwise reproducible like the fused kernels' (the ray segments of a tile are
+ * combined in LDS: one float atomic per tile and ray, at most two per pixel for rays of <= 257 samples; slabs summed in a fixed order). */
 
 /* Geodesic-side inputs, prepared once per ray set by bhn_geom_prepare (arrays of P floats). */
 typedef struct {
