@@ -126,5 +126,9 @@ print('4x256 step %.3f ms frac %.4f | fwd %.3f chain %.3f dW %.3f | clocks %s | 
   w['ms_per_step'], *[v['ms'] for v in rw['kernels'].values()], rw['inference_forward']['ms'], d['fwd_images_per_s'], d['general_path']['ms_per_step'],
   d['other_configs']['config3']['ms_per_step'], d['other_configs']['config5']['ms_per_step']))" | tee $O/line_$(date +%s).txt
   ;;
+examples)   # the two end-to-end examples on the final library
+  timeout 600 python examples/image_plane_recovery.py 2>&1 | grep -v amdgpu | tail -3 | tee $O/recovery.txt
+  ( cd /tmp && timeout 900 python $R/examples/fit_alma_lp.py 20 30 40 --config $R/examples/fit_alma_lp.yaml 2>&1 | grep -v amdgpu | tail -8 ) | tee $O/alma.txt
+  ;;
 *) echo "unknown job $J"; exit 1;;
 esac
