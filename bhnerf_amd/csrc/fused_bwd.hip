@@ -300,7 +300,7 @@ struct Ga0Consumer {
     int trl;                     // tr_lane_off(): the encoded-input tiles (DMA'd from the tape: its slot layout)
     int trl_ga;                  // the same for the staged gA_0 tiles, whose odd 256-byte rows swap their 64-byte lane halves (ga0_stage_swz)
 #ifndef BHN_GA0C_PF
-#define BHN_GA0C_PF 3            // fragment pairs in flight in the consumer block (8 registers each)
+#define BHN_GA0C_PF 2            // fragment pairs in flight in the consumer block (8 registers each); round 6 re-sweep: 2 beats 3 and 4 by 1 % of the kernel (profiles/r6_tunable_sweep.txt)
 #endif
     DEVI void run(f32x16 &acc, int npairs) const {
         constexpr int PF = BHN_GA0C_PF;

@@ -130,5 +130,8 @@ examples)   # the two end-to-end examples on the final library
   timeout 600 python examples/image_plane_recovery.py 2>&1 | grep -v amdgpu | tail -3 | tee $O/recovery.txt
   ( cd /tmp && timeout 900 python $R/examples/fit_alma_lp.py 20 30 40 --config $R/examples/fit_alma_lp.yaml 2>&1 | grep -v amdgpu | tail -8 ) | tee $O/alma.txt
   ;;
+sweep)      # re-sweep of compile-time tunables after this round's changes: libbhnerf_hip_<name>.so variants given as arguments, against the product
+  ab libbhnerf_hip.so "$@" | tee $O/ab_$(date +%s).txt
+  ;;
 *) echo "unknown job $J"; exit 1;;
 esac
