@@ -133,5 +133,8 @@ examples)   # the two end-to-end examples on the final library
 sweep)      # re-sweep of compile-time tunables after this round's changes: libbhnerf_hip_<name>.so variants given as arguments, against the product
   ab libbhnerf_hip.so "$@" | tee $O/ab_$(date +%s).txt
   ;;
+sweep128)   # the same for the 4x128 path (bench.py with its width-128 block): variants against the product
+  ab128 libbhnerf_hip.so "$@" | tee $O/ab_$(date +%s).txt
+  ;;
 *) echo "unknown job $J"; exit 1;;
 esac
