@@ -383,3 +383,67 @@ def test_recorded_tape_can_be_replayed(dev, problem, width):
     g1b = eng.render_bwd_tape(geom, tM0, d1).clone()
     assert float(g1.abs().max()) > 0 and not torch.equal(g1, g2)
     assert torch.equal(g1, g1b)
+
+
+@pytest.mark.parametrize('width', [128, 256])
+def test_clock_probe_stamps_and_tape_info(dev, problem, width):
+    """ABI 5's measurement aids through the C ABI: `bhn_frames.clock_probe` -- workgroup 0 of each fused MLP kernel stamps
+    {s_memtime, s_memrealtime} at its start and end into its own slot, nothing else changes (images and gradients bit-identical
+    with and without the probe) -- and `bhn_tape_info` against the workspace the library asks for."""
+    from bhnerf_amd import _hip, constants, engine as E, network
+    geo = problem['geo']
+    pred = network.NeRF_Predictor(8.0, 0.0, np.inf, np.inf, net_depth=4, net_width=width, mode='bf16', device=dev)
+    eng = pred.engine()
+    geom = pred.geometry(geo['coords'], geo['Omega'], geo['t_geos'], geo['J'], geo['g'], geo['dtau'], geo['Sigma'])
+    eng.pack(eng.flatten(network.MLP(4, width).init(1, 21)))
+    tM0 = E.frame_offsets(problem['t_frames'][:4], 0.0, geo['t_injection'], constants.GM_c3('hr'), dev)
+    dimg = torch.rand((4, geom.Sx, geom.R), device=dev) - 0.4
+    img0 = eng.render(geom, tM0).clone()
+    imt0 = eng.render_train(geom, tM0).clone()
+    g0 = eng.render_bwd_tape(geom, tM0, dimg).clone()
+    clk = torch.zeros((4 * _hip.BHN_CLK_SLOTS,), dtype=torch.int64, device=dev)
+    eng.clock_probe = clk
+    try:
+        img1 = eng.render(geom, tM0).clone()
+        imt1 = eng.render_train(geom, tM0).clone()
+        g1 = eng.render_bwd_tape(geom, tM0, dimg).clone()
+    finally:
+        eng.clock_probe = None
+    assert torch.equal(img0, img1) and torch.equal(imt0, imt1) and torch.equal(g0, g1)
+    c = clk.cpu().numpy().reshape(_hip.BHN_CLK_SLOTS, 4)
+    info = eng.tape_info((geom.P_eff + 31) // 32)
+    used = [_hip.BHN_CLK_FWD, _hip.BHN_CLK_FWD_TRAIN, _hip.BHN_CLK_CHAIN] + ([] if info['flags']['fused128'] else [_hip.BHN_CLK_DW])
+    for slot in used:
+        t0, r0, t1, r1 = (int(v) for v in c[slot])
+        assert t1 > t0 and r1 > r0, (slot, c[slot])
+        mhz = 100.0 * (t1 - t0) / (r1 - r0)                        # s_memrealtime counts at 100 MHz
+        assert 300.0 < mhz < 2600.0, (slot, mhz)
+    if info['flags']['fused128']:
+        assert not c[_hip.BHN_CLK_DW].any()                        # (no separate dW kernel on the fused 4x128 path)
+    # the tape the library lays out for these frames is what bhn_tape_info says it streams (forward + chain writes, rounded up)
+    assert info['flags']['fused128'] == (width == 128) and info['flags']['ga0_chain'] == (width == 256)
+    groups = 4 * ((geom.P_eff + 31) // 32)
+    assert eng.workspace(4, geom.P_eff).numel() >= groups * (info['fwd_write'] + info['chain_write'])
+
+
+def test_mfma_probe_reports_a_plausible_ceiling(dev):
+    """bhn_mfma_probe (bench.py: mfma_peak_this_box): the register-operand bf16 MFMA loop runs, its clock stamps are sane and
+    the rate it implies lies between a tenth of and the whole dense bf16 peak."""
+    import ctypes as C
+    from bhnerf_amd import _hip
+    lib = _hip.lib()
+    ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+    clk = torch.zeros((2 * ncu,), dtype=torch.int64, device=dev)
+    sink = torch.zeros((1024,), dtype=torch.float32, device=dev)
+    iters = 4000
+    _hip.check(lib.bhn_mfma_probe(ncu, iters, _hip.ptr(clk), _hip.ptr(sink), _hip.stream_ptr(dev)))
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    _hip.check(lib.bhn_mfma_probe(ncu, iters, _hip.ptr(clk), _hip.ptr(sink), _hip.stream_ptr(dev)))
+    b.record(); torch.cuda.synchronize()
+    tflops = ncu * 8 * iters * 16 * 32768.0 / (a.elapsed_time(b) * 1e-3) / 1e12
+    c = clk.cpu().numpy().reshape(ncu, 2)
+    mhz = np.median(100.0 * c[:, 0] / c[:, 1])
+    assert (c > 0).all() and 300.0 < mhz < 2600.0 and 250.0 < tflops < 2500.0, (mhz, tflops)
+    assert lib.bhn_mfma_probe(0, iters, None, _hip.ptr(sink), _hip.stream_ptr(dev)) == 1       # BHN_EINVAL
