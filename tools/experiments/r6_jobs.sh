@@ -136,5 +136,9 @@ sweep)      # re-sweep of compile-time tunables after this round's changes: libb
 sweep128)   # the same for the 4x128 path (bench.py with its width-128 block): variants against the product
   ab128 libbhnerf_hip.so "$@" | tee $O/ab_$(date +%s).txt
   ;;
+genab)      # general bf16 path: step time of 4x128 deg 5 / 4x256 deg 6 / 4x512 per library variant (the product library = the committed one)
+  BHNERF_HIP_LIB=$C/$2 python -m pytest tests/test_gpu_backward.py -m gpu -x -q -k "general or outside" 2>&1 | tail -3 | tee $O/pytest.txt      # (parity of the second library given)
+  for r in 1 2; do for l in "$@"; do for only in 1 2 3; do echo -n "$l "; BHNERF_HIP_LIB=$C/$l GEN_ONLY=$only python tools/general_path_bench.py 8 3 2>&1 | grep general; done; done; done | tee $O/ab.txt
+  ;;
 *) echo "unknown job $J"; exit 1;;
 esac
